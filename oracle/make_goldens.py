@@ -1,0 +1,237 @@
+"""Generate tests/golden/*.npz from the IMPORTED REFERENCE (this container only).
+
+TEST INFRASTRUCTURE ONLY.  Run:  python -m oracle.make_goldens
+Every fixture stores inputs-by-seed + the reference's outputs; while generating, the
+oracle restatement (oracle/nets.py, oracle/loss.py) is checked against the reference
+to <= 1e-5 relative so a drift between the two fails here, before anything is committed.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import loss as OL
+from . import nets as ON
+from . import ref_shim
+from . import weights as OW
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+SAMPLES_PER_TENSOR = 16
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def sample_indices(name, numel, k=SAMPLES_PER_TENSOR):
+    seed = int.from_bytes(name.encode()[-8:].rjust(8, b'\0'), 'little') % (2 ** 31)
+    return np.random.default_rng(seed).integers(0, numel, k)
+
+
+def e2e_case(tag, backbone, head, nc, B, H, Wd, seed=1234, dice=True):
+    ref = ref_shim.load()
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    x, y = OW.synthetic_batch(B, H, Wd, nc, seed)
+    model = ref_shim.build_reference_model(backbone, head, nc, sd)
+    # key / shape inventory must match the reference exactly
+    rsd = model.state_dict()
+    assert list(rsd.keys()) == list(sd.keys()) or set(rsd.keys()) == set(sd.keys()), 'key mismatch'
+    for k in rsd:
+        assert tuple(rsd[k].shape) == tuple(sd[k].shape), (k, rsd[k].shape, sd[k].shape)
+
+    out = {'backbone': backbone, 'head': head, 'nc': nc, 'B': B, 'H': H, 'W': Wd, 'seed': seed}
+    # eval-mode logits
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(x)
+    o_eval, _ = ON.model_forward(sd, x, backbone, head, training=False)
+    e = rel_err(o_eval, logits_eval)
+    print(f'[{tag}] eval logits oracle-vs-ref rel err {e:.2e}')
+    assert e < 2e-5, e
+    out['logits_eval'] = logits_eval.numpy()
+
+    # train-mode forward + criterion + backward
+    model.train()
+    model.zero_grad()
+    logits = model(x)
+    loss = ref.engine.criterion(logits, y, None, num_classes=nc, dice=dice, ignore_index=255)
+    loss.backward()
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var')))
+           for k, v in sd.items()}
+    o_tr, ctx = ON.model_forward(sdg, x, backbone, head, training=True)
+    # same loss graph as the reference here, so the gradient comparison isolates the network
+    # restatement (the closed-form criterion is pinned separately in loss_cases())
+    l2 = ref.engine.criterion(o_tr, y, None, num_classes=nc, dice=dice, ignore_index=255)
+    l2.backward()
+    l2c = OL.criterion_closed_form(o_tr.detach(), y, None, num_classes=nc, dice=dice, ignore_index=255)
+    assert abs(l2c.item() - l2.item()) < 1e-5 * max(1, abs(l2.item()))
+    e = rel_err(o_tr.detach(), logits.detach())
+    print(f'[{tag}] train logits rel err {e:.2e}; loss ref {loss.item():.6f} oracle {l2.item():.6f}')
+    assert e < 2e-5 and abs(loss.item() - l2.item()) < 2e-5 * max(1, abs(loss.item()))
+    out['logits_train'] = logits.detach().numpy()
+    out['loss'] = np.float64(loss.item())
+    names, norms, samp = [], [], []
+    worst = 0.
+    # parameters that only add a per-channel constant in front of a train-mode BN have a
+    # mathematically zero gradient (pure rounding noise): measure against the global scale too
+    gscale = max(p.grad.abs().max().item() for p in model.parameters() if p.grad is not None)
+    out['grad_global_max'] = np.float64(gscale)
+    for k, p in model.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        go = sdg[k].grad if sdg[k].grad is not None else torch.zeros_like(p)
+        denom = g.abs().max().item() + 1e-4 * gscale
+        worst = max(worst, (g - go).abs().max().item() / denom)
+        names.append(k)
+        norms.append(g.double().norm().item())
+        samp.append(g.flatten()[sample_indices(k, g.numel())].numpy())
+    print(f'[{tag}] worst per-tensor grad rel err oracle-vs-ref {worst:.2e}')
+    assert worst < 5e-4, worst
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms)
+    out['grad_samples'] = np.stack(samp)
+    # BN buffers after one train forward (captures quirk Q3)
+    bn_names, bn_vals = [], []
+    for k, v in model.state_dict().items():
+        if k.endswith(('running_mean', 'running_var', 'num_batches_tracked')):
+            e = rel_err(ctx.buffers[k].float(), v.float())
+            assert e < 1e-5, (k, e)
+            bn_names.append(k)
+            bn_vals.append(v.float().double().norm().item() if v.ndim else float(v))
+    out['bn_names'] = np.array(bn_names)
+    out['bn_norms'] = np.array(bn_vals)
+    np.savez_compressed(os.path.join(OUT, f'e2e_{tag}.npz'), **out)
+
+
+def loss_cases():
+    ref = ref_shim.load()
+    rng = np.random.default_rng(7)
+    cases = []
+    specs = [
+        # (B, C, H, W, dice, weighted, special)
+        (2, 19, 24, 24, True, False, 'band'),
+        (2, 150, 16, 16, True, False, 'absent'),
+        (3, 7, 16, 16, True, False, 'one_image_all_ignored'),
+        (2, 2, 16, 16, True, True, 'binary_weighted'),
+        (2, 21, 16, 16, False, False, 'ce_only'),
+        (2, 5, 8, 8, True, False, 'no_ignore_index'),
+    ]
+    out = {'n': len(specs)}
+    for i, (B, C, H, Wd, dice, weighted, special) in enumerate(specs):
+        logits = torch.from_numpy((rng.standard_normal((B, C, H, Wd)) * 2).astype(np.float32))
+        hi = C if special != 'absent' else C // 3
+        t = torch.from_numpy(rng.integers(0, hi, (B, H, Wd), dtype=np.int64))
+        ign = 255
+        if special == 'no_ignore_index':
+            ign = -100
+        else:
+            t[:, :2] = 255
+            t[torch.from_numpy(rng.random((B, H, Wd)) < 0.05)] = 255
+        if special == 'one_image_all_ignored':
+            t[1] = 255
+        w = torch.tensor([1.0, 2.0]) if weighted else None
+        lg = logits.clone().requires_grad_(True)
+        l = ref.engine.criterion(lg, t, w, num_classes=C, dice=dice, ignore_index=ign)
+        l.backward()
+        lo = logits.clone().requires_grad_(True)
+        l2 = OL.criterion_closed_form(lo, t, w, num_classes=C, dice=dice, ignore_index=ign)
+        l2.backward()
+        l3 = OL.criterion_loops(logits, t, w, num_classes=C, dice=dice, ignore_index=ign)
+        assert abs(l.item() - l2.item()) < 2e-6 and abs(l.item() - l3.item()) < 2e-6, (special, l.item(), l2.item(), l3.item())
+        assert (lg.grad - lo.grad).abs().max() < 1e-7, special
+        print(f'[loss {special}] ref {l.item():.7f} closed {l2.item():.7f} loops {l3.item():.7f}')
+        out[f'logits_{i}'] = logits.numpy()
+        out[f'target_{i}'] = t.numpy()
+        out[f'loss_{i}'] = np.float64(l.item())
+        out[f'grad_{i}'] = lg.grad.numpy()
+        out[f'meta_{i}'] = np.array([C, int(dice), int(weighted), ign])
+        out[f'name_{i}'] = special
+    np.savez_compressed(os.path.join(OUT, 'loss_cases.npz'), **out)
+
+
+def metrics_case():
+    ref = ref_shim.load()
+    rng = np.random.default_rng(11)
+    nc = 19
+    m = ref.metrics.Metrics(nc, 255, 'cpu')
+    cm = ref.utils.ConfusionMatrix(nc)
+    out = {'nc': nc}
+    for b in range(2):
+        logits = torch.from_numpy(rng.standard_normal((2, nc, 32, 32)).astype(np.float32))
+        t = torch.from_numpy(rng.integers(0, nc - 3, (2, 32, 32), dtype=np.int64))   # 3 classes absent from GT
+        t[:, :3] = 255
+        cm.update(t.flatten(), logits.argmax(1).flatten())
+        m.update(logits, t.flatten())
+        out[f'logits_{b}'] = logits.numpy()
+        out[f'target_{b}'] = t.numpy()
+        mat, hist = OL.confusion_counts(logits, t, nc, 255)
+        out[f'mat_batch_{b}'] = mat
+    assert np.array_equal(sum(out[f'mat_batch_{b}'] for b in range(2)), cm.mat.numpy())
+    out['mat'] = cm.mat.numpy()
+    out['hist'] = m.hist.numpy()
+    iou, f1, acc = m.compute_iou(), m.compute_f1(), m.compute_pixel_acc()
+    o_iou, o_f1, o_acc = OL.metrics_from_hist(torch.from_numpy(out['hist']))
+    # NaN != NaN, compare via string
+    assert str(iou) == str(o_iou) and str(f1) == str(o_f1) and str(acc) == str(o_acc)
+    out['iou'] = np.array(iou[0]); out['miou'] = iou[1]
+    out['f1'] = np.array(f1[0]); out['mf1'] = f1[1]
+    out['acc'] = np.array(acc[0]); out['macc'] = acc[1]
+    out['confmat_str'] = str(cm)
+    np.savez_compressed(os.path.join(OUT, 'metrics_case.npz'), **out)
+    print('[metrics] miou', iou[1], 'mf1', f1[1], 'macc', acc[1])
+
+
+class _PlainScaler:
+    """Stand-in for timm NativeScaler in fp32 CPU runs: backward + step, no clipping."""
+    def __call__(self, loss, optimizer, clip_grad=None, clip_mode='norm', parameters=None, create_graph=False):
+        loss.backward(create_graph=create_graph)
+        optimizer.step()
+
+
+def train_loop_case():
+    """engine.train_one_epoch (engine.py:18-70) on one synthetic batch repeated: the per-step loss
+    sequence pins forward + loss + backward + SGD update end to end."""
+    ref = ref_shim.load()
+    backbone, head, nc, B, H, Wd, seed, steps, lr = 'MiT-B0', 'SegFormerHead', 8, 2, 64, 64, 4321, 6, 0.01
+    sd = OW.make_state_dict(backbone, head, nc, seed, lively=True)
+    x, y = OW.synthetic_batch(B, H, Wd, nc, seed)
+    model = ref_shim.build_reference_model(backbone, head, nc, sd)
+    opt = torch.optim.SGD(model.parameters(), lr=lr, momentum=0.0)
+    torch.cuda.synchronize = lambda *a, **k: None          # engine.py:56 (quirk Q14)
+    losses = []
+
+    class Rec:
+        def add_scalar(self, name, v, it=None):
+            if name == 'train_loss':
+                losses.append(float(v))
+    args = types.SimpleNamespace(nb_classes=nc, dice=True, ignore_index=255, ignore_label=255, local_rank=0, device='cpu')
+    loader = [(x, y)] * steps
+    mean_loss, last_lr = ref.engine.train_one_epoch(model, opt, loader, 0, 'cpu', 1, None, None, _PlainScaler(), Rec(), args)
+    print('[train_loop] losses', losses, 'mean', mean_loss)
+    # evaluate with the reference's evaluate(): confusion matrix + metrics after training
+    confmat, metric = ref.engine.evaluate(args, model, [(x, y)], 'cpu', 1, None)
+    out = dict(backbone=backbone, head=head, nc=nc, B=B, H=H, W=Wd, seed=seed, steps=steps, lr=lr,
+               losses=np.array(losses), mean_loss=mean_loss, mat=confmat.mat.numpy(), hist=metric.hist.numpy(),
+               miou=metric.compute_iou()[1], mf1=metric.compute_f1()[1], macc=metric.compute_pixel_acc()[1])
+    np.savez_compressed(os.path.join(OUT, 'train_loop_segformer_b0.npz'), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    loss_cases()
+    metrics_case()
+    e2e_case('segformer_b0_64', 'MiT-B0', 'SegFormerHead', 19, 2, 64, 64)
+    e2e_case('segformer_b0_96x128', 'MiT-B0', 'SegFormerHead', 7, 1, 96, 128, seed=99)
+    e2e_case('mbv2_fpn_64', 'MobileNetV2', 'FPNHead', 21, 2, 64, 64)
+    e2e_case('convnext_uper_64', 'ConvNeXt', 'UPerHead', 19, 2, 64, 64)
+    e2e_case('convnextv2_tiny_uper_64', 'convnextv2_tiny', 'UPerHead', 19, 2, 64, 64)
+    train_loop_case()
+    print('goldens written to', OUT)
+
+
+if __name__ == '__main__':
+    sys.exit(main())
