@@ -1,0 +1,172 @@
+/*
+ * segfac.h -- C ABI of libsegfac_hip.so: the MI355X (gfx950) kernels underneath the
+ * Segmentation_Factory plugin API (SegmentationModel / backbones / heads / engine.criterion /
+ * util.metrics).  The reference has no native boundary on this path (it is eager PyTorch,
+ * SURVEY.md section 2.2); each entry point below names the reference code it stands in for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator);
+ *     kernels never allocate, free or keep pointers; workspaces are caller-provided.
+ *   - activations are token-major / NHWC: element (row, c) at base[row * ld + c]; `ld` in elements.
+ *   - dt: SEGF_F32 (0) or SEGF_BF16 (1) = storage type of activations; all arithmetic,
+ *     statistics and accumulation are fp32.  Parameters and parameter gradients are fp32.
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue, never synchronise.
+ *   - return 0 = enqueued; <0 = argument error (-1 shape/alignment, -2 dtype, -3 workspace);
+ *     >0 = hipError_t from the launch.  Nothing is printed.
+ */
+#ifndef SEGFAC_H
+#define SEGFAC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGF_F32 0
+#define SEGF_BF16 1
+#define SEGF_ERR_SHAPE (-1)
+#define SEGF_ERR_DTYPE (-2)
+#define SEGF_ERR_WORKSPACE (-3)
+
+/* library / build info: returns a static string "segfac-hip <version> gfx950" */
+const char* segf_version(void);
+
+/* ---- elementwise plumbing ------------------------------------------------------------------- */
+/* dst[i] = (dst_dt) src[i] */
+int segf_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, void* stream);
+/* out[a][c][b] = in[a][b][c]  (+ zero padding of the last output dim up to ldb_out):
+ * OIHW -> O(HW)I weight re-layout for NHWC im2col GEMMs (models/backbones/mit.py:105 conv weights),
+ * NCHW <-> NHWC at the plugin boundary (mit.py:198 permute).  */
+int segf_permute021(const void* in, int in_dt, void* out, int out_dt, int64_t A, int64_t Bd, int64_t Cd,
+                    int64_t ld_out, void* stream);
+/* y[r][c] = x[r][c] * scale[r / rows_per_group]   (DropPath backward, models/layers/drop_path.py:18-25) */
+int segf_scale_rows(int dt, const void* x, int64_t ldx, void* y, int64_t ldy, const float* scale,
+                    int64_t rows, int64_t cols, int64_t rows_per_group, void* stream);
+/* y = a + b  (residual / gradient fan-in), 2-D with leading dims */
+int segf_add(int dt, const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy,
+             int64_t rows, int64_t cols, void* stream);
+/* out[c] = sum_r x[r][c] as fp32 (bias gradients of nn.Linear / 1x1 conv).  ws >= segf_colsum_ws(rows, cols) floats */
+int64_t segf_colsum_ws(int64_t rows, int64_t cols);
+int segf_colsum(int dt, const void* x, int64_t ldx, int64_t rows, int64_t cols, float* out, float* ws, void* stream);
+
+/* ---- GEMM: nn.Linear / 1x1 conv / im2col'd conv, forward and both backward products -------------
+ * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ), fp32 accumulate.
+ *   layout 0: A stored [M][K] (lda), B stored [N][K] (ldb)   y  = x W^T      (F.linear forward)
+ *   layout 1: A stored [M][K],       B stored [K][N]         dx = dy W
+ *   layout 2: A stored [K][M],       B stored [K][N]         dW = dy^T x     (K = token count)
+ * epilogue: v = acc (+ bias[n]); if residual: v = residual[m][n] + (rscale ? rscale[m / rows_per_group] : 1) * v
+ * c_dt may be SEGF_F32 while dt is SEGF_BF16 (parameter gradients).
+ * split_k > 1 (layout 2 only) needs ws >= split_k * M * N floats; result is reduced deterministically.
+ * bf16 uses v_mfma_f32_16x16x32_bf16; f32 uses an fp32 FMA kernel (exact-fp32 parity mode).       */
+int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K,
+              const void* A, int64_t lda, const void* B, int64_t ldb,
+              void* C, int c_dt, int64_t ldc,
+              const float* bias, const void* residual, int64_t ldr,
+              const float* rscale, int64_t rows_per_group,
+              int split_k, float* ws, void* stream);
+int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K);
+
+/* ---- LayerNorm over the last dim (nn.LayerNorm eps 1e-5 in mit.py:107,136-140,178-190; ConvNeXt's
+ * channels-first LayerNorm, convnext.py:8-23, is the same kernel on NHWC rows) ---------------------- */
+int segf_layernorm_fwd(int dt, int64_t rows, int C, const void* x, const float* gamma, const float* beta,
+                       float eps, void* y, float* mean, float* rstd, void* stream);
+int64_t segf_layernorm_bwd_ws(int64_t rows, int C);
+int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* gamma,
+                       const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                       float* ws, void* stream);
+
+/* ---- BatchNorm2d (train: batch statistics) + ReLU/ReLU6 + Dropout2d, NHWC rows -------------------
+ * ConvModule of heads/segformer.py:21-29, layers/conv_module.py:4-9, mobilenetv2.py:5-11.
+ * stats: mean/var(biased) over rows; running stats updated with momentum and unbiased var.         */
+int64_t segf_bn_ws(int64_t rows, int C);
+int segf_bn_stats(int dt, int64_t rows, int C, const void* x, float* mean, float* rstd,
+                  float* running_mean, float* running_var, float momentum, float eps, float* ws, void* stream);
+/* y = act(gamma * (x-mean)*rstd + beta) * (chan_scale ? chan_scale[row / rows_per_sample][c] : 1); act 0 none, 1 relu, 2 relu6 */
+int segf_bn_apply(int dt, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, int act, const float* chan_scale,
+                  int64_t rows_per_sample, void* y, void* stream);
+/* training backward (batch statistics): dx, dgamma, dbeta.  eval_mode=1: statistics are constants. */
+int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* mean, const float* rstd,
+                const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_sample,
+                int eval_mode, void* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+
+/* ---- MiT spatial-reduction attention core (mit.py:52-57): O = softmax(Q K^T * scale) V -----------
+ * q: [B*N][ldq] with head h at columns h*hd; k, v likewise over B*Nkv rows; o: [B*N][ldo]; lse: [B][heads][N] */
+int segf_attention_fwd(int dt, int B, int heads, int N, int Nkv, int hd, const void* q, int64_t ldq,
+                       const void* k, int64_t ldk, const void* v, int64_t ldv, float scale,
+                       void* o, int64_t ldo, float* lse, void* stream);
+int64_t segf_attention_bwd_ws(int B, int heads, int N, int Nkv, int hd);
+int segf_attention_bwd(int dt, int B, int heads, int N, int Nkv, int hd, const void* q, int64_t ldq,
+                       const void* k, int64_t ldk, const void* v, int64_t ldv, float scale,
+                       const void* o, int64_t ldo, const void* d_o, int64_t lddo, const float* lse,
+                       void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                       float* ws, void* stream);
+
+/* ---- depthwise 3x3 conv + bias + GELU(erf) on NHWC (mit.py:62-71,98-99 DWConv -> F.gelu) ----------- */
+int segf_dwconv3x3_gelu_fwd(int dt, int B, int H, int W, int C, const void* x, const float* w /*[C][9]*/,
+                            const float* bias, int apply_gelu, void* y, void* stream);
+int64_t segf_dwconv3x3_bwd_ws(int B, int H, int W, int C);
+/* du = dy * gelu'(conv(x)+b) is written to `du` (same shape as x); dx = conv^T(du); dw[C][9], db[C] fp32 */
+int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
+                            int apply_gelu, const void* dy, void* du, void* dx, float* dw, float* db,
+                            float* ws, void* stream);
+
+/* ---- im2col / col2im for strided convs (PatchEmbed mit.py:105,127; sr conv mit.py:21,48) ---------
+ * col[(b,oy,ox)][(ky,kx,ci)] with leading dim ldcol (>= kh*kw*Cin, pad columns are zeroed).
+ * in_nchw_f32=1: input is the fp32 NCHW image (train_gpu.py tensor contract); else NHWC of dtype dt. */
+int segf_im2col(int dt, int in_nchw_f32, int B, int H, int W, int Cin, int kh, int kw, int stride, int pad,
+                int Ho, int Wo, const void* x, void* col, int64_t ldcol, void* stream);
+int segf_col2im(int dt, int B, int H, int W, int Cin, int kh, int kw, int stride, int pad,
+                int Ho, int Wo, const void* dcol, int64_t ldcol, void* dx, void* stream);
+
+/* ---- bilinear resize on NHWC (F.interpolate mode='bilinear'; heads/segformer.py:48, ppm.py:24,
+ * upernet.py:41,46, build_models.py:65); out may be a channel slice of a wider buffer (ldo) ---------- */
+int segf_bilinear_fwd(int dt, int B, int h, int w, int C, const void* in, int64_t ldi,
+                      int H, int W, void* out, int64_t ldo, int align_corners, void* stream);
+int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, int64_t ldi,
+                      int H, int W, const void* dout, int64_t ldo, int align_corners, void* stream);
+/* out (fp32 NCHW [B][C][H][W]) = bilinear(in NHWC [B][h][w][ldi]) -- materialised logits for API parity */
+int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, const void* in, int64_t ldi,
+                              int H, int W, float* out, void* stream);
+
+/* ---- fused final-upsample + CrossEntropy + Dice (build_models.py:65 + engine.py:10-15 +
+ * util/losses.py:126-177) ------------------------------------------------------------------------
+ * logits: NHWC [B][h][w][ldl] (low-res head output; h==H,w==W means "already full-res");
+ * target: int64 [B][H][W]; stats: fp32 [B][C][3] (I,P,T) + [4] {ce_sum, w_sum, n_valid, bad_label_flag};
+ * loss: fp32 [3] {total, ce, dice_loss}.  class_weight nullable ([C]).  dice=0 -> CE only.        */
+int64_t segf_ce_dice_stats_floats(int B, int C);
+int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
+                     const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
+                     float* stats, float* loss, void* stream);
+/* dlogits_full: NHWC [B][H][W][ldg] of dtype dt = d loss / d (upsampled logits) * grad_out[0];
+ * follow with segf_bilinear_bwd to get the low-res gradient when h != H.                            */
+int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
+                     const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
+                     const float* stats, const float* grad_out, void* dlogits_full, int64_t ldg, void* stream);
+
+/* ---- fused upsample + argmax + confusion matrix (engine.py:89-91; util/utils.py:99-109;
+ * util/metrics.py:24-27).  mat: int64 [n][n] += counts where 0<=t<n; hist: int64 [n][n] += counts
+ * where t != ignore_label (t>=n and != ignore is skipped and flagged in flag[0]).                  */
+int segf_argmax_confmat(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
+                        const int64_t* target, int64_t ignore_label, int64_t* mat, int64_t* hist,
+                        int32_t* flag, int64_t* pred_out /*nullable [B][H][W]*/, void* stream);
+
+/* ConfusionMatrix.update(a, b) on explicit int64 (ground truth, prediction) pairs (util/utils.py:99-109) and
+ * the Metrics.update bincount (util/metrics.py:24-27); mat / hist nullable.  flag bit0: label >= n that is not
+ * ignore_label, bit1: prediction out of range.                                                      */
+int segf_confmat_pairs(const int64_t* gt, const int64_t* pred, int64_t n, int C, int64_t ignore_label,
+                       int64_t* mat, int64_t* hist, int32_t* flag, void* stream);
+
+/* ---- optimizer step (engine.py:52-53 -> timm NativeScaler -> AGC clip -> AdamW) over flat fp32
+ * param/grad/state buffers.  A "unit" is one dim-0 row of a >=2-D weight or a whole 1-D tensor:
+ * unit_offset[u], unit_len[u] (elements), unit_flags[u] bit0 = apply weight decay.  clip_factor <= 0
+ * disables AGC.  See oracle/optim.py for the restated arithmetic (timm 0.9.2; "parity unpinned").   */
+int segf_agc_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   const int64_t* unit_offset, const int32_t* unit_len, const uint8_t* unit_flags, int nunits,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float clip_factor, float agc_eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

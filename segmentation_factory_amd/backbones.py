@@ -1,0 +1,205 @@
+"""Backbones behind the reference's plugin contract (models/build_models.py:25-29): a callable name that
+returns an nn.Module exposing ``.channels`` and ``forward(x[B,3,H,W]) -> 4 NCHW feature maps``.
+
+Internally every activation is a token-major ``[B*H*W, C]`` tensor in the compute dtype and every op is
+a HIP kernel (segmentation_factory_amd.functional).  The NCHW maps handed to the head are zero-copy
+permuted views of those token buffers.
+"""
+import torch
+from torch import nn
+
+from . import functional as Fh
+from .containers import ConvWeights, LayerNormWeights, LinearWeights, init_mit_style
+
+# reference models/backbones/mit.py:149-156
+mit_settings = {
+    'B0': [[32, 64, 160, 256], [2, 2, 2, 2]],
+    'B1': [[64, 128, 320, 512], [2, 2, 2, 2]],
+    'B2': [[64, 128, 320, 512], [3, 4, 6, 3]],
+    'B3': [[64, 128, 320, 512], [3, 4, 18, 3]],
+    'B4': [[64, 128, 320, 512], [3, 8, 27, 3]],
+    'B5': [[64, 128, 320, 512], [3, 6, 40, 3]],
+}
+
+
+class TokenMap:
+    """A feature map as tokens: data [B*H*W, C] (+ geometry).  ``nchw()`` is the plugin-API view."""
+    __slots__ = ('data', 'B', 'H', 'W')
+
+    def __init__(self, data, B, H, W):
+        self.data, self.B, self.H, self.W = data, B, H, W
+
+    def nchw(self):
+        return self.data.view(self.B, self.H, self.W, -1).permute(0, 3, 1, 2)
+
+
+def tokens_from_nchw(x, dtype):
+    """Accept an NCHW tensor from a foreign backbone/head: zero-copy when it is a permuted NHWC buffer."""
+    B, C, H, W = x.shape
+    t = x.permute(0, 2, 3, 1)
+    if not t.is_contiguous() or t.dtype != dtype:
+        from . import hip
+        src = x.contiguous()
+        t = hip.permute021(src, B, C, H * W, dtype)          # NCHW -> NHWC re-layout kernel
+        return TokenMap(t.view(B * H * W, C), B, H, W)
+    return TokenMap(t.reshape(B * H * W, C), B, H, W)
+
+
+class Attention(nn.Module):
+    """Spatial-reduction attention (mit.py:9-59)."""
+
+    def __init__(self, dim, head, sr_ratio):
+        super().__init__()
+        self.head, self.sr_ratio, self.dim = head, sr_ratio, dim
+        self.q = LinearWeights(dim, dim)
+        self.kv = LinearWeights(dim, dim * 2)
+        self.proj = LinearWeights(dim, dim)
+        if sr_ratio > 1:
+            self.sr = ConvWeights(dim, dim, sr_ratio, sr_ratio)
+            self.norm = LayerNormWeights(dim)
+        self.apply(init_mit_style)
+
+    def tokens(self, h, B, H, W, residual, rscale):
+        N = H * W
+        q = Fh.linear(h, self.q.weight, self.q.bias)
+        if self.sr_ratio > 1:
+            sr = self.sr_ratio
+            xr = Fh.conv_patch(h, self.sr.weight, self.sr.bias, (B, H, W, self.dim, sr, sr, 0))
+            xr = Fh.layer_norm(xr, self.norm.weight, self.norm.bias, self.norm.eps)
+            Nkv = ((H - sr) // sr + 1) * ((W - sr) // sr + 1)
+        else:
+            xr, Nkv = h, N
+        kv = Fh.linear(xr, self.kv.weight, self.kv.bias)
+        o = Fh.attention(q, kv, B, N, Nkv, self.head)
+        return Fh.linear(o, self.proj.weight, self.proj.bias, residual=residual, rscale=rscale, rows_per_group=N)
+
+
+class DWConv(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dwconv = ConvWeights(dim, dim, 3, 1, 1, groups=dim)
+
+
+class MLP(nn.Module):
+    """fc1 -> depthwise 3x3 -> GELU -> fc2 (mit.py:74-99)."""
+
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.fc1 = LinearWeights(c1, c2)
+        self.dwconv = DWConv(c2)
+        self.fc2 = LinearWeights(c2, c1)
+        self.apply(init_mit_style)
+
+    def tokens(self, h, B, H, W, residual, rscale):
+        f = Fh.linear(h, self.fc1.weight, self.fc1.bias)
+        g = Fh.dwconv3x3_gelu(f, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias, B, H, W, True)
+        return Fh.linear(g, self.fc2.weight, self.fc2.bias, residual=residual, rscale=rscale, rows_per_group=H * W)
+
+
+class PatchEmbed(nn.Module):
+    """Overlapped patch embedding: strided conv + LayerNorm (mit.py:102-131)."""
+
+    def __init__(self, c1=3, c2=32, patch_size=7, stride=4):
+        super().__init__()
+        self.c1, self.k, self.stride = c1, patch_size, stride
+        self.proj = ConvWeights(c1, c2, patch_size, stride, patch_size // 2)
+        self.norm = LayerNormWeights(c2)
+        self.apply(init_mit_style)
+
+    def tokens(self, x, B, H, W, image, dtype):
+        k, s, p = self.k, self.stride, self.k // 2
+        t = Fh.conv_patch(x, self.proj.weight, self.proj.bias, (B, H, W, self.c1, k, s, p), image=image, dtype=dtype)
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        return Fh.layer_norm(t, self.norm.weight, self.norm.bias, self.norm.eps), Ho, Wo
+
+
+class Block(nn.Module):
+    """x + DropPath(Attn(LN(x)));  x + DropPath(MLP(LN(x)))   (mit.py:134-146).  The residual add and the
+    per-sample DropPath scale are fused into the epilogue of the proj / fc2 GEMMs."""
+
+    def __init__(self, dim, head, sr_ratio=1, dpr=0.):
+        super().__init__()
+        self.norm1 = LayerNormWeights(dim)
+        self.attn = Attention(dim, head, sr_ratio)
+        self.drop_prob = float(dpr)
+        self.norm2 = LayerNormWeights(dim)
+        self.mlp = MLP(dim, int(dim * 4))
+
+    def tokens(self, x, B, H, W, scales):
+        s1, s2 = scales
+        h = Fh.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.attn.tokens(h, B, H, W, x, s1)
+        h = Fh.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.mlp.tokens(h, B, H, W, x, s2)
+
+
+class MiT(nn.Module):
+    """Mix Transformer encoder (mit.py:159-218), variants B0-B5."""
+
+    def __init__(self, model_name: str = 'B0', **kwargs):
+        super().__init__()
+        assert model_name in mit_settings.keys(), f"MiT model name should be in {list(mit_settings.keys())}"
+        embed_dims, depths = mit_settings[model_name]
+        drop_path_rate = 0.1
+        self.channels = embed_dims
+        self.depths = depths
+        self.compute_dtype = torch.bfloat16
+        self.stochastic_override = None      # tests: {'drop_path': keep[n_draws, B]}
+
+        self.patch_embed1 = PatchEmbed(3, embed_dims[0], 7, 4)
+        self.patch_embed2 = PatchEmbed(embed_dims[0], embed_dims[1], 3, 2)
+        self.patch_embed3 = PatchEmbed(embed_dims[1], embed_dims[2], 3, 2)
+        self.patch_embed4 = PatchEmbed(embed_dims[2], embed_dims[3], 3, 2)
+
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        heads, srs = [1, 2, 5, 8], [8, 4, 2, 1]
+        cur = 0
+        for s in range(4):
+            blocks = nn.ModuleList([Block(embed_dims[s], heads[s], srs[s], dpr[cur + i]) for i in range(depths[s])])
+            setattr(self, f'block{s + 1}', blocks)
+            setattr(self, f'norm{s + 1}', LayerNormWeights(embed_dims[s]))
+            cur += depths[s]
+
+    def _drop_path_scales(self, B, device):
+        """One [n_draws, B] tensor of keep/kp scales per forward (drop_path.py:18-25: x/kp*floor(kp+U)); blocks
+        with rate 0 use nn.Identity in the reference and draw nothing."""
+        rates = [blk.drop_prob for s in range(4) for blk in getattr(self, f'block{s + 1}')]
+        if not self.training or all(r == 0 for r in rates):
+            return [(None, None)] * len(rates)
+        draws = [r for r in rates if r > 0 for _ in range(2)]
+        kp = 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None]
+        if self.stochastic_override is not None and 'drop_path' in self.stochastic_override:
+            keep = self.stochastic_override['drop_path'].to(device=device, dtype=torch.float32)
+        else:
+            keep = torch.floor(kp + torch.rand(len(draws), B, device=device))
+        scale = (keep / kp).contiguous()
+        out, i = [], 0
+        for r in rates:
+            if r > 0:
+                out.append((scale[i], scale[i + 1]))
+                i += 2
+            else:
+                out.append((None, None))
+        return out
+
+    def forward_tokens(self, x):
+        """x: fp32 NCHW image.  Returns 4 TokenMaps (strides 4/8/16/32)."""
+        B, _, H, W = x.shape
+        dtype = self.compute_dtype
+        scales = self._drop_path_scales(B, x.device)
+        outs, bi = [], 0
+        cur, image = x, True
+        for s in range(4):
+            pe = getattr(self, f'patch_embed{s + 1}')
+            t, H, W = pe.tokens(cur, B, H, W, image, dtype)
+            for blk in getattr(self, f'block{s + 1}'):
+                t = blk.tokens(t, B, H, W, scales[bi])
+                bi += 1
+            nrm = getattr(self, f'norm{s + 1}')
+            t = Fh.layer_norm(t, nrm.weight, nrm.bias, nrm.eps)
+            outs.append(TokenMap(t, B, H, W))
+            cur, image = t, False
+        return outs
+
+    def forward(self, x):
+        return tuple(tm.nchw() for tm in self.forward_tokens(x))

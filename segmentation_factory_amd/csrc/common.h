@@ -1,0 +1,104 @@
+// Shared device helpers for the gfx950 kernels (wave64, fp32 math on f32/bf16 storage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/segfac.h"
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits
+
+#define SEGF_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+#define SEGF_DISPATCH_DT(dt, T, ...)                          \
+    if ((dt) == SEGF_F32) { typedef float T; __VA_ARGS__ }    \
+    else if ((dt) == SEGF_BF16) { typedef bf16_t T; __VA_ARGS__ } \
+    else return SEGF_ERR_DTYPE;
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    // plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 8 consecutive elements <-> 8 floats.  `aligned` = pointer is 16-byte (bf16) / 16-byte (f32) aligned.
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    uint4 u;
+    u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]); u.z = pack2bf(v[4], v[5]); u.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) { load8<float>(p, v); }
+
+// wave64 butterfly reductions over the lanes that differ in the low `width` lane bits (width pow2 <= 64)
+__device__ __forceinline__ float wave_sum(float v, int width = 64) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        if (o < width) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v, int width = 64) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        if (o < width) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// PyTorch bilinear source index (aten UpSample.h area_pixel_compute_source_index):
+// align_corners=False: src = (dst+0.5)*in/out-0.5 clamped at 0; True: src = dst*(in-1)/(out-1).
+__device__ __forceinline__ void bilinear_src(int d, int in, int out, int align_corners, int& i0, int& i1, float& l) {
+    float s;
+    if (align_corners) {
+        const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+        s = scale * d;
+    } else {
+        const float scale = (float)in / (float)out;
+        s = scale * (d + 0.5f) - 0.5f;
+        if (s < 0.f) s = 0.f;
+    }
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = s - (float)i0;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

@@ -1,0 +1,149 @@
+// Elementwise / re-layout plumbing kernels (HBM-bound streaming; 16 B per lane where alignment allows).
+#include "colreduce.h"
+
+extern "C" const char* segf_version(void) { return "segfac-hip 0.1 gfx950"; }
+
+// ---- cast ---------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n, bool vec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t n8 = n / 8;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+            float v[8];
+            load8<S>(src + i * 8, v);
+            store8<D>(dst + i * 8, v);
+        }
+        for (int64_t i = n8 * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+            stf<D>(dst + i, ldf<S>(src + i));
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+            stf<D>(dst + i, ldf<S>(src + i));
+    }
+}
+
+extern "C" int segf_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    const int blocks = (int)imin64(cdiv64(cdiv64(n, 8), 256), 2048);
+    SEGF_DISPATCH_DT(src_dt, S, {
+        SEGF_DISPATCH_DT(dst_dt, D, {
+            hipLaunchKernelGGL((cast_kernel<S, D>), dim3(blocks), dim3(256), 0, st, (const S*)src, (D*)dst, n, vec);
+        })
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- permute021: out[a][c][b] = in[a][b][c], 32x32 LDS-tiled transpose -----------------------------
+template <typename S, typename D>
+__global__ void permute021_kernel(const S* __restrict__ in, D* __restrict__ out, int64_t Bd, int64_t Cd, int64_t ld_out) {
+    __shared__ float tile[32][33];
+    const int64_t a = blockIdx.z;
+    const int64_t b0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    const S* src = in + a * Bd * Cd;
+    D* dst = out + a * Cd * ld_out;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t b = b0 + i, c = c0 + tx;
+        tile[i][tx] = (b < Bd && c < Cd) ? ldf<S>(src + b * Cd + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int64_t c = c0 + i, b = b0 + tx;
+        if (c < Cd && b < ld_out) stf<D>(dst + c * ld_out + b, b < Bd ? tile[tx][i] : 0.f);
+    }
+}
+
+extern "C" int segf_permute021(const void* in, int in_dt, void* out, int out_dt, int64_t A, int64_t Bd, int64_t Cd,
+                               int64_t ld_out, void* stream) {
+    if (A <= 0 || Bd <= 0 || Cd <= 0) return 0;
+    if (ld_out < Bd || A > 65535) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    // the b-tiles must also cover the zero padding columns [Bd, ld_out)
+    dim3 grid((unsigned)cdiv64(Cd, 32), (unsigned)cdiv64(ld_out, 32), (unsigned)A);
+    SEGF_DISPATCH_DT(in_dt, S, {
+        SEGF_DISPATCH_DT(out_dt, D, {
+            hipLaunchKernelGGL((permute021_kernel<S, D>), grid, dim3(256), 0, st, (const S*)in, (D*)out, Bd, Cd, ld_out);
+        })
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- 2-D elementwise with leading dims ---------------------------------------------------------------
+template <typename T, int MODE>   // MODE 0: y = x * scale[row / rpg]; MODE 1: y = a + b
+__global__ void ew2d_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, T* __restrict__ y,
+                            int64_t ldy, const float* __restrict__ scale, int64_t rows, int64_t cols, int64_t rpg, bool vec) {
+    const int64_t nchunk = (cols + 7) / 8;
+    const int64_t total = rows * nchunk;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / nchunk;
+        const int c0 = (int)(i - r * nchunk) * 8;
+        const int nv = (int)(cols - c0 < 8 ? cols - c0 : 8);
+        float va[8], vb[8];
+        load8_guard<T>(a + r * lda + c0, nv, vec, va);
+        if (MODE == 0) {
+            const float s = scale[r / rpg];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] *= s;
+        } else {
+            load8_guard<T>(b + r * ldb + c0, nv, vec, vb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] += vb[j];
+        }
+        store8_guard<T>(y + r * ldy + c0, nv, vec, va);
+    }
+}
+
+extern "C" int segf_scale_rows(int dt, const void* x, int64_t ldx, void* y, int64_t ldy, const float* scale,
+                               int64_t rows, int64_t cols, int64_t rows_per_group, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if (rows_per_group <= 0) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = rows * ((cols + 7) / 8);
+    const int blocks = (int)imin64(cdiv64(total, 256), 4096);
+    SEGF_DISPATCH_DT(dt, T, {
+        const bool vec = vec_ok_host<T>(x, ldx) && vec_ok_host<T>(y, ldy);
+        hipLaunchKernelGGL((ew2d_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)x, ldx, (const T*)nullptr, (int64_t)0,
+                           (T*)y, ldy, scale, rows, cols, rows_per_group, vec);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int segf_add(int dt, const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy,
+                        int64_t rows, int64_t cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = rows * ((cols + 7) / 8);
+    const int blocks = (int)imin64(cdiv64(total, 256), 4096);
+    SEGF_DISPATCH_DT(dt, T, {
+        const bool vec = vec_ok_host<T>(a, lda) && vec_ok_host<T>(b, ldb) && vec_ok_host<T>(y, ldy);
+        hipLaunchKernelGGL((ew2d_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)a, lda, (const T*)b, ldb, (T*)y,
+                           ldy, (const float*)nullptr, rows, cols, (int64_t)1, vec);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- column sum ----------------------------------------------------------------------------------------
+template <typename T> struct ColsumF {
+    const T* x; int64_t ld; bool vec;
+    __device__ void operator()(int64_t r, int c0, int nv, float (&v)[1][8]) const { load8_guard<T>(x + r * ld + c0, nv, vec, v[0]); }
+};
+
+extern "C" int64_t segf_colsum_ws(int64_t rows, int64_t cols) { return cr_ws_floats(rows, (int)cols, 1); }
+
+extern "C" int segf_colsum(int dt, const void* x, int64_t ldx, int64_t rows, int64_t cols, float* out, float* ws, void* stream) {
+    if (cols <= 0) return 0;
+    if (rows <= 0 || !ws) return rows <= 0 ? SEGF_ERR_SHAPE : SEGF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    SEGF_DISPATCH_DT(dt, T, {
+        ColsumF<T> f{(const T*)x, ldx, vec_ok_host<T>(x, ldx)};
+        return colreduce_launch<1>(f, rows, (int)cols, ws, out, st);
+    })
+    return 0;
+}

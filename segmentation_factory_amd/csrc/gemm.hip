@@ -1,0 +1,383 @@
+// GEMM for nn.Linear / 1x1 conv / im2col'd conv: forward (x W^T), data gradient (dy W) and weight
+// gradient (dy^T x) -- reference models/backbones/mit.py:45,52,58,98-99, models/heads/segformer.py:13,24,39.
+//
+// bf16 path: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 as 4x4 v_mfma_f32_16x16x32_bf16 tiles,
+//   register-staged global->LDS double buffering (one barrier per K step), XOR-swizzled LDS images:
+//     K-contiguous operand  : [128 rows][64 k] 128-B rows, 16-B chunk c stored at c ^ (row & 7) -> ds_read_b128 conflict-free
+//     reduction-major operand: [64 k][128 cols] 256-B rows, chunk c stored at c ^ 2*((k&3) + 4*((k>>3)&1)),
+//                              fragments through ds_read_b64_tr_b16 (hardware transpose), conflict-free
+//   MFMA is issued "swapped" (A := weight-side rows n, B := token-side cols m) so each lane owns 4 consecutive n
+//   of one output row m -> 8-byte (bf16) / 16-byte (f32) row-contiguous stores.
+// f32 path: exact-fp32 FMA kernel (64x64x16 tile, 4x4 per thread) used by the parity mode.
+#include <stdlib.h>
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    const float* bias; const void* residual; const float* rscale;
+    int64_t M, N, K, lda, ldb, ldc, ldr, rpg;
+    int64_t kchunk;          // K range per grid.z slice
+    float* ws;               // split-K partials [z][M][N] (nullptr when split_k == 1)
+    int a_vec, b_vec, c_vec, r_vec, use_tr;
+};
+
+#define GB_BM 128
+#define GB_BN 128
+#define GB_BK 64
+#define GB_TILE_BYTES 16384
+
+__device__ __forceinline__ uint4 ld8_bf16_guard(const bf16_t* p, int nvalid) {
+    bf16_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = j < nvalid ? p[j] : (bf16_t)0;
+    uint4 u;
+    u.x = t[0] | ((uint32_t)t[1] << 16); u.y = t[2] | ((uint32_t)t[3] << 16);
+    u.z = t[4] | ((uint32_t)t[5] << 16); u.w = t[6] | ((uint32_t)t[7] << 16);
+    return u;
+}
+
+// K-contiguous operand: element (row, k) at base[row*ld + k]; tile = rows [row0,row0+128) x k [k0,k0+64)
+__device__ __forceinline__ void gload_kc(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax,
+                                         int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const int64_t k = k0 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + r + 32 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < rmax && k < kend) {
+            const bf16_t* p = base + row * ld + k;
+            if (vec && k + 8 <= kend) v = *reinterpret_cast<const uint4*>(p);
+            else v = ld8_bf16_guard(p, (int)(kend - k < 8 ? kend - k : 8));
+        }
+        reg[i] = v;
+    }
+}
+__device__ __forceinline__ void swrite_kc(unsigned char* tile, const uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = r + 32 * i;
+        *reinterpret_cast<uint4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = reg[i];
+    }
+}
+// reduction-major operand: element (k, col) at base[k*ld + col]; tile = k [k0,k0+64) x cols [col0,col0+128)
+__device__ __forceinline__ int rm_swz(int krow) { return 2 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
+__device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax,
+                                         int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int64_t col = col0 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + r + 16 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < kend && col < cmax) {
+            const bf16_t* p = base + k * ld + col;
+            if (vec && col + 8 <= cmax) v = *reinterpret_cast<const uint4*>(p);
+            else v = ld8_bf16_guard(p, (int)(cmax - col < 8 ? cmax - col : 8));
+        }
+        reg[i] = v;
+    }
+}
+__device__ __forceinline__ void swrite_rm(unsigned char* tile, const uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int krow = r + 16 * i;
+        *reinterpret_cast<uint4*>(tile + krow * 256 + ((c ^ rm_swz(krow)) << 4)) = reg[i];
+    }
+}
+
+// fragment for mfma_f32_16x16x32_bf16: lane l holds X[idx = l&15][k = 8*(l>>4) + j], j = 0..7 of k-step s
+__device__ __forceinline__ bf16x8 frag_kc(const unsigned char* tile, int rb, int s, int lane) {
+    const int row = rb + (lane & 15);
+    const int chunk = 4 * s + (lane >> 4);
+    const uint4 u = *reinterpret_cast<const uint4*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+    return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ bf16x8 frag_rm_tr(const unsigned char* tile, int cb, int s, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int u = (cb >> 2) + p;          // 8-byte unit inside the 256-B row
+    const int chunk = u >> 1, half = u & 1;
+    s16x4 lo, hi;
+    {
+        const int krow = 32 * s + 8 * g + q;
+        const unsigned char* a = tile + krow * 256 + ((chunk ^ rm_swz(krow)) << 4) + half * 8;
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    }
+    {
+        const int krow = 32 * s + 8 * g + 4 + q;
+        const unsigned char* a = tile + krow * 256 + ((chunk ^ rm_swz(krow)) << 4) + half * 8;
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    }
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 frag_rm_scalar(const unsigned char* tile, int cb, int s, int lane) {
+    const int g = lane >> 4, col = cb + (lane & 15);
+    s16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int krow = 32 * s + 8 * g + j;
+        v[j] = *reinterpret_cast<const short*>(tile + krow * 256 + (((col >> 3) ^ rm_swz(krow)) << 4) + (col & 7) * 2);
+    }
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename OutT> __device__ __forceinline__ void store4(OutT* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+
+template <typename InT, typename OutT>
+__device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int64_t n0, float (&v)[4]) {
+    // v[r] is the accumulator of C[m][n0 + r]
+    if (m >= a.M || n0 >= a.N) return;
+    const int nv = (int)(a.N - n0 < 4 ? a.N - n0 : 4);
+    if (a.ws) {   // split-K partial: raw accumulators, fp32, ld = N
+        float* dst = a.ws + ((int64_t)blockIdx.z * a.M + m) * a.N + n0;
+        for (int r = 0; r < nv; ++r) dst[r] = v[r];
+        return;
+    }
+    if (a.bias)
+        for (int r = 0; r < nv; ++r) v[r] += a.bias[n0 + r];
+    if (a.residual) {
+        const float s = a.rscale ? a.rscale[m / a.rpg] : 1.f;
+        const InT* rp = reinterpret_cast<const InT*>(a.residual) + m * a.ldr + n0;
+        for (int r = 0; r < nv; ++r) v[r] = ldf<InT>(rp + r) + s * v[r];
+    }
+    OutT* dst = reinterpret_cast<OutT*>(a.C) + m * a.ldc + n0;
+    if (nv == 4 && a.c_vec) store4<OutT>(dst, v);
+    else
+        for (int r = 0; r < nv; ++r) stf<OutT>(dst + r, v[r]);
+}
+
+template <int LAYOUT, typename OutT, bool TR>
+__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GB_TILE_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.y * GB_BM, n0 = (int64_t)blockIdx.x * GB_BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * a.kchunk;
+    const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
+
+    f32x4 acc[4][4];   // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int64_t k0) {
+        if (LAYOUT == 2) gload_rm(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
+        else gload_kc(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
+        if (LAYOUT == 0) gload_kc(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
+        else gload_rm(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
+    };
+    auto swrite = [&](int buf) {
+        if (LAYOUT == 2) swrite_rm(smem[buf][0], ra); else swrite_kc(smem[buf][0], ra);
+        if (LAYOUT == 0) swrite_kc(smem[buf][1], rb); else swrite_rm(smem[buf][1], rb);
+    };
+
+    const int nk = (int)((kend - kbeg + GB_BK - 1) / GB_BK);
+    if (nk > 0) {
+        gload(kbeg);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * GB_BK);
+        const unsigned char* ta = smem[buf][0];
+        const unsigned char* tb = smem[buf][1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int mb = wm * 64 + t * 16, nb = wn * 64 + t * 16;
+                if (LAYOUT == 2) fa[t] = TR ? frag_rm_tr(ta, mb, s, lane) : frag_rm_scalar(ta, mb, s, lane);
+                else fa[t] = frag_kc(ta, mb, s, lane);
+                if (LAYOUT == 0) fb[t] = frag_kc(tb, nb, s, lane);
+                else fb[t] = TR ? frag_rm_tr(tb, nb, s, lane) : frag_rm_scalar(tb, nb, s, lane);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+        }
+        if (kt + 1 < nk) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i][j]: i (rows, 4*(lane>>4)+r) <-> n, j (cols, lane&15) <-> m
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int64_t m = m0 + wm * 64 + tm * 16 + (lane & 15);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int64_t n = n0 + wn * 64 + tn * 16 + 4 * (lane >> 4);
+            float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
+            gemm_epilogue4<bf16_t, OutT>(a, m, n, v);
+        }
+    }
+}
+
+// ---- exact fp32 FMA kernel ---------------------------------------------------------------------------
+#define GF_BM 64
+#define GF_BN 64
+#define GF_BK 16
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
+    __shared__ float As[GF_BK][GF_BM + 4];
+    __shared__ float Bs[GF_BK][GF_BN + 4];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // tx -> n (4 each), ty -> m (4 each)
+    const int64_t m0 = (int64_t)blockIdx.y * GF_BM, n0 = (int64_t)blockIdx.x * GF_BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * a.kchunk;
+    const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const float* A = reinterpret_cast<const float*>(a.A);
+    const float* B = reinterpret_cast<const float*>(a.B);
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += GF_BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            int kk, mm;
+            if (LAYOUT == 2) { mm = idx & 63; kk = idx >> 6; } else { kk = idx & 15; mm = idx >> 4; }
+            const int64_t m = m0 + mm, k = k0 + kk;
+            float v = 0.f;
+            if (m < a.M && k < kend) v = LAYOUT == 2 ? A[k * a.lda + m] : A[m * a.lda + k];
+            As[kk][mm] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            int kk, nn;
+            if (LAYOUT == 0) { kk = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kk = idx >> 6; }
+            const int64_t n = n0 + nn, k = k0 + kk;
+            float v = 0.f;
+            if (n < a.N && k < kend) v = LAYOUT == 0 ? B[n * a.ldb + k] : B[k * a.ldb + n];
+            Bs[kk][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GF_BK; ++kk) {
+            const float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+            const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+            const float am[4] = {av.x, av.y, av.z, av.w};
+            const float bn[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(am[i], bn[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+        gemm_epilogue4<float, float>(a, m0 + ty * 4 + i, n0 + tx * 4, v);
+    }
+}
+
+// ---- split-K reduction: C = sum_z ws[z] (fixed order) ---------------------------------------------------
+template <typename OutT>
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N, OutT* __restrict__ C, int64_t ldc) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < split; ++z) s += ws[(int64_t)z * total + i];
+        const int64_t m = i / N, n = i - m * N;
+        stf<OutT>(C + m * ldc + n, s);
+    }
+}
+
+extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
+    // layout 2 (weight gradient): K = token count.  Aim for >= 512 workgroups, >= 4 K-steps per slice.
+    const int64_t tiles = cdiv64(M, GB_BM) * cdiv64(N, GB_BN);
+    int64_t s = cdiv64(512, tiles);
+    const int64_t maxs = K / (4 * GB_BK);
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                         int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
+                         const float* rscale, int64_t rows_per_group, int split_k, float* ws, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K < 0 || layout < 0 || layout > 2) return SEGF_ERR_SHAPE;
+    if (dt != SEGF_F32 && dt != SEGF_BF16) return SEGF_ERR_DTYPE;
+    if (c_dt != SEGF_F32 && c_dt != SEGF_BF16) return SEGF_ERR_DTYPE;
+    if (dt == SEGF_F32 && c_dt != SEGF_F32) return SEGF_ERR_DTYPE;
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && (bias || residual)) return SEGF_ERR_SHAPE;
+    if (split_k > 1 && !ws) return SEGF_ERR_WORKSPACE;
+    if (rscale && rows_per_group <= 0) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.rscale = rscale;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.rpg = rows_per_group > 0 ? rows_per_group : 1;
+    const int64_t kstep = dt == SEGF_BF16 ? GB_BK : GF_BK;
+    int64_t kchunk = cdiv64(cdiv64(K, split_k), kstep) * kstep;
+    if (kchunk <= 0) kchunk = kstep;
+    split_k = (int)cdiv64(K > 0 ? K : 1, kchunk);
+    a.kchunk = kchunk;
+    a.ws = split_k > 1 ? ws : nullptr;
+    const size_t esz = dt == SEGF_BF16 ? 2 : 4, csz = c_dt == SEGF_BF16 ? 2 : 4;
+    a.a_vec = ((uintptr_t)A % 16 == 0) && ((lda * esz) % 16 == 0);
+    a.b_vec = ((uintptr_t)B % 16 == 0) && ((ldb * esz) % 16 == 0);
+    a.c_vec = ((uintptr_t)C % (4 * csz) == 0) && ((ldc * csz) % (4 * csz) == 0);
+    a.r_vec = 0;
+    {   // debugging switch: SEGFAC_GEMM_NO_TR=1 reads transposed fragments with scalar LDS loads instead of ds_read_b64_tr_b16
+        const char* e = getenv("SEGFAC_GEMM_NO_TR");
+        a.use_tr = (e && e[0] == '1') ? 0 : 1;
+    }
+    if (dt == SEGF_BF16) {
+        dim3 grid((unsigned)cdiv64(N, GB_BN), (unsigned)cdiv64(M, GB_BM), (unsigned)split_k);
+        if (grid.y > 65535u) return SEGF_ERR_SHAPE;
+#define LAUNCH_B(L, OT)                                                                                      \
+    do {                                                                                                     \
+        if (L == 0 || a.use_tr) hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, true>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, false>), grid, dim3(256), 0, st, a);                 \
+    } while (0)
+        if (c_dt == SEGF_F32 || a.ws) {
+            if (layout == 0) LAUNCH_B(0, float); else if (layout == 1) LAUNCH_B(1, float); else LAUNCH_B(2, float);
+        } else {
+            if (layout == 0) LAUNCH_B(0, bf16_t); else if (layout == 1) LAUNCH_B(1, bf16_t); else LAUNCH_B(2, bf16_t);
+        }
+#undef LAUNCH_B
+    } else {
+        dim3 grid((unsigned)cdiv64(N, GF_BN), (unsigned)cdiv64(M, GF_BM), (unsigned)split_k);
+        if (grid.y > 65535u) return SEGF_ERR_SHAPE;
+        if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<0>), grid, dim3(256), 0, st, a);
+        else if (layout == 1) hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, st, a);
+    }
+    SEGF_CHECK_LAUNCH();
+    if (a.ws) {
+        const int64_t total = M * N;
+        const int blocks = (int)imin64(cdiv64(total, 256), 2048);
+        if (c_dt == SEGF_F32)
+            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (float*)C, ldc);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (bf16_t*)C, ldc);
+        SEGF_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,424 @@
+// LayerNorm (rows = tokens, wave-shuffle statistics) and BatchNorm2d-on-NHWC (column statistics).
+// HBM-bound streaming kernels: each activation is read once per pass with 16-B lane accesses.
+//   LayerNorm: reference nn.LayerNorm in models/backbones/mit.py:107,129,136-140 (eps 1e-5) and the
+//              channels-first LayerNorm of convnext.py:8-23 / convnextv2.py:40-66 (eps 1e-6).
+//   BatchNorm: ConvModule of heads/segformer.py:21-29, layers/conv_module.py:4-9, mobilenetv2.py:5-11.
+#include "colreduce.h"
+
+// ---- LayerNorm -----------------------------------------------------------------------------------------
+// A row is spread over LPR = 2^lpr_log2 lanes (8 elements per lane per step, VPT steps); a wave handles
+// 64/LPR rows at once.  Two-pass statistics in registers (mean, then centred variance), fp32.
+template <typename T, int VPT>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, T* __restrict__ y,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                      int64_t rows, int C, float eps, int lpr_log2) {
+    const int lpr = 1 << lpr_log2;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (lpr - 1), rin = lane >> lpr_log2;
+    const int rows_per_wave = 64 >> lpr_log2;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float g[VPT][8], b[VPT][8];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c0 = (sub + i * lpr) * 8;
+        if (c0 < C) { load8f(gamma + c0, g[i]); load8f(beta + c0, b[i]); }
+    }
+    const float invC = 1.f / (float)C;
+    for (int64_t rbase = wave_global * rows_per_wave; rbase < rows; rbase += nwaves * rows_per_wave) {
+        const int64_t r = rbase + rin;
+        const bool rv = r < rows;
+        float v[VPT][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (sub + i * lpr) * 8;
+            if (rv && c0 < C) {
+                load8<T>(x + r * C + c0, v[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[i][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+            }
+        }
+        s = wave_sum(s, lpr);
+        const float mu = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (sub + i * lpr) * 8;
+            if (c0 < C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; q += d * d; }
+            }
+        }
+        q = wave_sum(q, lpr);
+        const float rs = rsqrtf(q * invC + eps);
+        if (rv) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int c0 = (sub + i * lpr) * 8;
+                if (c0 < C) {
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[i][j] + b[i][j];
+                    store8<T>(y + r * C + c0, o);
+                }
+            }
+            if (sub == 0) { mean_out[r] = mu; rstd_out[r] = rs; }
+        }
+    }
+}
+
+#define LN_BWD_MAX_BLOCKS 256
+template <typename T, int VPT>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, T* __restrict__ dx,
+                                                      float* __restrict__ partial /*[grid][2][C]*/, int64_t rows, int C,
+                                                      int lpr_log2) {
+    extern __shared__ float lds[];   // [4 waves][2][C]
+    const int lpr = 1 << lpr_log2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (lpr - 1), rin = lane >> lpr_log2;
+    const int rows_per_wave = 64 >> lpr_log2;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    float g[VPT][8], dg[VPT][8], db[VPT][8];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c0 = (sub + i * lpr) * 8;
+        if (c0 < C) load8f(gamma + c0, g[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+    }
+    const float invC = 1.f / (float)C;
+    for (int64_t rbase = wave_global * rows_per_wave; rbase < rows; rbase += nwaves * rows_per_wave) {
+        const int64_t r = rbase + rin;
+        const bool rv = r < rows;
+        const float mu = rv ? mean[r] : 0.f, rs = rv ? rstd[r] : 0.f;
+        float xh[VPT][8], gy[VPT][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (sub + i * lpr) * 8;
+            if (rv && c0 < C) {
+                float xv[8], dv[8];
+                load8<T>(x + r * C + c0, xv);
+                load8<T>(dy + r * C + c0, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[i][j] = (xv[j] - mu) * rs;
+                    dg[i][j] += dv[j] * xh[i][j];
+                    db[i][j] += dv[j];
+                    gy[i][j] = dv[j] * g[i][j];
+                    s1 += gy[i][j];
+                    s2 += gy[i][j] * xh[i][j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { xh[i][j] = 0.f; gy[i][j] = 0.f; }
+            }
+        }
+        s1 = wave_sum(s1, lpr) * invC;
+        s2 = wave_sum(s2, lpr) * invC;
+        if (rv) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int c0 = (sub + i * lpr) * 8;
+                if (c0 < C) {
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
+                    store8<T>(dx + r * C + c0, o);
+                }
+            }
+        }
+    }
+    // reduce dgamma / dbeta: across the row lanes of the wave (xor offsets >= lpr), then across waves via LDS
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = dg[i][j], c = db[i][j];
+            for (int o = 32; o >= lpr; o >>= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+            dg[i][j] = a; db[i][j] = c;
+        }
+    if (rin == 0) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c0 = (sub + i * lpr) * 8;
+            if (c0 < C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    lds[(wave * 2 + 0) * C + c0 + j] = dg[i][j];
+                    lds[(wave * 2 + 1) * C + c0 + j] = db[i][j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w) s += lds[(w * 2 + which) * C + c];
+        partial[((int64_t)blockIdx.x * 2 + which) * C + c] = s;
+    }
+}
+
+template <typename T>
+static void ln_fwd_launch(int vpt, int blocks, hipStream_t st, const T* x, const float* gamma, const float* beta, T* y,
+                          float* mean, float* rstd, int64_t rows, int C, float eps, int lpr_log2) {
+#define LN_F(V) hipLaunchKernelGGL((ln_fwd_kernel<T, V>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, C, eps, lpr_log2)
+    if (vpt == 1) LN_F(1); else if (vpt == 2) LN_F(2); else if (vpt == 3) LN_F(3); else LN_F(4);
+#undef LN_F
+}
+template <typename T>
+static void ln_bwd_launch(int vpt, int blocks, size_t shm, hipStream_t st, const T* x, const T* dy, const float* gamma,
+                          const float* mean, const float* rstd, T* dx, float* ws, int64_t rows, int C, int lpr_log2) {
+#define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, gamma, mean, rstd, dx, ws, rows, C, lpr_log2)
+    if (vpt == 1) LN_B(1); else if (vpt == 2) LN_B(2); else if (vpt == 3) LN_B(3); else LN_B(4);
+#undef LN_B
+}
+
+static inline int ln_plan(int C, int& lpr_log2) {
+    const int nchunk = C / 8;
+    lpr_log2 = 0;
+    while ((1 << lpr_log2) < nchunk && lpr_log2 < 6) ++lpr_log2;
+    return (nchunk + (1 << lpr_log2) - 1) >> lpr_log2;   // VPT
+}
+
+extern "C" int segf_layernorm_fwd(int dt, int64_t rows, int C, const void* x, const float* gamma, const float* beta,
+                                  float eps, void* y, float* mean, float* rstd, void* stream) {
+    if (rows <= 0) return 0;
+    if (C <= 0 || C % 8 != 0 || C > 2048) return SEGF_ERR_SHAPE;
+    if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)gamma % 16) || ((uintptr_t)beta % 16)) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    int lpr_log2;
+    const int vpt = ln_plan(C, lpr_log2);
+    const int rows_per_block = 4 * (64 >> lpr_log2);
+    const int blocks = (int)imin64(cdiv64(rows, rows_per_block), 4096);
+    SEGF_DISPATCH_DT(dt, T, { ln_fwd_launch<T>(vpt, blocks, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, lpr_log2); })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline int ln_bwd_blocks(int64_t rows, int C) {
+    int lpr_log2;
+    ln_plan(C, lpr_log2);
+    const int rows_per_block = 4 * (64 >> lpr_log2);
+    return (int)imin64(cdiv64(rows, (int64_t)rows_per_block * 4), LN_BWD_MAX_BLOCKS);
+}
+extern "C" int64_t segf_layernorm_bwd_ws(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(rows, C) * 2 * C; }
+
+extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* gamma,
+                                  const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                                  float* ws, void* stream) {
+    if (rows <= 0) return 0;
+    if (C <= 0 || C % 8 != 0 || C > 2048) return SEGF_ERR_SHAPE;
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    if (dbeta != dgamma + C) return SEGF_ERR_SHAPE;   // dgamma and dbeta are one [2][C] fp32 buffer
+    hipStream_t st = (hipStream_t)stream;
+    int lpr_log2;
+    const int vpt = ln_plan(C, lpr_log2);
+    const int blocks = ln_bwd_blocks(rows, C);
+    const size_t shm = (size_t)4 * 2 * C * sizeof(float);
+    SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2); })
+    SEGF_CHECK_LAUNCH();
+    const int64_t n = 2 * (int64_t)C;
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, ws, blocks, n, dgamma);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- BatchNorm on NHWC rows ---------------------------------------------------------------------------------
+template <typename T> struct BnStatF {
+    const T* x; int C; bool vec;
+    __device__ void operator()(int64_t r, int c0, int nv, float (&v)[2][8]) const {
+        load8_guard<T>(x + r * C + c0, nv, vec, v[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[1][j] = v[0][j] * v[0][j];
+    }
+};
+
+// sums[2][C] -> mean, rstd, running stats (fp64 combine: E[x^2]-mean^2 is formed in double)
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, double n, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                   float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = (double)sums[c] / n;
+    double var = (double)sums[C + c] / n - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = n > 1 ? var * n / (n - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+extern "C" int64_t segf_bn_ws(int64_t rows, int C) { return cr_ws_floats(rows, C, 2) + 2 * (int64_t)C; }
+
+extern "C" int segf_bn_stats(int dt, int64_t rows, int C, const void* x, float* mean, float* rstd, float* running_mean,
+                             float* running_var, float momentum, float eps, float* ws, void* stream) {
+    if (rows <= 0 || C <= 0) return SEGF_ERR_SHAPE;
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = ws + cr_ws_floats(rows, C, 2);
+    SEGF_DISPATCH_DT(dt, T, {
+        BnStatF<T> f{(const T*)x, C, vec_ok_host<T>(x, C)};
+        const int rc = colreduce_launch<2>(f, rows, C, ws, sums, st);
+        if (rc) return rc;
+    })
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, (double)rows, eps, momentum, mean,
+                       rstd, running_mean, running_var);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+__device__ __forceinline__ float bn_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+__device__ __forceinline__ float bn_act_mask(float pre, int act) {
+    if (act == 1) return pre > 0.f ? 1.f : 0.f;
+    if (act == 2) return (pre > 0.f && pre < 6.f) ? 1.f : 0.f;
+    return 1.f;
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                const float* __restrict__ cscale, int64_t rps, T* __restrict__ y, int64_t rows, int C, bool vec) {
+    const int nchunk = (C + 7) / 8;
+    const int64_t total = rows * nchunk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nchunk;
+        const int c0 = (int)(i - r * nchunk) * 8;
+        const int nv = C - c0 < 8 ? C - c0 : 8;
+        float v[8];
+        load8_guard<T>(x + r * C + c0, nv, vec, v);
+        const float* cs = cscale ? cscale + (r / rps) * C + c0 : nullptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nv) {
+                const int c = c0 + j;
+                float o = bn_act((v[j] - mean[c]) * rstd[c] * gamma[c] + beta[c], act);
+                if (cs) o *= cs[j];
+                v[j] = o;
+            }
+        }
+        store8_guard<T>(y + r * C + c0, nv, vec, v);
+    }
+}
+
+extern "C" int segf_bn_apply(int dt, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int act, const float* chan_scale,
+                             int64_t rows_per_sample, void* y, void* stream) {
+    if (rows <= 0 || C <= 0) return 0;
+    if (chan_scale && rows_per_sample <= 0) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = rows * ((C + 7) / 8);
+    const int blocks = (int)imin64(cdiv64(total, 256), 4096);
+    SEGF_DISPATCH_DT(dt, T, {
+        const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(y, C);
+        hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, act,
+                           chan_scale, rows_per_sample > 0 ? rows_per_sample : 1, (T*)y, rows, C, vec);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// backward sums: [0] = sum dyr, [1] = sum dyr * xhat, where dyr = dy * chan_scale * act'(pre)
+template <typename T> struct BnBwdF {
+    const T* x; const T* dy; const float* mean; const float* rstd; const float* gamma; const float* beta;
+    const float* cscale; int64_t rps; int C; int act; bool vec;
+    __device__ void operator()(int64_t r, int c0, int nv, float (&v)[2][8]) const {
+        float xv[8], dv[8];
+        load8_guard<T>(x + r * C + c0, nv, vec, xv);
+        load8_guard<T>(dy + r * C + c0, nv, vec, dv);
+        const float* cs = cscale ? cscale + (r / rps) * C + c0 : nullptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nv) {
+                const int c = c0 + j;
+                const float xh = (xv[j] - mean[c]) * rstd[c];
+                float d = dv[j] * bn_act_mask(xh * gamma[c] + beta[c], act);
+                if (cs) d *= cs[j];
+                v[0][j] = d;
+                v[1][j] = d * xh;
+            } else { v[0][j] = 0.f; v[1][j] = 0.f; }
+        }
+    }
+};
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    int act, const float* __restrict__ cscale, int64_t rps, const float* __restrict__ sums /*[2][C]: dbeta, dgamma*/,
+                                    int eval_mode, T* __restrict__ dx, int64_t rows, int C, bool vec) {
+    const int nchunk = (C + 7) / 8;
+    const int64_t total = rows * nchunk;
+    const float invn = 1.f / (float)rows;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nchunk;
+        const int c0 = (int)(i - r * nchunk) * 8;
+        const int nv = C - c0 < 8 ? C - c0 : 8;
+        float xv[8], dv[8];
+        load8_guard<T>(x + r * C + c0, nv, vec, xv);
+        load8_guard<T>(dy + r * C + c0, nv, vec, dv);
+        const float* cs = cscale ? cscale + (r / rps) * C + c0 : nullptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nv) {
+                const int c = c0 + j;
+                const float xh = (xv[j] - mean[c]) * rstd[c];
+                float d = dv[j] * bn_act_mask(xh * gamma[c] + beta[c], act);
+                if (cs) d *= cs[j];
+                float o = gamma[c] * rstd[c];
+                if (eval_mode) o *= d;
+                else o *= (d - sums[c] * invn - xh * sums[C + c] * invn);
+                xv[j] = o;
+            }
+        }
+        store8_guard<T>(dx + r * C + c0, nv, vec, xv);
+    }
+}
+
+// dgamma = sums[1], dbeta = sums[0] are produced in-place: caller passes dbeta = ws-resident [C], dgamma [C]
+__global__ void bn_copy_grads_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = sums[c];
+    dgamma[c] = sums[C + c];
+}
+
+extern "C" int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_sample,
+                           int eval_mode, void* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+    if (rows <= 0 || C <= 0) return SEGF_ERR_SHAPE;
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    if (chan_scale && rows_per_sample <= 0) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = ws + cr_ws_floats(rows, C, 2);
+    const int64_t rps = rows_per_sample > 0 ? rows_per_sample : 1;
+    const int64_t total = rows * ((C + 7) / 8);
+    const int blocks = (int)imin64(cdiv64(total, 256), 4096);
+    SEGF_DISPATCH_DT(dt, T, {
+        const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(dy, C) && vec_ok_host<T>(dx, C);
+        BnBwdF<T> f{(const T*)x, (const T*)dy, mean, rstd, gamma, beta, chan_scale, rps, C, act, vec};
+        const int rc = colreduce_launch<2>(f, rows, C, ws, sums, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)dy, mean, rstd,
+                           gamma, beta, act, chan_scale, rps, sums, eval_mode, (T*)dx, rows, C, vec);
+    })
+    SEGF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_copy_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,62 @@
+// Fused optimizer step over a flat fp32 parameter buffer: adaptive gradient clipping (unit-wise, AGC) + AdamW.
+// Stands in for what engine.py:52-53 triggers through timm 0.9.2's NativeScaler: dispatch_clip_grad(mode='agc',
+// value=0.02) followed by optimizer.step() of the AdamW that create_optimizer builds (train_gpu.py:99-102,269-270).
+// timm is not installed in the build image, so this arithmetic is restated from timm 0.9.2 / torch.optim.AdamW
+// semantics and pinned only by hand-derived known-answer tests ("parity unpinned"):
+//   unit = one output row of a >=2-D weight (dim 0), or the whole tensor for 1-D parameters
+//   max_norm = max(||p_unit||, agc_eps) * clip_factor;  g <- g * max_norm / max(||g_unit||, 1e-6)  if ||g_unit|| >= max_norm
+//   p <- p * (1 - lr * wd);  m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;
+//   p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// One wave per unit: two streaming passes over the unit (norms, then update); 7 x 4 B per parameter of HBM traffic.
+#include "common.h"
+
+__global__ void __launch_bounds__(256) agc_adamw_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         const int64_t* __restrict__ unit_off, const int32_t* __restrict__ unit_len,
+                                                         const uint8_t* __restrict__ unit_flags, int nunits, float lr, float b1,
+                                                         float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                         float clip_factor, float agc_eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = wave_global; u < nunits; u += nwaves) {
+        const int64_t off = unit_off[u];
+        const int len = unit_len[u];
+        float gscale = 1.f;
+        if (clip_factor > 0.f) {
+            float pn = 0.f, gn = 0.f;
+            for (int i = lane; i < len; i += 64) {
+                const float p = param[off + i], g = grad[off + i];
+                pn = fmaf(p, p, pn); gn = fmaf(g, g, gn);
+            }
+            pn = sqrtf(wave_sum(pn)); gn = sqrtf(wave_sum(gn));
+            const float max_norm = fmaxf(pn, agc_eps) * clip_factor;
+            if (!(gn < max_norm)) gscale = max_norm / fmaxf(gn, 1e-6f);
+        }
+        const float decay = (unit_flags[u] & 1) ? 1.f - lr * wd : 1.f;
+        const float step = lr / bc1;
+        for (int i = lane; i < len; i += 64) {
+            const float g = grad[off + i] * gscale;
+            float p = param[off + i] * decay;
+            const float mm = b1 * m[off + i] + (1.f - b1) * g;
+            const float vv = b2 * v[off + i] + (1.f - b2) * g * g;
+            p -= step * mm / (sqrtf(vv) / bc2_sqrt + eps);
+            param[off + i] = p; m[off + i] = mm; v[off + i] = vv;
+        }
+    }
+}
+
+extern "C" int segf_agc_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* unit_offset,
+                              const int32_t* unit_len, const uint8_t* unit_flags, int nunits, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, float clip_factor, float agc_eps, void* stream) {
+    if (nunits <= 0) return 0;
+    if (step < 1) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    const int blocks = imin((nunits + 3) / 4, 4096);
+    hipLaunchKernelGGL(agc_adamw_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, unit_offset, unit_len,
+                       unit_flags, nunits, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, clip_factor, agc_eps);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,147 @@
+// Bilinear resize on NHWC (F.interpolate mode='bilinear'): reference models/heads/segformer.py:48,
+// models/modules/ppm.py:24 (align_corners=True), models/heads/upernet.py:41,46, models/build_models.py:65.
+// Forward = gather of 4 taps; backward = gather-form transpose (each input pixel sums the output pixels that
+// reference it -- no atomics, deterministic).  Outputs may be channel slices of a wider concat buffer (ld*).
+#include "colreduce.h"
+
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ in, int64_t ldi, T* __restrict__ out, int64_t ldo, int B, int h, int w,
+                                    int C, int H, int W, int ac, bool vec) {
+    const int nch = (C + 7) / 8;
+    const int64_t total = (int64_t)B * H * W * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch);
+        int64_t t = idx / nch;
+        const int X = (int)(t % W); t /= W;
+        const int Y = (int)(t % H);
+        const int64_t b = t / H;
+        const int c0 = ch * 8, nv = C - c0 < 8 ? C - c0 : 8;
+        int y0, y1, x0, x1; float ly, lx;
+        bilinear_src(Y, h, H, ac, y0, y1, ly);
+        bilinear_src(X, w, W, ac, x0, x1, lx);
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        const T* base = in + b * h * w * ldi + c0;
+        load8_guard<T>(base + ((int64_t)y0 * w + x0) * ldi, nv, vec, v00);
+        load8_guard<T>(base + ((int64_t)y0 * w + x1) * ldi, nv, vec, v01);
+        load8_guard<T>(base + ((int64_t)y1 * w + x0) * ldi, nv, vec, v10);
+        load8_guard<T>(base + ((int64_t)y1 * w + x1) * ldi, nv, vec, v11);
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = w00 * v00[j] + w01 * v01[j] + w10 * v10[j] + w11 * v11[j];
+        store8_guard<T>(out + ((b * H + Y) * W + X) * ldo + c0, nv, vec, o);
+    }
+}
+
+// candidate output range [lo, hi] whose taps can touch input index i (checked exactly inside the loop)
+__device__ __forceinline__ void out_range(int i, int in, int out, int ac, int& lo, int& hi) {
+    const float inv = ac ? (in > 1 ? (float)(out - 1) / (float)(in - 1) : 0.f) : (float)out / (float)in;
+    float a, b;
+    if (ac) { a = (i - 1) * inv; b = (i + 1) * inv; }
+    else { a = (i - 1 + 0.5f) * inv - 0.5f; b = (i + 1 + 0.5f) * inv - 0.5f; }
+    lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+    if (in == 1 || (ac && in <= 1)) { lo = 0; hi = out - 1; }
+}
+
+template <typename T>
+__global__ void bilinear_bwd_kernel(T* __restrict__ din, int64_t ldi, const T* __restrict__ dout, int64_t ldo, int B, int h, int w,
+                                    int C, int H, int W, int ac, bool vec) {
+    const int nch = (C + 7) / 8;
+    const int64_t total = (int64_t)B * h * w * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch);
+        int64_t t = idx / nch;
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h);
+        const int64_t b = t / h;
+        const int c0 = ch * 8, nv = C - c0 < 8 ? C - c0 : 8;
+        int Ylo, Yhi, Xlo, Xhi;
+        out_range(y, h, H, ac, Ylo, Yhi);
+        out_range(x, w, W, ac, Xlo, Xhi);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int Y = Ylo; Y <= Yhi; ++Y) {
+            int y0, y1; float ly;
+            bilinear_src(Y, h, H, ac, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = Xlo; X <= Xhi; ++X) {
+                int x0, x1; float lx;
+                bilinear_src(X, w, W, ac, x0, x1, lx);
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx == 0.f) continue;
+                float v[8];
+                load8_guard<T>(dout + ((b * H + Y) * W + X) * ldo + c0, nv, vec, v);
+                const float ww = wy * wx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(ww, v[j], acc[j]);
+            }
+        }
+        store8_guard<T>(din + ((b * h + y) * w + x) * ldi + c0, nv, vec, acc);
+    }
+}
+
+extern "C" int segf_bilinear_fwd(int dt, int B, int h, int w, int C, const void* in, int64_t ldi, int H, int W, void* out,
+                                 int64_t ldo, int align_corners, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    if (h <= 0 || w <= 0 || ldi < C || ldo < C) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)imin64(cdiv64((int64_t)B * H * W * ((C + 7) / 8), 256), 8192);
+    SEGF_DISPATCH_DT(dt, T, {
+        const bool vec = vec_ok_host<T>(in, ldi) && vec_ok_host<T>(out, ldo);
+        hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)in, ldi, (T*)out, ldo, B, h, w, C, H, W, align_corners, vec);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, int64_t ldi, int H, int W, const void* dout,
+                                 int64_t ldo, int align_corners, void* stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return 0;
+    if (H <= 0 || W <= 0 || ldi < C || ldo < C) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)imin64(cdiv64((int64_t)B * h * w * ((C + 7) / 8), 256), 8192);
+    SEGF_DISPATCH_DT(dt, T, {
+        const bool vec = vec_ok_host<T>(din, ldi) && vec_ok_host<T>(dout, ldo);
+        hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (T*)din, ldi, (const T*)dout, ldo, B, h, w, C, H, W, align_corners, vec);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// materialised full-resolution logits for API parity with SegmentationModel.forward (build_models.py:62-66):
+// NHWC low-res -> fp32 NCHW full-res.  Thread per (b, c, Y, X) with X fastest (coalesced NCHW stores; taps hit L2).
+template <typename T>
+__global__ void bilinear_to_nchw_kernel(const T* __restrict__ in, int64_t ldi, float* __restrict__ out, int B, int h, int w, int C,
+                                        int H, int W) {
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(idx % W);
+        int64_t t = idx / W;
+        const int Y = (int)(t % H); t /= H;
+        const int c = (int)(t % C);
+        const int64_t b = t / C;
+        int y0, y1, x0, x1; float ly, lx;
+        bilinear_src(Y, h, H, 0, y0, y1, ly);
+        bilinear_src(X, w, W, 0, x0, x1, lx);
+        const T* base = in + b * h * w * ldi + c;
+        const float v00 = ldf<T>(base + ((int64_t)y0 * w + x0) * ldi), v01 = ldf<T>(base + ((int64_t)y0 * w + x1) * ldi);
+        const float v10 = ldf<T>(base + ((int64_t)y1 * w + x0) * ldi), v11 = ldf<T>(base + ((int64_t)y1 * w + x1) * ldi);
+        out[idx] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+}
+
+extern "C" int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, const void* in, int64_t ldi, int H, int W, float* out,
+                                         void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    if (h <= 0 || w <= 0 || ldi < C) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)imin64(cdiv64((int64_t)B * C * H * W, 256), 16384);
+    SEGF_DISPATCH_DT(dt, T, {
+        hipLaunchKernelGGL((bilinear_to_nchw_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)in, ldi, out, B, h, w, C, H, W);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,119 @@
+"""criterion / train_one_epoch / evaluate with the reference's signatures (engine.py:10-104).
+
+Differences that are deliberate: compute is bf16-with-fp32-accumulate inside
+the kernels instead of fp16 autocast + GradScaler; when the model offers ``forward_lowres`` the loss and the
+eval metrics consume the stride-4 head output directly (fused upsample), so the 157 MB/img full-resolution
+logits tensor is never written.
+"""
+import math
+import sys
+
+import torch
+
+from . import functional as Fh
+from . import utils
+from .backbones import TokenMap, tokens_from_nchw
+from .metrics import Metrics
+
+
+def _class_weight(loss_weight, device):
+    if loss_weight is None:
+        return None
+    return torch.as_tensor(loss_weight, dtype=torch.float32, device=device).contiguous()
+
+
+def criterion_lowres(lowres: TokenMap, target, size, loss_weight=None, num_classes: int = 2, dice: bool = True,
+                     ignore_index: int = -100):
+    """criterion(F.interpolate(head_out, size), target) without materialising the upsampled logits."""
+    H, W = size
+    nc = lowres.data.shape[1]
+    assert nc == num_classes, (nc, num_classes)
+    loss, parts, _ = Fh.upsample_ce_dice(lowres.data, target, (lowres.B, nc, lowres.H, lowres.W, H, W), ignore_index,
+                                         _class_weight(loss_weight, target.device), dice is True)
+    return loss
+
+
+def criterion(inputs, target, loss_weight=None, num_classes: int = 2, dice: bool = True, ignore_index: int = -100):
+    """engine.py:10-15: F.cross_entropy + (dice) util.losses.dice_loss on [B, C, H, W] logits."""
+    if isinstance(inputs, TokenMap):
+        return criterion_lowres(inputs, target, target.shape[-2:], loss_weight, num_classes, dice, ignore_index)
+    B, C, H, W = inputs.shape
+    dtype = inputs.dtype if inputs.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    t = inputs.permute(0, 2, 3, 1)
+    if t.is_contiguous() and inputs.dtype == dtype:
+        tm = TokenMap(t.reshape(B * H * W, C), B, H, W)              # zero-copy: already NHWC underneath
+    else:
+        tm = TokenMap(Fh.nchw_to_tokens(inputs.to(dtype)), B, H, W)
+    return criterion_lowres(tm, target, (H, W), loss_weight, num_classes, dice, ignore_index)
+
+
+def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, clip_grad, clip_mode, loss_scaler,
+                    writer=None, args=None):
+    model.train()
+    num_steps = len(dataloader)
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    metric_logger.add_meter('lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    header = 'Epoch: [{}]'.format(epoch)
+    loss_weight = torch.as_tensor([1.0, 2.0], device=device) if args.nb_classes == 2 else None   # engine.py:28-32
+    core = model.module if hasattr(model, 'module') else model
+    fused = hasattr(core, 'forward_lowres')
+
+    for idx, (img, lbl) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
+        img = img.to(device, non_blocking=True)
+        lbl = lbl.to(device, non_blocking=True)
+        optimizer.zero_grad()
+        if fused:
+            # DDP hooks fire on backward through the wrapped module's parameters either way
+            if hasattr(model, 'module'):
+                data, (b_, h_, w_) = model(img, lowres=True)
+                lo = TokenMap(data, b_, h_, w_)
+            else:
+                lo = core.forward_lowres(img)
+            loss = criterion_lowres(lo, lbl, img.shape[2:], loss_weight, num_classes=args.nb_classes, dice=args.dice,
+                                    ignore_index=args.ignore_index)
+        else:
+            loss = criterion(model(img), lbl, loss_weight, num_classes=args.nb_classes, dice=args.dice,
+                             ignore_index=args.ignore_index)
+        loss_value = loss.item()
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+        is_second_order = hasattr(optimizer, 'is_second_order') and optimizer.is_second_order
+        loss_scaler(loss, optimizer, clip_grad=clip_grad, clip_mode=clip_mode, parameters=model.parameters(),
+                    create_graph=is_second_order)
+        lr = optimizer.param_groups[0]["lr"]
+        metric_logger.update(loss=loss_value, lr=lr)
+        if writer is not None and idx % print_freq == 0 and getattr(args, 'local_rank', 0) == 0:
+            it = epoch * num_steps + idx
+            writer.add_scalar('train_loss', loss, it)
+            writer.add_scalar('train_lr', lr, it)
+    metric_logger.synchronize_between_processes()
+    return metric_logger.meters["loss"].global_avg, lr
+
+
+@torch.inference_mode()
+def evaluate(args, model, dataloader, device, print_freq, writer=None):
+    model.eval()
+    metric = Metrics(args.nb_classes, args.ignore_label, device)
+    confmat = utils.ConfusionMatrix(args.nb_classes)
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    header = 'Test:'
+    core = model.module if hasattr(model, 'module') else model
+    fused = hasattr(core, 'forward_lowres')
+    for idx, (images, labels) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
+        images = images.to(device, non_blocking=True)
+        labels = labels.to(device, non_blocking=True)
+        if fused:
+            lo = core.forward_lowres(images)
+            metric.update_lowres(lo, labels, images.shape[2:], confmat=confmat)     # one pass feeds both matrices
+        else:
+            outputs = model(images)
+            confmat.update(labels.flatten(), outputs.argmax(1).flatten())
+            metric.update(outputs, labels.flatten())
+        if writer and idx % print_freq == 0:
+            writer.add_scalar('valid_mf1', metric.compute_f1()[1])
+            writer.add_scalar('valid_acc', metric.compute_pixel_acc()[1])
+            writer.add_scalar('valid_mIOU', metric.compute_iou()[1])
+    confmat.reduce_from_all_processes()
+    metric.reduce_from_all_processes()
+    return confmat, metric

@@ -1,0 +1,355 @@
+"""Autograd operators over the HIP kernels (segmentation_factory_amd.hip).
+
+Activations are token-major 2-D tensors ``[B*H*W, C]`` (NHWC flattened) in the compute dtype
+(bf16 for speed, fp32 for the exact-parity mode); parameters and their gradients stay fp32.
+Every forward/backward below is a hand-written formula over C-ABI kernel calls -- torch autograd
+only sequences them.  Nothing here falls back to eager PyTorch math.
+"""
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+
+def _rowmajor(t):
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _w(param, dtype):
+    """fp32 master parameter -> compute dtype copy (bf16 cast kernel; identity in fp32 mode)."""
+    p = param.detach()
+    p = p if p.is_contiguous() else p.contiguous()
+    return hip.cast(p, dtype) if dtype != torch.float32 else p
+
+
+def _splitk(n_out, k_in, tokens):
+    return hip.pick_splitk(n_out, k_in, tokens)
+
+
+class LinearFn(Function):
+    """y = [residual + rscale[b] *] (x W^T + bias)   (nn.Linear / 1x1 conv on tokens).
+    reference: mit.py:45,52,58,98-99 (q/kv/proj/fc1/fc2), heads/segformer.py:13,24,39."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, rscale, rows_per_group, pad_to):
+        x = _rowmajor(x)
+        M, K = x.shape
+        N = weight.shape[0]
+        w = _w(weight.reshape(N, -1), x.dtype)
+        out = None
+        if pad_to and pad_to > N:
+            out = torch.empty((M, pad_to), dtype=x.dtype, device=x.device)[:, :N]
+        b = bias.detach() if bias is not None else None
+        y = hip.gemm(0, x, w, M, N, K, out=out, bias=b, residual=residual, rscale=rscale,
+                     rows_per_group=rows_per_group or 1)
+        ctx.save_for_backward(x, w, rscale)
+        ctx.meta = (M, N, K, bias is not None, residual is not None, rows_per_group or 1, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, rscale = ctx.saved_tensors
+        M, N, K, has_bias, has_res, rpg, wshape = ctx.meta
+        dy = _rowmajor(dy)
+        dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.gemm(1, dys, w, M, K, N)
+        if ctx.needs_input_grad[1]:
+            dw = hip.gemm(2, dys, x, N, K, M, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = hip.colsum(dys)
+        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None, None, None
+
+
+def linear(x, weight, bias=None, residual=None, rscale=None, rows_per_group=None, pad_to=None):
+    return LinearFn.apply(x, weight, bias, residual, rscale, rows_per_group, pad_to)
+
+
+class LayerNormFn(Function):
+    """nn.LayerNorm over the channel dim of token rows (mit.py:107,136-140; convnext.py:8-23 in NHWC)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x if x.is_contiguous() else x.contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y, mean, rstd = hip.layernorm_fwd(x, g, b, eps)
+        ctx.save_for_backward(x, g, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dg, db = hip.layernorm_bwd(x, dy, g, mean, rstd)
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class ConvPatchFn(Function):
+    """Strided conv as im2col + MFMA GEMM: PatchEmbed (mit.py:105,127: k7 s4 p3 / k3 s2 p1), the
+    spatial-reduction conv (mit.py:21,48: k = s = sr) and ConvNeXt's stem / downsample convs.
+    x is either the fp32 NCHW image (image=True) or NHWC tokens [B*H*W, Cin]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, image, dtype):
+        B, H, W, Cin, k, stride, pad = geom
+        O = weight.shape[0]
+        Ho = (H + 2 * pad - k) // stride + 1
+        Wo = (W + 2 * pad - k) // stride + 1
+        K = k * k * Cin
+        ld = (K + 7) // 8 * 8
+        x = x if x.is_contiguous() else x.contiguous()
+        col = hip.im2col(x, dtype, image, B, H, W, Cin, k, k, stride, pad, Ho, Wo, ld)
+        wmat = hip.permute021(weight.detach().contiguous(), O, Cin, k * k, dtype).view(O, K)   # [O][(ky,kx)][ci]
+        b = bias.detach() if bias is not None else None
+        y = hip.gemm(0, col, wmat, B * Ho * Wo, O, K, bias=b)
+        ctx.save_for_backward(x, wmat)
+        ctx.meta = (geom, image, dtype, O, Ho, Wo, K, ld, bias is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wmat = ctx.saved_tensors
+        geom, image, dtype, O, Ho, Wo, K, ld, has_bias, wshape = ctx.meta
+        B, H, W, Cin, k, stride, pad = geom
+        M = B * Ho * Wo
+        dy = _rowmajor(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            col = hip.im2col(x, dtype, image, B, H, W, Cin, k, k, stride, pad, Ho, Wo, ld)
+            dwm = hip.gemm(2, dy, col, O, K, M, out_dtype=torch.float32, split_k=_splitk(O, K, M))   # [O][(ky,kx)][ci]
+            dw = hip.permute021(dwm, O, k * k, Cin, torch.float32).view(wshape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = hip.colsum(dy)
+        if ctx.needs_input_grad[0] and not image:
+            dcol = hip.gemm(1, dy, wmat, M, K, O)
+            dx = hip.col2im(dcol, B, H, W, Cin, k, k, stride, pad, Ho, Wo)
+        return dx, dw, db, None, None, None
+
+
+def conv_patch(x, weight, bias, geom, image=False, dtype=None):
+    return ConvPatchFn.apply(x, weight, bias, geom, image, dtype or x.dtype)
+
+
+class AttentionFn(Function):
+    """softmax(Q K^T * scale) V per head (mit.py:52-57).  q: [B*N, C]; kv: [B*Nkv, 2C] = [k | v]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, N, Nkv, heads):
+        q, kv = _rowmajor(q), _rowmajor(kv)
+        Cc = q.shape[1]
+        hd = Cc // heads
+        scale = hd ** -0.5
+        o, lse = hip.attention_fwd(q, kv[:, :Cc], kv[:, Cc:], B, heads, N, Nkv, hd, scale)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.meta = (B, N, Nkv, heads, hd, scale, Cc)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        B, N, Nkv, heads, hd, scale, Cc = ctx.meta
+        do = _rowmajor(do)
+        dkv = torch.empty_like(kv)
+        dq = hip.attention_bwd(q, kv[:, :Cc], kv[:, Cc:], o, do, lse, B, heads, N, Nkv, hd, scale, dkv[:, :Cc], dkv[:, Cc:])
+        return dq, dkv, None, None, None, None
+
+
+def attention(q, kv, B, N, Nkv, heads):
+    return AttentionFn.apply(q, kv, B, N, Nkv, heads)
+
+
+class DWConvGeluFn(Function):
+    """gelu(depthwise3x3(x) + b) on NHWC tokens (mit.py:62-71 + F.gelu at :99)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, B, H, W, apply_gelu):
+        x = x if x.is_contiguous() else x.contiguous()
+        Cc = x.shape[1]
+        w9 = weight.detach().reshape(Cc, 9).contiguous()
+        b = bias.detach().contiguous() if bias is not None else None
+        y = hip.dwconv3x3_gelu_fwd(x, w9, b, B, H, W, Cc, apply_gelu)
+        ctx.save_for_backward(x, w9, b)
+        ctx.meta = (B, H, W, Cc, apply_gelu, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w9, b = ctx.saved_tensors
+        B, H, W, Cc, apply_gelu, wshape = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dw, db = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, apply_gelu)
+        return dx, dw.view(wshape), (db if b is not None else None), None, None, None, None
+
+
+def dwconv3x3_gelu(x, weight, bias, B, H, W, apply_gelu=True):
+    return DWConvGeluFn.apply(x, weight, bias, B, H, W, apply_gelu)
+
+
+class BatchNormActFn(Function):
+    """BatchNorm2d (+ReLU/ReLU6) (+Dropout2d channel scale) on NHWC rows.
+    ConvModule of heads/segformer.py:21-29, layers/conv_module.py:4-9, mobilenetv2.py:5-11; Dropout2d of
+    heads/segformer.py:40,57.  Training uses batch statistics and updates the running buffers in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample):
+        x = x if x.is_contiguous() else x.contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            mean, rstd = hip.bn_stats(x, running_mean, running_var, momentum, eps)
+        else:
+            mean = running_mean.detach().clone()
+            rstd = torch.rsqrt(running_var.detach() + eps)
+        y = hip.bn_apply(x, mean, rstd, g, b, act, chan_scale, rows_per_sample or 1)
+        ctx.save_for_backward(x, mean, rstd, g, b, chan_scale)
+        ctx.meta = (act, rows_per_sample or 1, not training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, g, b, chan_scale = ctx.saved_tensors
+        act, rps, eval_mode = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dg, db = hip.bn_bwd(x, dy, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
+        return dx, dg, db, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=1, chan_scale=None,
+                   rows_per_sample=None):
+    return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale,
+                                rows_per_sample)
+
+
+class SegformerProjectConcatFn(Function):
+    """The front half of SegFormerHead.forward (heads/segformer.py:42-50): per-scale Linear(C_i -> E),
+    bilinear resize to the stride-4 grid, channel concat in the order [c4, c3, c2, c1].  Every branch writes
+    straight into its column slice of one [B*H1*W1, 4E] buffer -- no torch.cat copy."""
+
+    @staticmethod
+    def forward(ctx, geoms, *args):
+        feats, weights, biases = args[0:4], args[4:8], args[8:12]
+        B = geoms[0][0]
+        H1, W1 = geoms[0][1], geoms[0][2]
+        E = weights[0].shape[0]
+        dtype = feats[0].dtype
+        M1 = B * H1 * W1
+        cat = torch.empty((M1, 4 * E), dtype=dtype, device=feats[0].device)
+        saved = []
+        for i in range(4):
+            f = _rowmajor(feats[i])
+            w = _w(weights[i], dtype)
+            _, h, wd = geoms[i]
+            sl = cat[:, (3 - i) * E:(4 - i) * E]
+            if i == 0:
+                hip.gemm(0, f, w, M1, E, f.shape[1], out=sl, bias=biases[i].detach())
+            else:
+                t = hip.gemm(0, f, w, B * h * wd, E, f.shape[1], bias=biases[i].detach())
+                hip.bilinear_fwd(t, B, h, wd, E, H1, W1, sl, align_corners=False)
+            saved += [f, w]
+        ctx.save_for_backward(*saved)
+        ctx.meta = (geoms, E)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        geoms, E = ctx.meta
+        saved = ctx.saved_tensors
+        dcat = _rowmajor(dcat)
+        B, H1, W1 = geoms[0]
+        dfs, dws, dbs = [], [], []
+        for i in range(4):
+            f, w = saved[2 * i], saved[2 * i + 1]
+            _, h, wd = geoms[i]
+            sl = dcat[:, (3 - i) * E:(4 - i) * E]
+            dy = sl if i == 0 else hip.bilinear_bwd(sl, B, h, wd, E, H1, W1, align_corners=False)
+            M, Ci = f.shape
+            dfs.append(hip.gemm(1, dy, w, M, Ci, E) if ctx.needs_input_grad[1 + i] else None)
+            dws.append(hip.gemm(2, dy, f, E, Ci, M, out_dtype=torch.float32, split_k=_splitk(E, Ci, M)))
+            dbs.append(hip.colsum(dy))
+        return (None, *dfs, *dws, *dbs)
+
+
+def segformer_project_concat(feats, weights, biases, geoms):
+    return SegformerProjectConcatFn.apply(tuple(geoms), *feats, *weights, *biases)
+
+
+class UpsampleCEDiceFn(Function):
+    """criterion(F.interpolate(logits, size), target): build_models.py:65 + engine.py:10-15 +
+    util/losses.py:126-177, without materialising full-resolution logits in the forward."""
+
+    @staticmethod
+    def forward(ctx, logits, target, geom, ignore_index, class_weight, dice):
+        B, Cc, h, w, H, W = geom
+        logits = _rowmajor(logits)
+        target = target.contiguous()
+        loss, stats = hip.ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice)
+        ctx.save_for_backward(logits, target, stats, class_weight)
+        ctx.meta = (geom, ignore_index, dice)
+        ctx.mark_non_differentiable(stats)
+        return loss[0], loss.detach(), stats
+
+    @staticmethod
+    def backward(ctx, gloss, _gparts, _gstats):
+        logits, target, stats, cw = ctx.saved_tensors
+        (B, Cc, h, w, H, W), ignore_index, dice = ctx.meta
+        ld = logits.stride(0)
+        go = gloss.reshape(1).to(torch.float32).contiguous()
+        dfull = hip.ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, cw, dice, stats, go,
+                                ld if (h == H and w == W) else (Cc + 7) // 8 * 8)
+        if h == H and w == W:
+            dl = dfull[:, :Cc]
+        else:
+            dl = hip.bilinear_bwd(dfull[:, :Cc], B, h, w, Cc, H, W, align_corners=False, ld_in=ld)[:, :Cc]
+        return dl, None, None, None, None, None
+
+
+def upsample_ce_dice(logits, target, geom, ignore_index=255, class_weight=None, dice=True):
+    """Returns (loss, parts[3] = {total, ce, dice_loss}, stats)."""
+    return UpsampleCEDiceFn.apply(logits, target, tuple(geom), int(ignore_index), class_weight, bool(dice))
+
+
+class UpsampleToNCHWFn(Function):
+    """F.interpolate(head_out, size=input, bilinear, align_corners=False) -> fp32 NCHW logits
+    (build_models.py:65), for callers that want the reference's materialised tensor."""
+
+    @staticmethod
+    def forward(ctx, logits, geom):
+        B, Cc, h, w, H, W = geom
+        logits = _rowmajor(logits)
+        ctx.meta = (geom, logits.dtype, logits.stride(0))
+        return hip.bilinear_to_nchw_f32(logits, B, h, w, Cc, H, W)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (B, Cc, h, w, H, W), dtype, ld = ctx.meta
+        dn = hip.permute021(dout.contiguous(), B, Cc, H * W, dtype).view(B * H * W, Cc)   # NCHW -> NHWC
+        dl = hip.bilinear_bwd(dn, B, h, w, Cc, H, W, align_corners=False, ld_in=ld)[:, :Cc]
+        return dl, None
+
+
+def upsample_to_nchw(logits, geom):
+    return UpsampleToNCHWFn.apply(logits, tuple(geom))
+
+
+class NCHWToTokensFn(Function):
+    """[B, C, H, W] -> token rows [B*H*W, C] through the re-layout kernel (both directions)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, Cc, H, W = x.shape
+        ctx.meta = (B, Cc, H, W, x.dtype)
+        return hip.permute021(x.contiguous(), B, Cc, H * W, x.dtype).view(B * H * W, Cc)
+
+    @staticmethod
+    def backward(ctx, dt):
+        B, Cc, H, W, dtype = ctx.meta
+        return hip.permute021(_rowmajor(dt).contiguous(), B, H * W, Cc, dtype).view(B, Cc, H, W)
+
+
+def nchw_to_tokens(x):
+    return NCHWToTokensFn.apply(x)

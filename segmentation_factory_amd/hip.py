@@ -1,0 +1,385 @@
+"""ctypes binding of libsegfac_hip.so (the C ABI declared in include/segfac.h).
+
+Only raw device pointers, sizes and the current HIP stream cross this boundary; torch is used
+for device memory (caching allocator) and stream handles, never for the arithmetic.  There is no
+CPU fallback: if the shared library is missing, or a kernel returns non-zero, a RuntimeError is
+raised (the reference's own error convention is Python exceptions).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsegfac_hip.so')
+F32, BF16 = 0, 1
+_lib = None
+
+_i, _l, _f, _p = C.c_int, C.c_int64, C.c_float, C.c_void_p
+_PROTOS = {
+    'segf_cast': (_i, [_p, _i, _p, _i, _l, _p]),
+    'segf_permute021': (_i, [_p, _i, _p, _i, _l, _l, _l, _l, _p]),
+    'segf_scale_rows': (_i, [_i, _p, _l, _p, _l, _p, _l, _l, _l, _p]),
+    'segf_add': (_i, [_i, _p, _l, _p, _l, _p, _l, _l, _l, _p]),
+    'segf_colsum_ws': (_l, [_l, _l]),
+    'segf_colsum': (_i, [_i, _p, _l, _l, _l, _p, _p, _p]),
+    'segf_gemm': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _p, _l, _p, _l, _i, _p, _p]),
+    'segf_gemm_pick_splitk': (_i, [_l, _l, _l]),
+    'segf_layernorm_fwd': (_i, [_i, _l, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
+    'segf_layernorm_bwd_ws': (_l, [_l, _i]),
+    'segf_layernorm_bwd': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_bn_ws': (_l, [_l, _i]),
+    'segf_bn_stats': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p]),
+    'segf_bn_apply': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p]),
+    'segf_bn_bwd': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p]),
+    'segf_attention_fwd': (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _l, _f, _p, _l, _p, _p]),
+    'segf_attention_bwd_ws': (_l, [_i, _i, _i, _i, _i]),
+    'segf_attention_bwd': (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _l, _f, _p, _l, _p, _l, _p,
+                                _p, _l, _p, _l, _p, _l, _p, _p]),
+    'segf_dwconv3x3_gelu_fwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
+    'segf_dwconv3x3_bwd_ws': (_l, [_i, _i, _i, _i]),
+    'segf_dwconv3x3_gelu_bwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_im2col': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p]),
+    'segf_col2im': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p]),
+    'segf_bilinear_fwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
+    'segf_bilinear_bwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
+    'segf_bilinear_to_nchw_f32': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p]),
+    'segf_ce_dice_stats_floats': (_l, [_i, _i]),
+    'segf_ce_dice_fwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p]),
+    'segf_ce_dice_bwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p, _l, _p]),
+    'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
+    'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
+    'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),
+    'segf_version': (C.c_char_p, []),
+}
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C segmentation_factory_amd/csrc`. There is no CPU/eager fallback.')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f'unsupported activation dtype {t.dtype}')
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError(f'{name} failed with code {rc} '
+                           f'({"argument error" if rc < 0 else "hipError_t"})')
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('segmentation_factory_amd kernels need device tensors (no CPU fallback)')
+
+
+def _f32(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+
+
+# ---- plumbing ------------------------------------------------------------------------------
+def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _need_cuda(src)
+    src = src.contiguous()
+    if src.dtype == dtype:
+        return src
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _chk(lib().segf_cast(_ptr(src), dt_of(src), _ptr(dst), BF16 if dtype == torch.bfloat16 else F32,
+                         src.numel(), _stream()), 'segf_cast')
+    return dst
+
+
+def permute021(x: torch.Tensor, A: int, Bd: int, Cd: int, out_dtype: torch.dtype, ld_out=None) -> torch.Tensor:
+    """out[a][c][b] = in[a][b][c]; last dim zero-padded to ld_out."""
+    _need_cuda(x)
+    ld_out = Bd if ld_out is None else ld_out
+    out = torch.empty((A, Cd, ld_out), dtype=out_dtype, device=x.device)
+    _chk(lib().segf_permute021(_ptr(x), dt_of(x), _ptr(out), BF16 if out_dtype == torch.bfloat16 else F32,
+                               A, Bd, Cd, ld_out, _stream()), 'segf_permute021')
+    return out
+
+
+def scale_rows(x: torch.Tensor, scale: torch.Tensor, rows_per_group: int) -> torch.Tensor:
+    _need_cuda(x, scale)
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    _chk(lib().segf_scale_rows(dt_of(x), _ptr(x), x.stride(0), _ptr(y), cols, _ptr(scale), rows, cols,
+                               rows_per_group, _stream()), 'segf_scale_rows')
+    return y
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _need_cuda(a, b)
+    rows, cols = a.shape
+    y = torch.empty((rows, cols), dtype=a.dtype, device=a.device)
+    _chk(lib().segf_add(dt_of(a), _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(y), cols, rows, cols, _stream()),
+         'segf_add')
+    return y
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws = _f32(lib().segf_colsum_ws(rows, cols), x.device)
+    _chk(lib().segf_colsum(dt_of(x), _ptr(x), x.stride(0), rows, cols, _ptr(out), _ptr(ws), _stream()), 'segf_colsum')
+    return out
+
+
+# ---- GEMM ------------------------------------------------------------------------------------
+def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, out=None, out_dtype=None, bias=None,
+         residual=None, rscale=None, rows_per_group=1, split_k=1) -> torch.Tensor:
+    """C[M,N] = A(m,k) B(k,n) (+bias) (residual + rscale * .).  A, B: 2-D tensors with unit inner stride."""
+    _need_cuda(A, B)
+    assert A.stride(-1) == 1 and B.stride(-1) == 1
+    dt = dt_of(A)
+    assert dt_of(B) == dt
+    out_dtype = out_dtype or A.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    assert out.stride(-1) == 1
+    ws = None
+    if split_k > 1:
+        ws = _f32(split_k * M * N, A.device)
+    _chk(_timed(('gemm', layout, M, N, K), lambda: lib().segf_gemm(
+        dt, layout, M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), dt_of(out), out.stride(0), _ptr(bias),
+        _ptr(residual), residual.stride(0) if residual is not None else 0, _ptr(rscale), rows_per_group, split_k, _ptr(ws),
+        _stream())), 'segf_gemm')
+    return out
+
+
+class KernelTimer:
+    """HIP-event timing of selected launches on the stream they are enqueued on (bench.py's roofline leg).
+    Usage: ``with KernelTimer(lambda key: key == ('gemm', 0, M, N, K)) as t: ...; t.summary()``."""
+    active = None
+
+    def __init__(self, match):
+        self.match, self.events = match, {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *a):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}   # (launches, avg ms)
+
+
+def _timed(key, fn):
+    t = KernelTimer.active
+    if t is None or not t.match(key):
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    t.events.setdefault(key, []).append((e0, e1))
+    return r
+
+
+def pick_splitk(M, N, K):
+    return lib().segf_gemm_pick_splitk(M, N, K)
+
+
+# ---- norms ---------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps):
+    _need_cuda(x, gamma, beta)
+    rows, Cc = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _chk(lib().segf_layernorm_fwd(dt_of(x), rows, Cc, _ptr(x), _ptr(gamma), _ptr(beta), eps, _ptr(y), _ptr(mean),
+                                  _ptr(rstd), _stream()), 'segf_layernorm_fwd')
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd):
+    rows, Cc = x.shape
+    dx = torch.empty_like(x)
+    dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
+    _chk(lib().segf_layernorm_bwd(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                  dgb.data_ptr(), dgb[1].data_ptr(), _ptr(ws), _stream()), 'segf_layernorm_bwd')
+    return dx, dgb[0], dgb[1]
+
+
+def bn_stats(x, running_mean, running_var, momentum, eps):
+    rows, Cc = x.shape
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = _f32(lib().segf_bn_ws(rows, Cc), x.device)
+    _chk(lib().segf_bn_stats(dt_of(x), rows, Cc, _ptr(x), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
+                             momentum, eps, _ptr(ws), _stream()), 'segf_bn_stats')
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample):
+    rows, Cc = x.shape
+    y = torch.empty_like(x)
+    _chk(lib().segf_bn_apply(dt_of(x), rows, Cc, _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), act,
+                             _ptr(chan_scale), rows_per_sample, _ptr(y), _stream()), 'segf_bn_apply')
+    return y
+
+
+def bn_bwd(x, dy, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode):
+    rows, Cc = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = _f32(lib().segf_bn_ws(rows, Cc), x.device)
+    _chk(lib().segf_bn_bwd(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), act,
+                           _ptr(chan_scale), rows_per_sample, int(eval_mode), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                           _ptr(ws), _stream()), 'segf_bn_bwd')
+    return dx, dgamma, dbeta
+
+
+# ---- attention ------------------------------------------------------------------------------------
+def attention_fwd(q, k, v, B, heads, N, Nkv, hd, scale):
+    """q: [B*N, >=heads*hd] view; k, v: [B*Nkv, ...] views (unit inner stride)."""
+    o = torch.empty((B * N, heads * hd), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=q.device)
+    _chk(lib().segf_attention_fwd(dt_of(q), B, heads, N, Nkv, hd, _ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v),
+                                  v.stride(0), scale, _ptr(o), o.stride(0), _ptr(lse), _stream()), 'segf_attention_fwd')
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, d_o, lse, B, heads, N, Nkv, hd, scale, dk, dv):
+    """dk / dv are written into caller-provided views (the two halves of the kv-linear gradient)."""
+    dq = torch.empty((B * N, heads * hd), dtype=q.dtype, device=q.device)
+    ws = _f32(lib().segf_attention_bwd_ws(B, heads, N, Nkv, hd), q.device)
+    _chk(lib().segf_attention_bwd(dt_of(q), B, heads, N, Nkv, hd, _ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v),
+                                  v.stride(0), scale, _ptr(o), o.stride(0), _ptr(d_o), d_o.stride(0), _ptr(lse),
+                                  _ptr(dq), dq.stride(0), _ptr(dk), dk.stride(0), _ptr(dv), dv.stride(0), _ptr(ws),
+                                  _stream()), 'segf_attention_bwd')
+    return dq
+
+
+# ---- spatial ----------------------------------------------------------------------------------------
+def dwconv3x3_gelu_fwd(x, w9, bias, B, H, W, Cc, apply_gelu=True):
+    y = torch.empty_like(x)
+    _chk(lib().segf_dwconv3x3_gelu_fwd(dt_of(x), B, H, W, Cc, _ptr(x), _ptr(w9), _ptr(bias), int(apply_gelu), _ptr(y),
+                                       _stream()), 'segf_dwconv3x3_gelu_fwd')
+    return y
+
+
+def dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, Cc, apply_gelu=True):
+    du = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = _f32(lib().segf_dwconv3x3_bwd_ws(B, H, W, Cc), x.device)
+    _chk(lib().segf_dwconv3x3_gelu_bwd(dt_of(x), B, H, W, Cc, _ptr(x), _ptr(w9), _ptr(bias), int(apply_gelu), _ptr(dy),
+                                       _ptr(du), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), _stream()),
+         'segf_dwconv3x3_gelu_bwd')
+    return dx, dw, db
+
+
+def im2col(x, dtype, in_nchw_f32, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo, ldcol):
+    _need_cuda(x)
+    col = torch.empty((B * Ho * Wo, ldcol), dtype=dtype, device=x.device)
+    _chk(lib().segf_im2col(BF16 if dtype == torch.bfloat16 else F32, int(in_nchw_f32), B, H, W, Cin, kh, kw, stride, pad,
+                           Ho, Wo, _ptr(x), _ptr(col), ldcol, _stream()), 'segf_im2col')
+    return col
+
+
+def col2im(dcol, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo):
+    dx = torch.empty((B * H * W, Cin), dtype=dcol.dtype, device=dcol.device)
+    _chk(lib().segf_col2im(dt_of(dcol), B, H, W, Cin, kh, kw, stride, pad, Ho, Wo, _ptr(dcol), dcol.stride(0), _ptr(dx),
+                           _stream()), 'segf_col2im')
+    return dx
+
+
+def bilinear_fwd(x, B, h, w, Cc, H, W, out, align_corners=False):
+    """x: [B*h*w, >=C] view; out: [B*H*W, >=C] view (may be a column slice of a concat buffer)."""
+    _chk(lib().segf_bilinear_fwd(dt_of(x), B, h, w, Cc, _ptr(x), x.stride(0), H, W, _ptr(out), out.stride(0),
+                                 int(align_corners), _stream()), 'segf_bilinear_fwd')
+    return out
+
+
+def bilinear_bwd(dout, B, h, w, Cc, H, W, align_corners=False, ld_in=None):
+    ld_in = Cc if ld_in is None else ld_in
+    din = torch.empty((B * h * w, ld_in), dtype=dout.dtype, device=dout.device)
+    if ld_in != Cc:
+        din.zero_()
+    _chk(lib().segf_bilinear_bwd(dt_of(dout), B, h, w, Cc, _ptr(din), ld_in, H, W, _ptr(dout), dout.stride(0),
+                                 int(align_corners), _stream()), 'segf_bilinear_bwd')
+    return din
+
+
+def bilinear_to_nchw_f32(x, B, h, w, Cc, H, W):
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    _chk(lib().segf_bilinear_to_nchw_f32(dt_of(x), B, h, w, Cc, _ptr(x), x.stride(0), H, W, _ptr(out), _stream()),
+         'segf_bilinear_to_nchw_f32')
+    return out
+
+
+# ---- loss / metrics ------------------------------------------------------------------------------------
+def ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice):
+    stats = _f32(lib().segf_ce_dice_stats_floats(B, Cc), logits.device)
+    loss = torch.empty(3, dtype=torch.float32, device=logits.device)
+    _chk(lib().segf_ce_dice_fwd(dt_of(logits), B, Cc, h, w, H, W, _ptr(logits), logits.stride(0), _ptr(target),
+                                int(ignore_index), _ptr(class_weight), int(dice), _ptr(stats), _ptr(loss), _stream()),
+         'segf_ce_dice_fwd')
+    return loss, stats
+
+
+def ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice, stats, grad_out, ldg):
+    dfull = torch.empty((B * H * W, ldg), dtype=logits.dtype, device=logits.device)
+    if ldg != Cc:
+        dfull.zero_()
+    _chk(lib().segf_ce_dice_bwd(dt_of(logits), B, Cc, h, w, H, W, _ptr(logits), logits.stride(0), _ptr(target),
+                                int(ignore_index), _ptr(class_weight), int(dice), _ptr(stats), _ptr(grad_out),
+                                _ptr(dfull), ldg, _stream()), 'segf_ce_dice_bwd')
+    return dfull
+
+
+def argmax_confmat(logits, B, Cc, h, w, H, W, target, ignore_label, mat, hist, flag, pred_out=None):
+    _chk(lib().segf_argmax_confmat(dt_of(logits), B, Cc, h, w, H, W, _ptr(logits), logits.stride(0), _ptr(target),
+                                   int(ignore_label), _ptr(mat), _ptr(hist), _ptr(flag), _ptr(pred_out), _stream()),
+         'segf_argmax_confmat')
+
+
+def confmat_pairs(gt, pred, Cc, ignore_label, mat, hist, flag):
+    _need_cuda(gt, pred)
+    _chk(lib().segf_confmat_pairs(_ptr(gt), _ptr(pred), gt.numel(), Cc, int(ignore_label), _ptr(mat), _ptr(hist),
+                                  _ptr(flag), _stream()), 'segf_confmat_pairs')
+
+
+def agc_adamw(param, grad, exp_avg, exp_avg_sq, unit_off, unit_len, unit_flags, lr, beta1, beta2, eps, weight_decay,
+              step, clip_factor, agc_eps=1e-3):
+    _chk(lib().segf_agc_adamw(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(unit_off), _ptr(unit_len),
+                              _ptr(unit_flags), unit_len.numel(), lr, beta1, beta2, eps, weight_decay, step, clip_factor,
+                              agc_eps, _stream()), 'segf_agc_adamw')

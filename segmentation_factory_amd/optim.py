@@ -1,0 +1,141 @@
+"""Optimizer side of the train step: what engine.py:52-53 calls through timm 0.9.2 in the reference
+(``loss_scaler(loss, optimizer, clip_grad=0.02, clip_mode='agc', parameters=..., create_graph=...)``).
+
+timm is not available in the build image and no reference test covers this arithmetic, so AGC / AdamW are
+restated from timm 0.9.2 + torch.optim.AdamW semantics ("parity unpinned") and checked against
+hand-derived known answers (tests/test_optim.py).  The step itself is one HIP kernel over flat buffers.
+"""
+import torch
+
+from . import hip
+
+
+class FusedAGCAdamW(torch.optim.Optimizer):
+    """AdamW whose step (optionally preceded by unit-wise adaptive gradient clipping) runs as a single
+    multi-tensor kernel (segf_agc_adamw).  Parameters are re-homed into one flat fp32 buffer (each
+    ``p.data`` becomes a view), gradients are gathered into a flat buffer of the same layout."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat = None
+        self._step = 0
+        self.agc_clip = 0.0          # set per step by NativeScaler when clip_mode == 'agc'
+
+    def _build(self):
+        ps, decay = [], []
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.requires_grad:
+                    ps.append(p)
+                    decay.append(g['weight_decay'] > 0)
+        dev = ps[0].device
+        total = sum(p.numel() for p in ps)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        offs, lens, flags = [], [], []
+        o = 0
+        for p, d in zip(ps, decay):
+            n = p.numel()
+            flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + n].view(p.shape)
+            rows = p.shape[0] if p.ndim > 1 else 1
+            cols = n // rows
+            for r in range(rows):
+                offs.append(o + r * cols)
+                lens.append(cols)
+                flags.append(1 if d else 0)
+            o += n
+        self._params = ps
+        self._flat = flat
+        self._grad = torch.zeros_like(flat)
+        self._grad_views, o = [], 0
+        for p in ps:
+            self._grad_views.append(self._grad[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat)
+        self._off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._len = torch.tensor(lens, dtype=torch.int32, device=dev)
+        self._flags = torch.tensor(flags, dtype=torch.uint8, device=dev)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self._flat is None:
+            self._build()
+        # gather the per-parameter gradients into the flat buffer with one multi-tensor copy
+        dst, src = [], []
+        for p, view in zip(self._params, self._grad_views):
+            if p.grad is not None:
+                dst.append(view)
+                src.append(p.grad)
+            else:
+                view.zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
+        g = self.param_groups[0]
+        wd = max(pg['weight_decay'] for pg in self.param_groups)
+        self._step += 1
+        hip.agc_adamw(self._flat, self._grad, self._m, self._v, self._off, self._len, self._flags, g['lr'], g['betas'][0],
+                      g['betas'][1], g['eps'], wd, self._step, float(self.agc_clip))
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['fused'] = dict(step=self._step, exp_avg=None if self._flat is None else self._m.cpu(),
+                           exp_avg_sq=None if self._flat is None else self._v.cpu())
+        return sd
+
+    def load_state_dict(self, sd):
+        fused = sd.pop('fused', None) if isinstance(sd, dict) else None
+        super().load_state_dict(sd)
+        if fused and fused.get('exp_avg') is not None:
+            if self._flat is None:
+                self._build()
+            self._step = fused['step']
+            self._m.copy_(fused['exp_avg'])
+            self._v.copy_(fused['exp_avg_sq'])
+
+
+class NativeScaler:
+    """Call-compatible stand-in for timm.utils.NativeScaler.  bf16 needs no loss scaling, so this is:
+    backward -> (optional) clipping -> optimizer.step().  ``state_dict`` keeps the checkpoint key 'scaler'."""
+    state_dict_key = 'amp_scaler'
+
+    def __call__(self, loss, optimizer, clip_grad=None, clip_mode='norm', parameters=None, create_graph=False,
+                 need_update=True):
+        loss.backward(create_graph=create_graph)
+        if not need_update:
+            return
+        if isinstance(optimizer, FusedAGCAdamW):
+            optimizer.agc_clip = float(clip_grad) if (clip_grad is not None and clip_mode == 'agc') else 0.0
+            if clip_grad is not None and clip_mode != 'agc':
+                raise NotImplementedError("FusedAGCAdamW fuses clip_mode='agc' only")
+        elif clip_grad is not None:
+            raise NotImplementedError('gradient clipping is fused into FusedAGCAdamW; use it or pass clip_grad=None')
+        optimizer.step()
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, sd):
+        pass
+
+
+def param_groups_weight_decay(model, weight_decay):
+    """timm.optim.optim_factory.param_groups_weight_decay: no decay for 1-D tensors and biases."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.ndim <= 1 or name.endswith('.bias')) else decay).append(p)
+    return [{'params': no_decay, 'weight_decay': 0.}, {'params': decay, 'weight_decay': weight_decay}]
+
+
+def create_optimizer(args, model):
+    """--opt adamw path of timm.optim.create_optimizer (train_gpu.py:269) on the fused kernel."""
+    if getattr(args, 'opt', 'adamw').lower() != 'adamw':
+        raise NotImplementedError("only --opt adamw is implemented on the MI355X path")
+    wd = getattr(args, 'weight_decay', 0.025)
+    kw = dict(lr=getattr(args, 'lr', 1e-3), weight_decay=wd, eps=getattr(args, 'opt_eps', None) or 1e-8)
+    betas = getattr(args, 'opt_betas', None)
+    if betas:
+        kw['betas'] = tuple(betas)
+    return FusedAGCAdamW(param_groups_weight_decay(model, wd), **kw)

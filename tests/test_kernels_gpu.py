@@ -1,0 +1,396 @@
+"""GPU parity tests of every HIP kernel (through the C ABI via segmentation_factory_amd.hip / functional)
+against a plain PyTorch fp32 CPU statement of the same op.  fp32 storage must match to ~1e-5; bf16 storage to
+bf16 rounding of inputs/outputs (fp32 accumulation inside)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
+
+
+def _close(got, ref, dtype, scale=None, fac=1.0):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    rt, at = _tol(dtype)
+    s = ref.abs().max().item() if scale is None else scale
+    err = (got - ref).abs().max().item()
+    assert err <= fac * (rt * s + at * 1e-2), f'max err {err:.3e} vs scale {s:.3e} ({dtype})'
+
+
+def _dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def _q(t, dtype):
+    """quantise a CPU fp32 tensor to the storage dtype and back (what the kernel actually sees)."""
+    return t.to(dtype).float()
+
+
+@pytest.fixture(scope='module')
+def hipmod():
+    from segmentation_factory_amd import hip
+    hip.lib()
+    return hip
+
+
+def test_plumbing(hipmod):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 37, 29, generator=g)
+    for dt in DTYPES:
+        out = hipmod.permute021(_dev(x), 5, 37, 29, dt, ld_out=40)
+        ref = torch.zeros(5, 29, 40)
+        ref[:, :, :37] = x.permute(0, 2, 1)
+        _close(out, ref, dt)
+    a = torch.randn(70, 150, generator=g)
+    b = torch.randn(70, 150, generator=g)
+    s = torch.rand(7, generator=g)
+    for dt in DTYPES:
+        _close(hipmod.cast(_dev(a), dt), a, dt)
+        _close(hipmod.scale_rows(_dev(a, dt), _dev(s), 10), _q(a, dt) * s.repeat_interleave(10)[:, None], dt)
+        _close(hipmod.add(_dev(a, dt), _dev(b, dt)), _q(a, dt) + _q(b, dt), dt)
+        _close(hipmod.colsum(_dev(a, dt)), _q(a, dt).sum(0), torch.float32, fac=4)
+    big = torch.randn(5000, 768, generator=g)
+    _close(hipmod.colsum(_dev(big)), big.sum(0), torch.float32, fac=20)
+    wide = torch.randn(300, 3072, generator=g)
+    _close(hipmod.colsum(_dev(wide, torch.bfloat16)), _q(wide, torch.bfloat16).sum(0), torch.float32, fac=20)
+
+
+GEMM_SHAPES = [(300, 150, 147), (257, 32, 32), (128, 128, 64), (1000, 768, 3072 // 4), (64, 768, 32), (513, 259, 1031)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('no_tr', ['0', '1'])
+def test_gemm_layouts(hipmod, dtype, no_tr):
+    os.environ['SEGFAC_GEMM_NO_TR'] = no_tr
+    try:
+        g = torch.Generator().manual_seed(1)
+        for (M, N, K) in GEMM_SHAPES:
+            x = torch.randn(M, K, generator=g)
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            dy = torch.randn(M, N, generator=g)
+            xq, wq, dyq = _q(x, dtype), _q(w, dtype), _q(dy, dtype)
+            y = hipmod.gemm(0, _dev(x, dtype), _dev(w, dtype), M, N, K)
+            _close(y, xq @ wq.t(), dtype)
+            dx = hipmod.gemm(1, _dev(dy, dtype), _dev(w, dtype), M, K, N)
+            _close(dx, dyq @ wq, dtype)
+            dw = hipmod.gemm(2, _dev(dy, dtype), _dev(x, dtype), N, K, M, out_dtype=torch.float32)
+            _close(dw, dyq.t() @ xq, torch.float32 if dtype == torch.float32 else dtype, fac=4)
+            sk = 3
+            dw2 = hipmod.gemm(2, _dev(dy, dtype), _dev(x, dtype), N, K, M, out_dtype=torch.float32, split_k=sk)
+            _close(dw2, dyq.t() @ xq, torch.float32 if dtype == torch.float32 else dtype, fac=4)
+    finally:
+        os.environ['SEGFAC_GEMM_NO_TR'] = '0'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gemm_epilogue_and_strides(hipmod, dtype):
+    g = torch.Generator().manual_seed(2)
+    M, N, K, rpg = 96, 150, 64, 32
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 8
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    s = torch.rand(M // rpg, generator=g) * 2
+    xq, wq, rq = _q(x, dtype), _q(w, dtype), _q(r, dtype)
+    ref = rq + s.repeat_interleave(rpg)[:, None] * (xq @ wq.t() + b)
+    y = hipmod.gemm(0, _dev(x, dtype), _dev(w, dtype), M, N, K, bias=_dev(b), residual=_dev(r, dtype), rscale=_dev(s),
+                    rows_per_group=rpg)
+    _close(y, ref, dtype)
+    # strided A (column slice of a wider buffer) and strided output slice
+    wide = torch.randn(M, 3 * K, generator=g)
+    out = torch.zeros(M, 2 * N + 10, dtype=dtype, device='cuda')
+    hipmod.gemm(0, _dev(wide, dtype)[:, K:2 * K], _dev(w, dtype), M, N, K, out=out[:, N:2 * N], bias=_dev(b))
+    _close(out[:, N:2 * N], _q(wide, dtype)[:, K:2 * K] @ wq.t() + b, dtype)
+    assert out[:, :N].abs().max().item() == 0 and out[:, 2 * N:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C', [32, 64, 160, 256, 768, 1536])
+def test_layernorm(dtype, C):
+    from segmentation_factory_amd import functional as Fh
+    g = torch.Generator().manual_seed(3)
+    rows = 333
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.5)
+    gam = 1 + 0.1 * torch.randn(C, generator=g)
+    bet = 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(rows, C, generator=g)
+    xr = _q(x, dtype).requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    ref.backward(_q(dy, dtype))
+    xd = _dev(x, dtype).requires_grad_(True)
+    gd, bd = _dev(gam).requires_grad_(True), _dev(bet).requires_grad_(True)
+    y = Fh.layer_norm(xd, gd, bd, 1e-5)
+    y.backward(_dev(dy, dtype))
+    _close(y, ref, dtype)
+    _close(xd.grad, xr.grad, dtype)
+    _close(gd.grad, gr.grad, dtype, fac=8)
+    _close(bd.grad, br.grad, dtype, fac=8)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_batchnorm_act(dtype, act):
+    from segmentation_factory_amd import functional as Fh
+    g = torch.Generator().manual_seed(4)
+    B, HW, C = 3, 50, 72
+    x = torch.randn(B * HW, C, generator=g) * 3 + 1
+    gam = 1 + 0.2 * torch.randn(C, generator=g)
+    bet = 0.5 * torch.randn(C, generator=g)
+    dy = torch.randn(B * HW, C, generator=g)
+    keep = (torch.rand(B, C, generator=g) > 0.2).float() / 0.9
+    rm0, rv0 = 0.1 * torch.randn(C, generator=g), 1 + 0.1 * torch.rand(C, generator=g)
+    for training in (True, False):
+        xr = _q(x, dtype).requires_grad_(True)
+        gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+        rm, rv = rm0.clone(), rv0.clone()
+        t = F.batch_norm(xr.t().reshape(1, C, -1), rm, rv, gr, br, training, 0.1, 1e-5)[0].t()
+        t = F.relu(t) if act == 1 else (F.relu6(t) if act == 2 else t)
+        ref = t * keep.repeat_interleave(HW, 0)
+        ref.backward(_q(dy, dtype))
+        xd = _dev(x, dtype).requires_grad_(True)
+        gd, bd = _dev(gam).requires_grad_(True), _dev(bet).requires_grad_(True)
+        rmd, rvd = _dev(rm0.clone()), _dev(rv0.clone())
+        y = Fh.batch_norm_act(xd, gd, bd, rmd, rvd, training, 0.1, 1e-5, act, _dev(keep), HW)
+        y.backward(_dev(dy, dtype))
+        _close(y, ref, dtype)
+        _close(xd.grad, xr.grad, dtype, fac=2)
+        _close(gd.grad, gr.grad, dtype, fac=8)
+        _close(bd.grad, br.grad, dtype, fac=8)
+        _close(rmd, rm, torch.float32, fac=4)
+        _close(rvd, rv, torch.float32, fac=4)
+
+
+def _attn_ref(q, kv, B, N, Nkv, heads):
+    C = q.shape[1]
+    hd = C // heads
+    qh = q.reshape(B, N, heads, hd).permute(0, 2, 1, 3)
+    k, v = kv.reshape(B, Nkv, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    a = ((qh @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(B * N, C)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 2, 100, 37, 32), (1, 1, 300, 256, 64), (2, 5, 64, 4, 32), (1, 8, 16, 16, 32), (1, 2, 700, 300, 64)])
+def test_attention(dtype, shape):
+    from segmentation_factory_amd import functional as Fh
+    B, heads, N, Nkv, hd = shape
+    C = heads * hd
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B * N, C, generator=g)
+    kv = torch.randn(B * Nkv, 2 * C, generator=g)
+    do = torch.randn(B * N, C, generator=g)
+    qr, kvr = _q(q, dtype).requires_grad_(True), _q(kv, dtype).requires_grad_(True)
+    ref = _attn_ref(qr, kvr, B, N, Nkv, heads)
+    ref.backward(_q(do, dtype))
+    qd, kvd = _dev(q, dtype).requires_grad_(True), _dev(kv, dtype).requires_grad_(True)
+    o = Fh.attention(qd, kvd, B, N, Nkv, heads)
+    o.backward(_dev(do, dtype))
+    _close(o, ref, dtype)
+    _close(qd.grad, qr.grad, dtype, fac=2)
+    _close(kvd.grad, kvr.grad, dtype, fac=4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('geom', [(2, 9, 13, 32), (1, 16, 16, 128), (2, 5, 3, 8), (1, 1, 1, 64)])
+def test_dwconv3x3_gelu(dtype, geom):
+    from segmentation_factory_amd import functional as Fh
+    B, H, W, C = geom
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B * H * W, C, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    b = torch.randn(C, generator=g) * 0.2
+    dy = torch.randn(B * H * W, C, generator=g)
+    xr = _q(x, dtype).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    t = F.conv2d(xr.reshape(B, H, W, C).permute(0, 3, 1, 2), wr, br, padding=1, groups=C)
+    ref = F.gelu(t).permute(0, 2, 3, 1).reshape(B * H * W, C)
+    ref.backward(_q(dy, dtype))
+    xd = _dev(x, dtype).requires_grad_(True)
+    wd, bd = _dev(w).requires_grad_(True), _dev(b).requires_grad_(True)
+    y = Fh.dwconv3x3_gelu(xd, wd, bd, B, H, W, True)
+    y.backward(_dev(dy, dtype))
+    _close(y, ref, dtype)
+    _close(xd.grad, xr.grad, dtype, fac=2)
+    _close(wd.grad, wr.grad, dtype, fac=8)
+    _close(bd.grad, br.grad, dtype, fac=8)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(2, 3, 32, 40, 32, 7, 4, 3, True), (2, 32, 16, 12, 64, 3, 2, 1, False),
+                                 (1, 64, 16, 16, 64, 4, 4, 0, False), (2, 160, 7, 9, 256, 3, 2, 1, False),
+                                 (1, 32, 16, 24, 32, 8, 8, 0, False)])
+def test_conv_patch(dtype, cfg):
+    from segmentation_factory_amd import functional as Fh
+    B, Cin, H, W, O, k, s, p, image = cfg
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(O, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(O, generator=g) * 0.1
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(B * Ho * Wo, O, generator=g)
+    xq = x if image else _q(x, dtype)
+    xr = xq.clone().requires_grad_(True)
+    wr, br = _q(w, dtype).requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr if not image else _q(xr, dtype), wr, br, stride=s, padding=p).permute(0, 2, 3, 1).reshape(B * Ho * Wo, O)
+    ref.backward(_q(dy, dtype))
+    if image:
+        xd = _dev(x)
+    else:
+        xd = _dev(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin).contiguous(), dtype).requires_grad_(True)
+    wd, bd = _dev(w).requires_grad_(True), _dev(b).requires_grad_(True)
+    y = Fh.conv_patch(xd, wd, bd, (B, H, W, Cin, k, s, p), image=image, dtype=dtype)
+    y.backward(_dev(dy, dtype))
+    _close(y, ref, dtype)
+    _close(wd.grad, wr.grad, dtype, fac=8)
+    _close(bd.grad, br.grad, dtype, fac=8)
+    if not image:
+        _close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(B * H * W, Cin), dtype, fac=2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(2, 4, 5, 16, 20, 24, False), (1, 6, 6, 16, 16, 8, True), (2, 1, 1, 7, 9, 16, True),
+                                 (1, 16, 16, 16, 16, 8, False), (2, 3, 7, 12, 9, 150, False), (1, 8, 8, 4, 4, 16, False)])
+def test_bilinear(hipmod, dtype, cfg):
+    B, h, w, H, W, C, ac = cfg
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, C, h, w, generator=g)
+    dy = torch.randn(B, C, H, W, generator=g)
+    xr = _q(x, dtype).requires_grad_(True)
+    ref = F.interpolate(xr, size=(H, W), mode='bilinear', align_corners=ac)
+    ref.backward(_q(dy, dtype))
+    xt = _dev(x.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous(), dtype)
+    buf = torch.zeros(B * H * W, C + 16, dtype=dtype, device='cuda')
+    hipmod.bilinear_fwd(xt, B, h, w, C, H, W, buf[:, 8:8 + C], align_corners=ac)
+    _close(buf[:, 8:8 + C], ref.permute(0, 2, 3, 1).reshape(B * H * W, C), dtype)
+    assert buf[:, :8].abs().max().item() == 0
+    dyt = _dev(dy.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous(), dtype)
+    din = hipmod.bilinear_bwd(dyt, B, h, w, C, H, W, align_corners=ac)
+    _close(din, xr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C), dtype, fac=4)
+    full = hipmod.bilinear_to_nchw_f32(xt, B, h, w, C, H, W)
+    if not ac:
+        _close(full, ref, dtype)
+
+
+def test_loss_golden_cases(golden_dir):
+    """engine.criterion captured from the reference (tests/golden/loss_cases.npz): fp32 kernels."""
+    from segmentation_factory_amd import engine
+    g = np.load(os.path.join(golden_dir, 'loss_cases.npz'))
+    for i in range(int(g['n'])):
+        C, dice, weighted, ign = [int(v) for v in g[f'meta_{i}']]
+        logits = torch.from_numpy(g[f'logits_{i}']).cuda().requires_grad_(True)
+        t = torch.from_numpy(g[f'target_{i}']).cuda()
+        w = torch.tensor([1.0, 2.0]).cuda() if weighted else None
+        loss = engine.criterion(logits, t, w, num_classes=C, dice=bool(dice), ignore_index=ign)
+        loss.backward()
+        name = str(g[f'name_{i}'])
+        assert abs(loss.item() - float(g[f'loss_{i}'])) < 5e-6 * max(1, abs(float(g[f'loss_{i}']))), name
+        err = (logits.grad.cpu().numpy() - g[f'grad_{i}'])
+        assert np.abs(err).max() < 2e-6 * max(1e-3, np.abs(g[f'grad_{i}']).max()) + 1e-9, name
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('cfg', [(2, 19, 8, 8, 32, 32), (2, 150, 6, 10, 24, 40), (1, 2, 5, 5, 20, 20), (3, 65, 4, 4, 4, 4)])
+def test_upsample_ce_dice_vs_oracle(dtype, cfg):
+    from oracle import loss as OL
+    from segmentation_factory_amd import functional as Fh
+    B, C, h, w, H, W = cfg
+    g = torch.Generator().manual_seed(9)
+    lo = torch.randn(B, C, h, w, generator=g) * 2
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    t[:, :2] = 255
+    if B > 1:
+        t[1] = 255 if cfg[1] == 65 else t[1]
+    lr = _q(lo, dtype).requires_grad_(True)
+    up = F.interpolate(lr, size=(H, W), mode='bilinear', align_corners=False)
+    ref = OL.criterion_closed_form(up, t, None, num_classes=C, dice=True, ignore_index=255)
+    ref.backward()
+    ld = (C + 7) // 8 * 8
+    buf = torch.zeros(B * h * w, ld, dtype=dtype, device='cuda')
+    buf[:, :C] = lo.permute(0, 2, 3, 1).reshape(B * h * w, C).to(dtype)
+    tok = buf[:, :C].requires_grad_(True)
+    loss, parts, _ = Fh.upsample_ce_dice(tok, t.cuda(), (B, C, h, w, H, W), 255, None, True)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < (1e-5 if dtype == torch.float32 else 2e-3) * max(1, abs(ref.item()))
+    _close(tok.grad, lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C), dtype, fac=2 if dtype == torch.float32 else 6)
+
+
+def test_argmax_confmat_and_metrics_golden(golden_dir):
+    from segmentation_factory_amd import utils
+    from segmentation_factory_amd.metrics import Metrics
+    g = np.load(os.path.join(golden_dir, 'metrics_case.npz'))
+    nc = int(g['nc'])
+    m = Metrics(nc, 255, 'cuda')
+    cm = utils.ConfusionMatrix(nc)
+    for b in range(2):
+        logits = torch.from_numpy(g[f'logits_{b}']).cuda()
+        t = torch.from_numpy(g[f'target_{b}']).cuda()
+        cm.update(t.flatten(), logits.argmax(1).flatten())
+        m.update(logits, t.flatten())
+    assert np.array_equal(cm.mat.cpu().numpy(), g['mat'])
+    assert np.array_equal(m.hist.cpu().numpy(), g['hist'])
+    iou, f1, acc = m.compute_iou(), m.compute_f1(), m.compute_pixel_acc()
+    assert iou[1] == float(g['miou']) and f1[1] == float(g['mf1']) and acc[1] == float(g['macc'])
+    assert np.allclose(np.array(iou[0]), g['iou'], equal_nan=True)
+    assert str(cm) == str(g['confmat_str'])
+
+
+def test_argmax_confmat_fused_upsample():
+    from oracle import loss as OL
+    from segmentation_factory_amd.backbones import TokenMap
+    from segmentation_factory_amd.metrics import Metrics
+    from segmentation_factory_amd import utils
+    g = torch.Generator().manual_seed(10)
+    B, C, h, w, H, W = 2, 150, 8, 8, 32, 32
+    lo = torch.randn(B, C, h, w, generator=g)
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    t[:, :3] = 255
+    up = F.interpolate(lo, size=(H, W), mode='bilinear', align_corners=False)
+    mat, hist = OL.confusion_counts(up, t, C, 255)
+    m, cm = Metrics(C, 255, 'cuda'), utils.ConfusionMatrix(C)
+    tm = TokenMap(lo.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous().cuda(), B, h, w)
+    m.update_lowres(tm, t.cuda(), (H, W), confmat=cm)
+    # bilinear rounding can flip exact near-ties; allow a handful of pixels
+    assert np.abs(cm.mat.cpu().numpy() - mat).sum() <= 4
+    assert np.abs(m.hist.cpu().numpy() - hist).sum() <= 4
+
+
+def test_agc_adamw_known_answers(hipmod):
+    """Hand-restated timm-0.9.2 AGC + torch AdamW arithmetic (parity unpinned: timm is not installed)."""
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler
+    g = torch.Generator().manual_seed(11)
+    w = torch.nn.Parameter(torch.randn(6, 10, generator=g).cuda())
+    b = torch.nn.Parameter(torch.randn(6, generator=g).cuda())
+    pw, pb = w.detach().cpu().clone(), b.detach().cpu().clone()
+    opt = FusedAGCAdamW([{'params': [b], 'weight_decay': 0.}, {'params': [w], 'weight_decay': 0.05}], lr=1e-2)
+    mw, vw, mb, vb = torch.zeros_like(pw), torch.zeros_like(pw), torch.zeros_like(pb), torch.zeros_like(pb)
+    for step in range(1, 4):
+        gw, gb = torch.randn(6, 10, generator=g) * 3, torch.randn(6, generator=g) * 3
+        w.grad, b.grad = gw.cuda(), gb.cuda()
+        opt.agc_clip = 0.02
+        opt.step()
+        # reference arithmetic
+        def agc(p, gr):
+            pn = p.norm(2, dim=tuple(range(1, p.ndim)), keepdim=True) if p.ndim > 1 else p.norm(2)
+            gn = gr.norm(2, dim=tuple(range(1, p.ndim)), keepdim=True) if p.ndim > 1 else gr.norm(2)
+            mx = pn.clamp(min=1e-3) * 0.02
+            return torch.where(gn < mx, gr, gr * (mx / gn.clamp(min=1e-6)))
+        for (p, gr, m_, v_, wd) in ((pw, gw, mw, vw, 0.05), (pb, gb, mb, vb, 0.)):
+            gr = agc(p, gr)
+            p.mul_(1 - 1e-2 * wd)
+            m_.mul_(0.9).add_(gr, alpha=0.1)
+            v_.mul_(0.999).addcmul_(gr, gr, value=0.001)
+            denom = v_.sqrt() / (1 - 0.999 ** step) ** 0.5 + 1e-8
+            p.addcdiv_(m_, denom, value=-1e-2 / (1 - 0.9 ** step))
+        assert (w.detach().cpu() - pw).abs().max() < 1e-5
+        assert (b.detach().cpu() - pb).abs().max() < 1e-5
