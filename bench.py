@@ -42,7 +42,9 @@ def cpu_baseline(sample_batch=2):
     """The oracle (CPU restatement of the reference path, validated bit-exact against the imported reference in
     the build container) timed on this host: forward + CE/Dice with the reference's B x C Python loop + backward."""
     from oracle import loss as OL, nets as ON, weights as OW
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share: oversubscribing stalls for minutes
+    ncores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(ncores)
     sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', NC, 0, lively=False)
     sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var')))
           for k, v in sd.items()}

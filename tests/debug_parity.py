@@ -1,0 +1,80 @@
+"""Stage-by-stage parity probe (test infrastructure; run on the GPU box):
+    python tests/debug_parity.py [H W [nc]]
+Builds the HIP SegFormer-B0 and the CPU oracle from the same numpy-seeded state dict and prints the max abs /
+relative error of every backbone stage, the head and the loss, in fp32 and bf16, so a regression can be
+located without bisecting kernels by hand."""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import nets as ON, loss as OL, weights as OW   # noqa: E402  (checker only)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+def main():
+    H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    W = int(sys.argv[2]) if len(sys.argv) > 2 else H
+    nc = int(sys.argv[3]) if len(sys.argv) > 3 else 19
+    B, seed = 2, 1234
+    from segmentation_factory_amd import SegmentationModel, criterion_lowres
+    from segmentation_factory_amd import functional as Fh
+    sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', nc, seed)
+    x, y = OW.synthetic_batch(B, H, W, nc, seed)
+    ctx = ON.Ctx(sd, True, None)
+    feats_o = ON.mit_forward(ctx, x, 'B0')
+    low_o = ON.segformer_head(ctx, feats_o)
+    for dtype in (torch.float32, torch.bfloat16):
+        print('==', dtype)
+        m = SegmentationModel('MiT-B0', num_classes=nc, seg_head='SegFormerHead', compute_dtype=dtype)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        for mod in m.backbone.modules():
+            if hasattr(mod, 'drop_prob'):
+                mod.drop_prob = 0.0          # stochastic rates forced to 0
+        m.decode_head.dropout.p = 0.0
+        bb = m.backbone
+        # stage 1 in pieces
+        t, h1, w1 = bb.patch_embed1.tokens(x.cuda(), B, H, W, True, dtype)
+        pe = F.conv2d(x, sd['backbone.patch_embed1.proj.weight'], sd['backbone.patch_embed1.proj.bias'], stride=4, padding=3)
+        pe = F.layer_norm(pe.flatten(2).transpose(1, 2), (32,), sd['backbone.patch_embed1.norm.weight'],
+                          sd['backbone.patch_embed1.norm.bias'], 1e-5)
+        print('patch_embed1+LN', rel(t.view(B, -1, 32), pe))
+        p = 'backbone.block1.0.'
+        hh = Fh.layer_norm(t, bb.block1[0].norm1.weight, bb.block1[0].norm1.bias, 1e-5)
+        ho = ON._ln_tokens(sd, p + 'norm1.', pe, 1e-5)
+        print('block1.0.norm1', rel(hh.view(B, -1, 32), ho))
+        a = bb.block1[0].attn.tokens(hh, B, h1, w1, None, None)
+        ao = ON.mit_attention(sd, p + 'attn.', ho, h1, w1, 1, 8)
+        print('block1.0.attn', rel(a.view(B, -1, 32), ao))
+        t1 = pe + ao
+        h2 = ON._ln_tokens(sd, p + 'norm2.', t1, 1e-5)
+        mo = ON.mit_mlp(sd, p + 'mlp.', h2, h1, w1)
+        mm = bb.block1[0].mlp.tokens(h2.reshape(-1, 32).to(dtype).cuda(), B, h1, w1, None, None)
+        print('block1.0.mlp', rel(mm.view(B, -1, 32), mo))
+        feats = bb.forward_tokens(x.cuda())
+        for i, (f, fo) in enumerate(zip(feats, feats_o)):
+            print(f'feat{i}', rel(f.nchw(), fo))
+        # head on oracle features (isolates the head)
+        from segmentation_factory_amd.backbones import tokens_from_nchw
+        tms = [tokens_from_nchw(fo.cuda().to(dtype).contiguous(), dtype) for fo in feats_o]
+        lo = m.decode_head.forward_tokens(tms)
+        print('head(on oracle feats)', rel(lo.nchw(), low_o))
+        lo = m.forward_lowres(x.cuda())
+        print('lowres logits e2e', rel(lo.nchw(), low_o))
+        full_o = F.interpolate(low_o, size=(H, W), mode='bilinear', align_corners=False)
+        loss_o = OL.criterion_closed_form(full_o, y, None, num_classes=nc, dice=True, ignore_index=255)
+        loss = criterion_lowres(lo, y.cuda(), (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+        print('loss', loss.item(), loss_o.item())
+
+
+if __name__ == '__main__':
+    main()

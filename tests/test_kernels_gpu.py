@@ -27,13 +27,13 @@ def _close(got, ref, dtype, scale=None, fac=1.0):
 
 
 def _dev(t, dtype=None):
-    t = t.cuda()
+    t = t.detach().cuda()
     return t.to(dtype) if dtype is not None else t
 
 
 def _q(t, dtype):
     """quantise a CPU fp32 tensor to the storage dtype and back (what the kernel actually sees)."""
-    return t.to(dtype).float()
+    return t.detach().to(dtype).float().clone()
 
 
 @pytest.fixture(scope='module')

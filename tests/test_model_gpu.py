@@ -22,10 +22,11 @@ def _build(backbone, head, nc, sd, dtype, B, deterministic=True):
     assert not missing and not unexpected
     m = m.cuda()
     if deterministic:
-        ndraw = ON.count_drop_path_draws(backbone)
-        m.backbone.stochastic_override = {'drop_path': torch.ones(ndraw, B)}
-        E = m.decode_head.embed_dim
-        m.decode_head.stochastic_override = {'dropout2d': torch.full((B, E), 0.9)}   # keep / (1 - p) == 1
+        # DropPath / Dropout2d rates forced to 0 on the instance
+        for mod in m.backbone.modules():
+            if hasattr(mod, 'drop_prob'):
+                mod.drop_prob = 0.0
+        m.decode_head.dropout.p = 0.0
     return m
 
 
