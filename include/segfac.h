@@ -132,17 +132,21 @@ int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, const void* in
 /* ---- fused final-upsample + CrossEntropy + Dice (build_models.py:65 + engine.py:10-15 +
  * util/losses.py:126-177) ------------------------------------------------------------------------
  * logits: NHWC [B][h][w][ldl] (low-res head output; h==H,w==W means "already full-res");
- * target: int64 [B][H][W]; stats: fp32 [B][C][3] (I,P,T) + [4] {ce_sum, w_sum, n_valid, bad_label_flag};
- * loss: fp32 [3] {total, ce, dice_loss}.  class_weight nullable ([C]).  dice=0 -> CE only.        */
+ * target: int64 [B][H][W]; stats (opaque to the caller, segf_ce_dice_stats_floats(B, C) floats): per image
+ * {I[C], P[C], T[C], ce_sum, w_sum, n_valid, bad_label_flag}, then the batch totals [4], then block partials;
+ * loss: fp32 [3] {total, ce, dice_loss}.  class_weight nullable ([C]).  dice=0 -> CE only.  C <= 192.
+ * When H/h == W/w is a power of two the upsample is fused in both directions (no full-resolution tensor).  */
 int64_t segf_ce_dice_stats_floats(int B, int C);
 int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
                      const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
                      float* stats, float* loss, void* stream);
-/* dlogits_full: NHWC [B][H][W][ldg] of dtype dt = d loss / d (upsampled logits) * grad_out[0];
- * follow with segf_bilinear_bwd to get the low-res gradient when h != H.                            */
+/* dlogits: NHWC [B][h][w][ldd] of dtype dt = grad_out[0] * d loss / d logits (the LOW-resolution head output; the
+ * transposed bilinear resize is applied inside; columns [C, ldd) are zeroed).  ws: segf_ce_dice_bwd_ws floats
+ * (0 on the fused power-of-two path; the generic path stages the full-resolution gradient there).        */
+int64_t segf_ce_dice_bwd_ws(int dt, int B, int C, int h, int w, int H, int W);
 int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
                      const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
-                     const float* stats, const float* grad_out, void* dlogits_full, int64_t ldg, void* stream);
+                     const float* stats, const float* grad_out, void* dlogits, int64_t ldd, float* ws, void* stream);
 
 /* ---- fused upsample + argmax + confusion matrix (engine.py:89-91; util/utils.py:99-109;
  * util/metrics.py:24-27).  mat: int64 [n][n] += counts where 0<=t<n; hist: int64 [n][n] += counts

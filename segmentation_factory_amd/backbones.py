@@ -167,7 +167,10 @@ class MiT(nn.Module):
         if not self.training or all(r == 0 for r in rates):
             return [(None, None)] * len(rates)
         draws = [r for r in rates if r > 0 for _ in range(2)]
-        kp = 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None]
+        key = (str(device), tuple(draws))
+        if getattr(self, '_kp_cache', (None, None))[0] != key:      # cached: a host->device copy cannot be graph-captured
+            self._kp_cache = (key, 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None])
+        kp = self._kp_cache[1]
         if self.stochastic_override is not None and 'drop_path' in self.stochastic_override:
             keep = self.stochastic_override['drop_path'].to(device=device, dtype=torch.float32)
         else:

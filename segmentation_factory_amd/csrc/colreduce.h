@@ -1,4 +1,6 @@
 // Generic deterministic column reduction: out[o][c] = sum_rows f(row, c)[o].
+// Functor protocol: `typename F::Col` = per-thread column state (per-channel parameters hoisted out of the row loop),
+// `f.init(c0, nvalid, col)` once, then `f(col, row, c0, nvalid, v)` per row.
 // Used for bias gradients, BatchNorm statistics / backward sums, depthwise-conv weight gradients.
 // Stage 1: grid (row blocks, channel slabs) -> partial[blk][NOUT][C]; stage 2: colreduce_finalize.
 #pragma once
@@ -56,6 +58,31 @@ static inline int64_t cr_ws_floats(int64_t rows, int C, int nout) {
     return (int64_t)p.nblk * nout * C;
 }
 
+// Block tail shared by the column reductions: sum acc[o][8] over the rl row lanes of the block (LDS, fixed order) and
+// write partial[blockIdx.x][o][c0..c0+nvalid).
+template <int NOUT>
+__device__ __forceinline__ void colreduce_block_tail(float (&acc)[NOUT][8], bool active, bool writer, int tx, int ch, int rl,
+                                                     int c0, int nvalid, int C, float* __restrict__ partial, float* red) {
+    for (int o = 0; o < NOUT; ++o) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = active ? acc[o][j] : 0.f;
+        __syncthreads();
+        if (writer) {
+            float s[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = 0.f;
+            for (int y = 0; y < rl; ++y)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += red[(y * ch + tx) * 8 + j];
+            float* dst = partial + ((int64_t)blockIdx.x * NOUT + o) * C + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nvalid) dst[j] = s[j];
+        }
+    }
+}
+
 template <int NOUT, typename F>
 __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(F f, int64_t rows, int C, int ch, int rl,
                                                                 int64_t rows_per_blk, float* __restrict__ partial) {
@@ -73,43 +100,46 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(F f, int64_t rows
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
     const int64_t r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
     if (active) {
+        typename F::Col col;
+        f.init(c0, nvalid, col);
         for (int64_t r = r0 + ty; r < r1; r += rl) {
             float v[NOUT][8];
-            f(r, c0, nvalid, v);
+            f(col, r, c0, nvalid, v);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[o][j] += v[o][j];
         }
     }
-    // reduce over the rl row lanes, one output at a time (8 KB of LDS)
-    for (int o = 0; o < NOUT; ++o) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = active ? acc[o][j] : 0.f;
-        __syncthreads();
-        if (ty == 0 && nvalid > 0) {
-            float s[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s[j] = 0.f;
-            for (int y = 0; y < rl; ++y)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s[j] += red[(y * ch + tx) * 8 + j];
-            float* dst = partial + ((int64_t)blockIdx.x * NOUT + o) * C + c0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j < nvalid) dst[j] = s[j];
-        }
-    }
+    colreduce_block_tail<NOUT>(acc, active, ty == 0 && nvalid > 0, tx, ch, rl, c0, nvalid, C, partial, red);
 }
 
-// out[i] = sum_b partial[b][i], i < n  (fixed order -> bitwise reproducible)
-static __global__ void colreduce_finalize_kernel(const float* __restrict__ partial, int nblk, int64_t n, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * n + i];
-    out[i] = s;
+// out[i] = sum_b partial[b][i], i < n.  16 outputs x 16 block-slices per workgroup: slice s adds b = s, s+16, ...
+// (independent loads in flight), then the 16 slice sums are added in fixed order -> bitwise reproducible.
+#define CRF_OUT 16
+#define CRF_SL 16
+static __global__ void __launch_bounds__(CRF_OUT * CRF_SL)
+colreduce_finalize_kernel(const float* __restrict__ partial, int nblk, int64_t n, float* __restrict__ out) {
+    __shared__ float red[CRF_SL][CRF_OUT + 1];
+    const int o = threadIdx.x % CRF_OUT, sl = threadIdx.x / CRF_OUT;
+    const int64_t i = (int64_t)blockIdx.x * CRF_OUT + o;
+    float acc = 0.f;
+    if (i < n) {
+#pragma unroll 4
+        for (int b = sl; b < nblk; b += CRF_SL) acc += partial[(int64_t)b * n + i];
+    }
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CRF_SL; ++k) t += red[k][o];
+        out[i] = t;
+    }
+}
+static inline void colreduce_finalize_launch(const float* partial, int nblk, int64_t n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, CRF_OUT)), dim3(CRF_OUT * CRF_SL), 0, st, partial,
+                       nblk, n, out);
 }
 
 template <int NOUT, typename F>
@@ -119,7 +149,7 @@ static inline int colreduce_launch(F f, int64_t rows, int C, float* ws, float* o
                        p.rl, p.rows_per_blk, ws);
     SEGF_CHECK_LAUNCH();
     const int64_t n = (int64_t)NOUT * C;
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, ws, p.nblk, n, out);
+    colreduce_finalize_launch(ws, p.nblk, n, out, st);
     SEGF_CHECK_LAUNCH();
     return 0;
 }

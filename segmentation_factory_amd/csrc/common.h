@@ -21,6 +21,19 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int64_t imin64(int64_t a, int64_t b) { return a < b ? a : b; }
 
+// "Column-fixed" streaming decomposition: a row is nchunk 16-byte chunks; the launch has T = blocks * 256 threads with
+// T % nchunk == 0, so global thread g keeps channel chunk (g % nchunk) for its whole grid-stride loop and its work items
+// are u = g / nchunk, g / nchunk + T / nchunk, ...  Per-channel parameters are loaded once per thread, accesses stay
+// flat-coalesced, and the loop carries no division.
+static inline int igcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+static inline int colfixed_blocks(int64_t units, int nchunk, int units_per_thread, int max_blocks) {
+    const int unit = nchunk / igcd(nchunk, 256);                      // blocks must be a multiple of this
+    int64_t want = cdiv64(cdiv64(units, units_per_thread > 0 ? units_per_thread : 1) * nchunk, 256);
+    if (want > max_blocks) want = max_blocks;
+    int64_t blocks = cdiv64(want < 1 ? 1 : want, unit) * unit;
+    return (int)blocks;
+}
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
     // plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)
@@ -64,18 +77,52 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const floa
 }
 __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) { load8<float>(p, v); }
 
-// wave64 butterfly reductions over the lanes that differ in the low `width` lane bits (width pow2 <= 64)
+// wave64 reductions.  The first four butterfly steps run as DPP-modified VALU ops (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror: after each step both partners hold the same partial, so the mirrors act as xor 4 / xor 8);
+// no LDS traffic.  Steps 16 / 32 use ds_bpermute (__shfl_xor) in the width-templated form, or four v_readlane + scalar adds
+// in the *_all forms (full wave, result wave-uniform).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+#define DPP_XOR1 0xB1
+#define DPP_XOR2 0x4E
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v, int width = 64) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        if (o < width) v += __shfl_xor(v, o, 64);
+    if (width > 1) v += dpp_mov<DPP_XOR1>(v);
+    if (width > 2) v += dpp_mov<DPP_XOR2>(v);
+    if (width > 4) v += dpp_mov<DPP_HALF_MIRROR>(v);
+    if (width > 8) v += dpp_mov<DPP_MIRROR>(v);
+    if (width > 16) v += __shfl_xor(v, 16, 64);
+    if (width > 32) v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v, int width = 64) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        if (o < width) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (width > 1) v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    if (width > 2) v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    if (width > 4) v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    if (width > 8) v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
+    if (width > 16) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (width > 32) v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
+}
+// full-wave reductions with a wave-uniform result (every lane must be active)
+__device__ __forceinline__ float wave_sum_all(float v) {
+    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max_all(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v)); v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+__device__ __forceinline__ float wave_min_all(float v) {
+    v = fminf(v, dpp_mov<DPP_XOR1>(v)); v = fminf(v, dpp_mov<DPP_XOR2>(v));
+    v = fminf(v, dpp_mov<DPP_HALF_MIRROR>(v)); v = fminf(v, dpp_mov<DPP_MIRROR>(v));
+    return fminf(fminf(readlane_f(v, 0), readlane_f(v, 16)), fminf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // PyTorch bilinear source index (aten UpSample.h area_pixel_compute_source_index):

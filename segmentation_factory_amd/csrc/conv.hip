@@ -7,29 +7,34 @@
 
 #define DW_PIX 4   // output pixels per thread along W (sliding 3x(PIX+2) window in registers)
 
-// y[b][y][x][c] = act( sum_{ky,kx} w[c][ky*3+kx] * x[b][y+ky-1][x+kx-1][c] + bias[c] );  FLIP: correlation with the
-// flipped kernel (= transposed conv for the data gradient), no bias / activation.
-template <typename T, bool FLIP>
+// Depthwise 3x3 on NHWC, column-fixed threads (common.h): a thread keeps one 8-channel chunk, its 9x8 weights and bias in
+// registers, and walks over (image, row, 4-pixel strip) units.
+//   MODE 0: y = act( sum_k w[c][k] x[p+off_k][c] + bias[c] )        (forward; act = GELU(erf) when apply_gelu)
+//   MODE 1: y = correlation with the flipped kernel, no bias / act   (data gradient: dx = conv^T(du))
+//   MODE 2: y = dy * gelu'( conv(x) + bias )                         (backward pass A: du; equals dy when !apply_gelu)
+template <typename T, int MODE>
 __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, int apply_gelu, T* __restrict__ y,
-                                                         int B, int H, int W, int C) {
+                                                         const float* __restrict__ bias, int apply_gelu,
+                                                         const T* __restrict__ dy, T* __restrict__ y, int B, int H, int W, int C) {
     const int nchunk = C / 8;
     const int wg = (W + DW_PIX - 1) / DW_PIX;
-    const int64_t total = (int64_t)B * H * wg * nchunk;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % nchunk);
-        int64_t t = idx / nchunk;
-        const int xg = (int)(t % wg); t /= wg;
-        const int yy = (int)(t % H);
-        const int b = (int)(t / H);
-        const int c0 = ch * 8, x0 = xg * DW_PIX;
-        float wk[9][8], bs[8];
+    const int units = B * H * wg;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ustep = (int)(((int64_t)gridDim.x * 256) / nchunk);
+    const int c0 = (int)(g % nchunk) * 8;
+    float wk[9][8], bs[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 8; ++j) {
 #pragma unroll
-            for (int kk = 0; kk < 9; ++kk) wk[kk][j] = w[(c0 + j) * 9 + (FLIP ? 8 - kk : kk)];
-            bs[j] = (!FLIP && bias) ? bias[c0 + j] : 0.f;
-        }
+        for (int kk = 0; kk < 9; ++kk) wk[kk][j] = w[(c0 + j) * 9 + (MODE == 1 ? 8 - kk : kk)];
+        bs[j] = (MODE != 1 && bias) ? bias[c0 + j] : 0.f;
+    }
+    for (int u = (int)(g / nchunk); u < units; u += ustep) {
+        const int xg = u % wg;
+        const int t = u / wg;
+        const int yy = t % H;
+        const int b = t / H;
+        const int x0 = xg * DW_PIX;
         float acc[DW_PIX][8];
 #pragma unroll
         for (int p = 0; p < DW_PIX; ++p)
@@ -59,72 +64,123 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int p = 0; p < DW_PIX; ++p) {
             if (x0 + p < W) {
-                if (!FLIP && apply_gelu) {
+                const int64_t off = (((int64_t)b * H + yy) * W + x0 + p) * C + c0;
+                if (MODE == 0 && apply_gelu) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[p][j] = gelu_erf(acc[p][j]);
                 }
-                store8<T>(y + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, acc[p]);
+                if (MODE == 2) {
+                    float gy[8];
+                    load8<T>(dy + off, gy);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[p][j] = apply_gelu ? gy[j] * gelu_erf_grad(acc[p][j]) : gy[j];
+                }
+                store8<T>(y + off, acc[p]);
             }
         }
     }
+}
+
+static inline int dw_blocks(int B, int H, int W, int C) {
+    return colfixed_blocks((int64_t)B * H * ((W + DW_PIX - 1) / DW_PIX), C / 8, 1, 16384);
 }
 
 extern "C" int segf_dwconv3x3_gelu_fwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
                                        int apply_gelu, void* y, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     if (C <= 0 || C % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) return SEGF_ERR_SHAPE;
+    if ((int64_t)B * H * W >= (1ll << 31)) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)B * H * ((W + DW_PIX - 1) / DW_PIX) * (C / 8);
-    const int blocks = (int)imin64(cdiv64(total, 256), 8192);
+    const int blocks = dw_blocks(B, H, W, C);
     SEGF_DISPATCH_DT(dt, T, {
-        hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, bias, apply_gelu, (T*)y, B, H, W, C);
+        hipLaunchKernelGGL((dwconv3x3_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, bias, apply_gelu,
+                           (const T*)nullptr, (T*)y, B, H, W, C);
     })
     SEGF_CHECK_LAUNCH();
     return 0;
 }
 
-// backward pass 1 (column reduction over pixels, 10 sums per channel): recompute u = conv(x)+b at the pixel,
-// du = dy * gelu'(u) (stored), dw[k] += du * x[p+off_k], db += du.
-template <typename T> struct DwBwdF {
-    const T* x; const T* dy; T* du; const float* w; const float* bias; int H, W, C, apply_gelu;
-    __device__ void operator()(int64_t r, int c0, int nv, float (&out)[10][8]) const {
-        const int xx = (int)(r % W);
-        const int64_t t = r / W;
-        const int yy = (int)(t % H);
-        const int64_t b = t / H;
-        float u[8], xv[9][8];
+// backward pass B (weight / bias gradient): dw[c][k] = sum_p du[p][c] * x[p+off_k][c], db[c] = sum_p du[p][c].
+// Block layout of the column reductions (colreduce.h): tx -> channel chunk, ty -> unit lane; a thread walks 4-pixel strips
+// with the x window in registers (18 x-loads + 4 du-loads per strip) and keeps its 10x8 sums in registers.
+#define DWG_MAX_BLOCKS 1024
+struct DwgPlan { int ch, rl, slabs, nblk, units_per_blk; };
+static inline DwgPlan dwg_plan(int B, int H, int W, int C) {
+    DwgPlan p;
+    const int nchunk = C / 8;
+    p.ch = nchunk < 256 ? nchunk : 256;
+    p.rl = 256 / p.ch;
+    p.slabs = (nchunk + p.ch - 1) / p.ch;
+    const int64_t units = (int64_t)B * H * ((W + DW_PIX - 1) / DW_PIX);
+    int64_t want = cdiv64(units, (int64_t)p.rl * 4);
+    int cap = DWG_MAX_BLOCKS / p.slabs;
+    if (cap < 1) cap = 1;
+    p.nblk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    p.units_per_blk = (int)cdiv64(units, p.nblk);
+    return p;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) dwconv3x3_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ du,
+                                                               float* __restrict__ partial, int B, int H, int W, int C, int ch,
+                                                               int rl, int units_per_blk) {
+    __shared__ float red[256 * 8];
+    const int tx = threadIdx.x % ch, ty = threadIdx.x / ch;
+    const int chunk = blockIdx.y * ch + tx;
+    const int c0 = chunk * 8;
+    const bool active = ty < rl && c0 < C;
+    const int wg = (W + DW_PIX - 1) / DW_PIX;
+    const int units = B * H * wg;
+    float acc[10][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = bias ? bias[c0 + j] : 0.f;
+    for (int o = 0; o < 10; ++o)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+    const int u0 = blockIdx.x * units_per_blk;
+    const int u1 = u0 + units_per_blk < units ? u0 + units_per_blk : units;
+    if (active) {
+        for (int u = u0 + ty; u < u1; u += rl) {
+            const int xg = u % wg;
+            const int t = u / wg;
+            const int yy = t % H;
+            const int b = t / H;
+            const int x0 = xg * DW_PIX;
+            float g[DW_PIX][8];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = yy + ky - 1, ix = xx + kx - 1;
-                const int kk = ky * 3 + kx;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                    load8<T>(x + ((b * H + iy) * W + ix) * C + c0, xv[kk]);
+            for (int p = 0; p < DW_PIX; ++p) {
+                if (x0 + p < W) load8<T>(du + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, g[p]);
+                else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) u[j] = fmaf(w[(c0 + j) * 9 + kk], xv[kk][j], u[j]);
-                } else {
+                    for (int j = 0; j < 8; ++j) g[p][j] = 0.f;
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[kk][j] = 0.f;
+                for (int j = 0; j < 8; ++j) acc[9][j] += g[p][j];
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = yy + ky - 1;
+                if (iy < 0 || iy >= H) continue;
+                const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
+#pragma unroll
+                for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                    const int ix = x0 + cx - 1;
+                    if (ix < 0 || ix >= W) continue;
+                    float v[8];
+                    load8<T>(row + (int64_t)ix * C, v);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int p = cx - kx;
+                        if (p >= 0 && p < DW_PIX) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(g[p][j], v[j], acc[ky * 3 + kx][j]);
+                        }
+                    }
                 }
             }
-        float g[8];
-        load8<T>(dy + r * C + c0, g);
-        if (apply_gelu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] *= gelu_erf_grad(u[j]);
         }
-        store8<T>(du + r * C + c0, g);
-#pragma unroll
-        for (int kk = 0; kk < 9; ++kk)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) out[kk][j] = g[j] * xv[kk][j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[9][j] = g[j];
     }
-};
+    colreduce_block_tail<10>(acc, active, ty == 0 && c0 < C, tx, ch, rl, c0, 8, C, partial, red);
+}
 
 // [10][C] sums -> dw[C][9], db[C]
 __global__ void dw_scatter_kernel(const float* __restrict__ sums, int C, float* __restrict__ dw, float* __restrict__ db) {
@@ -135,7 +191,8 @@ __global__ void dw_scatter_kernel(const float* __restrict__ sums, int C, float* 
 }
 
 extern "C" int64_t segf_dwconv3x3_bwd_ws(int B, int H, int W, int C) {
-    return cr_ws_floats((int64_t)B * H * W, C, 10) + 10 * (int64_t)C;
+    DwgPlan p = dwg_plan(B, H, W, C > 0 ? C : 8);
+    return (int64_t)p.nblk * 10 * C + 10 * (int64_t)C;
 }
 
 extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
@@ -144,18 +201,23 @@ extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     if (C <= 0 || C % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)du % 16) || ((uintptr_t)dx % 16))
         return SEGF_ERR_SHAPE;
+    if ((int64_t)B * H * W >= (1ll << 31)) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t rows = (int64_t)B * H * W;
-    float* sums = ws + cr_ws_floats(rows, C, 10);
-    const int64_t total = (int64_t)B * H * ((W + DW_PIX - 1) / DW_PIX) * (C / 8);
-    const int blocks = (int)imin64(cdiv64(total, 256), 8192);
+    DwgPlan p = dwg_plan(B, H, W, C);
+    float* sums = ws + (int64_t)p.nblk * 10 * C;
+    const int blocks = dw_blocks(B, H, W, C);
     SEGF_DISPATCH_DT(dt, T, {
-        DwBwdF<T> f{(const T*)x, (const T*)dy, (T*)du, w, bias, H, W, C, apply_gelu};
-        const int rc = colreduce_launch<10>(f, rows, C, ws, sums, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL((dwconv3x3_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)du, w, (const float*)nullptr, 0, (T*)dx, B, H, W, C);
+        // A: du = dy * gelu'(conv(x) + b);  B: dw / db partial sums;  C: dx = conv^T(du)
+        hipLaunchKernelGGL((dwconv3x3_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, bias, apply_gelu,
+                           (const T*)dy, (T*)du, B, H, W, C);
+        hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), dim3(p.nblk, p.slabs), dim3(256), 0, st, (const T*)x, (const T*)du, ws,
+                           B, H, W, C, p.ch, p.rl, p.units_per_blk);
+        hipLaunchKernelGGL((dwconv3x3_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)du, w, (const float*)nullptr, 0,
+                           (const T*)nullptr, (T*)dx, B, H, W, C);
     })
+    SEGF_CHECK_LAUNCH();
+    colreduce_finalize_launch(ws, p.nblk, 10 * (int64_t)C, sums, st);
     SEGF_CHECK_LAUNCH();
     hipLaunchKernelGGL(dw_scatter_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dw, db);
     SEGF_CHECK_LAUNCH();

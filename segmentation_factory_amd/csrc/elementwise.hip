@@ -132,7 +132,9 @@ extern "C" int segf_add(int dt, const void* a, int64_t lda, const void* b, int64
 // ---- column sum ----------------------------------------------------------------------------------------
 template <typename T> struct ColsumF {
     const T* x; int64_t ld; bool vec;
-    __device__ void operator()(int64_t r, int c0, int nv, float (&v)[1][8]) const { load8_guard<T>(x + r * ld + c0, nv, vec, v[0]); }
+    struct Col {};
+    __device__ void init(int, int, Col&) const {}
+    __device__ void operator()(const Col&, int64_t r, int c0, int nv, float (&v)[1][8]) const { load8_guard<T>(x + r * ld + c0, nv, vec, v[0]); }
 };
 
 extern "C" int64_t segf_colsum_ws(int64_t rows, int64_t cols) { return cr_ws_floats(rows, (int)cols, 1); }

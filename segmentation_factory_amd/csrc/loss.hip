@@ -3,27 +3,58 @@
 //              util/losses.py:126-177 (build_target / dice_coeff / multiclass_dice_coeff / dice_loss),
 //              engine.py:89-91 + util/utils.py:99-109 + util/metrics.py:24-27 (evaluate).
 // The reference materialises fp32 full-resolution logits, a softmax copy and a one-hot copy (3 x 157 MB per
-// 512^2 x 150-class image) and then loops over batch x class in Python.  Here one wave owns one full-resolution
-// pixel at a time with the classes spread over its 64 lanes (<= 3 classes per lane): the 4 low-resolution taps are
-// read as coalesced class rows, softmax statistics are two wave reductions, and the per-(image, class) Dice sums
-// I = sum p_c [t=c], P = sum p_c, T = sum [t=c] accumulate in lane registers.  Closed form:
+// 512^2 x 150-class image) and then loops over batch x class in Python.  Closed form:
 //   loss = CE + 1 - mean_{b,c} (2 I + eps) / (P + T + eps),   (P + T == 0  =>  denominator := 2 I)
-// Deterministic: per-block partials + fixed-order finalize, no atomics.
-#include "common.h"
+//   I = sum_valid p_c [t=c], P = sum_valid p_c, T = sum_valid [t=c]
+// Layout of the work: a wave owns one *cell* = the sc x sc full-resolution pixels that interpolate between the same
+// four low-resolution taps (sc = H/h, a power of two; align_corners=False puts cell (j,k) at Y in [sc*j+sc/2, sc*j+3sc/2)).
+// The classes are spread over the 64 lanes (<= 3 per lane); the four tap rows are read once per cell as coalesced
+// class rows, every pixel of the cell is interpolated in registers, softmax statistics are DPP wave reductions, and the
+// per-(image, class) Dice sums stay in lane registers.  Forward reads the low-res logits ~once plus the labels; the
+// backward recomputes the softmax per pixel and scatters d(logit) back onto the four taps through an LDS tile
+// (8x8 taps per workgroup, 9x9 cells incl. halo, four parity colours -> no atomics, bitwise reproducible), writing the
+// gradient of the LOW-resolution logits directly: no full-resolution tensor exists in either direction.
+// Non-power-of-two ratios fall back to the per-pixel kernels + segf_bilinear_bwd (still HIP).
+// Deterministic: per-block partials + fixed-order finalize, no float atomics.
+#include "colreduce.h"
 
-#define LS_NBLK 64          // blocks per image
+#define LS_NBLK 128         // workgroups per image in the forward / eval kernels
 #define LS_THREADS 256
 #define LS_EPS 1e-6f
+#define LS_TILE 8           // backward: low-res taps per workgroup tile edge
 
 struct LossGeom { int B, C, h, w, H, W; int64_t ldl; };
 
-// z[s] = upsampled logit of class lane + 64*s at full-res pixel (Y, X); invalid class slots get -inf
+static inline int pow2_scale(int h, int w, int H, int W) {
+    // sc >= 1 when H == sc*h, W == sc*w and sc is a power of two (exact source-index arithmetic); else 0
+    if (h <= 0 || w <= 0 || H % h || W % w) return 0;
+    const int sc = H / h;
+    if (W / w != sc || (sc & (sc - 1)) || sc > 8) return 0;   // sc*sc labels live one per lane
+    return sc;
+}
+
+// ---- per-lane class rows -------------------------------------------------------------------------------------
+template <typename T, int NS>
+__device__ __forceinline__ void load_tap(const T* __restrict__ p, int lane, int C, float (&t)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {     // unconditional loads from a clamped index: all taps of a cell stay in flight together
+        const int c = lane + 64 * s;
+        const float v = ldf<T>(p + (c < C ? c : C - 1));
+        t[s] = c < C ? v : 0.f;
+    }
+}
+
+// z[s] = upsampled logit of class lane + 64*s at full-res pixel (Y, X); invalid class slots get -inf  (generic path)
 template <typename T, int NS>
 __device__ __forceinline__ void pixel_logits(const T* __restrict__ img, const LossGeom& g, int Y, int X, int lane, float (&z)[NS]) {
     if (g.h == g.H && g.w == g.W) {
         const T* p = img + ((int64_t)Y * g.w + X) * g.ldl;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { const int c = lane + 64 * s; z[s] = c < g.C ? ldf<T>(p + c) : -INFINITY; }
+        for (int s = 0; s < NS; ++s) {
+            const int c = lane + 64 * s;
+            const float v = ldf<T>(p + (c < g.C ? c : g.C - 1));
+            z[s] = c < g.C ? v : -INFINITY;
+        }
         return;
     }
     int y0, y1, x0, x1; float ly, lx;
@@ -35,68 +66,76 @@ __device__ __forceinline__ void pixel_logits(const T* __restrict__ img, const Lo
     const T* p11 = img + ((int64_t)y1 * g.w + x1) * g.ldl;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int c = lane + 64 * s;
-        if (c < g.C) {
-            const float a = ldf<T>(p00 + c), b = ldf<T>(p01 + c), cc = ldf<T>(p10 + c), d = ldf<T>(p11 + c);
-            z[s] = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
-        } else z[s] = -INFINITY;
+        const int c = lane + 64 * s, ci = c < g.C ? c : g.C - 1;
+        const float a = ldf<T>(p00 + ci), b = ldf<T>(p01 + ci), cc = ldf<T>(p10 + ci), d = ldf<T>(p11 + ci);
+        const float v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+        z[s] = c < g.C ? v : -INFINITY;
     }
 }
 
-// softmax over the wave: p[s], returns log-sum-exp
+// softmax over the wave: p[s]; returns log-sum-exp (wave-uniform)
 template <int NS>
 __device__ __forceinline__ float wave_softmax(const float (&z)[NS], float (&p)[NS]) {
     float mx = z[0];
 #pragma unroll
     for (int s = 1; s < NS; ++s) mx = fmaxf(mx, z[s]);
-    mx = wave_max(mx);
+    mx = wave_max_all(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { p[s] = expf(z[s] - mx); sum += p[s]; }
-    sum = wave_sum(sum);
+    for (int s = 0; s < NS; ++s) { p[s] = __expf(z[s] - mx); sum += p[s]; }
+    sum = wave_sum_all(sum);
     const float inv = 1.f / sum;
 #pragma unroll
     for (int s = 0; s < NS; ++s) p[s] *= inv;
-    return mx + logf(sum);
+    return mx + __logf(sum);
 }
 
-// partial layout per (b, blk): [3][C] (I, P, T) then {ce_sum, w_sum, n_valid, bad}
+// A cell = the sc x sc full-res pixels between low-res taps (cj, ck) .. (cj+1, ck+1); cj in [-1, h-1] (taps clamp).
+struct Cell { int cj, ck, y0, y1, x0, x1; };
+__device__ __forceinline__ Cell make_cell(int cj, int ck, int h, int w, int halo) {
+    // halo == 0 (sc == 1, no resize): the cell is the pixel itself, all four taps coincide
+    Cell c; c.cj = cj; c.ck = ck;
+    c.y0 = cj < 0 ? 0 : cj; c.y1 = cj + halo > h - 1 ? h - 1 : cj + halo;
+    c.x0 = ck < 0 ? 0 : ck; c.x1 = ck + halo > w - 1 ? w - 1 : ck + halo;
+    return c;
+}
 template <typename T, int NS>
-__global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_kernel(const T* __restrict__ logits, LossGeom g,
-                                                                  const int64_t* __restrict__ target, int64_t ignore_index,
-                                                                  const float* __restrict__ cw, float* __restrict__ partial) {
-    __shared__ float red[4][3 * 64 * NS + 4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
-    const int64_t npix = (int64_t)g.H * g.W;
-    const int64_t nw = (int64_t)LS_NBLK * 4;
-    const int64_t per = (npix + nw - 1) / nw;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t p0 = wid * per, p1 = p0 + per < npix ? p0 + per : npix;
-    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
-    const int64_t* tg = target + (int64_t)b * npix;
-    float aI[NS], aP[NS], aT[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { aI[s] = 0.f; aP[s] = 0.f; aT[s] = 0.f; }
-    float ce = 0.f, wsum = 0.f, nvalid = 0.f, bad = 0.f;
-    for (int64_t p = p0; p < p1; ++p) {
-        const int64_t t = tg[p];
-        if (t == ignore_index) continue;                 // wave-uniform
-        if (t < 0 || t >= g.C) { bad = 1.f; continue; }  // the reference raises here (one_hot / cross_entropy)
-        const int Y = (int)(p / g.W), X = (int)(p - (int64_t)Y * g.W);
-        float z[NS], pr[NS];
-        pixel_logits<T, NS>(img, g, Y, X, lane, z);
-        const float lse = wave_softmax<NS>(z, pr);
-        const float wt = cw ? cw[t] : 1.f;
-        nvalid += 1.f; wsum += wt;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = lane + 64 * s;
-            aP[s] += pr[s];
-            if (c == (int)t) { aI[s] += pr[s]; aT[s] += 1.f; ce += wt * (lse - z[s]); }
+__device__ __forceinline__ void load_cell_taps(const T* __restrict__ img, const LossGeom& g, const Cell& c, int lane,
+                                               float (&t00)[NS], float (&t01)[NS], float (&t10)[NS], float (&t11)[NS]) {
+    load_tap<T, NS>(img + ((int64_t)c.y0 * g.w + c.x0) * g.ldl, lane, g.C, t00);
+    load_tap<T, NS>(img + ((int64_t)c.y0 * g.w + c.x1) * g.ldl, lane, g.C, t01);
+    load_tap<T, NS>(img + ((int64_t)c.y1 * g.w + c.x0) * g.ldl, lane, g.C, t10);
+    load_tap<T, NS>(img + ((int64_t)c.y1 * g.w + c.x1) * g.ldl, lane, g.C, t11);
+}
+// fractional weight of pixel coordinate d inside its cell (exact for power-of-two sc; matches bilinear_src)
+__device__ __forceinline__ float cell_frac(int d, int in, int out) {
+    int i0, i1; float l;
+    bilinear_src(d, in, out, 0, i0, i1, l);
+    return l;
+}
+
+// Labels of the cell's sc x sc pixels, one per lane (lane = a * sc + bb), fetched with a single vector load:
+// code = class index, or -1 (skip: outside the image or equal to `skip_label`), or -2 (out-of-range label).
+__device__ __forceinline__ int cell_label_codes(const int64_t* __restrict__ tg, const LossGeom& g, int sc, int off, int cj, int ck,
+                                                int lane, int64_t skip_label, int64_t* raw = nullptr) {
+    int code = -1;
+    if (lane < sc * sc) {
+        const int a = lane / sc, bb = lane - a * sc;
+        const int Y = sc * cj + off + a, X = sc * ck + off + bb;
+        if (Y >= 0 && Y < g.H && X >= 0 && X < g.W) {
+            const int64_t t = tg[(int64_t)Y * g.W + X];
+            if (raw) *raw = t;
+            code = t == skip_label ? -1 : ((t < 0 || t >= g.C) ? -2 : (int)t);
         }
     }
-    ce = wave_sum(ce);
+    return code;
+}
+
+// ---- forward: partial[blk][b][3C+4] = {I[C], P[C], T[C], ce_sum, w_sum, n_valid, bad} -------------------------------
+template <int NS>
+__device__ __forceinline__ void fwd_block_tail(float (&aI)[NS], float (&aP)[NS], float (&aT)[NS], float ce, float wsum,
+                                               float nvalid, float bad, int lane, int wave, int C, float* __restrict__ dst) {
+    __shared__ float red[4][3 * 64 * NS + 4];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         red[wave][0 * 64 * NS + 64 * s + lane] = aI[s];
@@ -108,32 +147,121 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_kernel(const T* __rest
         red[wave][3 * 64 * NS + 2] = nvalid; red[wave][3 * 64 * NS + 3] = bad;
     }
     __syncthreads();
-    float* dst = partial + ((int64_t)b * LS_NBLK + blockIdx.x) * (3 * g.C + 4);
     for (int i = threadIdx.x; i < 3 * 64 * NS + 4; i += LS_THREADS) {
-        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-        if (i >= 3 * 64 * NS) dst[3 * g.C + (i - 3 * 64 * NS)] = v;
+        const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        if (i >= 3 * 64 * NS) dst[3 * C + (i - 3 * 64 * NS)] = v;
         else {
             const int which = i / (64 * NS), c = i - which * 64 * NS;
-            if (c < g.C) dst[which * g.C + c] = v;
+            if (c < C) dst[which * C + c] = v;
         }
     }
 }
 
-// one block: partials -> stats[B][C][3] + tail[4], loss[3]
-__global__ void __launch_bounds__(256) ce_dice_finalize_kernel(const float* __restrict__ partial, int B, int C, int dice,
-                                                                float* __restrict__ stats, float* __restrict__ loss) {
+template <typename T, int NS>
+__global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_cells_kernel(const T* __restrict__ logits, LossGeom g, int sc,
+                                                                        const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                        const float* __restrict__ cw, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int halo = sc > 1 ? 1 : 0, off = sc >> 1;
+    const int ncx = g.w + halo, ncell = (g.h + halo) * ncx;
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * g.H * g.W;
+    float aI[NS], aP[NS], aT[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { aI[s] = 0.f; aP[s] = 0.f; aT[s] = 0.f; }
+    float ce = 0.f, wsum = 0.f, nvalid = 0.f, bad = 0.f;
+    for (int cell = blockIdx.x * 4 + wave; cell < ncell; cell += gridDim.x * 4) {
+        const Cell c = make_cell(cell / ncx - halo, cell % ncx - halo, g.h, g.w, halo);
+        float t00[NS], t01[NS], t10[NS], t11[NS];
+        load_cell_taps<T, NS>(img, g, c, lane, t00, t01, t10, t11);
+        const int codes = cell_label_codes(tg, g, sc, off, c.cj, c.ck, lane, ignore_index);
+        for (int a = 0; a < sc; ++a) {
+            const int Y = sc * c.cj + off + a;
+            if (Y < 0 || Y >= g.H) continue;
+            const float ly = cell_frac(Y, g.h, g.H);
+            float L[NS], R[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                L[s] = (1.f - ly) * t00[s] + ly * t10[s];
+                R[s] = (1.f - ly) * t01[s] + ly * t11[s];
+            }
+            for (int bb = 0; bb < sc; ++bb) {
+                const int t = __builtin_amdgcn_readlane(codes, a * sc + bb);     // wave-uniform
+                if (t == -1) continue;                           // ignored / outside
+                if (t == -2) { bad = 1.f; continue; }            // the reference raises here (one_hot / cross_entropy)
+                const int X = sc * c.ck + off + bb;
+                const float lx = cell_frac(X, g.w, g.W);
+                float z[NS], pr[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) z[s] = (lane + 64 * s) < g.C ? (1.f - lx) * L[s] + lx * R[s] : -INFINITY;
+                const float lse = wave_softmax<NS>(z, pr);
+                const float wt = cw ? cw[t] : 1.f;
+                nvalid += 1.f; wsum += wt;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    aP[s] += pr[s];
+                    if (lane + 64 * s == t) { aI[s] += pr[s]; aT[s] += 1.f; ce += wt * (lse - z[s]); }
+                }
+            }
+        }
+    }
+    ce = wave_sum_all(ce);
+    fwd_block_tail<NS>(aI, aP, aT, ce, wsum, nvalid, bad, lane, wave, g.C,
+                       partial + ((int64_t)blockIdx.x * g.B + b) * (3 * g.C + 4));
+}
+
+// generic ratio: one wave per full-res pixel at a time
+template <typename T, int NS>
+__global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_kernel(const T* __restrict__ logits, LossGeom g,
+                                                                  const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                  const float* __restrict__ cw, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int64_t npix = (int64_t)g.H * g.W;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const int64_t per = (npix + nw - 1) / nw;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t p0 = wid * per, p1 = p0 + per < npix ? p0 + per : npix;
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * npix;
+    float aI[NS], aP[NS], aT[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { aI[s] = 0.f; aP[s] = 0.f; aT[s] = 0.f; }
+    float ce = 0.f, wsum = 0.f, nvalid = 0.f, bad = 0.f;
+    for (int64_t p = p0; p < p1; ++p) {
+        const int64_t t = tg[p];
+        if (t == ignore_index) continue;
+        if (t < 0 || t >= g.C) { bad = 1.f; continue; }
+        const int Y = (int)(p / g.W), X = (int)(p - (int64_t)Y * g.W);
+        float z[NS], pr[NS];
+        pixel_logits<T, NS>(img, g, Y, X, lane, z);
+        const float lse = wave_softmax<NS>(z, pr);
+        const float wt = cw ? cw[t] : 1.f;
+        nvalid += 1.f; wsum += wt;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            aP[s] += pr[s];
+            if (lane + 64 * s == (int)t) { aI[s] += pr[s]; aT[s] += 1.f; ce += wt * (lse - z[s]); }
+        }
+    }
+    ce = wave_sum_all(ce);
+    fwd_block_tail<NS>(aI, aP, aT, ce, wsum, nvalid, bad, lane, wave, g.C,
+                       partial + ((int64_t)blockIdx.x * g.B + b) * (3 * g.C + 4));
+}
+
+// stats[b][3C+4] (already summed over blocks) -> stats tail[4] at stats[B*(3C+4)], loss[3] = {total, ce, dice_loss}
+__global__ void __launch_bounds__(256) ce_dice_loss_kernel(float* __restrict__ stats, int B, int C, int dice, float* __restrict__ loss) {
     __shared__ float red[256];
     __shared__ float tail[4];
     const int stride = 3 * C + 4;
     float dsum = 0.f;
     for (int i = threadIdx.x; i < B * C; i += 256) {
         const int b = i / C, c = i - b * C;
-        float I = 0.f, P = 0.f, T = 0.f;
-        for (int k = 0; k < LS_NBLK; ++k) {
-            const float* src = partial + ((int64_t)b * LS_NBLK + k) * stride;
-            I += src[c]; P += src[C + c]; T += src[2 * C + c];
-        }
-        stats[(int64_t)i * 3 + 0] = I; stats[(int64_t)i * 3 + 1] = P; stats[(int64_t)i * 3 + 2] = T;
+        const float* st = stats + (int64_t)b * stride;
+        const float I = st[c], P = st[C + c], T = st[2 * C + c];
         float sets = P + T;
         if (sets == 0.f) sets = 2.f * I;
         dsum += (2.f * I + LS_EPS) / (sets + LS_EPS);
@@ -141,7 +269,7 @@ __global__ void __launch_bounds__(256) ce_dice_finalize_kernel(const float* __re
     red[threadIdx.x] = dsum;
     if (threadIdx.x < 4) {
         float s = 0.f;
-        for (int k = 0; k < B * LS_NBLK; ++k) s += partial[(int64_t)k * stride + 3 * C + threadIdx.x];
+        for (int b = 0; b < B; ++b) s += stats[(int64_t)b * stride + 3 * C + threadIdx.x];
         tail[threadIdx.x] = s;
     }
     __syncthreads();
@@ -150,7 +278,7 @@ __global__ void __launch_bounds__(256) ce_dice_finalize_kernel(const float* __re
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        float* st = stats + (int64_t)B * C * 3;
+        float* st = stats + (int64_t)B * stride;
         st[0] = tail[0]; st[1] = tail[1]; st[2] = tail[2]; st[3] = tail[3];
         const float ce = tail[0] / tail[1];                        // 0/0 = NaN like F.cross_entropy on an all-ignored batch
         const float dl = dice ? 1.f - red[0] / (float)(B * C) : 0.f;
@@ -158,34 +286,155 @@ __global__ void __launch_bounds__(256) ce_dice_finalize_kernel(const float* __re
     }
 }
 
+// ---- backward ----------------------------------------------------------------------------------------------------
+// d loss / d I and d loss / d P of the Dice term for this lane's classes
+template <int NS>
+__device__ __forceinline__ void dice_coefs(const float* __restrict__ stats, int b, int B, int C, int dice, int lane,
+                                           float (&gI)[NS], float (&gP)[NS]) {
+    const float* st = stats + (int64_t)b * (3 * C + 4);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = lane + 64 * s;
+        float a = 0.f, bb = 0.f;
+        if (c < C && dice) {
+            const float I = st[c], P = st[C + c], Tt = st[2 * C + c];
+            const float sets = P + Tt;
+            if (sets != 0.f) {   // sets == 0: d = (2I+eps)/(2I+eps) == 1 -> zero gradient
+                const float nbc = 1.f / (float)(B * C);
+                a = -nbc * 2.f / (sets + LS_EPS);
+                bb = nbc * (2.f * I + LS_EPS) / ((sets + LS_EPS) * (sets + LS_EPS));
+            }
+        }
+        gI[s] = a; gP[s] = bb;
+    }
+}
+// dz[s] = go * d loss / d z_c for one valid pixel with label t
+template <int NS>
+__device__ __forceinline__ void pixel_grad(const float (&z)[NS], int t, int lane, const float (&gI)[NS], const float (&gP)[NS],
+                                           float wce, float go, float (&dz)[NS]) {
+    float pr[NS], G[NS];
+    wave_softmax<NS>(z, pr);
+    float dot = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        G[s] = gP[s] + (lane + 64 * s == t ? gI[s] : 0.f);
+        dot += G[s] * pr[s];
+    }
+    dot = wave_sum_all(dot);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        dz[s] = go * (pr[s] * (G[s] - dot) + wce * (pr[s] - (lane + 64 * s == t ? 1.f : 0.f)));
+}
+
+// Workgroup = LS_TILE x LS_TILE low-res taps of one image; it evaluates the (LS_TILE+1)^2 cells that touch them.
+template <typename T, int NS>
+__global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_cells_kernel(const T* __restrict__ logits, LossGeom g, int sc,
+                                                                        const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                        const float* __restrict__ cw, int dice,
+                                                                        const float* __restrict__ stats,
+                                                                        const float* __restrict__ grad_out, T* __restrict__ dlow,
+                                                                        int64_t ldd) {
+    __shared__ float accum[LS_TILE * LS_TILE][64 * NS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int tiles_x = (g.w + LS_TILE - 1) / LS_TILE;
+    const int ty0 = (blockIdx.x / tiles_x) * LS_TILE, tx0 = (blockIdx.x % tiles_x) * LS_TILE;
+    const int halo = sc > 1 ? 1 : 0, off = sc >> 1;
+    for (int i = threadIdx.x; i < LS_TILE * LS_TILE * 64 * NS; i += LS_THREADS) (&accum[0][0])[i] = 0.f;
+    float gI[NS], gP[NS];
+    dice_coefs<NS>(stats, b, g.B, g.C, dice, lane, gI, gP);
+    const float go = grad_out ? grad_out[0] : 1.f;
+    const float invW = 1.f / stats[(int64_t)g.B * (3 * g.C + 4) + 1];
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * g.H * g.W;
+    __syncthreads();
+    const int ncl = LS_TILE + halo;            // local cells per edge: lj in [0, ncl), cj = ty0 - halo + lj
+    const int ncol = halo ? 4 : 1;             // parity colours (no two cells of one colour share a tap)
+    for (int col = 0; col < ncol; ++col) {
+        const int pj = col >> 1, pk = col & 1;
+        const int nj = halo ? (ncl - pj + 1) / 2 : ncl, nk = halo ? (ncl - pk + 1) / 2 : ncl;
+        for (int idx = wave; idx < nj * nk; idx += 4) {
+            const int lj = halo ? 2 * (idx / nk) + pj : idx / nk, lk = halo ? 2 * (idx % nk) + pk : idx % nk;
+            const int cj = ty0 - halo + lj, ck = tx0 - halo + lk;
+            if (cj > g.h - 1 || ck > g.w - 1) continue;
+            const Cell c = make_cell(cj, ck, g.h, g.w, halo);
+            float t00[NS], t01[NS], t10[NS], t11[NS], A00[NS], A01[NS], A10[NS], A11[NS];
+            load_cell_taps<T, NS>(img, g, c, lane, t00, t01, t10, t11);
+            int codes = cell_label_codes(tg, g, sc, off, cj, ck, lane, ignore_index);
+            if (codes == -2) codes = -1;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { A00[s] = 0.f; A01[s] = 0.f; A10[s] = 0.f; A11[s] = 0.f; }
+            for (int a = 0; a < sc; ++a) {
+                const int Y = sc * cj + off + a;
+                if (Y < 0 || Y >= g.H) continue;
+                const float ly = cell_frac(Y, g.h, g.H);
+                float L[NS], R[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    L[s] = (1.f - ly) * t00[s] + ly * t10[s];
+                    R[s] = (1.f - ly) * t01[s] + ly * t11[s];
+                }
+                for (int bb = 0; bb < sc; ++bb) {
+                    const int t = __builtin_amdgcn_readlane(codes, a * sc + bb);     // wave-uniform
+                    if (t < 0) continue;
+                    const int X = sc * ck + off + bb;
+                    const float lx = cell_frac(X, g.w, g.W);
+                    float z[NS], dz[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) z[s] = (lane + 64 * s) < g.C ? (1.f - lx) * L[s] + lx * R[s] : -INFINITY;
+                    pixel_grad<NS>(z, t, lane, gI, gP, (cw ? cw[t] : 1.f) * invW, go, dz);
+                    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        A00[s] = fmaf(w00, dz[s], A00[s]); A01[s] = fmaf(w01, dz[s], A01[s]);
+                        A10[s] = fmaf(w10, dz[s], A10[s]); A11[s] = fmaf(w11, dz[s], A11[s]);
+                    }
+                }
+            }
+            // taps of this cell that belong to the tile (the others are recomputed by the neighbouring workgroups)
+            const int ly0 = c.y0 - ty0, ly1 = c.y1 - ty0, lx0 = c.x0 - tx0, lx1 = c.x1 - tx0;
+            const bool vy0 = ly0 >= 0 && ly0 < LS_TILE, vy1 = ly1 >= 0 && ly1 < LS_TILE;
+            const bool vx0 = lx0 >= 0 && lx0 < LS_TILE, vx1 = lx1 >= 0 && lx1 < LS_TILE;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int cc = lane + 64 * s;
+                if (vy0 && vx0) accum[ly0 * LS_TILE + lx0][cc] += A00[s];
+                if (vy0 && vx1) accum[ly0 * LS_TILE + lx1][cc] += A01[s];
+                if (vy1 && vx0) accum[ly1 * LS_TILE + lx0][cc] += A10[s];
+                if (vy1 && vx1) accum[ly1 * LS_TILE + lx1][cc] += A11[s];
+            }
+        }
+        __syncthreads();
+    }
+    for (int tap = wave; tap < LS_TILE * LS_TILE; tap += 4) {
+        const int y = ty0 + tap / LS_TILE, x = tx0 + tap % LS_TILE;
+        if (y >= g.h || x >= g.w) continue;
+        T* drow = dlow + (((int64_t)b * g.h + y) * g.w + x) * ldd;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cc = lane + 64 * s;
+            if (cc < ldd) stf<T>(drow + cc, cc < g.C ? accum[tap][cc] : 0.f);
+        }
+    }
+}
+
+// generic ratio: full-resolution gradient, one wave per pixel at a time; segf_bilinear_bwd follows
 template <typename T, int NS>
 __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_kernel(const T* __restrict__ logits, LossGeom g,
                                                                   const int64_t* __restrict__ target, int64_t ignore_index,
                                                                   const float* __restrict__ cw, int dice,
                                                                   const float* __restrict__ stats, const float* __restrict__ grad_out,
                                                                   T* __restrict__ dfull, int64_t ldg) {
-    __shared__ float gI[64 * NS], gP[64 * NS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
+    float gI[NS], gP[NS];
+    dice_coefs<NS>(stats, b, g.B, g.C, dice, lane, gI, gP);
     const float go = grad_out ? grad_out[0] : 1.f;
-    const float invW = 1.f / stats[(int64_t)g.B * g.C * 3 + 1];
-    for (int c = threadIdx.x; c < 64 * NS; c += LS_THREADS) {
-        float a = 0.f, bb = 0.f;
-        if (c < g.C && dice) {
-            const float* st = stats + ((int64_t)b * g.C + c) * 3;
-            const float I = st[0], P = st[1], Tt = st[2];
-            const float sets = P + Tt;
-            if (sets != 0.f) {   // sets == 0: d = (2I+eps)/(2I+eps) == 1 -> zero gradient
-                const float nbc = 1.f / (float)(g.B * g.C);
-                a = -nbc * 2.f / (sets + LS_EPS);                                   // d loss / d I
-                bb = nbc * (2.f * I + LS_EPS) / ((sets + LS_EPS) * (sets + LS_EPS));  // d loss / d P
-            }
-        }
-        gI[c] = a; gP[c] = bb;
-    }
-    __syncthreads();
+    const float invW = 1.f / stats[(int64_t)g.B * (3 * g.C + 4) + 1];
     const int64_t npix = (int64_t)g.H * g.W;
-    const int64_t nw = (int64_t)LS_NBLK * 4;
+    const int64_t nw = (int64_t)gridDim.x * 4;
     const int64_t per = (npix + nw - 1) / nw;
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const int64_t p0 = wid * per, p1 = p0 + per < npix ? p0 + per : npix;
@@ -195,55 +444,57 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_kernel(const T* __rest
     for (int64_t p = p0; p < p1; ++p) {
         const int64_t t = tg[p];
         T* drow = dimg + p * ldg;
+        float z[NS], dz[NS];
         if (t == ignore_index || t < 0 || t >= g.C) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) { const int c = lane + 64 * s; if (c < g.C) stf<T>(drow + c, 0.f); }
-            continue;
+            for (int s = 0; s < NS; ++s) dz[s] = 0.f;
+        } else {
+            const int Y = (int)(p / g.W), X = (int)(p - (int64_t)Y * g.W);
+            pixel_logits<T, NS>(img, g, Y, X, lane, z);
+            pixel_grad<NS>(z, (int)t, lane, gI, gP, (cw ? cw[t] : 1.f) * invW, go, dz);
         }
-        const int Y = (int)(p / g.W), X = (int)(p - (int64_t)Y * g.W);
-        float z[NS], pr[NS], G[NS];
-        pixel_logits<T, NS>(img, g, Y, X, lane, z);
-        wave_softmax<NS>(z, pr);
-        float dot = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int c = lane + 64 * s;
-            G[s] = gP[64 * s + lane] + (c == (int)t ? gI[64 * s + lane] : 0.f);
-            dot += G[s] * pr[s];
-        }
-        dot = wave_sum(dot);
-        const float wce = (cw ? cw[t] : 1.f) * invW;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = lane + 64 * s;
-            if (c < g.C) {
-                const float dz = pr[s] * (G[s] - dot) + wce * (pr[s] - (c == (int)t ? 1.f : 0.f));
-                stf<T>(drow + c, go * dz);
-            }
+            if (c < ldg) stf<T>(drow + c, c < g.C ? dz[s] : 0.f);
         }
     }
 }
 
 extern "C" int64_t segf_ce_dice_stats_floats(int B, int C) {
-    return (int64_t)B * C * 3 + 4 + (int64_t)B * LS_NBLK * (3 * C + 4);
+    return (int64_t)B * (3 * C + 4) + 4 + (int64_t)LS_NBLK * B * (3 * C + 4);
 }
 
+#define LS_NS_DISPATCH(ns, CALL) do { if ((ns) == 1) { CALL(1); } else if ((ns) == 2) { CALL(2); } else { CALL(3); } } while (0)
+
 template <typename T>
-static int ce_dice_fwd_launch(int ns, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
-                              int64_t ignore_index, const float* cw, float* partial) {
-    if (ns == 1) hipLaunchKernelGGL((ce_dice_fwd_kernel<T, 1>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, partial);
-    else if (ns == 2) hipLaunchKernelGGL((ce_dice_fwd_kernel<T, 2>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, partial);
-    else hipLaunchKernelGGL((ce_dice_fwd_kernel<T, 3>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, partial);
-    return 0;
+static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
+                       int64_t ignore_index, const float* cw, float* partial) {
+#define CALL(NS)                                                                                                                \
+    do {                                                                                                                        \
+        if (sc) hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,     \
+                                   ignore_index, cw, partial);                                                                  \
+        else hipLaunchKernelGGL((ce_dice_fwd_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index,    \
+                                cw, partial);                                                                                   \
+    } while (0)
+    LS_NS_DISPATCH(ns, CALL);
+#undef CALL
 }
 template <typename T>
-static int ce_dice_bwd_launch(int ns, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
-                              int64_t ignore_index, const float* cw, int dice, const float* stats, const float* grad_out,
-                              T* dfull, int64_t ldg) {
-    if (ns == 1) hipLaunchKernelGGL((ce_dice_bwd_kernel<T, 1>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, dice, stats, grad_out, dfull, ldg);
-    else if (ns == 2) hipLaunchKernelGGL((ce_dice_bwd_kernel<T, 2>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, dice, stats, grad_out, dfull, ldg);
-    else hipLaunchKernelGGL((ce_dice_bwd_kernel<T, 3>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, dice, stats, grad_out, dfull, ldg);
-    return 0;
+static void bwd_cells_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
+                             int64_t ignore_index, const float* cw, int dice, const float* stats, const float* grad_out,
+                             T* dlow, int64_t ldd) {
+#define CALL(NS) hipLaunchKernelGGL((ce_dice_bwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target, ignore_index, cw, dice, stats, grad_out, dlow, ldd)
+    LS_NS_DISPATCH(ns, CALL);
+#undef CALL
+}
+template <typename T>
+static void bwd_generic_launch(int ns, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
+                               int64_t ignore_index, const float* cw, int dice, const float* stats, const float* grad_out,
+                               T* dfull, int64_t ldg) {
+#define CALL(NS) hipLaunchKernelGGL((ce_dice_bwd_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, dice, stats, grad_out, dfull, ldg)
+    LS_NS_DISPATCH(ns, CALL);
+#undef CALL
 }
 
 extern "C" int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
@@ -252,40 +503,148 @@ extern "C" int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W
     if (B <= 0 || C <= 0 || C > 192 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || ldl < C || B > 65535) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     LossGeom g{B, C, h, w, H, W, ldl};
-    float* partial = stats + (int64_t)B * C * 3 + 4;
+    float* partial = stats + (int64_t)B * (3 * C + 4) + 4;
     const int ns = (C + 63) / 64;
-    SEGF_DISPATCH_DT(dt, T, { ce_dice_fwd_launch<T>(ns, dim3(LS_NBLK, B), st, (const T*)logits, g, target, ignore_index, class_weight, partial); })
+    const int sc = pow2_scale(h, w, H, W);
+    const dim3 grid(LS_NBLK, B);
+    SEGF_DISPATCH_DT(dt, T, { fwd_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, partial); })
     SEGF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ce_dice_finalize_kernel, dim3(1), dim3(256), 0, st, partial, B, C, dice, stats, loss);
+    colreduce_finalize_launch(partial, LS_NBLK, (int64_t)B * (3 * C + 4), stats, st);
+    SEGF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_dice_loss_kernel, dim3(1), dim3(256), 0, st, stats, B, C, dice, loss);
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+
+// workspace (floats) of segf_ce_dice_bwd: 0 on the fused path, the full-resolution gradient on the generic path
+extern "C" int64_t segf_ce_dice_bwd_ws(int dt, int B, int C, int h, int w, int H, int W) {
+    if (pow2_scale(h, w, H, W)) return 0;
+    const int64_t ldg = (C + 7) / 8 * 8;
+    const int64_t bytes = (int64_t)B * H * W * ldg * (dt == SEGF_BF16 ? 2 : 4);
+    return (bytes + 3) / 4;
+}
+
+extern "C" int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, int64_t ldi, int H, int W, const void* dout,
+                                 int64_t ldo, int align_corners, void* stream);
 
 extern "C" int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
                                 const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
-                                const float* stats, const float* grad_out, void* dlogits_full, int64_t ldg, void* stream) {
-    if (B <= 0 || C <= 0 || C > 192 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || ldl < C || ldg < C || B > 65535) return SEGF_ERR_SHAPE;
+                                const float* stats, const float* grad_out, void* dlogits, int64_t ldd, float* ws, void* stream) {
+    if (B <= 0 || C <= 0 || C > 192 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || ldl < C || ldd < C || B > 65535) return SEGF_ERR_SHAPE;
+    if (ldd > 64 * ((C + 63) / 64)) return SEGF_ERR_SHAPE;     // pad columns are zero-filled by the class lanes
     hipStream_t st = (hipStream_t)stream;
     LossGeom g{B, C, h, w, H, W, ldl};
     const int ns = (C + 63) / 64;
-    SEGF_DISPATCH_DT(dt, T, {
-        ce_dice_bwd_launch<T>(ns, dim3(LS_NBLK, B), st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)dlogits_full, ldg);
-    })
+    const int sc = pow2_scale(h, w, H, W);
+    if (sc) {
+        const dim3 grid(((h + LS_TILE - 1) / LS_TILE) * ((w + LS_TILE - 1) / LS_TILE), B);
+        SEGF_DISPATCH_DT(dt, T, { bwd_cells_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)dlogits, ldd); })
+        SEGF_CHECK_LAUNCH();
+        return 0;
+    }
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    const int64_t ldg = (C + 7) / 8 * 8;
+    SEGF_DISPATCH_DT(dt, T, { bwd_generic_launch<T>(ns, dim3(LS_NBLK, B), st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)ws, ldg); })
     SEGF_CHECK_LAUNCH();
-    return 0;
+    if (ldd > C) {
+        const hipError_t e = hipMemsetAsync(dlogits, 0, (size_t)B * h * w * ldd * (dt == SEGF_BF16 ? 2 : 4), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return segf_bilinear_bwd(dt, B, h, w, C, dlogits, ldd, H, W, ws, ldg, 0, stream);
 }
 
 // ---- fused upsample + argmax + confusion matrix ----------------------------------------------------------------
+// prediction = lowest class index attaining the maximum (torch.argmax); indices < 192 are exact in fp32
+template <int NS>
+__device__ __forceinline__ int wave_argmax(const float (&z)[NS], int lane, int C) {
+    float mx = z[0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) mx = fmaxf(mx, z[s]);
+    mx = wave_max_all(mx);
+    float best = 1e9f;
+#pragma unroll
+    for (int s = NS - 1; s >= 0; --s) if (z[s] == mx) best = (float)(lane + 64 * s);
+    best = wave_min_all(best);
+    const int bi = (int)best;
+    return bi < C ? bi : 0;        // all-NaN row
+}
+__device__ __forceinline__ void confmat_count(int64_t t, int pred, int C, int64_t ignore_label, unsigned long long* mat,
+                                              unsigned long long* hist, int* flag) {
+    const bool in_mat = t >= 0 && t < C;
+    if (in_mat) atomicAdd(mat + t * C + pred, 1ull);
+    if (t != ignore_label) {
+        if (in_mat) atomicAdd(hist + t * C + pred, 1ull);
+        else atomicOr(flag, 1);    // label >= n that is not ignore_label: the reference's bincount shape check fails
+    }
+}
+
+template <typename T, int NS>
+__global__ void __launch_bounds__(LS_THREADS) argmax_confmat_cells_kernel(const T* __restrict__ logits, LossGeom g, int sc,
+                                                                           const int64_t* __restrict__ target, int64_t ignore_label,
+                                                                           unsigned long long* __restrict__ mat,
+                                                                           unsigned long long* __restrict__ hist, int* __restrict__ flag,
+                                                                           int64_t* __restrict__ pred_out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int halo = sc > 1 ? 1 : 0, off = sc >> 1;
+    const int ncx = g.w + halo, ncell = (g.h + halo) * ncx;
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t npix = (int64_t)g.H * g.W;
+    const int64_t* tg = target + (int64_t)b * npix;
+    for (int cell = blockIdx.x * 4 + wave; cell < ncell; cell += gridDim.x * 4) {
+        const Cell c = make_cell(cell / ncx - halo, cell % ncx - halo, g.h, g.w, halo);
+        float t00[NS], t01[NS], t10[NS], t11[NS];
+        // code -3 = inside the image but counted nowhere (label == ignore_label and outside [0, C)); the raw label
+        // stays in its lane for the counting step
+        int64_t raw = -1;
+        load_cell_taps<T, NS>(img, g, c, lane, t00, t01, t10, t11);
+        int codes = cell_label_codes(tg, g, sc, off, c.cj, c.ck, lane, INT64_MIN, &raw);
+        if (codes == -2 && raw == ignore_label) codes = -3;
+        int preds = 0;
+        for (int a = 0; a < sc; ++a) {
+            const int Y = sc * c.cj + off + a;
+            if (Y < 0 || Y >= g.H) continue;
+            const float ly = cell_frac(Y, g.h, g.H);
+            float L[NS], R[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                L[s] = (1.f - ly) * t00[s] + ly * t10[s];
+                R[s] = (1.f - ly) * t01[s] + ly * t11[s];
+            }
+            for (int bb = 0; bb < sc; ++bb) {
+                const int t = __builtin_amdgcn_readlane(codes, a * sc + bb);     // wave-uniform
+                if (t == -1 || (t == -3 && !pred_out)) continue;
+                const int X = sc * c.ck + off + bb;
+                const float lx = cell_frac(X, g.w, g.W);
+                float z[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) z[s] = (lane + 64 * s) < g.C ? (1.f - lx) * L[s] + lx * R[s] : -INFINITY;
+                const int best = wave_argmax<NS>(z, lane, g.C);
+                if (lane == a * sc + bb) preds = best;
+            }
+        }
+        // every pixel's lane counts its own (label, prediction) pair: sc*sc atomics issued together
+        if (codes != -1 && (codes != -3 || pred_out)) {
+            const int a = lane / sc, bb = lane - a * sc;
+            const int Y = sc * c.cj + off + a, X = sc * c.ck + off + bb;
+            if (pred_out) pred_out[(int64_t)b * npix + (int64_t)Y * g.W + X] = preds;
+            if (codes != -3) confmat_count(raw, preds, g.C, ignore_label, mat, hist, flag);
+        }
+    }
+}
+
 template <typename T, int NS>
 __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_kernel(const T* __restrict__ logits, LossGeom g,
                                                                      const int64_t* __restrict__ target, int64_t ignore_label,
                                                                      unsigned long long* __restrict__ mat,
                                                                      unsigned long long* __restrict__ hist, int* __restrict__ flag,
                                                                      int64_t* __restrict__ pred_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int64_t npix = (int64_t)g.H * g.W;
-    const int64_t nw = (int64_t)LS_NBLK * 4;
+    const int64_t nw = (int64_t)gridDim.x * 4;
     const int64_t per = (npix + nw - 1) / nw;
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     const int64_t p0 = wid * per, p1 = p0 + per < npix ? p0 + per : npix;
@@ -293,39 +652,30 @@ __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_kernel(const T* __r
     const int64_t* tg = target + (int64_t)b * npix;
     for (int64_t p = p0; p < p1; ++p) {
         const int64_t t = tg[p];
-        const bool in_mat = t >= 0 && t < g.C;
-        const bool in_hist = t != ignore_label;
-        if (!pred_out && !in_mat && !in_hist) continue;
+        if (!pred_out && !(t >= 0 && t < g.C) && t == ignore_label) continue;
         const int Y = (int)(p / g.W), X = (int)(p - (int64_t)Y * g.W);
         float z[NS];
         pixel_logits<T, NS>(img, g, Y, X, lane, z);
-        float mx = z[0];
-#pragma unroll
-        for (int s = 1; s < NS; ++s) mx = fmaxf(mx, z[s]);
-        mx = wave_max(mx);
-        int best = 0x7fffffff;                 // first (lowest) index attaining the maximum, like torch.argmax
-#pragma unroll
-        for (int s = NS - 1; s >= 0; --s) if (z[s] == mx) best = lane + 64 * s;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(best, o, 64); best = other < best ? other : best; }
+        const int best = wave_argmax<NS>(z, lane, g.C);
         if (lane == 0) {
-            if (best >= g.C) best = 0;         // all-NaN row
             if (pred_out) pred_out[(int64_t)b * npix + p] = best;
-            if (in_mat) atomicAdd(mat + t * g.C + best, 1ull);
-            if (in_hist) {
-                if (in_mat) atomicAdd(hist + t * g.C + best, 1ull);
-                else atomicOr(flag, 1);        // label >= n that is not ignore_label: the reference's bincount shape check fails
-            }
+            confmat_count(t, best, g.C, ignore_label, mat, hist, flag);
         }
     }
 }
 
 template <typename T>
-static void argmax_launch(int ns, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target, int64_t ign,
-                          unsigned long long* mat, unsigned long long* hist, int* flag, int64_t* pred_out) {
-    if (ns == 1) hipLaunchKernelGGL((argmax_confmat_kernel<T, 1>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ign, mat, hist, flag, pred_out);
-    else if (ns == 2) hipLaunchKernelGGL((argmax_confmat_kernel<T, 2>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ign, mat, hist, flag, pred_out);
-    else hipLaunchKernelGGL((argmax_confmat_kernel<T, 3>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ign, mat, hist, flag, pred_out);
+static void argmax_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
+                          int64_t ign, unsigned long long* mat, unsigned long long* hist, int* flag, int64_t* pred_out) {
+#define CALL(NS)                                                                                                                \
+    do {                                                                                                                        \
+        if (sc) hipLaunchKernelGGL((argmax_confmat_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,  \
+                                   ign, mat, hist, flag, pred_out);                                                             \
+        else hipLaunchKernelGGL((argmax_confmat_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ign, mat,     \
+                                hist, flag, pred_out);                                                                          \
+    } while (0)
+    LS_NS_DISPATCH(ns, CALL);
+#undef CALL
 }
 
 extern "C" int segf_argmax_confmat(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
@@ -335,10 +685,11 @@ extern "C" int segf_argmax_confmat(int dt, int B, int C, int h, int w, int H, in
     hipStream_t st = (hipStream_t)stream;
     LossGeom g{B, C, h, w, H, W, ldl};
     const int ns = (C + 63) / 64;
-    SEGF_DISPATCH_DT(dt, T, {
-        argmax_launch<T>(ns, dim3(LS_NBLK, B), st, (const T*)logits, g, target, ignore_label, (unsigned long long*)mat,
-                         (unsigned long long*)hist, (int*)flag, pred_out);
-    })
+    const int sc = pow2_scale(h, w, H, W);
+    const dim3 grid(LS_NBLK, B);
+    unsigned long long* m = (unsigned long long*)mat;
+    unsigned long long* hs = (unsigned long long*)hist;
+    SEGF_DISPATCH_DT(dt, T, { argmax_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_label, m, hs, (int*)flag, pred_out); })
     SEGF_CHECK_LAUNCH();
     return 0;
 }

@@ -228,7 +228,7 @@ extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, co
     SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2); })
     SEGF_CHECK_LAUNCH();
     const int64_t n = 2 * (int64_t)C;
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, ws, blocks, n, dgamma);
+    colreduce_finalize_launch(ws, blocks, n, dgamma, st);
     SEGF_CHECK_LAUNCH();
     return 0;
 }
@@ -236,7 +236,9 @@ extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, co
 // ---- BatchNorm on NHWC rows ---------------------------------------------------------------------------------
 template <typename T> struct BnStatF {
     const T* x; int C; bool vec;
-    __device__ void operator()(int64_t r, int c0, int nv, float (&v)[2][8]) const {
+    struct Col {};
+    __device__ void init(int, int, Col&) const {}
+    __device__ void operator()(const Col&, int64_t r, int c0, int nv, float (&v)[2][8]) const {
         load8_guard<T>(x + r * C + c0, nv, vec, v[0]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[1][j] = v[0][j] * v[0][j];
@@ -291,27 +293,37 @@ __device__ __forceinline__ float bn_act_mask(float pre, int act) {
     return 1.f;
 }
 
+// y = act(a * x + b) * chan_scale, a = gamma * rstd, b = beta - mean * a: column-fixed threads, parameters in registers
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                const float* __restrict__ cscale, int64_t rps, T* __restrict__ y, int64_t rows, int C, bool vec) {
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int act, const float* __restrict__ cscale,
+                                                        int64_t rps, T* __restrict__ y, int64_t rows, int C, bool vec) {
     const int nchunk = (C + 7) / 8;
-    const int64_t total = rows * nchunk;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / nchunk;
-        const int c0 = (int)(i - r * nchunk) * 8;
-        const int nv = C - c0 < 8 ? C - c0 : 8;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t T_ = (int64_t)gridDim.x * 256;
+    const int ch = (int)(g % nchunk);
+    const int64_t rstep = T_ / nchunk;
+    const int c0 = ch * 8;
+    const int nv = C - c0 < 8 ? C - c0 : 8;
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + (j < nv ? j : 0);
+        a[j] = gamma[c] * rstd[c];
+        b[j] = beta[c] - mean[c] * a[j];
+    }
+#pragma unroll 2
+    for (int64_t r = g / nchunk; r < rows; r += rstep) {
         float v[8];
         load8_guard<T>(x + r * C + c0, nv, vec, v);
-        const float* cs = cscale ? cscale + (r / rps) * C + c0 : nullptr;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j < nv) {
-                const int c = c0 + j;
-                float o = bn_act((v[j] - mean[c]) * rstd[c] * gamma[c] + beta[c], act);
-                if (cs) o *= cs[j];
-                v[j] = o;
-            }
+        for (int j = 0; j < 8; ++j) v[j] = bn_act(fmaf(v[j], a[j], b[j]), act);
+        if (cscale) {
+            float cs[8];
+            load8_guard<float>(cscale + (r / rps) * C + c0, nv, vec, cs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= cs[j];
         }
         store8_guard<T>(y + r * C + c0, nv, vec, v);
     }
@@ -323,10 +335,9 @@ extern "C" int segf_bn_apply(int dt, int64_t rows, int C, const void* x, const f
     if (rows <= 0 || C <= 0) return 0;
     if (chan_scale && rows_per_sample <= 0) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = rows * ((C + 7) / 8);
-    const int blocks = (int)imin64(cdiv64(total, 256), 4096);
+    const int blocks = colfixed_blocks(rows, (C + 7) / 8, 4, 8192);
     SEGF_DISPATCH_DT(dt, T, {
-        const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(y, C);
+        const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(y, C) && (C % 8 == 0);
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, act,
                            chan_scale, rows_per_sample > 0 ? rows_per_sample : 1, (T*)y, rows, C, vec);
     })
@@ -335,56 +346,74 @@ extern "C" int segf_bn_apply(int dt, int64_t rows, int C, const void* x, const f
 }
 
 // backward sums: [0] = sum dyr, [1] = sum dyr * xhat, where dyr = dy * chan_scale * act'(pre)
+struct BnCol { float mean[8], rstd[8], a[8], b[8]; };
+__device__ __forceinline__ void bn_col_init(const float* mean, const float* rstd, const float* gamma, const float* beta, int c0,
+                                            int nv, BnCol& col) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + (j < nv ? j : 0);
+        col.mean[j] = mean[c]; col.rstd[j] = rstd[c];
+        col.a[j] = gamma[c]; col.b[j] = beta[c];
+    }
+}
 template <typename T> struct BnBwdF {
     const T* x; const T* dy; const float* mean; const float* rstd; const float* gamma; const float* beta;
     const float* cscale; int64_t rps; int C; int act; bool vec;
-    __device__ void operator()(int64_t r, int c0, int nv, float (&v)[2][8]) const {
-        float xv[8], dv[8];
+    typedef BnCol Col;
+    __device__ void init(int c0, int nv, Col& col) const { bn_col_init(mean, rstd, gamma, beta, c0, nv, col); }
+    __device__ void operator()(const Col& col, int64_t r, int c0, int nv, float (&v)[2][8]) const {
+        float xv[8], dv[8], cs[8];
         load8_guard<T>(x + r * C + c0, nv, vec, xv);
         load8_guard<T>(dy + r * C + c0, nv, vec, dv);
-        const float* cs = cscale ? cscale + (r / rps) * C + c0 : nullptr;
+        if (cscale) load8_guard<float>(cscale + (r / rps) * C + c0, nv, vec, cs);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (j < nv) {
-                const int c = c0 + j;
-                const float xh = (xv[j] - mean[c]) * rstd[c];
-                float d = dv[j] * bn_act_mask(xh * gamma[c] + beta[c], act);
-                if (cs) d *= cs[j];
-                v[0][j] = d;
-                v[1][j] = d * xh;
-            } else { v[0][j] = 0.f; v[1][j] = 0.f; }
+            const float xh = (xv[j] - col.mean[j]) * col.rstd[j];
+            float d = dv[j] * bn_act_mask(fmaf(xh, col.a[j], col.b[j]), act);
+            if (cscale) d *= cs[j];
+            v[0][j] = j < nv ? d : 0.f;
+            v[1][j] = j < nv ? d * xh : 0.f;
         }
     }
 };
 
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    int act, const float* __restrict__ cscale, int64_t rps, const float* __restrict__ sums /*[2][C]: dbeta, dgamma*/,
-                                    int eval_mode, T* __restrict__ dx, int64_t rows, int C, bool vec) {
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                            const float* __restrict__ cscale, int64_t rps,
+                                                            const float* __restrict__ sums /*[2][C]: dbeta, dgamma*/,
+                                                            int eval_mode, T* __restrict__ dx, int64_t rows, int C, bool vec) {
     const int nchunk = (C + 7) / 8;
-    const int64_t total = rows * nchunk;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t T_ = (int64_t)gridDim.x * 256;
+    const int ch = (int)(g % nchunk);
+    const int64_t rstep = T_ / nchunk;
+    const int c0 = ch * 8;
+    const int nv = C - c0 < 8 ? C - c0 : 8;
     const float invn = 1.f / (float)rows;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / nchunk;
-        const int c0 = (int)(i - r * nchunk) * 8;
-        const int nv = C - c0 < 8 ? C - c0 : 8;
-        float xv[8], dv[8];
+    BnCol col;
+    bn_col_init(mean, rstd, gamma, beta, c0, nv, col);
+    float k1[8], k2[8], gr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + (j < nv ? j : 0);
+        k1[j] = eval_mode ? 0.f : sums[c] * invn;
+        k2[j] = eval_mode ? 0.f : sums[C + c] * invn;
+        gr[j] = col.a[j] * col.rstd[j];
+    }
+#pragma unroll 2
+    for (int64_t r = g / nchunk; r < rows; r += rstep) {
+        float xv[8], dv[8], cs[8];
         load8_guard<T>(x + r * C + c0, nv, vec, xv);
         load8_guard<T>(dy + r * C + c0, nv, vec, dv);
-        const float* cs = cscale ? cscale + (r / rps) * C + c0 : nullptr;
+        if (cscale) load8_guard<float>(cscale + (r / rps) * C + c0, nv, vec, cs);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (j < nv) {
-                const int c = c0 + j;
-                const float xh = (xv[j] - mean[c]) * rstd[c];
-                float d = dv[j] * bn_act_mask(xh * gamma[c] + beta[c], act);
-                if (cs) d *= cs[j];
-                float o = gamma[c] * rstd[c];
-                if (eval_mode) o *= d;
-                else o *= (d - sums[c] * invn - xh * sums[C + c] * invn);
-                xv[j] = o;
-            }
+            const float xh = (xv[j] - col.mean[j]) * col.rstd[j];
+            float d = dv[j] * bn_act_mask(fmaf(xh, col.a[j], col.b[j]), act);
+            if (cscale) d *= cs[j];
+            xv[j] = gr[j] * (d - k1[j] - xh * k2[j]);
         }
         store8_guard<T>(dx + r * C + c0, nv, vec, xv);
     }
@@ -407,10 +436,9 @@ extern "C" int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const voi
     hipStream_t st = (hipStream_t)stream;
     float* sums = ws + cr_ws_floats(rows, C, 2);
     const int64_t rps = rows_per_sample > 0 ? rows_per_sample : 1;
-    const int64_t total = rows * ((C + 7) / 8);
-    const int blocks = (int)imin64(cdiv64(total, 256), 4096);
+    const int blocks = colfixed_blocks(rows, (C + 7) / 8, 4, 8192);
     SEGF_DISPATCH_DT(dt, T, {
-        const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(dy, C) && vec_ok_host<T>(dx, C);
+        const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(dy, C) && vec_ok_host<T>(dx, C) && (C % 8 == 0);
         BnBwdF<T> f{(const T*)x, (const T*)dy, mean, rstd, gamma, beta, chan_scale, rps, C, act, vec};
         const int rc = colreduce_launch<2>(f, rows, C, ws, sums, st);
         if (rc) return rc;

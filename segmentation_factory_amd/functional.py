@@ -297,14 +297,8 @@ class UpsampleCEDiceFn(Function):
     def backward(ctx, gloss, _gparts, _gstats):
         logits, target, stats, cw = ctx.saved_tensors
         (B, Cc, h, w, H, W), ignore_index, dice = ctx.meta
-        ld = logits.stride(0)
         go = gloss.reshape(1).to(torch.float32).contiguous()
-        dfull = hip.ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, cw, dice, stats, go,
-                                ld if (h == H and w == W) else (Cc + 7) // 8 * 8)
-        if h == H and w == W:
-            dl = dfull[:, :Cc]
-        else:
-            dl = hip.bilinear_bwd(dfull[:, :Cc], B, h, w, Cc, H, W, align_corners=False, ld_in=ld)[:, :Cc]
+        dl = hip.ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, cw, dice, stats, go)[:, :Cc]
         return dl, None, None, None, None, None
 
 

@@ -46,7 +46,8 @@ _PROTOS = {
     'segf_bilinear_to_nchw_f32': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p]),
     'segf_ce_dice_stats_floats': (_l, [_i, _i]),
     'segf_ce_dice_fwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p]),
-    'segf_ce_dice_bwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p, _l, _p]),
+    'segf_ce_dice_bwd_ws': (_l, [_i, _i, _i, _i, _i, _i, _i]),
+    'segf_ce_dice_bwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p, _l, _p, _p]),
     'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
     'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),
@@ -356,14 +357,17 @@ def ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, d
     return loss, stats
 
 
-def ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice, stats, grad_out, ldg):
-    dfull = torch.empty((B * H * W, ldg), dtype=logits.dtype, device=logits.device)
-    if ldg != Cc:
-        dfull.zero_()
-    _chk(lib().segf_ce_dice_bwd(dt_of(logits), B, Cc, h, w, H, W, _ptr(logits), logits.stride(0), _ptr(target),
-                                int(ignore_index), _ptr(class_weight), int(dice), _ptr(stats), _ptr(grad_out),
-                                _ptr(dfull), ldg, _stream()), 'segf_ce_dice_bwd')
-    return dfull
+def ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice, stats, grad_out):
+    """d loss / d (low-res logits), same row stride as `logits` (pad columns zeroed)."""
+    ld = logits.stride(0)
+    dlow = torch.empty((B * h * w, ld), dtype=logits.dtype, device=logits.device)
+    dt = dt_of(logits)
+    nws = lib().segf_ce_dice_bwd_ws(dt, B, Cc, h, w, H, W)
+    ws = _f32(nws, logits.device) if nws else None
+    _chk(lib().segf_ce_dice_bwd(dt, B, Cc, h, w, H, W, _ptr(logits), ld, _ptr(target), int(ignore_index),
+                                _ptr(class_weight), int(dice), _ptr(stats), _ptr(grad_out), _ptr(dlow), ld, _ptr(ws),
+                                _stream()), 'segf_ce_dice_bwd')
+    return dlow
 
 
 def argmax_confmat(logits, B, Cc, h, w, H, W, target, ignore_label, mat, hist, flag, pred_out=None):

@@ -57,11 +57,24 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         self._len = torch.tensor(lens, dtype=torch.int32, device=dev)
         self._flags = torch.tensor(flags, dtype=torch.uint8, device=dev)
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def ensure_built(self):
         if self._flat is None:
             self._build()
-        # gather the per-parameter gradients into the flat buffer with one multi-tensor copy
+
+    @property
+    def flat_params(self):
+        self.ensure_built()
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        self.ensure_built()
+        return self._grad
+
+    @torch.no_grad()
+    def gather_grads(self):
+        """Copy every parameter's .grad into the flat gradient buffer (multi-tensor copy; graph-capturable)."""
+        self.ensure_built()
         dst, src = [], []
         for p, view in zip(self._params, self._grad_views):
             if p.grad is not None:
@@ -71,11 +84,20 @@ class FusedAGCAdamW(torch.optim.Optimizer):
                 view.zero_()
         if dst:
             torch._foreach_copy_(dst, src)
+
+    @torch.no_grad()
+    def apply_flat(self):
+        """AGC + AdamW over the flat buffers: one kernel launch (bias corrections are host scalars of this step)."""
         g = self.param_groups[0]
         wd = max(pg['weight_decay'] for pg in self.param_groups)
         self._step += 1
         hip.agc_adamw(self._flat, self._grad, self._m, self._v, self._off, self._len, self._flags, g['lr'], g['betas'][0],
                       g['betas'][1], g['eps'], wd, self._step, float(self.agc_clip))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.gather_grads()
+        self.apply_flat()
 
     def state_dict(self):
         sd = super().state_dict()

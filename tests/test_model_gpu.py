@@ -179,3 +179,38 @@ def test_full_size_cfg2_fp32_and_bf16_vs_oracle():
     assert abs(losses[torch.float32] - ref_loss) <= 1e-4 * abs(ref_loss)
     assert (outs[torch.bfloat16] - o).abs().max() <= 6e-2 * scale
     assert abs(losses[torch.bfloat16] - ref_loss) <= 2e-2 * abs(ref_loss)
+
+
+def test_graphed_step_matches_eager_step():
+    """segmentation_factory_amd.graph.GraphedTrainStep (one hipGraph per step + fused AGC/AdamW) must walk the same
+    loss curve as the eager engine.py:36-53 sequence (zero_grad, forward, criterion, backward, clip + step)."""
+    from segmentation_factory_amd import criterion_lowres
+    from segmentation_factory_amd.graph import GraphedTrainStep
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler, param_groups_weight_decay
+    backbone, head, nc, B, H, W, seed = 'MiT-B0', 'SegFormerHead', 19, 2, 64, 64, 3
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    x, y = OW.synthetic_batch(B, H, W, nc, seed)
+    x, y = x.cuda(), y.cuda()
+
+    def loss_fn(model, img, lbl):
+        return criterion_lowres(model.forward_lowres(img), lbl, (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+
+    curves = []
+    for graphed in (False, True):
+        model = _build(backbone, head, nc, sd, torch.float32, B).train()
+        opt = FusedAGCAdamW(param_groups_weight_decay(model, 0.025), lr=1e-3)
+        losses = []
+        if graphed:
+            gs = GraphedTrainStep(model, opt, loss_fn, (x, y), clip_grad=0.02, clip_mode='agc', warmup=1)
+            for _ in range(4):
+                losses.append(gs.step(x, y).item())
+        else:
+            scaler = NativeScaler()
+            for _ in range(4):
+                opt.zero_grad(set_to_none=True)
+                loss = loss_fn(model, x, y)
+                losses.append(loss.item())
+                scaler(loss, opt, clip_grad=0.02, clip_mode='agc', parameters=model.parameters())
+        curves.append(losses)
+    assert curves[0][0] != curves[0][-1]                       # the optimizer actually moved the loss
+    np.testing.assert_allclose(curves[1], curves[0], rtol=2e-5)
