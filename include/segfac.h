@@ -34,6 +34,9 @@ const char* segf_version(void);
 /* ---- elementwise plumbing ------------------------------------------------------------------- */
 /* dst[i] = (dst_dt) src[i] */
 int segf_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, void* stream);
+/* dst[r][c] = (dst_dt) src[r][c], r < rows, c < cols, with leading dimensions (elements): weight packing / column slices */
+int segf_cast2d(const void* src, int src_dt, int64_t ld_src, void* dst, int dst_dt, int64_t ld_dst, int64_t rows, int64_t cols,
+                void* stream);
 /* out[a][c][b] = in[a][b][c]  (+ zero padding of the last output dim up to ldb_out):
  * OIHW -> O(HW)I weight re-layout for NHWC im2col GEMMs (models/backbones/mit.py:105 conv weights),
  * NCHW <-> NHWC at the plugin boundary (mit.py:198 permute).  */
@@ -125,6 +128,12 @@ int segf_bilinear_fwd(int dt, int B, int h, int w, int C, const void* in, int64_
                       int H, int W, void* out, int64_t ldo, int align_corners, void* stream);
 int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, int64_t ldi,
                       int H, int W, const void* dout, int64_t ldo, int align_corners, void* stream);
+/* out = base + sum_{k<nsrc} bilinear_up(src_k), all NHWC of dtype dt, C % 8 == 0: the accumulation step of the folded
+ * SegFormerHead (heads/segformer.py:44-56: Linear -> resize -> concat -> 1x1 conv is affine, and bilinear resizing
+ * commutes with affine maps, so the per-scale products are formed at native resolution and added here).  nsrc <= 3.  */
+int segf_upsample_add(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
+                      const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
+                      const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners, void* stream);
 /* out (fp32 NCHW [B][C][H][W]) = bilinear(in NHWC [B][h][w][ldi]) -- materialised logits for API parity */
 int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, const void* in, int64_t ldi,
                               int H, int W, float* out, void* stream);

@@ -36,6 +36,30 @@ extern "C" int segf_cast(const void* src, int src_dt, void* dst, int dst_dt, int
     return 0;
 }
 
+// ---- strided 2-D cast / copy: dst[r][c] = (D) src[r][c] with leading dimensions (weight packing, column extraction) ----
+template <typename S, typename D>
+__global__ void cast2d_kernel(const S* __restrict__ src, int64_t lds, D* __restrict__ dst, int64_t ldd, int64_t rows, int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i - r * cols;
+        stf<D>(dst + r * ldd + c, ldf<S>(src + r * lds + c));
+    }
+}
+extern "C" int segf_cast2d(const void* src, int src_dt, int64_t ld_src, void* dst, int dst_dt, int64_t ld_dst, int64_t rows,
+                           int64_t cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if (ld_src < 1 || ld_dst < 1) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)imin64(cdiv64(rows * cols, 256), 2048);
+    SEGF_DISPATCH_DT(src_dt, S, {
+        SEGF_DISPATCH_DT(dst_dt, D, {
+            hipLaunchKernelGGL((cast2d_kernel<S, D>), dim3(blocks), dim3(256), 0, st, (const S*)src, ld_src, (D*)dst, ld_dst, rows, cols);
+        })
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- permute021: out[a][c][b] = in[a][b][c], 32x32 LDS-tiled transpose -----------------------------
 template <typename S, typename D>
 __global__ void permute021_kernel(const S* __restrict__ in, D* __restrict__ out, int64_t Bd, int64_t Cd, int64_t ld_out) {

@@ -294,15 +294,28 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
     }
 }
 
-// ---- split-K reduction: C = sum_z ws[z] (fixed order) ---------------------------------------------------
+// ---- split-K reduction: C = sum_z ws[z] (fixed order): 16 outputs x 16 slice-lanes per workgroup, slice lane s adds
+// z = s, s+16, ... with independent loads in flight, then the 16 lane sums are added in fixed order --------------------
 template <typename OutT>
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N, OutT* __restrict__ C, int64_t ldc) {
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                             OutT* __restrict__ C, int64_t ldc) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int64_t total = M * N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < split; ++z) s += ws[(int64_t)z * total + i];
+    const int64_t i = (int64_t)blockIdx.x * 16 + o;
+    float acc = 0.f;
+    if (i < total) {
+#pragma unroll 4
+        for (int z = sl; z < split; z += 16) acc += ws[(int64_t)z * total + i];
+    }
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][o];
         const int64_t m = i / N, n = i - m * N;
-        stf<OutT>(C + m * ldc + n, s);
+        stf<OutT>(C + m * ldc + n, t);
     }
 }
 
@@ -312,7 +325,7 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     int64_t s = cdiv64(512, tiles);
     const int64_t maxs = K / (4 * GB_BK);
     if (s > maxs) s = maxs;
-    if (s > 64) s = 64;
+    if (s > 512) s = 512;
     if (s < 1) s = 1;
     return (int)s;
 }
@@ -372,7 +385,7 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
     SEGF_CHECK_LAUNCH();
     if (a.ws) {
         const int64_t total = M * N;
-        const int blocks = (int)imin64(cdiv64(total, 256), 2048);
+        const unsigned blocks = (unsigned)cdiv64(total, 16);
         if (c_dt == SEGF_F32)
             hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (float*)C, ldc);
         else

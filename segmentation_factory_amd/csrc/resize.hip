@@ -32,6 +32,71 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ in, int64_t ldi, T* __
     }
 }
 
+// out = base + sum_k bilinear_up(src_k): the folded SegFormerHead (heads/segformer.py:44-56).  Because bilinear
+// interpolation is linear and its weights sum to one, conv1x1(cat(up(Linear_i(x_i)))) == sum_i up(x_i (F_i W_i)^T) + sum_i F_i b_i;
+// the per-scale products are formed at their native resolution and this kernel adds them on the stride-4 grid.
+struct UpSrc { const void* p; int h, w; int64_t ld; };
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_add_kernel(const T* __restrict__ base, int64_t ldb, UpSrc s0, UpSrc s1, UpSrc s2,
+                                                            int nsrc, T* __restrict__ out, int64_t ldo, int B, int H, int W, int C,
+                                                            int ac) {
+    const int nch = C / 8;
+    const int64_t total = (int64_t)B * H * W * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch);
+        int64_t t = idx / nch;
+        const int X = (int)(t % W); t /= W;
+        const int Y = (int)(t % H);
+        const int64_t b = t / H;
+        const int c0 = ch * 8;
+        float acc[8];
+        load8<T>(base + ((b * H + Y) * W + X) * ldb + c0, acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k >= nsrc) break;
+            const UpSrc s = k == 0 ? s0 : (k == 1 ? s1 : s2);
+            int y0, y1, x0, x1; float ly, lx;
+            bilinear_src(Y, s.h, H, ac, y0, y1, ly);
+            bilinear_src(X, s.w, W, ac, x0, x1, lx);
+            const T* sb = reinterpret_cast<const T*>(s.p) + b * s.h * s.w * s.ld + c0;
+            float v00[8], v01[8], v10[8], v11[8];
+            load8<T>(sb + ((int64_t)y0 * s.w + x0) * s.ld, v00);
+            load8<T>(sb + ((int64_t)y0 * s.w + x1) * s.ld, v01);
+            load8<T>(sb + ((int64_t)y1 * s.w + x0) * s.ld, v10);
+            load8<T>(sb + ((int64_t)y1 * s.w + x1) * s.ld, v11);
+            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w00 * v00[j] + w01 * v01[j] + w10 * v10[j] + w11 * v11[j];
+        }
+        store8<T>(out + ((b * H + Y) * W + X) * ldo + c0, acc);
+    }
+}
+
+extern "C" int segf_upsample_add(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
+                                 const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
+                                 const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
+                                 void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    if (nsrc < 0 || nsrc > 3 || C % 8 != 0 || ldb < C || ldo < C) return SEGF_ERR_SHAPE;
+    const int64_t esz = dt == SEGF_BF16 ? 2 : 4;
+    const void* ptrs[5] = {base, out, src0, src1, src2};
+    const int64_t lds[5] = {ldb, ldo, ld0, ld1, ld2};
+    for (int i = 0; i < 2 + nsrc; ++i)
+        if (!ptrs[i] || ((uintptr_t)ptrs[i] % 16) || ((lds[i] * esz) % 16) || lds[i] < C) return SEGF_ERR_SHAPE;
+    const int hs[3] = {h0, h1, h2}, ws[3] = {w0, w1, w2};
+    for (int i = 0; i < nsrc; ++i)
+        if (hs[i] <= 0 || ws[i] <= 0) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)imin64(cdiv64((int64_t)B * H * W * (C / 8), 256), 16384);
+    UpSrc s0{src0, h0, w0, ld0}, s1{src1, h1, w1, ld1}, s2{src2, h2, w2, ld2};
+    SEGF_DISPATCH_DT(dt, T, {
+        hipLaunchKernelGGL((upsample_add_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)base, ldb, s0, s1, s2, nsrc, (T*)out,
+                           ldo, B, H, W, C, align_corners);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 // candidate output range [lo, hi] whose taps can touch input index i (checked exactly inside the loop)
 __device__ __forceinline__ void out_range(int i, int in, int out, int ac, int& lo, int& hi) {
     const float inv = ac ? (in > 1 ? (float)(out - 1) / (float)(in - 1) : 0.f) : (float)out / (float)in;

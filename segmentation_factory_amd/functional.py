@@ -278,6 +278,80 @@ def segformer_project_concat(feats, weights, biases, geoms):
     return SegformerProjectConcatFn.apply(tuple(geoms), *feats, *weights, *biases)
 
 
+class SegformerFoldedFuseFn(Function):
+    """linear_fuse.conv( cat_i( resize( linear_c{i}(x_i) ) ) ) of SegFormerHead.forward (heads/segformer.py:42-56) with
+    the algebra folded: Linear -> bilinear resize -> concat -> 1x1 conv (no bias) is affine in x_i, and bilinear resizing
+    commutes with affine maps (its weights sum to one), so
+        y = sum_i resize_i( x_i G_i^T ) + beta,   G_i = F_i W_i  [E, C_i],   beta = sum_i F_i b_i,
+    where F_i is the column block of the fuse weight that multiplies scale i in the reversed concat [c4, c3, c2, c1].
+    The [B*H1*W1, 4E] concat buffer and the 4E -> E GEMM over it (77 of the model's 89 GFLOP/img at cfg2) never exist;
+    the per-scale products run at native resolution (1.6 GFLOP/img).  The backward returns gradients for the ORIGINAL
+    parameters (linear_c{i}.proj.{weight,bias}, linear_fuse.conv.weight) by the chain rule through G_i and beta."""
+
+    @staticmethod
+    def forward(ctx, geoms, *args):
+        feats, weights, biases, wf = args[0:4], args[4:8], args[8:12], args[12]
+        B, H1, W1 = geoms[0]
+        E = weights[0].shape[0]
+        dtype = feats[0].dtype
+        dev = feats[0].device
+        wf32 = wf.detach().reshape(E, 4 * E)
+        wfc = _w(wf32 if wf32.is_contiguous() else wf32.contiguous(), dtype)
+        ts, saved = [], []
+        for i in range(4):
+            x = _rowmajor(feats[i])
+            Ci = x.shape[1]
+            # W'_i = [W_i | b_i | 0] (bias as one extra input column): one GEMM yields G_i = F_i W_i and beta_i = F_i b_i
+            Wp = torch.zeros((E, Ci + 8), dtype=dtype, device=dev)
+            hip.cast2d(weights[i].detach(), Wp[:, :Ci])
+            hip.cast2d(biases[i].detach().unsqueeze(1), Wp[:, Ci:Ci + 1])
+            Fi = wfc[:, (3 - i) * E:(4 - i) * E]
+            Gp = hip.gemm(1, Fi, Wp, E, Ci + 8, E, out_dtype=torch.float32)                # [E, Ci+8] fp32
+            G = torch.empty((E, Ci), dtype=dtype, device=dev)
+            hip.cast2d(Gp[:, :Ci], G)
+            beta_i = torch.empty(E, dtype=torch.float32, device=dev)
+            hip.cast2d(Gp[:, Ci:Ci + 1], beta_i.unsqueeze(1))
+            _, h, w = geoms[i]
+            ts.append(hip.gemm(0, x, G, B * h * w, E, Ci, bias=beta_i))   # a constant row passes through the resize unchanged
+            saved += [x, G, Wp]
+        y = hip.upsample_add(ts[0], [(ts[i], geoms[i][1], geoms[i][2]) for i in range(1, 4)], B, H1, W1, E)
+        ctx.save_for_backward(wfc, *saved)
+        ctx.meta = (geoms, E, dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        geoms, E, dtype = ctx.meta
+        sv = ctx.saved_tensors
+        wfc = sv[0]
+        B, H1, W1 = geoms[0]
+        dy = _rowmajor(dy)
+        dev = dy.device
+        dbeta = hip.colsum(dy)               # [E] fp32; colsum(resize^T(dy)) == colsum(dy): the resize weights sum to one
+        dwf = torch.empty((E, 4 * E), dtype=torch.float32, device=dev)
+        dxs, dws, dbs = [], [], []
+        for i in range(4):
+            x, G, Wp = sv[1 + 3 * i], sv[2 + 3 * i], sv[3 + 3 * i]
+            _, h, w = geoms[i]
+            M, Ci = x.shape
+            dt = dy if i == 0 else hip.bilinear_bwd(dy, B, h, w, E, H1, W1, align_corners=False)
+            dxs.append(hip.gemm(1, dt, G, M, Ci, E) if ctx.needs_input_grad[1 + i] else None)
+            dGp = torch.zeros((E, Ci + 8), dtype=torch.float32, device=dev)                 # d [G_i | beta_i | 0]
+            hip.gemm(2, dt, x, E, Ci, M, out=dGp[:, :Ci], split_k=_splitk(E, Ci, M))
+            hip.cast2d(dbeta.unsqueeze(1), dGp[:, Ci:Ci + 1])
+            dGc = _w(dGp, dtype)
+            Fi = wfc[:, (3 - i) * E:(4 - i) * E]
+            hip.gemm(0, dGc, Wp, E, E, Ci + 8, out=dwf[:, (3 - i) * E:(4 - i) * E])          # dF_i = dG_i W_i^T + dbeta b_i^T
+            dWp = hip.gemm(2, Fi, dGc, E, Ci + 8, E, out_dtype=torch.float32)               # [dW_i | db_i | 0] = F_i^T dG'_i
+            dws.append(dWp[:, :Ci])
+            dbs.append(dWp[:, Ci])
+        return (None, *dxs, *dws, *dbs, dwf.view(E, 4 * E, 1, 1))
+
+
+def segformer_folded_fuse(feats, weights, biases, fuse_weight, geoms):
+    return SegformerFoldedFuseFn.apply(tuple(geoms), *feats, *weights, *biases, fuse_weight)
+
+
 class UpsampleCEDiceFn(Function):
     """criterion(F.interpolate(logits, size), target): build_models.py:65 + engine.py:10-15 +
     util/losses.py:126-177, without materialising full-resolution logits in the forward."""

@@ -54,6 +54,7 @@ class SegFormerHead(nn.Module):
         self.embed_dim, self.num_classes = embed_dim, num_classes
         self.compute_dtype = torch.bfloat16
         self.stochastic_override = None               # tests: {'dropout2d': keep[B, embed_dim]}
+        self.fold = True      # fold Linear -> resize -> concat -> 1x1 conv algebraically (functional.SegformerFoldedFuseFn)
 
     def forward_tokens(self, feats):
         """feats: 4 TokenMaps.  Returns a TokenMap of logits at stride 4 (leading dim padded to 8)."""
@@ -63,9 +64,13 @@ class SegFormerHead(nn.Module):
         B, H1, W1 = feats[0].B, feats[0].H, feats[0].W
         E, nc = self.embed_dim, self.num_classes
         lins = [getattr(self, f'linear_c{i + 1}').proj for i in range(4)]
-        cat = Fh.segformer_project_concat([f.data for f in feats], [l.weight for l in lins], [l.bias for l in lins],
-                                          [(f.B, f.H, f.W) for f in feats])
-        x = Fh.linear(cat, self.linear_fuse.conv.weight)                       # 1x1 conv 4E -> E, no bias
+        geoms = [(f.B, f.H, f.W) for f in feats]
+        if self.fold and all(f.data.shape[1] % 8 == 0 for f in feats) and E % 8 == 0:
+            x = Fh.segformer_folded_fuse([f.data for f in feats], [l.weight for l in lins], [l.bias for l in lins],
+                                         self.linear_fuse.conv.weight, geoms)
+        else:                                                                  # the reference's literal op order
+            cat = Fh.segformer_project_concat([f.data for f in feats], [l.weight for l in lins], [l.bias for l in lins], geoms)
+            x = Fh.linear(cat, self.linear_fuse.conv.weight)                   # 1x1 conv 4E -> E, no bias
         bn = self.linear_fuse.bn
         drop = dropout2d_scale(self.training and self.dropout.p > 0, B, E, x.device, self.stochastic_override)
         x = Fh.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps,

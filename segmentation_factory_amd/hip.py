@@ -18,6 +18,7 @@ _lib = None
 _i, _l, _f, _p = C.c_int, C.c_int64, C.c_float, C.c_void_p
 _PROTOS = {
     'segf_cast': (_i, [_p, _i, _p, _i, _l, _p]),
+    'segf_cast2d': (_i, [_p, _i, _l, _p, _i, _l, _l, _l, _p]),
     'segf_permute021': (_i, [_p, _i, _p, _i, _l, _l, _l, _l, _p]),
     'segf_scale_rows': (_i, [_i, _p, _l, _p, _l, _p, _l, _l, _l, _p]),
     'segf_add': (_i, [_i, _p, _l, _p, _l, _p, _l, _l, _l, _p]),
@@ -43,6 +44,7 @@ _PROTOS = {
     'segf_col2im': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p]),
     'segf_bilinear_fwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
     'segf_bilinear_bwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
+    'segf_upsample_add': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p]),
     'segf_bilinear_to_nchw_f32': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p]),
     'segf_ce_dice_stats_floats': (_l, [_i, _i]),
     'segf_ce_dice_fwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p]),
@@ -117,6 +119,18 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)
     _chk(lib().segf_cast(_ptr(src), dt_of(src), _ptr(dst), BF16 if dtype == torch.bfloat16 else F32,
                          src.numel(), _stream()), 'segf_cast')
+    return dst
+
+
+def cast2d(src: torch.Tensor, dst: torch.Tensor):
+    """dst[r, c] = src[r, c] with dtype conversion; both 2-D with unit inner stride (any row stride), or 1-D."""
+    _need_cuda(src, dst)
+    if src.ndim == 1:
+        src, dst = src.view(1, -1) if src.stride(0) == 1 else src.unsqueeze(1), dst.view(1, -1) if dst.stride(0) == 1 else dst.unsqueeze(1)
+    rows, cols = src.shape
+    assert tuple(dst.shape) == (rows, cols) and (cols == 1 or (src.stride(1) == 1 and dst.stride(1) == 1))
+    _chk(lib().segf_cast2d(_ptr(src), dt_of(src), src.stride(0), _ptr(dst), dt_of(dst), dst.stride(0), rows, cols, _stream()),
+         'segf_cast2d')
     return dst
 
 
@@ -338,6 +352,21 @@ def bilinear_bwd(dout, B, h, w, Cc, H, W, align_corners=False, ld_in=None):
     _chk(lib().segf_bilinear_bwd(dt_of(dout), B, h, w, Cc, _ptr(din), ld_in, H, W, _ptr(dout), dout.stride(0),
                                  int(align_corners), _stream()), 'segf_bilinear_bwd')
     return din
+
+
+def upsample_add(base, srcs, B, H, W, Cc, align_corners=False):
+    """out = base + sum_k bilinear_up(src_k); srcs = [(tokens [B*h*w, C], h, w), ...] (at most 3)."""
+    out = torch.empty((B * H * W, Cc), dtype=base.dtype, device=base.device)
+    a = []
+    for k in range(3):
+        if k < len(srcs):
+            t, h, w = srcs[k]
+            a += [_ptr(t), h, w, t.stride(0)]
+        else:
+            a += [None, 0, 0, 0]
+    _chk(lib().segf_upsample_add(dt_of(base), B, H, W, Cc, _ptr(base), base.stride(0), len(srcs), *a, _ptr(out), Cc,
+                                 int(align_corners), _stream()), 'segf_upsample_add')
+    return out
 
 
 def bilinear_to_nchw_f32(x, B, h, w, Cc, H, W):

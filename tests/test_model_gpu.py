@@ -214,3 +214,28 @@ def test_graphed_step_matches_eager_step():
         curves.append(losses)
     assert curves[0][0] != curves[0][-1]                       # the optimizer actually moved the loss
     np.testing.assert_allclose(curves[1], curves[0], rtol=2e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_folded_head_equals_literal_head(dtype):
+    """SegformerFoldedFuseFn (algebraically folded Linear->resize->concat->1x1 conv) vs the literal op order of
+    heads/segformer.py:42-56 on the same HIP kernels: outputs and every parameter gradient."""
+    from segmentation_factory_amd import criterion_lowres
+    backbone, head, nc, B, H, W, seed = 'MiT-B0', 'SegFormerHead', 19, 2, 96, 128, 11
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    x, y = OW.synthetic_batch(B, H, W, nc, seed)
+    res = {}
+    for fold in (False, True):
+        m = _build(backbone, head, nc, sd, dtype, B).train()
+        m.decode_head.fold = fold
+        lo = m.forward_lowres(x.cuda())
+        loss = criterion_lowres(lo, y.cuda(), (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+        loss.backward()
+        res[fold] = (lo.data.float().cpu(), {k: p.grad.float().cpu() for k, p in m.named_parameters()})
+    # fp32: the two orders differ by ~1e-6 before BatchNorm, whose 1/sigma (random-init channels have tiny variance) amplifies it
+    tol = 1e-2 if dtype == torch.float32 else 4e-2
+    assert (res[True][0] - res[False][0]).abs().max() <= tol * res[False][0].abs().max()
+    gmax = max(g.abs().max().item() for g in res[False][1].values())
+    for k, g in res[False][1].items():
+        err = (res[True][1][k] - g).abs().max().item()
+        assert err <= tol * (g.abs().max().item() + 0.05 * gmax), (k, err, g.abs().max().item())
