@@ -10,7 +10,8 @@
 // Backward = two passes sharing the recomputed probabilities P = exp(S - lse):
 //   pass 1 (query-parallel): D = rowsum(dO*O), dQ = scale * sum_j P(dP - D) K_j
 //   pass 2 (key-parallel, query chunks -> deterministic partial slabs): dK_j, dV_j
-#include "common.h"
+#include <stdlib.h>
+#include "attention_mfma.h"
 
 #define AT_KT 64        // K/V rows per LDS tile
 #define AT_QT 32        // query rows per LDS tile in the key-parallel pass
@@ -288,6 +289,8 @@ extern "C" int segf_attention_fwd(int dt, int B, int heads, int N, int Nkv, int 
     if (Nkv <= 0 || (hd != 32 && hd != 64) || heads > 65535 || B > 65535) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int vec = attn_vec_ok(dt, q, ldq) && attn_vec_ok(dt, k, ldk) && attn_vec_ok(dt, v, ldv) && attn_vec_ok(dt, o, ldo);
+    if (dt == SEGF_BF16 && vec && !getenv("SEGFAC_ATTN_NO_MFMA"))
+        return attn_mfma_fwd(hd, B, heads, N, Nkv, q, ldq, k, ldk, v, ldv, scale, o, ldo, lse, st);
     const int qpb = AT_THREADS / (hd / 32);
     dim3 grid((N + qpb - 1) / qpb, heads, B);
     SEGF_DISPATCH_DT(dt, T, {
@@ -331,6 +334,16 @@ extern "C" int segf_attention_bwd(int dt, int B, int heads, int N, int Nkv, int 
     const int C = heads * hd;
     const int64_t rows = (int64_t)B * Nkv;
     const int rblocks = (int)imin64(cdiv64(rows * 2 * C, 256), 2048);
+    if (dt == SEGF_BF16 && vec && attn_vec_ok(dt, dk, lddk) && attn_vec_ok(dt, dv, lddv) && !getenv("SEGFAC_ATTN_NO_MFMA")) {
+        // the slab rows are written with 16-byte stores: 2*C*4 bytes per row is always a multiple of 16
+        const int rc = attn_mfma_bwd(hd, B, heads, N, Nkv, q, ldq, k, ldk, v, ldv, scale, o, ldo, d_o, lddo, lse, dq, lddq, Dbuf,
+                                     slab, nchunk, qchunk, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL((attn_dkv_reduce_kernel<bf16_t>), dim3(rblocks), dim3(256), 0, st, slab, nchunk, rows, C, (bf16_t*)dk,
+                           lddk, (bf16_t*)dv, lddv);
+        SEGF_CHECK_LAUNCH();
+        return 0;
+    }
     SEGF_DISPATCH_DT(dt, T, {
         if (hd == 32) {
             hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 32>), g1, dim3(AT_THREADS), 0, st, (const T*)q, ldq, (const T*)k, ldk,

@@ -1,0 +1,421 @@
+// MFMA kernels for the MiT spatial-reduction attention core, bf16 storage / fp32 accumulate
+// (reference models/backbones/mit.py:52-57: attn = softmax(q k^T * scale); x = attn v).
+//
+// Everything is computed "transposed" so that the softmax axis lies along accumulator REGISTERS and the query index along
+// LANES (v_mfma_f32_16x16x32_bf16, C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg):
+//   S^T [key][query] = K Q^T     A = K rows (16 B per lane from the LDS tile), B = Q rows (registers, loaded once)
+//   O^T [d][query]  += V^T P^T   B = P^T taken straight from the S^T accumulators (no lane movement, no LDS round trip):
+//                                k-slot j of lane group g is key 4g+j (j<4, first 16-key tile) / 16+4g+(j-4) (second tile);
+//                                A = V^T read from the row-major [key][d] LDS tile with ds_read_b64_tr_b16 in that same order.
+// Online softmax over 32-key steps; per-query statistics live one per lane (+ two ds_bpermute hops across the 4 lane groups).
+// K/V are staged through LDS in chunks of AM_KC keys, so Nkv = 256 (512^2 inputs) is one stage and Nkv = 2048
+// (1024x2048, MiT-B2) is eight.  The backward is two kernels sharing the same fragment algebra:
+//   dq  : S^T form again, dS^T feeds dQ^T += K^T dS^T directly from the accumulators
+//   dkv : S form (rows = queries), each wave owns 64 keys whose K/V fragments stay in registers for the whole kernel;
+//         Q / dO tiles go through LDS; dV^T += dO^T P and dK^T += Q^T dS take P / dS from the accumulators.
+#include "attention_mfma.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define AM_KC 256      // keys per LDS stage
+#define AM_THREADS 256
+
+__device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* __restrict__ p, bool valid) {
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (valid) u = *reinterpret_cast<const uint4*>(p);
+    return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ bf16x8 ld_frag_lds(const bf16_t* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+}
+// transposed fragment from a row-major [row][HD] bf16 LDS tile: element j<4 <- row r_lo + j, j>=4 <- row r_hi + (j-4),
+// column c_base + (lane & 15)
+template <int HD>
+__device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* tile, int r_lo, int r_hi, int c_base, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3;
+    const bf16_t* a = tile + (r_lo + q) * HD + c_base + 4 * p;
+    const bf16_t* b = tile + (r_hi + q) * HD + c_base + 4 * p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b);
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// two accumulator tiles (rows 4g+r of the first / second 16-row tile) -> one bf16 operand fragment
+__device__ __forceinline__ bf16x8 pack_acc(const float (&a)[4], const float (&b)[4]) {
+    uint4 u;
+    u.x = pack2bf(a[0], a[1]); u.y = pack2bf(a[2], a[3]); u.z = pack2bf(b[0], b[1]); u.w = pack2bf(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ float xgroup_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float xgroup_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+// stage rows [r0, r0 + nrows) x HD of a [rows][ld] global matrix into a dense [nrows][HD] LDS tile (zero beyond rmax)
+template <int HD>
+__device__ __forceinline__ void stage_rows(bf16_t* tile, const bf16_t* __restrict__ src, int64_t ld, int r0, int nrows, int rmax) {
+    constexpr int CPR = HD / 8;                      // 16-byte chunks per row
+    for (int i = threadIdx.x; i < nrows * CPR; i += AM_THREADS) {
+        const int r = i / CPR, c = i - r * CPR;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rmax) u = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + r) * ld + c * 8);
+        *reinterpret_cast<uint4*>(tile + r * HD + c * 8) = u;
+    }
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------
+template <int HD, int QW>
+__global__ void __launch_bounds__(AM_THREADS) attn_mfma_fwd_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                                    const bf16_t* __restrict__ k, int64_t ldk,
+                                                                    const bf16_t* __restrict__ v, int64_t ldv,
+                                                                    bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
+                                                                    int heads, int N, int Nkv, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[AM_KC * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[AM_KC * HD];
+    constexpr int KS = HD / 32, DT = HD / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * (16 * QW);
+    const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
+    const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
+    const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
+    bf16x8 Qf[QW][KS];
+#pragma unroll
+    for (int t = 0; t < QW; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int row = q0 + 16 * t + c;
+            Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
+        }
+    f32x4 O[DT][QW];
+    float m[QW], l[QW];
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        m[t] = -INFINITY; l[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) O[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int kc0 = 0; kc0 < Nkv; kc0 += AM_KC) {
+        const int nk = Nkv - kc0 < AM_KC ? Nkv - kc0 : AM_KC;
+        const int nk32 = (nk + 31) & ~31;
+        __syncthreads();
+        stage_rows<HD>(Ks, Kb, ldk, kc0, nk32, Nkv);
+        stage_rows<HD>(Vs, Vb, ldv, kc0, nk32, Nkv);
+        __syncthreads();
+        if (q0 >= N) continue;                       // wave-uniform; the wave still takes part in the barriers
+        for (int kb = 0; kb < nk; kb += 32) {
+            bf16x8 Kf[2][KS], Vf[DT];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) Kf[kt][s] = ld_frag_lds(Ks + (kb + 16 * kt + c) * HD + 32 * s + 8 * g);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) Vf[d] = ld_frag_tr<HD>(Vs, kb + 4 * g, kb + 16 + 4 * g, 16 * d, lane);
+#pragma unroll
+            for (int t = 0; t < QW; ++t) {
+                float sv[2][4];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kc0 + kb + 16 * kt + 4 * g + r;
+                        sv[kt][r] = key < Nkv ? S[r] * scale : -INFINITY;
+                    }
+                }
+                float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
+                                 fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
+                mx = xgroup_max(mx);
+                const float mnew = fmaxf(m[t], mx);
+                const float alpha = __expf(m[t] - mnew);
+                float ps = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sv[kt][r] = __expf(sv[kt][r] - mnew); ps += sv[kt][r]; }
+                l[t] = l[t] * alpha + ps;
+                m[t] = mnew;
+                const bf16x8 Pf = pack_acc(sv[0], sv[1]);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    O[d][t] *= alpha;
+                    O[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[d], Pf, O[d][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (q0 >= N) return;
+    bf16_t* Ob = o + (int64_t)b * N * ldo + h * HD;
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        const float lt = xgroup_sum(l[t]);
+        const float inv = 1.f / lt;
+        const int row = q0 + 16 * t + c;
+        if (row < N) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const uint2 u = make_uint2(pack2bf(O[d][t][0] * inv, O[d][t][1] * inv), pack2bf(O[d][t][2] * inv, O[d][t][3] * inv));
+                *reinterpret_cast<uint2*>(Ob + (int64_t)row * ldo + 16 * d + 4 * g) = u;
+            }
+            if (g == 0) lse[((int64_t)b * heads + h) * N + row] = m[t] + __logf(lt);
+        }
+    }
+}
+
+int attn_mfma_fwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                  const void* v, int64_t ldv, float scale, void* o, int64_t ldo, float* lse, hipStream_t st) {
+    constexpr int QW = 2;
+    dim3 grid((unsigned)cdiv64(N, 4 * 16 * QW), heads, B);
+    if (hd == 32)
+        hipLaunchKernelGGL((attn_mfma_fwd_kernel<32, QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                           (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
+    else
+        hipLaunchKernelGGL((attn_mfma_fwd_kernel<64, QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                           (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- backward, query side: D = rowsum(dO * O), dQ = scale * (P o (dP - D)) K ---------------------------------------------
+template <int HD, int QW>
+__global__ void __launch_bounds__(AM_THREADS) attn_mfma_bwd_dq_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                                       const bf16_t* __restrict__ k, int64_t ldk,
+                                                                       const bf16_t* __restrict__ v, int64_t ldv,
+                                                                       const bf16_t* __restrict__ o, int64_t ldo,
+                                                                       const bf16_t* __restrict__ dO, int64_t lddo,
+                                                                       const float* __restrict__ lse, bf16_t* __restrict__ dq,
+                                                                       int64_t lddq, float* __restrict__ Dbuf, int heads, int N,
+                                                                       int Nkv, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[AM_KC * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[AM_KC * HD];
+    constexpr int KS = HD / 32, DT = HD / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * (16 * QW);
+    const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
+    const bf16_t* Ob = o + (int64_t)b * N * ldo + h * HD;
+    const bf16_t* dOb = dO + (int64_t)b * N * lddo + h * HD;
+    const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
+    const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
+    bf16x8 Qf[QW][KS], dOf[QW][KS];
+    float Dq[QW], lq[QW];
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        const int row = q0 + 16 * t + c;
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
+            dOf[t][s] = ld_frag_global(dOb + (int64_t)row * lddo + 32 * s + 8 * g, row < N);
+            const bf16x8 of = ld_frag_global(Ob + (int64_t)row * ldo + 32 * s + 8 * g, row < N);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)dOf[t][s][j] * (float)of[j];
+        }
+        Dq[t] = xgroup_sum(part);
+        lq[t] = row < N ? lse[((int64_t)b * heads + h) * N + row] : INFINITY;
+        if (g == 0 && row < N) Dbuf[((int64_t)b * heads + h) * N + row] = Dq[t];
+    }
+    f32x4 dQ[DT][QW];
+#pragma unroll
+    for (int t = 0; t < QW; ++t)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) dQ[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc0 = 0; kc0 < Nkv; kc0 += AM_KC) {
+        const int nk = Nkv - kc0 < AM_KC ? Nkv - kc0 : AM_KC;
+        const int nk32 = (nk + 31) & ~31;
+        __syncthreads();
+        stage_rows<HD>(Ks, Kb, ldk, kc0, nk32, Nkv);
+        stage_rows<HD>(Vs, Vb, ldv, kc0, nk32, Nkv);
+        __syncthreads();
+        if (q0 >= N) continue;
+        for (int kb = 0; kb < nk; kb += 32) {
+            bf16x8 Kf[2][KS], Vf[2][KS], KT[DT];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    Kf[kt][s] = ld_frag_lds(Ks + (kb + 16 * kt + c) * HD + 32 * s + 8 * g);
+                    Vf[kt][s] = ld_frag_lds(Vs + (kb + 16 * kt + c) * HD + 32 * s + 8 * g);
+                }
+#pragma unroll
+            for (int d = 0; d < DT; ++d) KT[d] = ld_frag_tr<HD>(Ks, kb + 4 * g, kb + 16 + 4 * g, 16 * d, lane);
+#pragma unroll
+            for (int t = 0; t < QW; ++t) {
+                float ds[2][4];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
+                        dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kc0 + kb + 16 * kt + 4 * g + r;
+                        const float p = key < Nkv ? __expf(S[r] * scale - lq[t]) : 0.f;
+                        ds[kt][r] = p * (dP[r] - Dq[t]) * scale;
+                    }
+                }
+                const bf16x8 dSf = pack_acc(ds[0], ds[1]);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf, dQ[d][t], 0, 0, 0);
+            }
+        }
+    }
+    if (q0 >= N) return;
+    bf16_t* dQb = dq + (int64_t)b * N * lddq + h * HD;
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        const int row = q0 + 16 * t + c;
+        if (row < N) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const uint2 u = make_uint2(pack2bf(dQ[d][t][0], dQ[d][t][1]), pack2bf(dQ[d][t][2], dQ[d][t][3]));
+                *reinterpret_cast<uint2*>(dQb + (int64_t)row * lddq + 16 * d + 4 * g) = u;
+            }
+        }
+    }
+}
+
+// ---- backward, key side: dV = P^T dO, dK = scale * (P o (dP - D))^T Q, summed over one query chunk ------------------------
+// grid (key blocks of 256, query chunks, B*heads); wave w owns keys [256*bx + 64w, +64): its K / V fragments (B operands)
+// stay in registers; Q / dO tiles of 32 queries pass through LDS.  Output: fp32 slab[z][b*Nkv + key][2C] partial sums.
+template <int HD>
+__global__ void __launch_bounds__(AM_THREADS) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                                        const bf16_t* __restrict__ k, int64_t ldk,
+                                                                        const bf16_t* __restrict__ v, int64_t ldv,
+                                                                        const bf16_t* __restrict__ dO, int64_t lddo,
+                                                                        const float* __restrict__ lse, const float* __restrict__ Dbuf,
+                                                                        float* __restrict__ slab, int heads, int N, int Nkv, int B,
+                                                                        int qchunk, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs[32 * HD];
+    __shared__ float Ls[32], Ds[32];
+    constexpr int KS = HD / 32, DT = HD / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.z, b = bh / heads, h = bh - b * heads;
+    const int z = blockIdx.y;
+    const int key0 = blockIdx.x * 256 + wave * 64;
+    const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
+    const bf16_t* dOb = dO + (int64_t)b * N * lddo + h * HD;
+    const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
+    const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
+    const float* lb = lse + ((int64_t)b * heads + h) * N;
+    const float* Db = Dbuf + ((int64_t)b * heads + h) * N;
+    bf16x8 Kf[4][KS], Vf[4][KS];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int key = key0 + 16 * kt + c;
+            Kf[kt][s] = ld_frag_global(Kb + (int64_t)key * ldk + 32 * s + 8 * g, key < Nkv);
+            Vf[kt][s] = ld_frag_global(Vb + (int64_t)key * ldv + 32 * s + 8 * g, key < Nkv);
+        }
+    f32x4 dK[DT][4], dV[DT][4];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { dK[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int qbeg = z * qchunk, qend = qbeg + qchunk < N ? qbeg + qchunk : N;
+    for (int qt0 = qbeg; qt0 < qend; qt0 += 32) {
+        __syncthreads();
+        stage_rows<HD>(Qs, Qb, ldq, qt0, 32, qend);
+        stage_rows<HD>(dOs, dOb, lddo, qt0, 32, qend);
+        if (threadIdx.x < 32) {
+            const int row = qt0 + threadIdx.x;
+            Ls[threadIdx.x] = row < qend ? lb[row] : INFINITY;      // exp(s - inf) = 0: rows beyond the chunk contribute nothing
+            Ds[threadIdx.x] = row < qend ? Db[row] : 0.f;
+        }
+        __syncthreads();
+        if (key0 >= Nkv) continue;
+        float P[2][4][4], dS[2][4][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            bf16x8 Qa[KS], dOa[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Qa[s] = ld_frag_lds(Qs + (16 * qt + c) * HD + 32 * s + 8 * g);
+                dOa[s] = ld_frag_lds(dOs + (16 * qt + c) * HD + 32 * s + 8 * g);
+            }
+            float lr[4], dr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { lr[r] = Ls[16 * qt + 4 * g + r]; dr[r] = Ds[16 * qt + 4 * g + r]; }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qa[s], Kf[kt][s], S, 0, 0, 0);
+                    dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOa[s], Vf[kt][s], dP, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(S[r] * scale - lr[r]);
+                    P[qt][kt][r] = p;
+                    dS[qt][kt][r] = p * (dP[r] - dr[r]) * scale;
+                }
+            }
+        }
+        bf16x8 dOT[DT], QT[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            dOT[d] = ld_frag_tr<HD>(dOs, 4 * g, 16 + 4 * g, 16 * d, lane);
+            QT[d] = ld_frag_tr<HD>(Qs, 4 * g, 16 + 4 * g, 16 * d, lane);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const bf16x8 Pf = pack_acc(P[0][kt], P[1][kt]);
+            const bf16x8 dSf = pack_acc(dS[0][kt], dS[1][kt]);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                dV[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOT[d], Pf, dV[d][kt], 0, 0, 0);
+                dK[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QT[d], dSf, dK[d][kt], 0, 0, 0);
+            }
+        }
+    }
+    if (key0 >= Nkv) return;
+    const int C = heads * HD;
+    float* sb = slab + (int64_t)z * B * Nkv * 2 * C;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int key = key0 + 16 * kt + c;
+        if (key < Nkv) {
+            float* row = sb + ((int64_t)b * Nkv + key) * 2 * C + h * HD;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                *reinterpret_cast<float4*>(row + 16 * d + 4 * g) = make_float4(dK[d][kt][0], dK[d][kt][1], dK[d][kt][2], dK[d][kt][3]);
+                *reinterpret_cast<float4*>(row + C + 16 * d + 4 * g) = make_float4(dV[d][kt][0], dV[d][kt][1], dV[d][kt][2], dV[d][kt][3]);
+            }
+        }
+    }
+}
+
+int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                  const void* v, int64_t ldv, float scale, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                  const float* lse, void* dq, int64_t lddq, float* Dbuf, float* slab, int nchunk, int qchunk, hipStream_t st) {
+    constexpr int QW = 2;
+    dim3 g1((unsigned)cdiv64(N, 4 * 16 * QW), heads, B);
+    dim3 g2((unsigned)cdiv64(Nkv, 256), nchunk, B * heads);
+    const bf16_t* Q = (const bf16_t*)q; const bf16_t* K = (const bf16_t*)k; const bf16_t* V = (const bf16_t*)v;
+    const bf16_t* O = (const bf16_t*)o; const bf16_t* DO = (const bf16_t*)d_o;
+    if (hd == 32) {
+        hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<32, QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo,
+                           lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+        hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<32>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf,
+                           slab, heads, N, Nkv, B, qchunk, scale);
+    } else {
+        hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<64, QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo,
+                           lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+        hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf,
+                           slab, heads, N, Nkv, B, qchunk, scale);
+    }
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
