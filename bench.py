@@ -5,11 +5,12 @@ loss + backward + AGC/AdamW step) of SegFormer-B0 *as the reference builds it* (
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL gradient all-reduce via DDP)
+      bench.py --gpus N --steps K --warmup W          (one rank per GPU; each rank replays its hipGraph, then ONE RCCL
+                                                       all-reduce of the flat gradient buffer, then the fused optimizer)
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with a `roofline` object for the dominant
-kernel (the 3072->768 fuse GEMM, MFMA-bound; HIP-event timed inside the timed region) and a `cpu_baseline`
-object (the CPU oracle port of the reference path timed on this host's cores, bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement), with a `roofline` object for the dominant kernel
+(gemm_bf16_kernel<0>, heaviest launch = the HBM-bound classifier GEMM; HIP-event timed on its launch stream) and a
+`cpu_baseline` object (the CPU oracle port of the reference path timed on this host's cores, bounded sample).
 """
 import argparse
 import json
@@ -25,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK = 2.5e15       # dense bf16 MFMA peak, FLOP/s (MI355X_MICROARCH.md)
+HBM_PEAK = 8.0e12             # HBM3E peak, B/s (MI355X_MICROARCH.md; ~6.3e12 achievable)
 FWD_GFLOP_PER_IMG = 89.05     # reference graph as written, forward
 NC, H, W = 150, 512, 512
 
@@ -101,7 +103,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    M, N, K = args.batch * (H // 4) * (W // 4), 768, 3072
+    # dominant kernel of the step by GPU time (profiles/): gemm_bf16_kernel<0>; its heaviest launch is the classifier
+    # linear_pred 1x1 conv [B*128*128, 768] x [768, 150] (heads/segformer.py:39,57) -- N = 150 makes it HBM-bound
+    # (125 flop per algorithmic byte < the ~312 flop/B ridge), so the roofline leg prices it in bytes.
+    M, N, K = args.batch * (H // 4) * (W // 4), NC, 768
     fuse_key = ('gemm', 0, M, N, K)
     if args.eager:
         scaler = NativeScaler()
@@ -152,20 +157,23 @@ def main():
         step(False)
     sync()
     fb = time.perf_counter() - t1
-    # roofline leg: the dominant launch of the step (linear_fuse GEMM), the same C-ABI call on the same shapes,
-    # HIP-event timed on the launch stream right after the timed region (individual launches inside a graph replay
-    # cannot be bracketed by events; the rocprofv3 summary under profiles/ gives the in-graph duration)
+    # roofline leg: the heaviest launch of the dominant kernel, the same C-ABI call on the same shapes, HIP-event timed on
+    # the launch stream right after the timed region (launches inside a graph replay cannot be bracketed by events; the
+    # rocprofv3 summary of this command under profiles/ gives the in-graph duration of the same launch)
+    ldc = (N + 7) // 8 * 8
     A_ = torch.randn(M, K, device=dev).to(dtype)
     W_ = torch.randn(N, K, device=dev).to(dtype)
-    O_ = torch.empty(M, N, device=dev, dtype=dtype)
+    b_ = torch.zeros(N, device=dev)
+    O_ = torch.empty(M, ldc, device=dev, dtype=dtype)[:, :N]
     with hip.KernelTimer(lambda k: k == fuse_key) as kt:
         for _ in range(max(args.steps, 5)):
-            hip.gemm(0, A_, W_, M, N, K, out=O_)
+            hip.gemm(0, A_, W_, M, N, K, out=O_, bias=b_)
+    esz = A_.element_size()
+    alg_bytes = esz * (M * K + N * K + M * N)
     del A_, W_, O_
 
     if rank == 0:
         nl, avg_ms = kt.summary().get(fuse_key, (0, float('nan')))
-        achieved = 2.0 * M * N * K / (avg_ms * 1e-3) / 1e12
         ips = world * args.batch * args.steps / elapsed
         out = {
             "metric": "images/sec/GPU fwd+bwd SegFormer-B0 512x512 bf16; mIoU parity vs CPU ref",
@@ -180,12 +188,14 @@ def main():
                        "launch": "eager" if args.eager else "hipGraph(zero_grad+fwd+loss+bwd+grad gather) + RCCL all-reduce + fused AGC/AdamW"},
             "images_per_sec_per_gpu": round(ips / world, 2),
             "fwd_loss_bwd_only_images_per_sec": round(world * args.batch * args.steps / fb, 2),
-            "model_tflops_reference_graph": round(3 * FWD_GFLOP_PER_IMG * 1e9 * ips / 1e12, 1),
-            "roofline": {"kernel": "gemm_bf16_kernel<0> linear_fuse 1x1 conv [B*128*128,3072]x[3072,768]", "bound": "mfma",
-                         "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                         "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None,
-                         "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4),
-                         "algorithmic_flops_per_launch": 2.0 * M * N * K},
+            "reference_graph_tflops_equivalent": round(3 * FWD_GFLOP_PER_IMG * 1e9 * ips / 1e12, 1),
+            "roofline": {"kernel": "gemm_bf16_kernel<0> (dominant kernel by GPU time); heaviest launch = linear_pred 1x1 conv "
+                                   "[B*128*128,768]x[768,150]", "bound": "hbm",
+                         "achieved": round(alg_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(alg_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": None,
+                         "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                         "flops_per_launch": 2.0 * M * N * K,
+                         "mfma_frac_same_launch": round(2.0 * M * N * K / (avg_ms * 1e-3) / MFMA_BF16_PEAK, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
