@@ -114,6 +114,31 @@ int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const void* x, c
                             int apply_gelu, const void* dy, void* du, void* dx, float* dw, float* db,
                             float* ws, void* stream);
 
+/* ---- depthwise 7x7 conv + bias on NHWC (ConvNeXt Block.dwconv, convnext.py:29,39; convnextv2.py:88,101) --------------
+ * wt: fp32 [49][C] (the [C][1][7][7] parameter transposed with segf_permute021); C % 8 == 0.                    */
+int segf_dwconv7x7_fwd(int dt, int B, int H, int W, int C, const void* x, const float* wt, const float* bias, void* y,
+                       void* stream);
+int64_t segf_dwconv7x7_bwd_ws(int B, int H, int W, int C);
+/* dx = conv^T(dy) (skipped when dx == NULL); dw fp32 [C][49]; db fp32 [C] (nullable) */
+int segf_dwconv7x7_bwd(int dt, int B, int H, int W, int C, const void* x, const float* wt, const void* dy, void* dx,
+                       float* dw, float* db, float* ws, void* stream);
+
+/* ---- 3x3 conv, stride 1, pad 1, NHWC, as an implicit MFMA GEMM (no im2col buffer): ConvModule(.., 3, 1, 1) of
+ * heads/upernet.py:26,28, modules/ppm.py:19, heads/fpn.py:19.  bf16 only; P = B*H*W pixels.
+ *   mode 0: y[P][ldy]  = conv(x[P][ldx], w[Cout][9*Cin])            (+ bias[Cout], nullable)
+ *   mode 1: y = dx[P][ldy] = conv^T: x := dy[P][ldx], w := wt[Cin][9*Cout] (weights transposed to [ci][tap][co])
+ *   mode 2: y = dw fp32 [Cout][9*Cin] (ldy): x[P][ldx], w := dy[P][ldw]; split_k slices P, ws >= split_k*Cout*9*Cin floats */
+int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, const void* x, int64_t ldx, const void* w, int64_t ldw,
+                 void* y, int y_dt, int64_t ldy, const float* bias, int split_k, float* ws, void* stream);
+
+/* y = gelu_erf(u) (mode 0) or dy * gelu_erf'(u) (mode 1), flat, n % 8 == 0 (nn.GELU, convnext.py:32,43) */
+int segf_gelu(int dt, int mode, const void* u, const void* dy, void* y, int64_t n, void* stream);
+/* out[r] = sum_c a[r][c] b[r][c] (+ extra_a[r] extra_b[r]), fp32: d gamma of a layer scale folded into the weights */
+int segf_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* extra_a, const float* extra_b,
+                float* out, int64_t rows, int64_t cols, void* stream);
+/* nn.AdaptiveAvgPool2d(S) on NHWC (modules/ppm.py:13): bwd=0 in[B][H][W][C] -> out[B][S][S][C]; bwd=1 the transpose */
+int segf_adaptive_avgpool(int dt, int bwd, int B, int H, int W, int C, int S, const void* in, void* out, void* stream);
+
 /* ---- im2col / col2im for strided convs (PatchEmbed mit.py:105,127; sr conv mit.py:21,48) ---------
  * col[(b,oy,ox)][(ky,kx,ci)] with leading dim ldcol (>= kh*kw*Cin, pad columns are zeroed).
  * in_nchw_f32=1: input is the fp32 NCHW image (train_gpu.py tensor contract); else NHWC of dtype dt. */

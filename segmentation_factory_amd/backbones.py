@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from . import functional as Fh
-from .containers import ConvWeights, LayerNormWeights, LinearWeights, init_mit_style
+from .containers import ChannelsFirstLayerNormWeights, ConvWeights, LayerNormWeights, LinearWeights, init_mit_style
 
 # reference models/backbones/mit.py:149-156
 mit_settings = {
@@ -206,3 +206,189 @@ class MiT(nn.Module):
 
     def forward(self, x):
         return tuple(tm.nchw() for tm in self.forward_tokens(x))
+
+
+# ---- ConvNeXt / ConvNeXtV2 (models/backbones/convnext.py, convnextv2.py) -------------------------------------------------
+# reference models/backbones/convnext.py:70-76
+convnext_settings = {
+    'T': [[3, 3, 9, 3], [96, 192, 384, 768], 0.1],
+    'S': [[3, 3, 27, 3], [96, 192, 384, 768], 0.4],
+    'B': [[3, 3, 27, 3], [128, 256, 512, 1024], 0.5],
+    'L': [[3, 3, 27, 3], [192, 384, 768, 1536], 0.5],
+    'XL': [[3, 3, 27, 3], [256, 512, 1024, 2048], 0.5],
+}
+
+
+def _init_convnext(m):
+    """convnext.py:103-106 / convnextv2.py:164-167: trunc_normal(.02) weights, zero bias for Conv2d and Linear."""
+    from .containers import trunc_normal_
+    if isinstance(m, (nn.Conv2d, nn.Linear)):
+        trunc_normal_(m.weight, std=.02)
+        nn.init.constant_(m.bias, 0)
+
+
+class GRNWeights(nn.Module):
+    """Global Response Normalization parameters (convnextv2.py:68-80): gamma, beta of shape [1, 1, 1, dim]."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.zeros(1, 1, 1, dim))
+        self.beta = nn.Parameter(torch.zeros(1, 1, 1, dim))
+
+
+class ConvNeXtBlock(nn.Module):
+    """dwconv 7x7 -> LayerNorm -> Linear 4x -> GELU -> [GRN] -> Linear -> [x gamma] -> DropPath + residual
+    (convnext.py:26-51; convnextv2.py:83-113).  The layer scale is folded into pwconv2's parameters and the residual +
+    per-sample DropPath scale into its GEMM epilogue."""
+
+    def __init__(self, dim, dpr=0., init_value=1e-6, v2=False):
+        super().__init__()
+        self.dim, self.v2 = dim, v2
+        self.dwconv = ConvWeights(dim, dim, 7, 1, 3, groups=dim)
+        self.norm = LayerNormWeights(dim, eps=1e-6)
+        self.pwconv1 = LinearWeights(dim, 4 * dim)
+        self.pwconv2 = LinearWeights(4 * dim, dim)
+        if v2:
+            self.grn = GRNWeights(4 * dim)
+        elif init_value > 0:
+            self.gamma = nn.Parameter(init_value * torch.ones((dim)), requires_grad=True)
+        self.drop_prob = float(dpr)
+
+    def tokens(self, x, B, H, W, scale):
+        h = Fh.dwconv7x7(x, self.dwconv.weight, self.dwconv.bias, B, H, W)
+        h = Fh.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps)
+        h = Fh.gelu(Fh.linear(h, self.pwconv1.weight, self.pwconv1.bias))
+        if self.v2:
+            h = Fh.grn(h, self.grn.gamma, self.grn.beta, B, H * W)
+            return Fh.linear(h, self.pwconv2.weight, self.pwconv2.bias, residual=x, rscale=scale, rows_per_group=H * W)
+        if hasattr(self, 'gamma'):
+            return Fh.linear_layer_scale(h, self.pwconv2.weight, self.pwconv2.bias, self.gamma, residual=x, rscale=scale,
+                                         rows_per_group=H * W)
+        return Fh.linear(h, self.pwconv2.weight, self.pwconv2.bias, residual=x, rscale=scale, rows_per_group=H * W)
+
+
+class _ConvNeXtBase(nn.Module):
+    """Shared trunk of ConvNeXt (convnext.py:79-120) and ConvNeXtV2 (convnextv2.py:116-178): stem conv k4 s4 + channels-first
+    LayerNorm, three [LayerNorm + conv k2 s2] downsamplers, four block stages, one output LayerNorm per stage.  The
+    channels-first LayerNorm of the reference is the ordinary row LayerNorm on NHWC tokens (eps 1e-6, biased variance)."""
+
+    def _build(self, depths, dims, drop_path_rate, v2):
+        self.channels = dims
+        self.depths = depths
+        self.compute_dtype = torch.bfloat16
+        self.stochastic_override = None      # tests: {'drop_path': keep[n_draws, B]}
+        self.downsample_layers = nn.ModuleList()
+        self.downsample_layers.append(nn.Sequential(ConvWeights(3, dims[0], 4, 4), ChannelsFirstLayerNormWeights(dims[0])))
+        for i in range(3):
+            self.downsample_layers.append(nn.Sequential(ChannelsFirstLayerNormWeights(dims[i]), ConvWeights(dims[i], dims[i + 1], 2, 2)))
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.stages = nn.ModuleList()
+        cur = 0
+        for i in range(4):
+            self.stages.append(nn.Sequential(*[ConvNeXtBlock(dims[i], dpr[cur + j], v2=v2) for j in range(depths[i])]))
+            cur += depths[i]
+        for i in range(4):
+            self.add_module(f'norm{i}', ChannelsFirstLayerNormWeights(dims[i]))
+        self.apply(_init_convnext)
+
+    def _drop_path_scales(self, B, device):
+        """One keep/kp scale row per block with rate > 0 (drop_path.py:18-25; rate-0 blocks are nn.Identity)."""
+        rates = [blk.drop_prob for st in self.stages for blk in st]
+        if not self.training or all(r == 0 for r in rates):
+            return [None] * len(rates)
+        draws = [r for r in rates if r > 0]
+        key = (str(device), tuple(draws))
+        if getattr(self, '_kp_cache', (None, None))[0] != key:
+            self._kp_cache = (key, 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None])
+        kp = self._kp_cache[1]
+        if self.stochastic_override is not None and 'drop_path' in self.stochastic_override:
+            keep = self.stochastic_override['drop_path'].to(device=device, dtype=torch.float32)
+        else:
+            keep = torch.floor(kp + torch.rand(len(draws), B, device=device))
+        scale = (keep / kp).contiguous()
+        out, i = [], 0
+        for r in rates:
+            out.append(scale[i] if r > 0 else None)
+            i += 1 if r > 0 else 0
+        return out
+
+    def forward_tokens(self, x):
+        B, _, H, W = x.shape
+        dtype = self.compute_dtype
+        scales = self._drop_path_scales(B, x.device)
+        outs, bi = [], 0
+        t = None
+        for i in range(4):
+            ds = self.downsample_layers[i]
+            if i == 0:
+                conv, ln = ds[0], ds[1]
+                t = Fh.conv_patch(x, conv.weight, conv.bias, (B, H, W, 3, 4, 4, 0), image=True, dtype=dtype)
+                H, W = (H - 4) // 4 + 1, (W - 4) // 4 + 1
+                t = Fh.layer_norm(t, ln.weight, ln.bias, ln.eps)
+            else:
+                ln, conv = ds[0], ds[1]
+                t = Fh.layer_norm(t, ln.weight, ln.bias, ln.eps)
+                t = Fh.conv_patch(t, conv.weight, conv.bias, (B, H, W, self.channels[i - 1], 2, 2, 0))
+                H, W = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+            for blk in self.stages[i]:
+                t = blk.tokens(t, B, H, W, scales[bi])
+                bi += 1
+            nrm = getattr(self, f'norm{i}')
+            outs.append(TokenMap(Fh.layer_norm(t, nrm.weight, nrm.bias, nrm.eps), B, H, W))
+        return outs
+
+    def forward(self, x):
+        return [tm.nchw() for tm in self.forward_tokens(x)]
+
+
+class ConvNeXt(_ConvNeXtBase):
+    """models/backbones/convnext.py:79-120; the reference's plugin API only reaches the default variant 'T'."""
+
+    def __init__(self, model_name: str = 'T') -> None:
+        super().__init__()
+        assert model_name in convnext_settings.keys(), f"ConvNeXt model name should be in {list(convnext_settings.keys())}"
+        depths, embed_dims, drop_path_rate = convnext_settings[model_name]
+        self._build(depths, embed_dims, drop_path_rate, v2=False)
+
+
+class ConvNeXtV2(_ConvNeXtBase):
+    """models/backbones/convnextv2.py:116-178 (GRN blocks, no layer scale)."""
+
+    def __init__(self, in_chans=3, depths=(3, 3, 9, 3), dims=(96, 192, 384, 768), drop_path_rate=0.):
+        super().__init__()
+        assert in_chans == 3
+        self._build(list(depths), list(dims), drop_path_rate, v2=True)
+
+
+# factory functions with the reference's names (incl. its 'convnext_pico' spelling), widths and stochastic-depth rates
+# (convnextv2.py:181-233)
+def convnextv2_atto(**kw):
+    return ConvNeXtV2(depths=[2, 2, 6, 2], dims=[40, 80, 160, 320], drop_path_rate=0.0, **kw)
+
+
+def convnextv2_femto(**kw):
+    return ConvNeXtV2(depths=[2, 2, 6, 2], dims=[48, 96, 192, 384], drop_path_rate=0.0, **kw)
+
+
+def convnext_pico(**kw):
+    return ConvNeXtV2(depths=[2, 2, 6, 2], dims=[64, 128, 256, 512], drop_path_rate=0.0, **kw)
+
+
+def convnextv2_nano(**kw):
+    return ConvNeXtV2(depths=[2, 2, 8, 2], dims=[80, 160, 320, 640], drop_path_rate=0.0, **kw)
+
+
+def convnextv2_tiny(**kw):
+    return ConvNeXtV2(depths=[3, 3, 9, 3], dims=[96, 192, 384, 768], drop_path_rate=0.1, **kw)
+
+
+def convnextv2_base(**kw):
+    return ConvNeXtV2(depths=[3, 3, 27, 3], dims=[128, 256, 512, 1024], drop_path_rate=0.4, **kw)
+
+
+def convnextv2_large(**kw):
+    return ConvNeXtV2(depths=[3, 3, 27, 3], dims=[192, 384, 768, 1536], drop_path_rate=0.5, **kw)
+
+
+def convnextv2_huge(**kw):
+    return ConvNeXtV2(depths=[3, 3, 27, 3], dims=[352, 704, 1408, 2816], drop_path_rate=0.5, **kw)

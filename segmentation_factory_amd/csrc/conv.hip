@@ -224,6 +224,200 @@ extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const
     return 0;
 }
 
+// ---- depthwise 7x7 (ConvNeXt Block.dwconv, models/backbones/convnext.py:29,39; convnextv2.py:88,101) ---------------------
+// Column-fixed threads (8-channel chunk per thread), 8 output pixels per strip.  The weights arrive pre-transposed as
+// wt[49][C] fp32 so that one kernel row (7 taps x 8 channels) is 14 16-byte loads held in registers while the strip's
+// 14 input columns of that row stream through.  FLIP = correlation with the flipped kernel (data gradient).
+#define DW7_PIX 8
+template <typename T, bool FLIP>
+__global__ void __launch_bounds__(256) dwconv7x7_kernel(const T* __restrict__ x, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, T* __restrict__ y, int B, int H, int W, int C) {
+    const int nchunk = C / 8;
+    const int wg = (W + DW7_PIX - 1) / DW7_PIX;
+    const int units = B * H * wg;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int ustep = (int)(((int64_t)gridDim.x * 256) / nchunk);
+    const int c0 = (int)(g % nchunk) * 8;
+    float bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[j] = (!FLIP && bias) ? bias[c0 + j] : 0.f;
+    for (int u = (int)(g / nchunk); u < units; u += ustep) {
+        const int xg = u % wg;
+        const int t = u / wg;
+        const int yy = t % H;
+        const int b = t / H;
+        const int x0 = xg * DW7_PIX;
+        float acc[DW7_PIX][8];
+#pragma unroll
+        for (int p = 0; p < DW7_PIX; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
+        for (int ky = 0; ky < 7; ++ky) {
+            const int iy = yy + ky - 3;
+            if (iy < 0 || iy >= H) continue;
+            float wk[7][8];
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) load8f(wt + (int64_t)(FLIP ? 48 - (ky * 7 + kx) : ky * 7 + kx) * C + c0, wk[kx]);
+            const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
+#pragma unroll
+            for (int cx = 0; cx < DW7_PIX + 6; ++cx) {
+                const int ix = x0 + cx - 3;
+                if (ix < 0 || ix >= W) continue;
+                float v[8];
+                load8<T>(row + (int64_t)ix * C, v);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int p = cx - kx;
+                    if (p >= 0 && p < DW7_PIX) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wk[kx][j], v[j], acc[p][j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < DW7_PIX; ++p)
+            if (x0 + p < W) store8<T>(y + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, acc[p]);
+    }
+}
+
+// weight / bias gradient, one kernel row per grid.z: sums[ky][kx<7][C] = sum_p dy[p][c] x[p + (ky-3, kx-3)][c];
+// slot 7 of row ky == 3 carries db[c] = sum_p dy[p][c].  Same block layout / deterministic tail as colreduce.h.
+struct Dw7Plan { int ch, rl, slabs, nblk, units_per_blk; };
+static inline Dw7Plan dw7_plan(int B, int H, int W, int C) {
+    Dw7Plan p;
+    const int nchunk = C / 8;
+    p.ch = nchunk < 256 ? nchunk : 256;
+    p.rl = 256 / p.ch;
+    p.slabs = (nchunk + p.ch - 1) / p.ch;
+    const int64_t units = (int64_t)B * H * ((W + DW7_PIX - 1) / DW7_PIX);
+    int64_t want = cdiv64(units, (int64_t)p.rl * 2);
+    int cap = 256 / p.slabs;
+    if (cap < 1) cap = 1;
+    p.nblk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    p.units_per_blk = (int)cdiv64(units, p.nblk);
+    return p;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               float* __restrict__ partial, int B, int H, int W, int C, int ch,
+                                                               int rl, int units_per_blk) {
+    __shared__ float red[256 * 8];
+    const int tx = threadIdx.x % ch, ty = threadIdx.x / ch;
+    const int c0 = (blockIdx.y * ch + tx) * 8;
+    const bool active = ty < rl && c0 < C;
+    const int ky = blockIdx.z;
+    const int wg = (W + DW7_PIX - 1) / DW7_PIX;
+    const int units = B * H * wg;
+    float acc[8][8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+    const int u0 = blockIdx.x * units_per_blk;
+    const int u1 = u0 + units_per_blk < units ? u0 + units_per_blk : units;
+    if (active) {
+        for (int u = u0 + ty; u < u1; u += rl) {
+            const int xg = u % wg;
+            const int t = u / wg;
+            const int yy = t % H;
+            const int b = t / H;
+            const int x0 = xg * DW7_PIX;
+            const int iy = yy + ky - 3;
+            float gq[DW7_PIX][8];
+#pragma unroll
+            for (int p = 0; p < DW7_PIX; ++p) {
+                if (x0 + p < W) load8<T>(dy + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, gq[p]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gq[p][j] = 0.f;
+                }
+                if (ky == 3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[7][j] += gq[p][j];
+                }
+            }
+            if (iy < 0 || iy >= H) continue;
+            const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
+#pragma unroll
+            for (int cx = 0; cx < DW7_PIX + 6; ++cx) {
+                const int ix = x0 + cx - 3;
+                if (ix < 0 || ix >= W) continue;
+                float v[8];
+                load8<T>(row + (int64_t)ix * C, v);
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int p = cx - kx;
+                    if (p >= 0 && p < DW7_PIX) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[kx][j] = fmaf(gq[p][j], v[j], acc[kx][j]);
+                    }
+                }
+            }
+        }
+    }
+    // partial[(ky * nblk + blk)][8][C]
+    float* pz = partial + (int64_t)ky * gridDim.x * 8 * C;
+    colreduce_block_tail<8>(acc, active, ty == 0 && c0 < C, tx, ch, rl, c0, 8, C, pz, red);
+}
+// sums[7][8][C] -> dw[C][49], db[C]
+__global__ void dw7_scatter_kernel(const float* __restrict__ sums, int C, float* __restrict__ dw, float* __restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int ky = 0; ky < 7; ++ky)
+        for (int kx = 0; kx < 7; ++kx) dw[c * 49 + ky * 7 + kx] = sums[((int64_t)ky * 8 + kx) * C + c];
+    if (db) db[c] = sums[((int64_t)3 * 8 + 7) * C + c];
+}
+
+static inline int dw7_blocks(int B, int H, int W, int C) {
+    return colfixed_blocks((int64_t)B * H * ((W + DW7_PIX - 1) / DW7_PIX), C / 8, 1, 16384);
+}
+static inline int dw7_check(int B, int H, int W, int C, const void* a, const void* b) {
+    if (C <= 0 || C % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return SEGF_ERR_SHAPE;
+    if ((int64_t)B * H * W >= (1ll << 31)) return SEGF_ERR_SHAPE;
+    return 0;
+}
+
+extern "C" int segf_dwconv7x7_fwd(int dt, int B, int H, int W, int C, const void* x, const float* wt, const float* bias, void* y,
+                                  void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (dw7_check(B, H, W, C, x, y) || ((uintptr_t)wt % 16)) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    SEGF_DISPATCH_DT(dt, T, {
+        hipLaunchKernelGGL((dwconv7x7_kernel<T, false>), dim3(dw7_blocks(B, H, W, C)), dim3(256), 0, st, (const T*)x, wt, bias, (T*)y, B, H, W, C);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int64_t segf_dwconv7x7_bwd_ws(int B, int H, int W, int C) {
+    Dw7Plan p = dw7_plan(B, H, W, C > 0 ? C : 8);
+    return (int64_t)7 * p.nblk * 8 * C + 56 * (int64_t)C;
+}
+// dx = conv^T(dy) (nullable: skipped when dx == nullptr); dw[C][49], db[C] fp32
+extern "C" int segf_dwconv7x7_bwd(int dt, int B, int H, int W, int C, const void* x, const float* wt, const void* dy, void* dx,
+                                  float* dw, float* db, float* ws, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (dw7_check(B, H, W, C, x, dy) || ((uintptr_t)wt % 16) || ((uintptr_t)dx % 16)) return SEGF_ERR_SHAPE;
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Dw7Plan p = dw7_plan(B, H, W, C);
+    float* sums = ws + (int64_t)7 * p.nblk * 8 * C;
+    SEGF_DISPATCH_DT(dt, T, {
+        if (dx)
+            hipLaunchKernelGGL((dwconv7x7_kernel<T, true>), dim3(dw7_blocks(B, H, W, C)), dim3(256), 0, st, (const T*)dy, wt,
+                               (const float*)nullptr, (T*)dx, B, H, W, C);
+        hipLaunchKernelGGL((dwconv7x7_wgrad_kernel<T>), dim3(p.nblk, p.slabs, 7), dim3(256), 0, st, (const T*)x, (const T*)dy, ws, B,
+                           H, W, C, p.ch, p.rl, p.units_per_blk);
+    })
+    SEGF_CHECK_LAUNCH();
+    for (int ky = 0; ky < 7; ++ky)
+        colreduce_finalize_launch(ws + (int64_t)ky * p.nblk * 8 * C, p.nblk, 8 * (int64_t)C, sums + (int64_t)ky * 8 * C, st);
+    SEGF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dw7_scatter_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dw, db);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- im2col / col2im ---------------------------------------------------------------------------------------
 // NHWC input, 8 channels per thread: col[m][(ky*kw+kx)*Cin + ci]
 template <typename T>

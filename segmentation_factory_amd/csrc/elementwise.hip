@@ -173,3 +173,53 @@ extern "C" int segf_colsum(int dt, const void* x, int64_t ldx, int64_t rows, int
     })
     return 0;
 }
+
+
+// ---- GELU(erf) forward / backward, flat (ConvNeXt Block.act, convnext.py:32,43: nn.GELU between the pointwise linears) -----
+template <typename T, int MODE>   // MODE 0: y = gelu(u);  MODE 1: y = dy * gelu'(u)
+__global__ void gelu_kernel(const T* __restrict__ u, const T* __restrict__ dy, T* __restrict__ y, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8], g[8];
+        load8<T>(u + i * 8, v);
+        if (MODE == 1) load8<T>(dy + i * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = MODE == 0 ? gelu_erf(v[j]) : g[j] * gelu_erf_grad(v[j]);
+        store8<T>(y + i * 8, v);
+    }
+}
+extern "C" int segf_gelu(int dt, int mode, const void* u, const void* dy, void* y, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    if (n % 8 || ((uintptr_t)u % 16) || ((uintptr_t)y % 16) || (mode == 1 && (!dy || ((uintptr_t)dy % 16))) || mode < 0 || mode > 1)
+        return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)imin64(cdiv64(n / 8, 256), 8192);
+    SEGF_DISPATCH_DT(dt, T, {
+        if (mode == 0) hipLaunchKernelGGL((gelu_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)u, (const T*)nullptr, (T*)y, n / 8);
+        else hipLaunchKernelGGL((gelu_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)u, (const T*)dy, (T*)y, n / 8);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- out[r] = sum_c a[r][c] * b[r][c] (+ extra_a[r] * extra_b[r]) : gradient of a per-row scale folded into a weight matrix
+// (ConvNeXt layer scale gamma, convnext.py:34,46: W' = diag(gamma) W, b' = gamma o b) ----------------------------------
+__global__ void __launch_bounds__(256) rowdot_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                      const float* __restrict__ ea, const float* __restrict__ eb, float* __restrict__ out,
+                                                      int64_t rows, int64_t cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int64_t c = lane; c < cols; c += 64) s = fmaf(a[r * lda + c], b[r * ldb + c], s);
+    s = wave_sum_all(s);
+    if (lane == 0) out[r] = s + (ea ? ea[r] * eb[r] : 0.f);
+}
+extern "C" int segf_rowdot(const float* a, int64_t lda, const float* b, int64_t ldb, const float* extra_a, const float* extra_b,
+                           float* out, int64_t rows, int64_t cols, void* stream) {
+    if (rows <= 0) return 0;
+    if (cols < 0 || (extra_a && !extra_b)) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st, a, lda, b, ldb, extra_a, extra_b, out, rows, cols);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -24,6 +24,10 @@ struct GemmArgs {
     int64_t kchunk;          // K range per grid.z slice
     float* ws;               // split-K partials [z][M][N] (nullptr when split_k == 1)
     int a_vec, b_vec, c_vec, r_vec, use_tr;
+    // implicit 3x3 convolution (stride 1, pad 1) over an NHWC operand [B][cH][cW][ld >= cC]: the gathered operand's K (layout 0,
+    // operand A) or N (layout 2, operand B) axis is (tap = ky*3+kx, channel); csign = +1 reads pixel + offset(tap) (forward,
+    // weight gradient), -1 reads pixel - offset(tap) (data gradient = correlation of dy with the transposed weights)
+    int cH, cW, cC, csign;
 };
 
 #define GB_BM 128
@@ -90,6 +94,48 @@ __device__ __forceinline__ void swrite_rm(unsigned char* tile, const uint4 (&reg
     for (int i = 0; i < 4; ++i) {
         const int krow = r + 16 * i;
         *reinterpret_cast<uint4*>(tile + krow * 256 + ((c ^ rm_swz(krow)) << 4)) = reg[i];
+    }
+}
+
+// implicit-im2col variants: the 128 tile rows are output pixels (ry, rx precomputed per thread), k = tap * C + channel
+__device__ __forceinline__ void gload_kc_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax, int64_t k0,
+                                              int64_t kend, const GemmArgs& a, const int (&ry)[4], const int (&rx)[4],
+                                              uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const int64_t k = k0 + c * 8;
+    const int tap = (int)(k / a.cC);
+    const int ci = (int)(k - (int64_t)tap * a.cC);
+    const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + r + 32 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int yy = ry[i] + dy, xx = rx[i] + dx;
+        if (row < rmax && k < kend && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
+            v = *reinterpret_cast<const uint4*>(base + (row + (int64_t)dy * a.cW + dx) * ld + ci);
+        reg[i] = v;
+    }
+}
+// reduction-major gathered operand: tile rows are pixels k, tile columns are (tap, channel); the thread's column chunk is fixed
+__device__ __forceinline__ void gload_rm_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax, int64_t k0,
+                                              int64_t kend, const GemmArgs& a, uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int64_t col = col0 + c * 8;
+    const int tap = (int)(col / a.cC);
+    const int ci = (int)(col - (int64_t)tap * a.cC);
+    const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + r + 16 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < kend && col < cmax) {
+            const int x = (int)(k % a.cW);
+            const int y = (int)((k / a.cW) % a.cH);
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
+                v = *reinterpret_cast<const uint4*>(base + (k + (int64_t)dy * a.cW + dx) * ld + ci);
+        }
+        reg[i] = v;
     }
 }
 
@@ -160,7 +206,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int
         for (int r = 0; r < nv; ++r) stf<OutT>(dst + r, v[r]);
 }
 
-template <int LAYOUT, typename OutT, bool TR>
+template <int LAYOUT, typename OutT, bool TR, bool CONV = false>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GB_TILE_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -178,10 +224,21 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[4], rb[4];
+    int ry[4], rx[4];
+    if (CONV && LAYOUT == 0) {       // output pixel of each of this thread's 4 tile rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = m0 + (threadIdx.x >> 3) + 32 * i;
+            rx[i] = (int)(row % a.cW);
+            ry[i] = (int)((row / a.cW) % a.cH);
+        }
+    }
     auto gload = [&](int64_t k0) {
         if (LAYOUT == 2) gload_rm(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
+        else if (CONV) gload_kc_conv(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
         else gload_kc(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
         if (LAYOUT == 0) gload_kc(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
+        else if (CONV && LAYOUT == 2) gload_rm_conv(B, a.ldb, n0, a.N, k0, kend, a, rb);
         else gload_rm(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
     };
     auto swrite = [&](int buf) {
@@ -357,6 +414,7 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
     a.b_vec = ((uintptr_t)B % 16 == 0) && ((ldb * esz) % 16 == 0);
     a.c_vec = ((uintptr_t)C % (4 * csz) == 0) && ((ldc * csz) % (4 * csz) == 0);
     a.r_vec = 0;
+    a.cH = a.cW = a.cC = 0; a.csign = 1;
     {   // debugging switch: SEGFAC_GEMM_NO_TR=1 reads transposed fragments with scalar LDS loads instead of ds_read_b64_tr_b16
         const char* e = getenv("SEGFAC_GEMM_NO_TR");
         a.use_tr = (e && e[0] == '1') ? 0 : 1;
@@ -390,6 +448,60 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
             hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (float*)C, ldc);
         else
             hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (bf16_t*)C, ldc);
+        SEGF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+
+// ---- 3x3 convolution (stride 1, pad 1) on NHWC as an implicit GEMM: no im2col matrix is materialised -------------------------
+// reference: ConvModule(.., 3, 1, 1) of models/heads/upernet.py:26,28, models/modules/ppm.py:19, models/heads/fpn.py:19.
+//   mode 0  y[pix][co]  = sum_{tap,ci} x[pix+off(tap)][ci] * w[co][tap*Cin+ci]        x: [P][ldx], w: [Cout][9*Cin], y: [P][ldy]
+//   mode 1  dx[pix][ci] = sum_{tap,co} dy[pix-off(tap)][co] * wt[ci][tap*Cout+co]     x := dy [P][ldx], w := wt [Cin][9*Cout]
+//   mode 2  dw[co][tap*Cin+ci] = sum_pix dy[pix][co] * x[pix+off(tap)][ci]            x: [P][ldx], w := dy [P][ldw], y := dw fp32
+// P = B*H*W.  bf16 only (the fp32 parity mode goes through segf_im2col + segf_gemm).  Channel counts must be multiples of 8.
+extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, const void* x, int64_t ldx, const void* w, int64_t ldw,
+                            void* y, int y_dt, int64_t ldy, const float* bias, int split_k, float* ws, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (mode < 0 || mode > 2 || Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8) return SEGF_ERR_SHAPE;
+    if (y_dt != SEGF_F32 && y_dt != SEGF_BF16) return SEGF_ERR_DTYPE;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((ldx * 2) % 16) || ((ldw * 2) % 16)) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = (int64_t)B * H * W;
+    GemmArgs a;
+    a.bias = bias; a.residual = nullptr; a.rscale = nullptr; a.ldr = 0; a.rpg = 1;
+    a.a_vec = 1; a.b_vec = 1; a.r_vec = 0; a.use_tr = 1;
+    a.cH = H; a.cW = W; a.csign = mode == 1 ? -1 : 1;
+    int layout;
+    if (mode == 0) { layout = 0; a.M = P; a.N = Cout; a.K = 9 * (int64_t)Cin; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cin; }
+    else if (mode == 1) { layout = 0; a.M = P; a.N = Cin; a.K = 9 * (int64_t)Cout; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cout; }
+    else { layout = 2; a.M = Cout; a.N = 9 * (int64_t)Cin; a.K = P; a.A = w; a.lda = ldw; a.B = x; a.ldb = ldx; a.cC = Cin; }
+    if (mode == 2 && bias) return SEGF_ERR_SHAPE;
+    a.C = y; a.ldc = ldy;
+    if (split_k < 1) split_k = 1;
+    if (mode != 2) split_k = 1;
+    if (split_k > 1 && !ws) return SEGF_ERR_WORKSPACE;
+    int64_t kchunk = cdiv64(cdiv64(a.K, split_k), GB_BK) * GB_BK;
+    split_k = (int)cdiv64(a.K, kchunk);
+    a.kchunk = kchunk;
+    a.ws = split_k > 1 ? ws : nullptr;
+    const size_t csz = y_dt == SEGF_BF16 ? 2 : 4;
+    a.c_vec = ((uintptr_t)y % (4 * csz) == 0) && ((ldy * csz) % (4 * csz) == 0);
+    dim3 grid((unsigned)cdiv64(a.N, GB_BN), (unsigned)cdiv64(a.M, GB_BM), (unsigned)split_k);
+    if (grid.y > 65535u) return SEGF_ERR_SHAPE;
+    const bool f32out = y_dt == SEGF_F32 || a.ws;
+    if (layout == 0) {
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<0, float, true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<0, bf16_t, true, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<2, float, true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<2, bf16_t, true, true>), grid, dim3(256), 0, st, a);
+    }
+    SEGF_CHECK_LAUNCH();
+    if (a.ws) {
+        const unsigned blocks = (unsigned)cdiv64(a.M * a.N, 16);
+        if (y_dt == SEGF_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (float*)y, ldy);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (bf16_t*)y, ldy);
         SEGF_CHECK_LAUNCH();
     }
     return 0;

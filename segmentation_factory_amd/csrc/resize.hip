@@ -210,3 +210,67 @@ extern "C" int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, con
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- AdaptiveAvgPool2d on NHWC (PPM, models/modules/ppm.py:13; bins [floor(i*in/out), ceil((i+1)*in/out)) ) ---------------
+template <typename T, bool BWD>   // BWD: din[pix] = sum over bins containing pix of dout[bin] / |bin|
+__global__ void adaptive_pool_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int S) {
+    const int nch = C / 8;
+    const int64_t total = BWD ? (int64_t)B * H * W * nch : (int64_t)B * S * S * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(idx % nch) * 8;
+        int64_t t = idx / nch;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (!BWD) {
+            const int ox = (int)(t % S); t /= S;
+            const int oy = (int)(t % S);
+            const int64_t b = t / S;
+            const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S, x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    float v[8];
+                    load8<T>(in + ((b * H + y) * W + x) * C + c0, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                }
+            const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] *= inv;
+            store8<T>(out + ((b * S + oy) * S + ox) * C + c0, acc);
+        } else {
+            const int x = (int)(t % W); t /= W;
+            const int y = (int)(t % H);
+            const int64_t b = t / H;
+            for (int oy = 0; oy < S; ++oy) {
+                const int y0 = (oy * H) / S, y1 = ((oy + 1) * H + S - 1) / S;
+                if (y < y0 || y >= y1) continue;
+                for (int ox = 0; ox < S; ++ox) {
+                    const int x0 = (ox * W) / S, x1 = ((ox + 1) * W + S - 1) / S;
+                    if (x < x0 || x >= x1) continue;
+                    float v[8];
+                    load8<T>(in + ((b * S + oy) * S + ox) * C + c0, v);     // in = dout [B][S][S][C]
+                    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(inv, v[j], acc[j]);
+                }
+            }
+            store8<T>(out + ((b * H + y) * W + x) * C + c0, acc);
+        }
+    }
+}
+// bwd == 0: in [B][H][W][C] -> out [B][S][S][C];  bwd == 1: in = dout [B][S][S][C] -> out = din [B][H][W][C]
+extern "C" int segf_adaptive_avgpool(int dt, int bwd, int B, int H, int W, int C, int S, const void* in, void* out, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || S <= 0) return 0;
+    if (C <= 0 || C % 8 || ((uintptr_t)in % 16) || ((uintptr_t)out % 16)) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (bwd ? (int64_t)B * H * W : (int64_t)B * S * S) * (C / 8);
+    const int blocks = (int)imin64(cdiv64(total, 256), 4096);
+    SEGF_DISPATCH_DT(dt, T, {
+        if (bwd) hipLaunchKernelGGL((adaptive_pool_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, S);
+        else hipLaunchKernelGGL((adaptive_pool_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)in, (T*)out, B, H, W, C, S);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

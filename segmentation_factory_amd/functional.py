@@ -352,6 +352,209 @@ def segformer_folded_fuse(feats, weights, biases, fuse_weight, geoms):
     return SegformerFoldedFuseFn.apply(tuple(geoms), *feats, *weights, *biases, fuse_weight)
 
 
+class DWConv7Fn(Function):
+    """Depthwise 7x7 conv + bias on NHWC tokens (ConvNeXt Block.dwconv, convnext.py:29,39; convnextv2.py:88,101)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, B, H, W):
+        x = x if x.is_contiguous() else x.contiguous()
+        Cc = x.shape[1]
+        wt = hip.permute021(weight.detach().reshape(1, Cc, 49), 1, Cc, 49, torch.float32).view(49, Cc)
+        y = hip.dwconv7x7_fwd(x, wt, bias.detach() if bias is not None else None, B, H, W, Cc)
+        ctx.save_for_backward(x, wt)
+        ctx.meta = (B, H, W, Cc, weight.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        B, H, W, Cc, wshape, has_bias = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx, dw, db = hip.dwconv7x7_bwd(x, wt, dy, B, H, W, Cc, need_dx=ctx.needs_input_grad[0], need_db=has_bias)
+        return dx, dw.view(wshape), db, None, None, None
+
+
+def dwconv7x7(x, weight, bias, B, H, W):
+    return DWConv7Fn.apply(x, weight, bias, B, H, W)
+
+
+class Conv3x3Fn(Function):
+    """3x3 / stride 1 / pad 1 convolution without bias on NHWC tokens as an implicit MFMA GEMM (ConvModule(c1, c2, 3, 1, 1):
+    heads/upernet.py:26,28, modules/ppm.py:19, heads/fpn.py:19).  x may be a column slice of a wider concat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, B, H, W):
+        x = _rowmajor(x)
+        O, I = weight.shape[0], weight.shape[1]
+        wm = hip.permute021(weight.detach().reshape(O, I, 9), O, I, 9, x.dtype).view(O, 9 * I)          # [O][(ky,kx)][ci]
+        y = hip.conv3x3(0, x, wm, B, H, W, I, O)
+        ctx.save_for_backward(x, weight.detach())
+        ctx.meta = (B, H, W, I, O, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, I, O, wshape = ctx.meta
+        dy = _rowmajor(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = hip.permute021(w.reshape(1, O, I * 9), 1, O, I * 9, dy.dtype).view(I, 9 * O)             # [ci][(ky,kx)][co]
+            dx = hip.conv3x3(1, dy, wt, B, H, W, I, O)
+        if ctx.needs_input_grad[1]:
+            dwm = hip.conv3x3(2, x, dy, B, H, W, I, O, split_k=_splitk(O, 9 * I, B * H * W))               # [O][(ky,kx)][ci] fp32
+            dw = hip.permute021(dwm.view(O, 9, I), O, 9, I, torch.float32).view(wshape)
+        return dx, dw, None, None, None
+
+
+def conv3x3(x, weight, B, H, W):
+    """bf16: implicit GEMM; fp32 parity mode: im2col + exact-fp32 GEMM (ConvPatchFn)."""
+    if x.dtype == torch.bfloat16 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0:
+        return Conv3x3Fn.apply(x, weight, B, H, W)
+    return ConvPatchFn.apply(x, weight, None, (B, H, W, weight.shape[1], 3, 1, 1), False, x.dtype)
+
+
+class GeluFn(Function):
+    """nn.GELU (erf) between ConvNeXt's pointwise linears (convnext.py:32,43)."""
+
+    @staticmethod
+    def forward(ctx, u):
+        u = u if u.is_contiguous() else u.contiguous()
+        ctx.save_for_backward(u)
+        return hip.gelu_fwd(u)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (u,) = ctx.saved_tensors
+        return hip.gelu_bwd(u, dy if dy.is_contiguous() else dy.contiguous())
+
+
+def gelu(u):
+    return GeluFn.apply(u)
+
+
+class LinearLayerScaleFn(Function):
+    """x_in + drop_path( gamma * (x W^T + b) )  (convnext.py:44-49).  The layer scale is folded into the parameters
+    (W' = diag(gamma) W, b' = gamma o b) so the activation is never touched; gradients for W, b and gamma follow by the
+    chain rule: dW = gamma o dW', db = gamma o db', dgamma[c] = <dW'[c], W[c]> + db'[c] b[c]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, residual, rscale, rows_per_group):
+        x = _rowmajor(x)
+        M, K = x.shape
+        N = weight.shape[0]
+        w32, b32, g32 = weight.detach(), bias.detach(), gamma.detach().contiguous()
+        ws = hip.scale_rows(w32 if w32.is_contiguous() else w32.contiguous(), g32, 1)              # fp32 [N, K]
+        bs = hip.scale_rows(b32.view(N, 1), g32, 1).view(N)
+        wc = _w(ws, x.dtype)
+        y = hip.gemm(0, x, wc, M, N, K, bias=bs, residual=residual, rscale=rscale, rows_per_group=rows_per_group or 1)
+        ctx.save_for_backward(x, wc, w32, b32, g32, rscale)
+        ctx.meta = (M, N, K, residual is not None, rows_per_group or 1)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wc, w32, b32, g32, rscale = ctx.saved_tensors
+        M, N, K, has_res, rpg = ctx.meta
+        dy = _rowmajor(dy)
+        dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
+        dx = hip.gemm(1, dys, wc, M, K, N) if ctx.needs_input_grad[0] else None
+        dws = hip.gemm(2, dys, x, N, K, M, out_dtype=torch.float32, split_k=_splitk(N, K, M))        # d W'
+        dbs = hip.colsum(dys)                                                                       # d b'
+        dw = hip.scale_rows(dws, g32, 1)
+        db = hip.scale_rows(dbs.view(N, 1), g32, 1).view(N)
+        dg = hip.rowdot(dws, w32 if w32.is_contiguous() else w32.contiguous(), dbs, b32)
+        return dx, dw, db, dg, (dy if has_res else None), None, None
+
+
+def linear_layer_scale(x, weight, bias, gamma, residual=None, rscale=None, rows_per_group=None):
+    return LinearLayerScaleFn.apply(x, weight, bias, gamma, residual, rscale, rows_per_group)
+
+
+class AdaptiveAvgPoolFn(Function):
+    """nn.AdaptiveAvgPool2d(S) on NHWC tokens (modules/ppm.py:13)."""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W, S):
+        x = x if x.is_contiguous() else x.contiguous()
+        ctx.meta = (B, H, W, x.shape[1], S)
+        return hip.adaptive_avgpool(x, B, H, W, x.shape[1], S)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Cc, S = ctx.meta
+        return hip.adaptive_avgpool(dy if dy.is_contiguous() else dy.contiguous(), B, H, W, Cc, S, bwd=True), None, None, None, None
+
+
+def adaptive_avgpool(x, B, H, W, S):
+    return AdaptiveAvgPoolFn.apply(x, B, H, W, S)
+
+
+class UpsampleAddFn(Function):
+    """lateral + F.interpolate(top, size=lateral.shape[-2:], bilinear, align_corners=False)  (heads/upernet.py:41)."""
+
+    @staticmethod
+    def forward(ctx, base, top, geom):
+        B, H, W, h, w = geom
+        base, top = _rowmajor(base), _rowmajor(top)
+        ctx.meta = (geom, base.shape[1])
+        return hip.upsample_add(base, [(top, h, w)], B, H, W, base.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (B, H, W, h, w), Cc = ctx.meta
+        dy = _rowmajor(dy)
+        dtop = hip.bilinear_bwd(dy, B, h, w, Cc, H, W, align_corners=False) if ctx.needs_input_grad[1] else None
+        return dy, dtop, None
+
+
+def upsample_add(base, top, geom):
+    return UpsampleAddFn.apply(base, top, tuple(geom))
+
+
+class ResizeConcatFn(Function):
+    """torch.cat([F.interpolate(f_i, size=(H, W), bilinear, align_corners=ac_i) ...], dim=1) on NHWC tokens: every branch is
+    written straight into its column slice of one [B*H*W, sum C_i] buffer (modules/ppm.py:23-26, heads/upernet.py:45-49).
+    A branch that already has the target size is copied (F.interpolate to the same size is the identity)."""
+
+    @staticmethod
+    def forward(ctx, geoms, aligns, size, *feats):
+        B, H, W = size
+        Cs = [f.shape[1] for f in feats]
+        cat = torch.empty((B * H * W, sum(Cs)), dtype=feats[0].dtype, device=feats[0].device)
+        off = 0
+        for f, (h, w), ac, Cc in zip(feats, geoms, aligns, Cs):
+            f = _rowmajor(f)
+            sl = cat[:, off:off + Cc]
+            if (h, w) == (H, W):
+                hip.cast2d(f, sl)
+            else:
+                hip.bilinear_fwd(f, B, h, w, Cc, H, W, sl, align_corners=ac)
+            off += Cc
+        ctx.meta = (geoms, aligns, size, Cs)
+        return cat
+
+    @staticmethod
+    def backward(ctx, dcat):
+        geoms, aligns, (B, H, W), Cs = ctx.meta
+        dcat = _rowmajor(dcat)
+        grads, off = [], 0
+        for i, ((h, w), ac, Cc) in enumerate(zip(geoms, aligns, Cs)):
+            sl = dcat[:, off:off + Cc]
+            if not ctx.needs_input_grad[3 + i]:
+                grads.append(None)
+            elif (h, w) == (H, W):
+                grads.append(sl)
+            else:
+                grads.append(hip.bilinear_bwd(sl, B, h, w, Cc, H, W, align_corners=ac))
+            off += Cc
+        return (None, None, None, *grads)
+
+
+def resize_concat(feats, geoms, aligns, size):
+    return ResizeConcatFn.apply(tuple(geoms), tuple(aligns), tuple(size), *feats)
+
+
 class UpsampleCEDiceFn(Function):
     """criterion(F.interpolate(logits, size), target): build_models.py:65 + engine.py:10-15 +
     util/losses.py:126-177, without materialising full-resolution logits in the forward."""

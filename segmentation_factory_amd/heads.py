@@ -8,7 +8,7 @@ from . import functional as Fh
 from .backbones import TokenMap, tokens_from_nchw
 from .containers import BatchNormWeights, ConvWeights, LinearWeights
 
-__all__ = ['SegFormerHead']
+__all__ = ['SegFormerHead', 'UPerHead']
 
 DROPOUT2D_P = 0.1
 
@@ -78,6 +78,93 @@ class SegFormerHead(nn.Module):
         if self.training:
             bn.num_batches_tracked += 1
         logits = Fh.linear(x, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 7) // 8 * 8)
+        return TokenMap(logits, B, H1, W1)
+
+    def forward(self, features):
+        tms = [f if isinstance(f, TokenMap) else tokens_from_nchw(f, self.compute_dtype) for f in features]
+        return self.forward_tokens(tms).nchw()
+
+
+
+def _conv_module(c1, c2, k, s=1, p=0):
+    """ConvModule = Conv2d(bias=False) + BatchNorm2d + ReLU (models/layers/conv_module.py:4-9) as an nn.Sequential so the
+    state_dict keys stay `<name>.0.weight`, `<name>.1.{weight,bias,running_mean,running_var,num_batches_tracked}`."""
+    return nn.Sequential(ConvWeights(c1, c2, k, s, p, bias=False), BatchNormWeights(c2))
+
+
+def _bn_relu(x, bn, training, chan_scale=None, rows_per_sample=None):
+    y = Fh.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, act=1,
+                          chan_scale=chan_scale, rows_per_sample=rows_per_sample)
+    if training:
+        bn.num_batches_tracked += 1
+    return y
+
+
+class PPM(nn.Module):
+    """Pyramid Pooling Module (models/modules/ppm.py:7-27)."""
+
+    def __init__(self, c1, c2=128, scales=(1, 2, 3, 6)):
+        super().__init__()
+        self.scales = tuple(scales)
+        self.stages = nn.ModuleList([nn.Sequential(nn.AdaptiveAvgPool2d(scale), _conv_module(c1, c2, 1)) for scale in scales])
+        self.bottleneck = _conv_module(c1 + c2 * len(scales), c2, 3, 1, 1)
+
+    def tokens(self, x: TokenMap, training):
+        B, H, W = x.B, x.H, x.W
+        C1 = x.data.shape[1]
+        outs, geoms = [], []
+        for S, stage in zip(self.scales, self.stages):
+            conv, bn = stage[1][0], stage[1][1]
+            p = Fh.adaptive_avgpool(x.data, B, H, W, S)                    # [B*S*S, C1]
+            p = _bn_relu(Fh.linear(p, conv.weight), bn, training)         # 1x1 conv (no bias) + BN + ReLU
+            outs.append(p)
+            geoms.append((S, S))
+        feats = [x.data] + outs[::-1]                                      # ppm.py:25: [x] + outs[::-1]
+        gs = [(H, W)] + geoms[::-1]
+        cat = Fh.resize_concat(feats, gs, [False] + [True] * len(outs), (B, H, W))     # align_corners=True (ppm.py:23)
+        conv, bn = self.bottleneck[0], self.bottleneck[1]
+        return _bn_relu(Fh.conv3x3(cat, conv.weight, B, H, W), bn, training)
+
+
+class UPerHead(nn.Module):
+    """Unified Perceptual Parsing head (models/heads/upernet.py:11-50): PPM on C5, top-down FPN with 1x1 laterals and 3x3
+    output convs, all levels resized to stride 4 and concatenated, 3x3 bottleneck, Dropout2d(0.1), 1x1 classifier."""
+
+    def __init__(self, in_channels, channel=128, num_classes: int = 19, scales=(1, 2, 3, 6)):
+        super().__init__()
+        self.ppm = PPM(in_channels[-1], channel, scales)
+        self.fpn_in = nn.ModuleList()
+        self.fpn_out = nn.ModuleList()
+        for in_ch in in_channels[:-1]:
+            self.fpn_in.append(_conv_module(in_ch, channel, 1))
+            self.fpn_out.append(_conv_module(channel, channel, 3, 1, 1))
+        self.bottleneck = _conv_module(len(in_channels) * channel, channel, 3, 1, 1)
+        self.dropout = nn.Dropout2d(DROPOUT2D_P)
+        self.conv_seg = ConvWeights(channel, num_classes, 1)
+        self.embed_dim, self.num_classes = channel, num_classes
+        self.compute_dtype = torch.bfloat16
+        self.stochastic_override = None               # tests: {'dropout2d': keep[B, channel]}
+
+    def forward_tokens(self, feats):
+        tr = self.training
+        B = feats[0].B
+        ch, nc = self.embed_dim, self.num_classes
+        f = TokenMap(self.ppm.tokens(feats[-1], tr), B, feats[-1].H, feats[-1].W)
+        fpn = [f]
+        for i in reversed(range(len(feats) - 1)):
+            lat_conv, lat_bn = self.fpn_in[i][0], self.fpn_in[i][1]
+            fi = feats[i]
+            lat = _bn_relu(Fh.linear(fi.data, lat_conv.weight), lat_bn, tr)
+            f = TokenMap(Fh.upsample_add(lat, f.data, (B, fi.H, fi.W, f.H, f.W)), B, fi.H, fi.W)     # upernet.py:41
+            oc, obn = self.fpn_out[i][0], self.fpn_out[i][1]
+            fpn.append(TokenMap(_bn_relu(Fh.conv3x3(f.data, oc.weight, B, fi.H, fi.W), obn, tr), B, fi.H, fi.W))
+        fpn.reverse()
+        H1, W1 = fpn[0].H, fpn[0].W
+        cat = Fh.resize_concat([t.data for t in fpn], [(t.H, t.W) for t in fpn], [False] * len(fpn), (B, H1, W1))
+        conv, bn = self.bottleneck[0], self.bottleneck[1]
+        drop = dropout2d_scale(tr and self.dropout.p > 0, B, ch, cat.device, self.stochastic_override)
+        x = _bn_relu(Fh.conv3x3(cat, conv.weight, B, H1, W1), bn, tr, chan_scale=drop, rows_per_sample=H1 * W1)
+        logits = Fh.linear(x, self.conv_seg.weight, self.conv_seg.bias, pad_to=(nc + 7) // 8 * 8)
         return TokenMap(logits, B, H1, W1)
 
     def forward(self, features):

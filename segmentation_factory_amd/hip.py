@@ -40,6 +40,13 @@ _PROTOS = {
     'segf_dwconv3x3_gelu_fwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     'segf_dwconv3x3_bwd_ws': (_l, [_i, _i, _i, _i]),
     'segf_dwconv3x3_gelu_bwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_dwconv7x7_fwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    'segf_dwconv7x7_bwd_ws': (_l, [_i, _i, _i, _i]),
+    'segf_dwconv7x7_bwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_conv3x3': (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _l, _p, _i, _p, _p]),
+    'segf_gelu': (_i, [_i, _i, _p, _p, _p, _l, _p]),
+    'segf_rowdot': (_i, [_p, _l, _p, _l, _p, _p, _p, _l, _l, _p]),
+    'segf_adaptive_avgpool': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     'segf_im2col': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _l, _p]),
     'segf_col2im': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p]),
     'segf_bilinear_fwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
@@ -320,6 +327,69 @@ def dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, Cc, apply_gelu=True):
                                        _ptr(du), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), _stream()),
          'segf_dwconv3x3_gelu_bwd')
     return dx, dw, db
+
+
+def dwconv7x7_fwd(x, wt49, bias, B, H, W, Cc):
+    """x: [B*H*W, C]; wt49: fp32 [49, C] (transposed depthwise weight)."""
+    y = torch.empty_like(x)
+    _chk(lib().segf_dwconv7x7_fwd(dt_of(x), B, H, W, Cc, _ptr(x), _ptr(wt49), _ptr(bias), _ptr(y), _stream()),
+         'segf_dwconv7x7_fwd')
+    return y
+
+
+def dwconv7x7_bwd(x, wt49, dy, B, H, W, Cc, need_dx=True, need_db=True):
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty((Cc, 49), dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_db else None
+    ws = _f32(lib().segf_dwconv7x7_bwd_ws(B, H, W, Cc), x.device)
+    _chk(lib().segf_dwconv7x7_bwd(dt_of(x), B, H, W, Cc, _ptr(x), _ptr(wt49), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws),
+                                  _stream()), 'segf_dwconv7x7_bwd')
+    return dx, dw, db
+
+
+def conv3x3(mode, x, w, B, H, W, Cin, Cout, out=None, out_dtype=None, bias=None, split_k=1):
+    """Implicit-GEMM 3x3 convolution (bf16).  mode 0: y = conv(x, w[Cout, 9*Cin]); mode 1: dx from (dy, wt[Cin, 9*Cout]);
+    mode 2: dw[Cout, 9*Cin] fp32 from (x, dy).  x / w / out are 2-D views with unit inner stride."""
+    _need_cuda(x, w)
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(-1) == 1 and w.stride(-1) == 1
+    P = B * H * W
+    shape = {0: (P, Cout), 1: (P, Cin), 2: (Cout, 9 * Cin)}[mode]
+    if out is None:
+        out = torch.empty(shape, dtype=out_dtype or (torch.float32 if mode == 2 else x.dtype), device=x.device)
+    ws = _f32(split_k * shape[0] * shape[1], x.device) if (mode == 2 and split_k > 1) else None
+    key = ('conv3x3', mode, P, Cin, Cout)
+    _chk(_timed(key, lambda: lib().segf_conv3x3(mode, B, H, W, Cin, Cout, _ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(out),
+                                                dt_of(out), out.stride(0), _ptr(bias), split_k, _ptr(ws), _stream())),
+         'segf_conv3x3')
+    return out
+
+
+def gelu_fwd(u):
+    y = torch.empty_like(u)
+    _chk(lib().segf_gelu(dt_of(u), 0, _ptr(u), None, _ptr(y), u.numel(), _stream()), 'segf_gelu')
+    return y
+
+
+def gelu_bwd(u, dy):
+    du = torch.empty_like(u)
+    _chk(lib().segf_gelu(dt_of(u), 1, _ptr(u), _ptr(dy), _ptr(du), u.numel(), _stream()), 'segf_gelu')
+    return du
+
+
+def rowdot(a, b, extra_a=None, extra_b=None):
+    """out[r] = sum_c a[r, c] * b[r, c] (+ extra_a[r] * extra_b[r]); fp32 2-D inputs."""
+    rows, cols = a.shape
+    out = torch.empty(rows, dtype=torch.float32, device=a.device)
+    _chk(lib().segf_rowdot(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(extra_a), _ptr(extra_b), _ptr(out), rows, cols,
+                           _stream()), 'segf_rowdot')
+    return out
+
+
+def adaptive_avgpool(x, B, H, W, Cc, S, bwd=False):
+    """bwd=False: x [B*H*W, C] -> [B*S*S, C];  bwd=True: x = dout [B*S*S, C] -> din [B*H*W, C]."""
+    out = torch.empty(((B * H * W) if bwd else (B * S * S), Cc), dtype=x.dtype, device=x.device)
+    _chk(lib().segf_adaptive_avgpool(dt_of(x), int(bwd), B, H, W, Cc, S, _ptr(x), _ptr(out), _stream()), 'segf_adaptive_avgpool')
+    return out
 
 
 def im2col(x, dtype, in_nchw_f32, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo, ldcol):

@@ -394,3 +394,107 @@ def test_agc_adamw_known_answers(hipmod):
             p.addcdiv_(m_, denom, value=-1e-2 / (1 - 0.9 ** step))
         assert (w.detach().cpu() - pw).abs().max() < 1e-5
         assert (b.detach().cpu() - pb).abs().max() < 1e-5
+
+
+# ---- ConvNeXt / UPerNet kernels ------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('geom', [(2, 9, 13, 32), (1, 16, 16, 96), (2, 5, 3, 8), (1, 1, 1, 64)])
+def test_dwconv7x7(dtype, geom):
+    from segmentation_factory_amd import functional as Fh
+    B, H, W, C = geom
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, 7, 7, generator=g) * 0.2
+    b = torch.randn(C, generator=g) * 0.1
+    dy = torch.randn(B, C, H, W, generator=g)
+    xr = _q(x, dtype).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br, padding=3, groups=C)
+    ref.backward(_q(dy, dtype))
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(B * H * W, C)   # noqa: E731
+    xd = _dev(tok(x), dtype).requires_grad_(True)
+    wd, bd = _dev(w).requires_grad_(True), _dev(b).requires_grad_(True)
+    y = Fh.dwconv7x7(xd, wd, bd, B, H, W)
+    y.backward(_dev(tok(dy), dtype))
+    _close(y, tok(ref), dtype)
+    _close(xd.grad, tok(xr.grad), dtype)
+    _close(wd.grad, wr.grad, dtype, fac=4)
+    _close(bd.grad, br.grad, dtype, fac=4)
+
+
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 16, 24), (1, 5, 7, 64, 8), (2, 16, 12, 128, 136), (1, 1, 1, 8, 8)])
+def test_conv3x3_implicit_gemm(cfg):
+    """bf16 implicit-GEMM 3x3 conv (forward, data gradient, weight gradient) vs F.conv2d on bf16-rounded inputs; the input
+    is a column slice of a wider buffer as in the UPerNet concat."""
+    from segmentation_factory_amd import functional as Fh
+    B, H, W, I, O = cfg
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, I, H, W, generator=g)
+    w = torch.randn(O, I, 3, 3, generator=g) * (2.0 / (9 * I)) ** 0.5
+    dy = torch.randn(B, O, H, W, generator=g)
+    xr = _q(x, dtype).requires_grad_(True)
+    wr = _q(w, dtype).requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, padding=1)
+    ref.backward(_q(dy, dtype))
+    tok = lambda t, c: t.permute(0, 2, 3, 1).reshape(B * H * W, c)   # noqa: E731
+    buf = torch.zeros(B * H * W, I + 16, dtype=dtype, device='cuda')
+    buf[:, 8:8 + I] = tok(x, I).to(dtype).cuda()
+    xd = buf[:, 8:8 + I].detach().requires_grad_(True)
+    wd = _dev(w).requires_grad_(True)
+    y = Fh.conv3x3(xd, wd, B, H, W)
+    y.backward(_dev(tok(dy, O), dtype))
+    _close(y, tok(ref, O), dtype)
+    _close(xd.grad, tok(xr.grad, I), dtype)
+    _close(wd.grad, wr.grad, dtype, fac=2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gelu_avgpool_layerscale(dtype):
+    from segmentation_factory_amd import functional as Fh
+    g = torch.Generator().manual_seed(8)
+    u = torch.randn(64, 48, generator=g) * 2
+    dy = torch.randn(64, 48, generator=g)
+    ur = _q(u, dtype).requires_grad_(True)
+    F.gelu(ur).backward(_q(dy, dtype))
+    ud = _dev(u, dtype).requires_grad_(True)
+    y = Fh.gelu(ud)
+    y.backward(_dev(dy, dtype))
+    _close(y, F.gelu(_q(u, dtype)), dtype)
+    _close(ud.grad, ur.grad, dtype)
+    # adaptive average pooling, every PPM scale, non-divisible sizes
+    B, H, W, C = 2, 7, 5, 16
+    x = torch.randn(B, C, H, W, generator=g)
+    for S in (1, 2, 3, 6):
+        xr = _q(x, dtype).requires_grad_(True)
+        ref = F.adaptive_avg_pool2d(xr, S)
+        d = torch.randn(B, C, S, S, generator=g)
+        ref.backward(_q(d, dtype))
+        xd = _dev(x.permute(0, 2, 3, 1).reshape(B * H * W, C), dtype).requires_grad_(True)
+        yp = Fh.adaptive_avgpool(xd, B, H, W, S)
+        yp.backward(_dev(d.permute(0, 2, 3, 1).reshape(B * S * S, C), dtype))
+        _close(yp, ref.permute(0, 2, 3, 1).reshape(B * S * S, C), dtype)
+        _close(xd.grad, xr.grad.permute(0, 2, 3, 1).reshape(B * H * W, C), dtype)
+    # linear + layer scale + residual + per-sample DropPath scale (ConvNeXt block tail)
+    M, K, N, Bn = 96, 64, 24, 3
+    x = torch.randn(M, K, generator=g)
+    res = torch.randn(M, N, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g) * 0.1
+    gam = torch.rand(N, generator=g) + 0.5
+    rs = torch.tensor([0.0, 1.25, 1.25])
+    d = torch.randn(M, N, generator=g)
+    xr, rr = _q(x, dtype).requires_grad_(True), _q(res, dtype).requires_grad_(True)
+    wr, br, gr = w.clone().requires_grad_(True), b.clone().requires_grad_(True), gam.clone().requires_grad_(True)
+    ref = rr + rs.repeat_interleave(M // Bn)[:, None] * (gr * F.linear(xr, wr, br))
+    ref.backward(_q(d, dtype))
+    xd, rd = _dev(x, dtype).requires_grad_(True), _dev(res, dtype).requires_grad_(True)
+    wd, bd, gd = _dev(w).requires_grad_(True), _dev(b).requires_grad_(True), _dev(gam).requires_grad_(True)
+    yl = Fh.linear_layer_scale(xd, wd, bd, gd, residual=rd, rscale=_dev(rs), rows_per_group=M // Bn)
+    yl.backward(_dev(d, dtype))
+    _close(yl, ref, dtype, fac=2)
+    _close(xd.grad, xr.grad, dtype, fac=2)
+    _close(rd.grad, rr.grad, dtype)
+    _close(wd.grad, wr.grad, dtype, fac=4)
+    _close(bd.grad, br.grad, dtype, fac=4)
+    _close(gd.grad, gr.grad, dtype, fac=4)

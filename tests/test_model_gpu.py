@@ -30,7 +30,7 @@ def _build(backbone, head, nc, sd, dtype, B, deterministic=True):
     return m
 
 
-@pytest.mark.parametrize('tag', ['segformer_b0_64', 'segformer_b0_96x128'])
+@pytest.mark.parametrize('tag', ['segformer_b0_64', 'segformer_b0_96x128', 'convnext_uper_64'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_e2e_against_reference_golden(golden_dir, tag, dtype):
     from segmentation_factory_amd import criterion_lowres
@@ -60,6 +60,12 @@ def test_e2e_against_reference_golden(golden_dir, tag, dtype):
     gmax = float(g['grad_global_max'])
     params = dict(model.named_parameters())
     rt = 3e-3 if fp32 else 0.12
+    if 'convnext' in tag:
+        # ConvNeXt + UPerHead at 64x64, batch 2: twelve BatchNorms over 2..512 samples (PPM's 1x1 map: two values) make the
+        # gradients ill-conditioned -- fp32 reorderings show up at ~5e-3, bf16 storage at ~30 % of a parameter's gradient
+        # norm (tests/debug_convnext.py measures 15 % median even at 160x160, batch 4).  The kernels themselves are pinned
+        # by tests/test_kernels_gpu.py; this case pins the composition in the exact-fp32 mode.
+        rt = 2e-2 if fp32 else 1.0
     bad = []
     for i, name in enumerate(g['grad_names']):
         name = str(name)
