@@ -66,6 +66,7 @@ def test_e2e_against_reference_golden(golden_dir, tag, dtype):
         # norm (tests/debug_convnext.py measures 15 % median even at 160x160, batch 4).  The kernels themselves are pinned
         # by tests/test_kernels_gpu.py; this case pins the composition in the exact-fp32 mode.
         rt = 2e-2 if fp32 else 1.0
+    norms_only = ('convnext' in tag) and not fp32      # bf16 at this degenerate size: per-parameter gradient NORMS only
     bad = []
     for i, name in enumerate(g['grad_names']):
         name = str(name)
@@ -75,7 +76,10 @@ def test_e2e_against_reference_golden(golden_dir, tag, dtype):
         ref_norm = float(g['grad_norms'][i])
         got = gr.flatten()[sample_indices(name, gr.numel())].numpy()
         tol = rt * (np.abs(g['grad_samples'][i]).max() + ref_norm / max(1.0, np.sqrt(gr.numel()))) + rt * 1e-2 * gmax
-        if np.abs(got - g['grad_samples'][i]).max() > tol or abs(gr.double().norm().item() - ref_norm) > rt * ref_norm + rt * 1e-1 * gmax:
+        if norms_only:
+            if abs(gr.double().norm().item() - ref_norm) > 0.35 * ref_norm + 1e-1 * gmax:
+                bad.append((name, gr.double().norm().item(), ref_norm))
+        elif np.abs(got - g['grad_samples'][i]).max() > tol or abs(gr.double().norm().item() - ref_norm) > rt * ref_norm + rt * 1e-1 * gmax:
             bad.append((name, float(np.abs(got - g['grad_samples'][i]).max()), tol, gr.double().norm().item(), ref_norm))
     assert not bad, bad[:8]
     if fp32:
