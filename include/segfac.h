@@ -93,6 +93,14 @@ int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, cons
                 const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_sample,
                 int eval_mode, void* dx, float* dgamma, float* dbeta, float* ws, void* stream);
 
+/* ---- Global Response Normalization (ConvNeXtV2 GRN, convnextv2.py:68-80) on NHWC rows, B images of rows_per_sample rows:
+ * y = gamma * (x * Nx) + beta + x, Nx = ||x||_2(H,W) / (mean_c ||x||_2 + 1e-6).  sumsq_out [B][C] is saved for the backward. */
+int64_t segf_grn_ws(int B, int64_t rows_per_sample, int C, int bwd);
+int segf_grn_fwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const float* gamma, const float* beta, void* y,
+                 float* a_scratch, float* sumsq_out, float* ws, void* stream);
+int segf_grn_bwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const void* dy, const float* gamma,
+                 const float* sumsq_saved, void* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+
 /* ---- MiT spatial-reduction attention core (mit.py:52-57): O = softmax(Q K^T * scale) V -----------
  * q: [B*N][ldq] with head h at columns h*hd; k, v likewise over B*Nkv rows; o: [B*N][ldo]; lse: [B][heads][N] */
 int segf_attention_fwd(int dt, int B, int heads, int N, int Nkv, int hd, const void* q, int64_t ldq,

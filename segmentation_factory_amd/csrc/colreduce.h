@@ -97,8 +97,11 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(F f, int64_t rows
     for (int o = 0; o < NOUT; ++o)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
-    const int64_t r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
+    // blockIdx.z = batch index of the batched form: rows [z*rows, (z+1)*rows), partials [z][blk][NOUT][C]
+    const int64_t rbase = (int64_t)blockIdx.z * rows;
+    const int64_t r0 = rbase + (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r1 = r0 + rows_per_blk < rbase + rows ? r0 + rows_per_blk : rbase + rows;
+    partial += (int64_t)blockIdx.z * gridDim.x * NOUT * C;
     if (active) {
         typename F::Col col;
         f.init(c0, nvalid, col);
@@ -123,6 +126,8 @@ colreduce_finalize_kernel(const float* __restrict__ partial, int nblk, int64_t n
     __shared__ float red[CRF_SL][CRF_OUT + 1];
     const int o = threadIdx.x % CRF_OUT, sl = threadIdx.x / CRF_OUT;
     const int64_t i = (int64_t)blockIdx.x * CRF_OUT + o;
+    partial += (int64_t)blockIdx.y * nblk * n;       // batched form: blockIdx.y = batch
+    out += (int64_t)blockIdx.y * n;
     float acc = 0.f;
     if (i < n) {
 #pragma unroll 4
@@ -137,8 +142,8 @@ colreduce_finalize_kernel(const float* __restrict__ partial, int nblk, int64_t n
         out[i] = t;
     }
 }
-static inline void colreduce_finalize_launch(const float* partial, int nblk, int64_t n, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, CRF_OUT)), dim3(CRF_OUT * CRF_SL), 0, st, partial,
+static inline void colreduce_finalize_launch(const float* partial, int nblk, int64_t n, float* out, hipStream_t st, int nbatch = 1) {
+    hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, CRF_OUT), nbatch), dim3(CRF_OUT * CRF_SL), 0, st, partial,
                        nblk, n, out);
 }
 
@@ -150,6 +155,19 @@ static inline int colreduce_launch(F f, int64_t rows, int C, float* ws, float* o
     SEGF_CHECK_LAUNCH();
     const int64_t n = (int64_t)NOUT * C;
     colreduce_finalize_launch(ws, p.nblk, n, out, st);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// batched form: nbatch independent reductions over `rows` consecutive rows each -> out[nbatch][NOUT][C];
+// ws >= nbatch * cr_ws_floats(rows, C, NOUT)
+template <int NOUT, typename F>
+static inline int colreduce_launch_batched(F f, int64_t rows, int nbatch, int C, float* ws, float* out, hipStream_t st) {
+    CRPlan p = cr_plan(rows, C);
+    hipLaunchKernelGGL((colreduce_kernel<NOUT, F>), dim3(p.nblk, p.slabs, nbatch), dim3(CR_THREADS), 0, st, f, rows, C, p.ch,
+                       p.rl, p.rows_per_blk, ws);
+    SEGF_CHECK_LAUNCH();
+    colreduce_finalize_launch(ws, p.nblk, (int64_t)NOUT * C, out, st, nbatch);
     SEGF_CHECK_LAUNCH();
     return 0;
 }

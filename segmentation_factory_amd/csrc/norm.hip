@@ -450,3 +450,157 @@ extern "C" int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const voi
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- Global Response Normalization (ConvNeXtV2, models/backbones/convnextv2.py:68-80) on NHWC rows -----------------------
+//   Gx[b][c] = ||x[b,:,:,c]||_2 ;  Nx = Gx / (mean_c Gx + 1e-6) ;  y = gamma * (x * Nx) + beta + x = a[b][c] * x + beta[c]
+// forward : batched column reduction (sum x^2) -> per-image coefficient kernel -> streaming apply
+// backward: batched column reduction (sum dy*x, sum dy) -> coefficient kernel -> dx = a * dy + K * x, with
+//           K[b][c] = dL/dGx / Gx,  dL/dGx[c] = A[c]/(m+eps) - (1/C) sum_c' A[c'] Gx[c'] / (m+eps)^2,  A = gamma * sum_p dy*x
+#define GRN_EPS 1e-6f
+template <typename T> struct GrnSqF {
+    const T* x; int C; bool vec;
+    struct Col {};
+    __device__ void init(int, int, Col&) const {}
+    __device__ void operator()(const Col&, int64_t r, int c0, int nv, float (&v)[1][8]) const {
+        load8_guard<T>(x + r * C + c0, nv, vec, v[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[0][j] *= v[0][j];
+    }
+};
+template <typename T> struct GrnBwdF {
+    const T* x; const T* dy; int C; bool vec;
+    struct Col {};
+    __device__ void init(int, int, Col&) const {}
+    __device__ void operator()(const Col&, int64_t r, int c0, int nv, float (&v)[2][8]) const {
+        float xv[8];
+        load8_guard<T>(x + r * C + c0, nv, vec, xv);
+        load8_guard<T>(dy + r * C + c0, nv, vec, v[1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[0][j] = v[1][j] * xv[j];
+    }
+};
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum_all(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// one block per image.  fwd (S1 == nullptr): a[b][c] = 1 + gamma Nx, stash Gx.  bwd: also K[b][c] and per-image dgamma parts.
+__global__ void __launch_bounds__(256) grn_coef_kernel(const float* __restrict__ sumsq, const float* __restrict__ gamma, int C,
+                                                        float* __restrict__ a, float* __restrict__ G_out,
+                                                        const float* __restrict__ S1, float* __restrict__ K, float* __restrict__ dg_part) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* sq = sumsq + (int64_t)b * C;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += sqrtf(sq[c]);
+    const float m = block_sum_256(s, red) / (float)C;
+    const float inv = 1.f / (m + GRN_EPS);
+    float t = 0.f;
+    if (S1)
+        for (int c = threadIdx.x; c < C; c += 256) t += gamma[c] * S1[(int64_t)b * 2 * C + c] * sqrtf(sq[c]);
+    const float AG = S1 ? block_sum_256(t, red) : 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float G = sqrtf(sq[c]);
+        const float nx = G * inv;
+        a[(int64_t)b * C + c] = 1.f + gamma[c] * nx;
+        if (G_out) G_out[(int64_t)b * C + c] = sq[c];       // saved for the backward: per-image sum of squares
+        if (S1) {
+            const float s1 = S1[(int64_t)b * 2 * C + c];
+            const float dG = gamma[c] * s1 * inv - AG * inv * inv / (float)C;
+            K[(int64_t)b * C + c] = G > 0.f ? dG / G : 0.f;
+            dg_part[(int64_t)b * C + c] = nx * s1;
+        }
+    }
+}
+// y = a[b][c] * x + (k ? k[b][c] * x2 : beta[c])     fwd: (x, a, beta);  bwd: dx = a * dy + K * x  (x := dy, x2 := x)
+template <typename T>
+__global__ void __launch_bounds__(256) grn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ a,
+                                                         const float* __restrict__ k, const float* __restrict__ beta, T* __restrict__ y,
+                                                         int64_t rows, int64_t rps, int C) {
+    const int nchunk = C / 8;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rstep = ((int64_t)gridDim.x * 256) / nchunk;
+    const int c0 = (int)(g % nchunk) * 8;
+    float bt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bt[j] = beta ? beta[c0 + j] : 0.f;
+    for (int64_t r = g / nchunk; r < rows; r += rstep) {
+        const int64_t b = r / rps;
+        float v[8], av[8];
+        load8<T>(x + r * C + c0, v);
+        load8f(a + b * C + c0, av);
+        if (k) {
+            float w[8], kv[8];
+            load8<T>(x2 + r * C + c0, w);
+            load8f(k + b * C + c0, kv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(av[j], v[j], kv[j] * w[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaf(av[j], v[j], bt[j]);
+        }
+        store8<T>(y + r * C + c0, v);
+    }
+}
+// dgamma[c] = sum_b dg_part[b][c], dbeta[c] = sum_b S[b][1][c]
+__global__ void grn_param_grads_kernel(const float* __restrict__ dg_part, const float* __restrict__ S, int B, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float g = 0.f, bsum = 0.f;
+    for (int b = 0; b < B; ++b) { g += dg_part[(int64_t)b * C + c]; bsum += S[((int64_t)b * 2 + 1) * C + c]; }
+    dgamma[c] = g; dbeta[c] = bsum;
+}
+
+// workspace (floats): forward B*cr_ws(rows,C,1) + B*C; backward B*cr_ws(rows,C,2) + 4*B*C
+extern "C" int64_t segf_grn_ws(int B, int64_t rows_per_sample, int C, int bwd) {
+    return (int64_t)B * cr_ws_floats(rows_per_sample, C, bwd ? 2 : 1) + (bwd ? 4 : 1) * (int64_t)B * C;
+}
+// y = gamma * (x * Nx) + beta + x;  a_out [B][C] (scratch) and g_out [B][C] (sum_p x^2, saved for the backward)
+extern "C" int segf_grn_fwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const float* gamma, const float* beta,
+                            void* y, float* a_out, float* g_out, float* ws, void* stream) {
+    if (B <= 0 || rows_per_sample <= 0) return 0;
+    if (C <= 0 || C % 8 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) return SEGF_ERR_SHAPE;
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* sumsq = ws + (int64_t)B * cr_ws_floats(rows_per_sample, C, 1);
+    const int64_t rows = (int64_t)B * rows_per_sample;
+    SEGF_DISPATCH_DT(dt, T, {
+        GrnSqF<T> f{(const T*)x, C, true};
+        const int rc = colreduce_launch_batched<1>(f, rows_per_sample, B, C, ws, sumsq, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(grn_coef_kernel, dim3(B), dim3(256), 0, st, sumsq, gamma, C, a_out, g_out, (const float*)nullptr,
+                           (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL((grn_apply_kernel<T>), dim3(colfixed_blocks(rows, C / 8, 4, 8192)), dim3(256), 0, st, (const T*)x,
+                           (const T*)nullptr, a_out, (const float*)nullptr, beta, (T*)y, rows, rows_per_sample, C);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int segf_grn_bwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const void* dy, const float* gamma,
+                            const float* g_saved, void* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+    if (B <= 0 || rows_per_sample <= 0) return 0;
+    if (C <= 0 || C % 8 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return SEGF_ERR_SHAPE;
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* S = ws + (int64_t)B * cr_ws_floats(rows_per_sample, C, 2);      // [B][2][C]: sum dy*x, sum dy
+    float* a = S + 2 * (int64_t)B * C;
+    float* K = a + (int64_t)B * C;
+    const int64_t rows = (int64_t)B * rows_per_sample;
+    SEGF_DISPATCH_DT(dt, T, {
+        GrnBwdF<T> f{(const T*)x, (const T*)dy, C, true};
+        const int rc = colreduce_launch_batched<2>(f, rows_per_sample, B, C, ws, S, st);
+        if (rc) return rc;
+        // dg_part reuses the front of the (now consumed) partial workspace
+        hipLaunchKernelGGL(grn_coef_kernel, dim3(B), dim3(256), 0, st, g_saved, gamma, C, a, (float*)nullptr, S, K, ws);
+        hipLaunchKernelGGL((grn_apply_kernel<T>), dim3(colfixed_blocks(rows, C / 8, 4, 8192)), dim3(256), 0, st, (const T*)dy,
+                           (const T*)x, a, K, (const float*)nullptr, (T*)dx, rows, rows_per_sample, C);
+    })
+    SEGF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(grn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, S, B, C, dgamma, dbeta);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -471,6 +471,31 @@ def linear_layer_scale(x, weight, bias, gamma, residual=None, rscale=None, rows_
     return LinearLayerScaleFn.apply(x, weight, bias, gamma, residual, rscale, rows_per_group)
 
 
+class GRNFn(Function):
+    """Global Response Normalization of ConvNeXtV2 (convnextv2.py:68-80) on NHWC tokens; gamma / beta are [1,1,1,C]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, B, rows_per_sample):
+        x = x if x.is_contiguous() else x.contiguous()
+        g = gamma.detach().reshape(-1).contiguous()
+        b = beta.detach().reshape(-1).contiguous()
+        y, sq = hip.grn_fwd(x, g, b, B, rows_per_sample)
+        ctx.save_for_backward(x, g, sq)
+        ctx.meta = (B, rows_per_sample, gamma.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, sq = ctx.saved_tensors
+        B, rps, pshape = ctx.meta
+        dx, dg, db = hip.grn_bwd(x, dy if dy.is_contiguous() else dy.contiguous(), g, sq, B, rps)
+        return dx, dg.view(pshape), db.view(pshape), None, None
+
+
+def grn(x, gamma, beta, B, rows_per_sample):
+    return GRNFn.apply(x, gamma, beta, B, rows_per_sample)
+
+
 class AdaptiveAvgPoolFn(Function):
     """nn.AdaptiveAvgPool2d(S) on NHWC tokens (modules/ppm.py:13)."""
 

@@ -498,3 +498,30 @@ def test_gelu_avgpool_layerscale(dtype):
     _close(wd.grad, wr.grad, dtype, fac=4)
     _close(bd.grad, br.grad, dtype, fac=4)
     _close(gd.grad, gr.grad, dtype, fac=4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_grn(dtype):
+    """ConvNeXtV2 GRN (convnextv2.py:68-80) forward/backward incl. gamma / beta gradients and an all-zero channel."""
+    from segmentation_factory_amd import functional as Fh
+    g = torch.Generator().manual_seed(12)
+    B, H, W, C = 3, 5, 7, 48
+    x = torch.randn(B, H, W, C, generator=g)
+    x[..., 5] = 0
+    gam = torch.randn(1, 1, 1, C, generator=g) * 0.5
+    bet = torch.randn(1, 1, 1, C, generator=g) * 0.1
+    dy = torch.randn(B, H, W, C, generator=g)
+    xr = _q(x, dtype).requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    Gx = torch.norm(xr, p=2, dim=(1, 2), keepdim=True)
+    Nx = Gx / (Gx.mean(dim=-1, keepdim=True) + 1e-6)
+    ref = gr * (xr * Nx) + br + xr
+    ref.backward(_q(dy, dtype))
+    xd = _dev(x.reshape(-1, C), dtype).requires_grad_(True)
+    gd, bd = _dev(gam).requires_grad_(True), _dev(bet).requires_grad_(True)
+    y = Fh.grn(xd, gd, bd, B, H * W)
+    y.backward(_dev(dy.reshape(-1, C), dtype))
+    _close(y, ref.reshape(-1, C), dtype)
+    _close(xd.grad, xr.grad.reshape(-1, C), dtype, fac=2)
+    _close(gd.grad, gr.grad, dtype, fac=4)
+    _close(bd.grad, br.grad, dtype, fac=4)
