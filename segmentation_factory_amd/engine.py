@@ -57,10 +57,36 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
     loss_weight = torch.as_tensor([1.0, 2.0], device=device) if args.nb_classes == 2 else None   # engine.py:28-32
     core = model.module if hasattr(model, 'module') else model
     fused = hasattr(core, 'forward_lowres')
+    use_graph = bool(getattr(args, 'hip_graph', False)) and fused
 
     for idx, (img, lbl) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
         img = img.to(device, non_blocking=True)
         lbl = lbl.to(device, non_blocking=True)
+        if use_graph:
+            # the whole step (zero_grad, forward, criterion, backward, gradient gather) replayed as one hipGraph, followed by
+            # the RCCL all-reduce of the flat gradient buffer and the fused AGC/AdamW kernel (graph.py)
+            from .graph import GraphedTrainStep
+            key = (tuple(img.shape), tuple(lbl.shape), clip_grad, clip_mode)
+            gs = getattr(core, '_graphed_step', None)
+            if gs is None or gs.key != key:
+                def loss_fn(m, x, y, _lw=loss_weight, _hw=tuple(img.shape[2:])):
+                    return criterion_lowres(m.forward_lowres(x), y, _hw, _lw, num_classes=args.nb_classes, dice=args.dice,
+                                            ignore_index=args.ignore_index)
+                gs = GraphedTrainStep(core, optimizer, loss_fn, (img, lbl), clip_grad=clip_grad, clip_mode=clip_mode)
+                gs.key = key
+                core._graphed_step = gs
+            loss = gs.step(img, lbl)
+            loss_value = loss.item()
+            if not math.isfinite(loss_value):
+                print("Loss is {}, stopping training".format(loss_value))
+                sys.exit(1)
+            lr = optimizer.param_groups[0]["lr"]
+            metric_logger.update(loss=loss_value, lr=lr)
+            if writer is not None and idx % print_freq == 0 and getattr(args, 'local_rank', 0) == 0:
+                it = epoch * num_steps + idx
+                writer.add_scalar('train_loss', loss_value, it)
+                writer.add_scalar('train_lr', lr, it)
+            continue
         optimizer.zero_grad()
         if fused:
             # DDP hooks fire on backward through the wrapped module's parameters either way

@@ -18,6 +18,26 @@ import torch.distributed as dist
 from .optim import FusedAGCAdamW
 
 
+def allreduce_mean_(flat: torch.Tensor, group=None):
+    """In-place mean over ranks of one flat buffer: the whole data-parallel exchange of a step (collective C1 of SURVEY.md
+    section 2.3).  RCCL ('nccl') averages inside the collective; gloo (CPU tests) sums and divides."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return flat
+    if dist.get_backend(group) == 'nccl':
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
+    return flat
+
+
+def broadcast_flat_(flat: torch.Tensor, src: int = 0, group=None):
+    """Rank `src`'s parameters to everyone (what DistributedDataParallel does at construction, train_gpu.py:233-236)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer: FusedAGCAdamW, loss_fn, example_inputs, clip_grad=None, clip_mode='agc',
                  warmup: int = 2, process_group=None):
@@ -32,8 +52,7 @@ class GraphedTrainStep:
             raise NotImplementedError("clip_mode='agc' is the fused mode (engine.py:52-53 default)")
         self.opt.agc_clip = float(clip_grad) if clip_grad is not None else 0.0
         self.opt.ensure_built()                 # parameters are re-homed into the flat buffer BEFORE capture
-        if self.world > 1:                      # DDP's initial parameter broadcast from rank 0
-            dist.broadcast(self.opt.flat_params, src=0, group=self.group)
+        broadcast_flat_(self.opt.flat_params, 0, self.group)     # DDP's initial parameter broadcast from rank 0
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -53,8 +72,7 @@ class GraphedTrainStep:
         for dst, src in zip(self.static_inputs, inputs):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
-        if self.world > 1:
-            dist.all_reduce(self.opt.flat_grads, op=dist.ReduceOp.AVG, group=self.group)
+        allreduce_mean_(self.opt.flat_grads, self.group)
         self.opt.apply_flat()
         return self.loss
 

@@ -117,6 +117,14 @@ ddp = torch.nn.parallel.DistributedDataParallel(lin)
 x = torch.full((2, 4), float(rank + 1))
 ddp(x).sum().backward()
 assert torch.allclose(lin.weight.grad, torch.full((3, 4), 3.0)), lin.weight.grad   # mean of (2*1, 2*2) = 3
+# the graphed step's exchange: ONE all-reduce (mean) of the flat gradient buffer + rank-0 parameter broadcast
+from segmentation_factory_amd.graph import allreduce_mean_, broadcast_flat_
+flat = torch.arange(6, dtype=torch.float32) * (rank + 1)
+allreduce_mean_(flat)
+assert torch.allclose(flat, torch.arange(6, dtype=torch.float32) * 1.5), flat
+params = torch.full((5,), float(rank + 7))
+broadcast_flat_(params, 0)
+assert torch.all(params == 7.0)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -130,3 +138,29 @@ def test_two_process_gloo_reductions(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_train_gpu_cli_flags_and_scheduler_quirk():
+    """The CLI keeps the reference's flags and defaults (train_gpu.py:33-184); the default schedule is inert (quirk Q9)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('train_gpu_cli', os.path.join(ROOT, 'train_gpu.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import argparse
+    args = argparse.ArgumentParser(parents=[mod.get_args_parser()]).parse_args([])
+    assert (args.batch_size, args.epochs, args.clip_grad, args.clip_mode, args.opt, args.lr, args.weight_decay) == (4, 5, 0.02, 'agc', 'adamw', 1e-3, 0.025)
+    assert (args.backbone, args.heads, args.nb_classes, args.image_size, args.ignore_index, args.dice) == ('MiT-B2', 'SegFormerHead', 19, 1024, 255, True)
+    assert (args.warmup_lr, args.min_lr, args.sched, args.lr_ep, args.device, args.dist_url) == (2e-4, 1e-4, 'cosine', False, 'cuda', 'env://')
+    from segmentation_factory_amd.scheduler import create_scheduler
+    import torch
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([p], lr=args.lr)
+    sch, _ = create_scheduler(args, opt)
+    assert opt.param_groups[0]['lr'] == args.warmup_lr            # constructor writes the warm-up start value
+    for e in range(3):
+        sch.step(e)
+    assert opt.param_groups[0]['lr'] == args.warmup_lr            # ... and step(epoch) never moves it without --lr-ep
+    ds = mod.SyntheticSegDataset(4, 32, 7)
+    img, lbl = ds[1]
+    assert img.shape == (3, 32, 32) and img.dtype == torch.float32 and lbl.dtype == torch.int64 and int(lbl[0, 0]) == 255
+    assert int(lbl[2:].max()) < 7

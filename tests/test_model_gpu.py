@@ -251,3 +251,26 @@ def test_folded_head_equals_literal_head(dtype):
     for k, g in res[False][1].items():
         err = (res[True][1][k] - g).abs().max().item()
         assert err <= tol * (g.abs().max().item() + 0.05 * gmax), (k, err, g.abs().max().item())
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_train_gpu_cli_synthetic(tmp_path, graph):
+    """train_gpu.py end to end on generated data: two epochs of MiT-B0 + SegFormerHead at 64x64, checkpoint written with
+    the reference's keys (train_gpu.py:354-362), auto-resume picks it up (train_gpu.py:281-307)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / 'out'
+    cmd = [sys.executable, os.path.join(root, 'train_gpu.py'), '--dataset', 'synthetic', '--data_len', '8', '--image_size', '64',
+           '--nb_classes', '5', '--backbone', 'MiT-B0', '--heads', 'SegFormerHead', '--batch-size', '2', '--val_batch_size', '2',
+           '--epochs', '2', '--save_weights_dir', str(out), '--writer_output', str(tmp_path), '--train_print_freq', '1',
+           '--val_print_freq', '1', '--lr', '1e-3'] + (['--hip-graph'] if graph else [])
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'Start training for 2 epochs' in r.stdout and 'Val_mIOU' in r.stdout
+    ck = torch.load(str(out / 'MiT-B0_SegFormerHead_best_model.pth'), map_location='cpu', weights_only=False)
+    assert {'model_state', 'optimizer_state', 'scheduler_state', 'best_mIoU', 'F1_Score', 'Acc', 'scaler'} <= set(ck)
+    assert (out / 'model.txt').exists() and (out / 'args.txt').exists()
+    r2 = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0 and 'Loading local checkpoint' in r2.stdout, r2.stdout[-2000:] + r2.stderr[-2000:]
