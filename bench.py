@@ -69,6 +69,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward+loss+backward only')
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3'],
+                    help='cfg2 = SegFormer-B0 (headline); cfg3 = ConvNeXt-T + UPerHead, both 150 classes at 512x512')
     ap.add_argument('--eager', action='store_true', help='per-kernel launches + torch DDP instead of the hipGraph step')
     args = ap.parse_args()
 
@@ -88,7 +90,8 @@ def main():
     from segmentation_factory_amd.graph import GraphedTrainStep
     torch.manual_seed(1234)          # identical initial weights on every rank (rank 0's are broadcast anyway)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    core = SegmentationModel('MiT-B0', num_classes=NC, seg_head='SegFormerHead', compute_dtype=dtype).to(dev).train()
+    bb_name, head_name = ('MiT-B0', 'SegFormerHead') if args.config == 'cfg2' else ('ConvNeXt', 'UPerHead')
+    core = SegmentationModel(bb_name, num_classes=NC, seg_head=head_name, compute_dtype=dtype).to(dev).train()
     opt = FusedAGCAdamW(param_groups_weight_decay(core, 0.025), lr=2e-4)
     x, y = synthetic_batch(args.batch, seed=rank)
     x, y = x.to(dev), y.to(dev)
@@ -180,9 +183,10 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "SegFormer-B0 (MiT-B0 + 768-wide SegFormerHead as the reference builds it), ADE20K-shape "
-                                   "150 classes, 512x512, full train step (zero_grad+fwd+CE/Dice+bwd+AGC/AdamW)"
-                                   if with_opt else "same, forward+loss+backward only",
+            "config": {"workload": ("SegFormer-B0 (MiT-B0 + 768-wide SegFormerHead as the reference builds it)" if args.config == 'cfg2'
+                                    else "ConvNeXt-T + 768-wide UPerHead (BASELINE cfg3 model, single GPU)") +
+                                   ", ADE20K-shape 150 classes, 512x512, " +
+                                   ("full train step (zero_grad+fwd+CE/Dice+bwd+AGC/AdamW)" if with_opt else "forward+loss+backward only"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "init": "random (reference initialisers)", "loss_after": round(final_loss, 4),
                        "launch": "eager" if args.eager else "hipGraph(zero_grad+fwd+loss+bwd+grad gather) + RCCL all-reduce + fused AGC/AdamW"},

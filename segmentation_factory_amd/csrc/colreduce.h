@@ -7,7 +7,7 @@
 #include "common.h"
 
 #define CR_THREADS 256
-#define CR_MAX_BLOCKS 512
+#define CR_MAX_BLOCKS 2048
 
 // guarded 8-wide load: vector path when the chunk is complete and the row is 16-byte aligned
 template <typename T>
@@ -46,7 +46,7 @@ static inline CRPlan cr_plan(int64_t rows, int C) {
     p.ch = nchunk < CR_THREADS ? nchunk : CR_THREADS;
     p.rl = CR_THREADS / p.ch;
     p.slabs = (nchunk + p.ch - 1) / p.ch;
-    int64_t want = cdiv64(rows, (int64_t)p.rl * 16);
+    int64_t want = cdiv64(rows, (int64_t)p.rl * 32);
     int cap = CR_MAX_BLOCKS / p.slabs;
     if (cap < 1) cap = 1;
     p.nblk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
@@ -105,7 +105,18 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(F f, int64_t rows
     if (active) {
         typename F::Col col;
         f.init(c0, nvalid, col);
-        for (int64_t r = r0 + ty; r < r1; r += rl) {
+        // two rows per iteration: both rows' loads are issued before either is consumed (memory-level parallelism)
+        int64_t r = r0 + ty;
+        for (; r + rl < r1; r += 2 * rl) {
+            float v[NOUT][8], w[NOUT][8];
+            f(col, r, c0, nvalid, v);
+            f(col, r + rl, c0, nvalid, w);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o][j] += v[o][j] + w[o][j];
+        }
+        if (r < r1) {
             float v[NOUT][8];
             f(col, r, c0, nvalid, v);
 #pragma unroll

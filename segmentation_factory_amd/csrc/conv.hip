@@ -445,28 +445,37 @@ __global__ void im2col_nhwc_kernel(const T* __restrict__ x, T* __restrict__ col,
         store8<T>(col + m * ldcol + (int64_t)(ky * kw + kx) * Cin + ch * 8, v);
     }
 }
-// fp32 NCHW image input (Cin small, e.g. 3): one output element per thread, pad columns zeroed
+// fp32 NCHW image input (Cin small, e.g. 3): a thread builds 8 consecutive columns of one im2col row (scalar gathers from
+// the image, which stays L2-resident) and issues ONE 16-byte store; pad columns [K, ldcol) are zeroed.  ldcol % 8 == 0.
 template <typename T>
 __global__ void im2col_nchw_kernel(const float* __restrict__ x, T* __restrict__ col, int64_t ldcol, int B, int H, int W, int Cin,
                                    int kh, int kw, int stride, int pad, int Ho, int Wo) {
-    const int64_t total = (int64_t)B * Ho * Wo * ldcol;
+    const int nch = (int)(ldcol / 8);
+    const int64_t total = (int64_t)B * Ho * Wo * nch;
     const int K = kh * kw * Cin;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int kcol = (int)(idx % ldcol);
-        const int64_t m = idx / ldcol;
-        float v = 0.f;
-        if (kcol < K) {
-            const int ci = kcol % Cin;
-            const int kk = kcol / Cin;
-            const int kx = kk % kw, ky = kk / kw;
-            const int ox = (int)(m % Wo);
-            const int64_t t2 = m / Wo;
-            const int oy = (int)(t2 % Ho);
-            const int64_t b = t2 / Ho;
-            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((b * Cin + ci) * H + iy) * W + ix];
+        const int ch = (int)(idx % nch);
+        const int64_t m = idx / nch;
+        const int ox = (int)(m % Wo);
+        const int64_t t2 = m / Wo;
+        const int oy = (int)(t2 % Ho);
+        const int64_t b = t2 / Ho;
+        const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kcol = ch * 8 + j;
+            float val = 0.f;
+            if (kcol < K) {
+                const int ci = kcol % Cin;
+                const int kk = kcol / Cin;
+                const int kx = kk % kw, ky = kk / kw;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = x[((b * Cin + ci) * H + iy) * W + ix];
+            }
+            v[j] = val;
         }
-        stf<T>(col + idx, v);
+        store8<T>(col + m * ldcol + ch * 8, v);
     }
 }
 // pad columns [K, ldcol) of the NHWC im2col matrix
@@ -488,7 +497,9 @@ extern "C" int segf_im2col(int dt, int in_nchw_f32, int B, int H, int W, int Cin
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * Ho * Wo;
     if (in_nchw_f32) {
-        const int blocks = (int)imin64(cdiv64(rows * ldcol, 256), 8192);
+        const int64_t esz0 = dt == SEGF_BF16 ? 2 : 4;
+        if (ldcol % 8 || ((uintptr_t)col % 16) || ((ldcol * esz0) % 16)) return SEGF_ERR_SHAPE;
+        const int blocks = (int)imin64(cdiv64(rows * (ldcol / 8), 256), 16384);
         SEGF_DISPATCH_DT(dt, T, {
             hipLaunchKernelGGL((im2col_nchw_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)x, (T*)col, ldcol, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
         })

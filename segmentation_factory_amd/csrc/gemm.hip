@@ -24,6 +24,7 @@ struct GemmArgs {
     int64_t kchunk;          // K range per grid.z slice
     float* ws;               // split-K partials [z][M][N] (nullptr when split_k == 1)
     int a_vec, b_vec, c_vec, r_vec, use_tr;
+    int c_vec16;             // C rows allow 16-byte stores (bf16 output, LDS-staged epilogue)
     // implicit 3x3 convolution (stride 1, pad 1) over an NHWC operand [B][cH][cW][ld >= cC]: the gathered operand's K (layout 0,
     // operand A) or N (layout 2, operand B) axis is (tap = ky*3+kx, channel); csign = +1 reads pixel + offset(tap) (forward,
     // weight gradient), -1 reads pixel - offset(tap) (data gradient = correlation of dy with the transposed weights)
@@ -34,6 +35,7 @@ struct GemmArgs {
 #define GB_BN 128
 #define GB_BK 64
 #define GB_TILE_BYTES 16384
+#define GB_STG_LD 132      // fp32 epilogue staging row stride (128 + 4 pad)
 
 __device__ __forceinline__ uint4 ld8_bf16_guard(const bf16_t* p, int nvalid) {
     bf16_t t[8];
@@ -278,6 +280,60 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
         __syncthreads();
     }
     // D[i][j]: i (rows, 4*(lane>>4)+r) <-> n, j (cols, lane&15) <-> m
+    if (sizeof(OutT) == 2 && !a.ws && a.c_vec16) {
+        // bf16 output: stage the fp32 accumulators through LDS (two half-tiles of 64 rows) so that every thread applies the
+        // epilogue to 8 consecutive columns of one row and issues a 16-byte store: full 256-byte row segments per 16 lanes
+        // instead of 8-byte pieces scattered over 16 rows (the memory-bound GEMMs of the step are store-bound otherwise)
+        float* stg = reinterpret_cast<float*>(&smem[0][0][0]);     // [64][GB_STG_LD] floats = 33.8 KB of the 64 KB
+        const int tchunk = threadIdx.x & 15, trow = threadIdx.x >> 4;
+        const int64_t ncol = n0 + tchunk * 8;
+        float bs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bs[j] = (a.bias && ncol + j < a.N) ? a.bias[ncol + j] : 0.f;
+        const bool full = ncol + 8 <= a.N;
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();
+            if (wm == half) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        *reinterpret_cast<f32x4*>(stg + (tm * 16 + (lane & 15)) * GB_STG_LD + wn * 64 + tn * 16 + 4 * (lane >> 4)) = acc[tn][tm];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = trow + 16 * i;
+                const int64_t m = m0 + half * 64 + r;
+                if (m >= a.M || ncol >= a.N) continue;
+                float v[8];
+                const float4 lo = *reinterpret_cast<const float4*>(stg + r * GB_STG_LD + tchunk * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(stg + r * GB_STG_LD + tchunk * 8 + 4);
+                v[0] = lo.x + bs[0]; v[1] = lo.y + bs[1]; v[2] = lo.z + bs[2]; v[3] = lo.w + bs[3];
+                v[4] = hi.x + bs[4]; v[5] = hi.y + bs[5]; v[6] = hi.z + bs[6]; v[7] = hi.w + bs[7];
+                if (a.residual) {
+                    const float sc = a.rscale ? a.rscale[m / a.rpg] : 1.f;
+                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(a.residual) + m * a.ldr + ncol;
+                    float rv[8];
+                    if (full && a.r_vec) load8<bf16_t>(rp, rv);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rv[j] = ncol + j < a.N ? bf2f(rp[j]) : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = rv[j] + sc * v[j];
+                }
+                bf16_t* dst = reinterpret_cast<bf16_t*>(a.C) + m * a.ldc + ncol;
+                if (full) store8<bf16_t>(dst, v);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (ncol + j < a.N) dst[j] = f2bf(v[j]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
         const int64_t m = m0 + wm * 64 + tm * 16 + (lane & 15);
@@ -413,7 +469,8 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
     a.a_vec = ((uintptr_t)A % 16 == 0) && ((lda * esz) % 16 == 0);
     a.b_vec = ((uintptr_t)B % 16 == 0) && ((ldb * esz) % 16 == 0);
     a.c_vec = ((uintptr_t)C % (4 * csz) == 0) && ((ldc * csz) % (4 * csz) == 0);
-    a.r_vec = 0;
+    a.r_vec = residual ? (((uintptr_t)residual % 16 == 0) && ((ldr * esz) % 16 == 0)) : 0;
+    a.c_vec16 = ((uintptr_t)C % 16 == 0) && ((ldc * csz) % 16 == 0);
     a.cH = a.cW = a.cC = 0; a.csign = 1;
     {   // debugging switch: SEGFAC_GEMM_NO_TR=1 reads transposed fragments with scalar LDS loads instead of ds_read_b64_tr_b16
         const char* e = getenv("SEGFAC_GEMM_NO_TR");
@@ -487,6 +544,7 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     a.ws = split_k > 1 ? ws : nullptr;
     const size_t csz = y_dt == SEGF_BF16 ? 2 : 4;
     a.c_vec = ((uintptr_t)y % (4 * csz) == 0) && ((ldy * csz) % (4 * csz) == 0);
+    a.c_vec16 = ((uintptr_t)y % 16 == 0) && ((ldy * csz) % 16 == 0);
     dim3 grid((unsigned)cdiv64(a.N, GB_BN), (unsigned)cdiv64(a.M, GB_BM), (unsigned)split_k);
     if (grid.y > 65535u) return SEGF_ERR_SHAPE;
     const bool f32out = y_dt == SEGF_F32 || a.ws;

@@ -90,6 +90,32 @@ __device__ __forceinline__ float wave_softmax(const float (&z)[NS], float (&p)[N
     return mx + __logf(sum);
 }
 
+// softmax with a wave-uniform upper bound `mb` of max(z) in place of the exact maximum (every pixel of a cell is a convex
+// combination of the cell's four taps, so the taps' maximum bounds all of them: one wave reduction per CELL instead of
+// one per pixel).  Mathematically identical (softmax is shift invariant); if the bound is so loose that the sum
+// underflows, the exact-maximum path is taken instead (wave-uniform branch, practically never).
+template <int NS>
+__device__ __forceinline__ float wave_softmax_bounded(const float (&z)[NS], float mb, float (&p)[NS]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { p[s] = __expf(z[s] - mb); sum += p[s]; }
+    sum = wave_sum_all(sum);
+    if (!(sum > 1e-30f)) return wave_softmax<NS>(z, p);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p[s] *= inv;
+    return mb + __logf(sum);
+}
+template <int NS>
+__device__ __forceinline__ float cell_max_bound(const float (&t00)[NS], const float (&t01)[NS], const float (&t10)[NS],
+                                                const float (&t11)[NS], int lane, int C) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (lane + 64 * s < C) mx = fmaxf(mx, fmaxf(fmaxf(t00[s], t01[s]), fmaxf(t10[s], t11[s])));
+    return wave_max_all(mx);
+}
+
 // A cell = the sc x sc full-res pixels between low-res taps (cj, ck) .. (cj+1, ck+1); cj in [-1, h-1] (taps clamp).
 struct Cell { int cj, ck, y0, y1, x0, x1; };
 __device__ __forceinline__ Cell make_cell(int cj, int ck, int h, int w, int halo) {
@@ -165,6 +191,9 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_cells_kernel(const T* 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int halo = sc > 1 ? 1 : 0, off = sc >> 1;
+    // in-cell interpolation weight of pixel offset a: (a + 0.5) / sc -- exact for the power-of-two ratios of this path and
+    // equal to bilinear_src's fraction; at the clamped borders both taps coincide, so any weight gives the same value
+    const float inv_sc = 1.f / (float)sc, fhalo = (float)halo;
     const int ncx = g.w + halo, ncell = (g.h + halo) * ncx;
     const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
     const int64_t* tg = target + (int64_t)b * g.H * g.W;
@@ -177,10 +206,11 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_cells_kernel(const T* 
         float t00[NS], t01[NS], t10[NS], t11[NS];
         load_cell_taps<T, NS>(img, g, c, lane, t00, t01, t10, t11);
         const int codes = cell_label_codes(tg, g, sc, off, c.cj, c.ck, lane, ignore_index);
+        const float mb = cell_max_bound<NS>(t00, t01, t10, t11, lane, g.C);
         for (int a = 0; a < sc; ++a) {
             const int Y = sc * c.cj + off + a;
             if (Y < 0 || Y >= g.H) continue;
-            const float ly = cell_frac(Y, g.h, g.H);
+            const float ly = (a + 0.5f) * inv_sc * fhalo;
             float L[NS], R[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -191,12 +221,11 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_cells_kernel(const T* 
                 const int t = __builtin_amdgcn_readlane(codes, a * sc + bb);     // wave-uniform
                 if (t == -1) continue;                           // ignored / outside
                 if (t == -2) { bad = 1.f; continue; }            // the reference raises here (one_hot / cross_entropy)
-                const int X = sc * c.ck + off + bb;
-                const float lx = cell_frac(X, g.w, g.W);
+                const float lx = (bb + 0.5f) * inv_sc * fhalo;
                 float z[NS], pr[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) z[s] = (lane + 64 * s) < g.C ? (1.f - lx) * L[s] + lx * R[s] : -INFINITY;
-                const float lse = wave_softmax<NS>(z, pr);
+                const float lse = wave_softmax_bounded<NS>(z, mb, pr);
                 const float wt = cw ? cw[t] : 1.f;
                 nvalid += 1.f; wsum += wt;
 #pragma unroll
@@ -311,9 +340,9 @@ __device__ __forceinline__ void dice_coefs(const float* __restrict__ stats, int 
 // dz[s] = go * d loss / d z_c for one valid pixel with label t
 template <int NS>
 __device__ __forceinline__ void pixel_grad(const float (&z)[NS], int t, int lane, const float (&gI)[NS], const float (&gP)[NS],
-                                           float wce, float go, float (&dz)[NS]) {
+                                           float wce, float go, float (&dz)[NS], float mb = INFINITY) {
     float pr[NS], G[NS];
-    wave_softmax<NS>(z, pr);
+    if (mb == INFINITY) wave_softmax<NS>(z, pr); else wave_softmax_bounded<NS>(z, mb, pr);
     float dot = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -341,6 +370,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_cells_kernel(const T* 
     const int tiles_x = (g.w + LS_TILE - 1) / LS_TILE;
     const int ty0 = (blockIdx.x / tiles_x) * LS_TILE, tx0 = (blockIdx.x % tiles_x) * LS_TILE;
     const int halo = sc > 1 ? 1 : 0, off = sc >> 1;
+    const float inv_sc = 1.f / (float)sc, fhalo = (float)halo;
     for (int i = threadIdx.x; i < LS_TILE * LS_TILE * 64 * NS; i += LS_THREADS) (&accum[0][0])[i] = 0.f;
     float gI[NS], gP[NS];
     dice_coefs<NS>(stats, b, g.B, g.C, dice, lane, gI, gP);
@@ -363,12 +393,13 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_cells_kernel(const T* 
             load_cell_taps<T, NS>(img, g, c, lane, t00, t01, t10, t11);
             int codes = cell_label_codes(tg, g, sc, off, cj, ck, lane, ignore_index);
             if (codes == -2) codes = -1;
+            const float mb = cell_max_bound<NS>(t00, t01, t10, t11, lane, g.C);
 #pragma unroll
             for (int s = 0; s < NS; ++s) { A00[s] = 0.f; A01[s] = 0.f; A10[s] = 0.f; A11[s] = 0.f; }
             for (int a = 0; a < sc; ++a) {
                 const int Y = sc * cj + off + a;
                 if (Y < 0 || Y >= g.H) continue;
-                const float ly = cell_frac(Y, g.h, g.H);
+                const float ly = (a + 0.5f) * inv_sc * fhalo;
                 float L[NS], R[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -378,12 +409,11 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_cells_kernel(const T* 
                 for (int bb = 0; bb < sc; ++bb) {
                     const int t = __builtin_amdgcn_readlane(codes, a * sc + bb);     // wave-uniform
                     if (t < 0) continue;
-                    const int X = sc * ck + off + bb;
-                    const float lx = cell_frac(X, g.w, g.W);
+                    const float lx = (bb + 0.5f) * inv_sc * fhalo;
                     float z[NS], dz[NS];
 #pragma unroll
                     for (int s = 0; s < NS; ++s) z[s] = (lane + 64 * s) < g.C ? (1.f - lx) * L[s] + lx * R[s] : -INFINITY;
-                    pixel_grad<NS>(z, t, lane, gI, gP, (cw ? cw[t] : 1.f) * invW, go, dz);
+                    pixel_grad<NS>(z, t, lane, gI, gP, (cw ? cw[t] : 1.f) * invW, go, dz, mb);
                     const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
@@ -588,6 +618,7 @@ __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_cells_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     const int halo = sc > 1 ? 1 : 0, off = sc >> 1;
+    const float inv_sc = 1.f / (float)sc, fhalo = (float)halo;
     const int ncx = g.w + halo, ncell = (g.h + halo) * ncx;
     const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
     const int64_t npix = (int64_t)g.H * g.W;
@@ -605,7 +636,7 @@ __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_cells_kernel(const 
         for (int a = 0; a < sc; ++a) {
             const int Y = sc * c.cj + off + a;
             if (Y < 0 || Y >= g.H) continue;
-            const float ly = cell_frac(Y, g.h, g.H);
+            const float ly = (a + 0.5f) * inv_sc * fhalo;
             float L[NS], R[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -616,7 +647,7 @@ __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_cells_kernel(const 
                 const int t = __builtin_amdgcn_readlane(codes, a * sc + bb);     // wave-uniform
                 if (t == -1 || (t == -3 && !pred_out)) continue;
                 const int X = sc * c.ck + off + bb;
-                const float lx = cell_frac(X, g.w, g.W);
+                const float lx = (bb + 0.5f) * inv_sc * fhalo;
                 float z[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) z[s] = (lane + 64 * s) < g.C ? (1.f - lx) * L[s] + lx * R[s] : -INFINITY;

@@ -148,6 +148,60 @@ __global__ void bilinear_bwd_kernel(T* __restrict__ din, int64_t ldi, const T* _
     }
 }
 
+// Integer-ratio fast path of the transposed resize (H == R*h, W == R*w, align_corners=False; R = 2, 4, 8 cover every
+// resize of the SegFormer / UPerNet heads at 512^2): the <= 2R x 2R window of output pixels that touch an input pixel and
+// its separable weights are known per thread up front (weights come from the same bilinear_src as the forward, so the
+// clamped borders are exact); the inner loop is load + fma only.
+template <typename T, int R>
+__global__ void __launch_bounds__(256) bilinear_bwd_int_kernel(T* __restrict__ din, int64_t ldi, const T* __restrict__ dout,
+                                                                int64_t ldo, int B, int h, int w, int C) {
+    constexpr int WIN = 2 * R;
+    const int H = R * h, W = R * w, off = R / 2;
+    const int nch = C / 8;
+    const int64_t total = (int64_t)B * h * w * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch);
+        int64_t t = idx / nch;
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h);
+        const int64_t b = t / h;
+        const int c0 = ch * 8;
+        const int Y0 = y == 0 ? 0 : R * (y - 1) + off, X0 = x == 0 ? 0 : R * (x - 1) + off;
+        float wx[WIN];
+#pragma unroll
+        for (int j = 0; j < WIN; ++j) {
+            const int X = X0 + j;
+            int x0, x1; float lx;
+            bilinear_src(X < W ? X : W - 1, w, W, 0, x0, x1, lx);
+            wx[j] = X < W ? (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f) : 0.f;
+        }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const T* src = dout + (b * H * W) * ldo + c0;
+        for (int i = 0; i < WIN; ++i) {
+            const int Y = Y0 + i;
+            if (Y >= H) break;
+            int y0, y1; float ly;
+            bilinear_src(Y, h, H, 0, y0, y1, ly);
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            const T* row = src + ((int64_t)Y * W + X0) * ldo;
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) {
+                if (wx[j] != 0.f) {
+                    float v[8];
+                    load8<T>(row + (int64_t)j * ldo, v);
+                    const float ww = wy * wx[j];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(ww, v[q], acc[q]);
+                }
+            }
+        }
+        store8<T>(din + ((b * h + y) * w + x) * ldi + c0, acc);
+    }
+}
+
 extern "C" int segf_bilinear_fwd(int dt, int B, int h, int w, int C, const void* in, int64_t ldi, int H, int W, void* out,
                                  int64_t ldo, int align_corners, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
@@ -167,9 +221,17 @@ extern "C" int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, 
     if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return 0;
     if (H <= 0 || W <= 0 || ldi < C || ldo < C) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = (int)imin64(cdiv64((int64_t)B * h * w * ((C + 7) / 8), 256), 8192);
+    const int blocks = (int)imin64(cdiv64((int64_t)B * h * w * ((C + 7) / 8), 256), 16384);
+    const int R = (H % h == 0 && W % w == 0 && H / h == W / w) ? H / h : 0;
     SEGF_DISPATCH_DT(dt, T, {
         const bool vec = vec_ok_host<T>(din, ldi) && vec_ok_host<T>(dout, ldo);
+        if (vec && !align_corners && C % 8 == 0 && (R == 2 || R == 4 || R == 8)) {
+            if (R == 2) hipLaunchKernelGGL((bilinear_bwd_int_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (T*)din, ldi, (const T*)dout, ldo, B, h, w, C);
+            else if (R == 4) hipLaunchKernelGGL((bilinear_bwd_int_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, (T*)din, ldi, (const T*)dout, ldo, B, h, w, C);
+            else hipLaunchKernelGGL((bilinear_bwd_int_kernel<T, 8>), dim3(blocks), dim3(256), 0, st, (T*)din, ldi, (const T*)dout, ldo, B, h, w, C);
+            SEGF_CHECK_LAUNCH();
+            return 0;
+        }
         hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, (T*)din, ldi, (const T*)dout, ldo, B, h, w, C, H, W, align_corners, vec);
     })
     SEGF_CHECK_LAUNCH();
