@@ -186,12 +186,12 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 }
 
 template <typename InT, typename OutT>
-__device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int64_t n0, float (&v)[4]) {
+__device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int64_t n0, float (&v)[4], unsigned zslice) {
     // v[r] is the accumulator of C[m][n0 + r]
     if (m >= a.M || n0 >= a.N) return;
     const int nv = (int)(a.N - n0 < 4 ? a.N - n0 : 4);
     if (a.ws) {   // split-K partial: raw accumulators, fp32, ld = N
-        float* dst = a.ws + ((int64_t)blockIdx.z * a.M + m) * a.N + n0;
+        float* dst = a.ws + ((int64_t)zslice * a.M + m) * a.N + n0;
         for (int r = 0; r < nv; ++r) dst[r] = v[r];
         return;
     }
@@ -213,8 +213,19 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GB_TILE_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int64_t m0 = (int64_t)blockIdx.y * GB_BM, n0 = (int64_t)blockIdx.x * GB_BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * a.kchunk;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the hardware id is
+    // remapped (bijectively) such that each XCD walks a CONTIGUOUS range of logical tiles, n-tile fastest: the column tiles
+    // of one row tile -- and, for split-K, all tiles of one K slab -- run back to back on one XCD and share their operand
+    // through that L2 instead of each fetching it from HBM.  Speed only; any placement computes the same result.
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    // (split-K weight-gradient launches keep the hardware order: measured slower with the remap)
+    const unsigned wgid = LAYOUT == 2 ? orig : (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const unsigned bx = wgid % gx, by = (wgid / gx) % gy, bz = wgid / (gx * gy);
+    const int64_t m0 = (int64_t)by * GB_BM, n0 = (int64_t)bx * GB_BN;
+    const int64_t kbeg = (int64_t)bz * a.kchunk;
     const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
@@ -341,7 +352,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
         for (int tn = 0; tn < 4; ++tn) {
             const int64_t n = n0 + wn * 64 + tn * 16 + 4 * (lane >> 4);
             float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
-            gemm_epilogue4<bf16_t, OutT>(a, m, n, v);
+            gemm_epilogue4<bf16_t, OutT>(a, m, n, v, bz);
         }
     }
 }
@@ -403,7 +414,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         float v[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-        gemm_epilogue4<float, float>(a, m0 + ty * 4 + i, n0 + tx * 4, v);
+        gemm_epilogue4<float, float>(a, m0 + ty * 4 + i, n0 + tx * 4, v, blockIdx.z);
     }
 }
 

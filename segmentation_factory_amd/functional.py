@@ -35,26 +35,48 @@ class LinearFn(Function):
         x = _rowmajor(x)
         M, K = x.shape
         N = weight.shape[0]
-        w = _w(weight.reshape(N, -1), x.dtype)
-        out = None
-        if pad_to and pad_to > N:
-            out = torch.empty((M, pad_to), dtype=x.dtype, device=x.device)[:, :N]
-        b = bias.detach() if bias is not None else None
-        y = hip.gemm(0, x, w, M, N, K, out=out, bias=b, residual=residual, rscale=rscale,
-                     rows_per_group=rows_per_group or 1)
+        Np = pad_to if (pad_to and pad_to > N) else N
+        if Np > N:
+            # column-padded output (e.g. 150 classes -> 152): the layer is run as an Np-wide linear whose extra weight rows
+            # and biases are zero, so the pad columns of y are exact zeros, every 16-byte chunk of a row is either fully
+            # valid or fully padding, and the backward products take the padded gradient as it stands
+            assert residual is None
+            w = torch.zeros((Np, K), dtype=x.dtype, device=x.device)
+            hip.cast2d(weight.detach().reshape(N, -1), w[:N])
+            b = None
+            if bias is not None:
+                b = torch.zeros(Np, dtype=torch.float32, device=x.device)
+                hip.cast2d(bias.detach().unsqueeze(1), b[:N].unsqueeze(1))
+            y = hip.gemm(0, x, w, M, Np, K, bias=b)[:, :N]
+        else:
+            w = _w(weight.reshape(N, -1), x.dtype)
+            b = bias.detach() if bias is not None else None
+            y = hip.gemm(0, x, w, M, N, K, bias=b, residual=residual, rscale=rscale, rows_per_group=rows_per_group or 1)
         ctx.save_for_backward(x, w, rscale)
-        ctx.meta = (M, N, K, bias is not None, residual is not None, rows_per_group or 1, weight.shape)
+        ctx.meta = (M, N, K, bias is not None, residual is not None, rows_per_group or 1, weight.shape, Np)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, rscale = ctx.saved_tensors
-        M, N, K, has_bias, has_res, rpg, wshape = ctx.meta
+        M, N, K, has_bias, has_res, rpg, wshape, Np = ctx.meta
         dy = _rowmajor(dy)
+        if Np > N and dy.stride(0) == Np:
+            # the gradient arrives in a column-padded buffer; every kernel of this library that writes padded rows zero-fills
+            # the pad (segfac.h), so the products run Np wide and the zero rows / columns are sliced away afterwards
+            dyp = dy.as_strided((M, Np), (Np, 1))
+            dx = hip.gemm(1, dyp, w, M, K, Np) if ctx.needs_input_grad[0] else None
+            dw = db = None
+            if ctx.needs_input_grad[1]:
+                dw = hip.gemm(2, dyp, x, Np, K, M, out_dtype=torch.float32, split_k=_splitk(Np, K, M))[:N].view(wshape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dyp)[:N]
+            return dx, dw, db, None, None, None, None
+        wv = w[:N] if Np > N else w
         dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = hip.gemm(1, dys, w, M, K, N)
+            dx = hip.gemm(1, dys, wv, M, K, N)
         if ctx.needs_input_grad[1]:
             dw = hip.gemm(2, dys, x, N, K, M, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
         if has_bias and ctx.needs_input_grad[2]:
