@@ -40,23 +40,31 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
         for (int p = 0; p < DW_PIX; ++p)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
+        // every tap load is unconditional (clamped address, value masked afterwards): a conditional load costs a branch plus a
+        // full s_waitcnt per load, which serialises the 18 loads of a strip behind each other's memory latency
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = yy + ky - 1;
-            if (iy < 0 || iy >= H) continue;
-            const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
+            const bool vy = iy >= 0 && iy < H;
+            const T* row = x + (((int64_t)b * H + (vy ? iy : yy)) * W) * C + c0;
+            float v[DW_PIX + 2][8];
 #pragma unroll
             for (int cx = 0; cx < DW_PIX + 2; ++cx) {
                 const int ix = x0 + cx - 1;
-                if (ix < 0 || ix >= W) continue;
-                float v[8];
-                load8<T>(row + (int64_t)ix * C, v);
+                load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[cx]);
+            }
+#pragma unroll
+            for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                const int ix = x0 + cx - 1;
+                const bool ok = vy && ix >= 0 && ix < W;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[cx][j] = ok ? v[cx][j] : 0.f;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int p = cx - kx;            // output pixel that sees this column through tap kx
                     if (p >= 0 && p < DW_PIX) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wk[ky * 3 + kx][j], v[j], acc[p][j]);
+                        for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wk[ky * 3 + kx][j], v[cx][j], acc[p][j]);
                     }
                 }
             }
@@ -82,7 +90,8 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
 }
 
 static inline int dw_blocks(int B, int H, int W, int C) {
-    return colfixed_blocks((int64_t)B * H * ((W + DW_PIX - 1) / DW_PIX), C / 8, 1, 16384);
+    // 8 strips per thread: the 72 per-channel weights a thread keeps in registers are loaded once per 8 strips
+    return colfixed_blocks((int64_t)B * H * ((W + DW_PIX - 1) / DW_PIX), C / 8, 8, 16384);
 }
 
 extern "C" int segf_dwconv3x3_gelu_fwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
@@ -148,31 +157,38 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_kernel(const T* __restric
             float g[DW_PIX][8];
 #pragma unroll
             for (int p = 0; p < DW_PIX; ++p) {
-                if (x0 + p < W) load8<T>(du + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, g[p]);
-                else {
+                const int xp = x0 + p < W ? x0 + p : W - 1;
+                load8<T>(du + (((int64_t)b * H + yy) * W + xp) * C + c0, g[p]);
+            }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) g[p][j] = 0.f;
-                }
+            for (int p = 0; p < DW_PIX; ++p) {
+                const bool ok = x0 + p < W;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[9][j] += g[p][j];
+                for (int j = 0; j < 8; ++j) { g[p][j] = ok ? g[p][j] : 0.f; acc[9][j] += g[p][j]; }
             }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = yy + ky - 1;
-                if (iy < 0 || iy >= H) continue;
-                const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
+                const bool vy = iy >= 0 && iy < H;
+                const T* row = x + (((int64_t)b * H + (vy ? iy : yy)) * W) * C + c0;
+                float v[DW_PIX + 2][8];
 #pragma unroll
                 for (int cx = 0; cx < DW_PIX + 2; ++cx) {
                     const int ix = x0 + cx - 1;
-                    if (ix < 0 || ix >= W) continue;
-                    float v[8];
-                    load8<T>(row + (int64_t)ix * C, v);
+                    load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[cx]);
+                }
+#pragma unroll
+                for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                    const int ix = x0 + cx - 1;
+                    const bool ok = vy && ix >= 0 && ix < W;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[cx][j] = ok ? v[cx][j] : 0.f;
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int p = cx - kx;
                         if (p >= 0 && p < DW_PIX) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(g[p][j], v[j], acc[ky * 3 + kx][j]);
+                            for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(g[p][j], v[cx][j], acc[ky * 3 + kx][j]);
                         }
                     }
                 }
@@ -254,23 +270,34 @@ __global__ void __launch_bounds__(256) dwconv7x7_kernel(const T* __restrict__ x,
             for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
         for (int ky = 0; ky < 7; ++ky) {
             const int iy = yy + ky - 3;
-            if (iy < 0 || iy >= H) continue;
+            if (iy < 0 || iy >= H) continue;            // wave-divergent only at the image border rows
             float wk[7][8];
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) load8f(wt + (int64_t)(FLIP ? 48 - (ky * 7 + kx) : ky * 7 + kx) * C + c0, wk[kx]);
             const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
+            // unconditional, clamped loads in two batches of 7 columns (a branch per load would serialise their latencies)
 #pragma unroll
-            for (int cx = 0; cx < DW7_PIX + 6; ++cx) {
-                const int ix = x0 + cx - 3;
-                if (ix < 0 || ix >= W) continue;
-                float v[8];
-                load8<T>(row + (int64_t)ix * C, v);
+            for (int half = 0; half < 2; ++half) {
+                float v[7][8];
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    const int p = cx - kx;
-                    if (p >= 0 && p < DW7_PIX) {
+                for (int q = 0; q < 7; ++q) {
+                    const int ix = x0 + half * 7 + q - 3;
+                    load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[q]);
+                }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wk[kx][j], v[j], acc[p][j]);
+                for (int q = 0; q < 7; ++q) {
+                    const int cx = half * 7 + q;
+                    const int ix = x0 + cx - 3;
+                    const bool ok = ix >= 0 && ix < W;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[q][j] = ok ? v[q][j] : 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const int p = cx - kx;
+                        if (p >= 0 && p < DW7_PIX) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wk[kx][j], v[q][j], acc[p][j]);
+                        }
                     }
                 }
             }
@@ -327,8 +354,8 @@ __global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restric
             float gq[DW7_PIX][8];
 #pragma unroll
             for (int p = 0; p < DW7_PIX; ++p) {
-                if (x0 + p < W) load8<T>(dy + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, gq[p]);
-                else {
+                load8<T>(dy + (((int64_t)b * H + yy) * W + (x0 + p < W ? x0 + p : W - 1)) * C + c0, gq[p]);
+                if (!(x0 + p < W)) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) gq[p][j] = 0.f;
                 }
@@ -340,17 +367,27 @@ __global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restric
             if (iy < 0 || iy >= H) continue;
             const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
 #pragma unroll
-            for (int cx = 0; cx < DW7_PIX + 6; ++cx) {
-                const int ix = x0 + cx - 3;
-                if (ix < 0 || ix >= W) continue;
-                float v[8];
-                load8<T>(row + (int64_t)ix * C, v);
+            for (int half = 0; half < 2; ++half) {
+                float v[7][8];
 #pragma unroll
-                for (int kx = 0; kx < 7; ++kx) {
-                    const int p = cx - kx;
-                    if (p >= 0 && p < DW7_PIX) {
+                for (int q = 0; q < 7; ++q) {
+                    const int ix = x0 + half * 7 + q - 3;
+                    load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[q]);
+                }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[kx][j] = fmaf(gq[p][j], v[j], acc[kx][j]);
+                for (int q = 0; q < 7; ++q) {
+                    const int cx = half * 7 + q;
+                    const int ix = x0 + cx - 3;
+                    const bool ok = ix >= 0 && ix < W;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[q][j] = ok ? v[q][j] : 0.f;
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const int p = cx - kx;
+                        if (p >= 0 && p < DW7_PIX) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[kx][j] = fmaf(gq[p][j], v[q][j], acc[kx][j]);
+                        }
                     }
                 }
             }
@@ -370,7 +407,7 @@ __global__ void dw7_scatter_kernel(const float* __restrict__ sums, int C, float*
 }
 
 static inline int dw7_blocks(int B, int H, int W, int C) {
-    return colfixed_blocks((int64_t)B * H * ((W + DW7_PIX - 1) / DW7_PIX), C / 8, 1, 16384);
+    return colfixed_blocks((int64_t)B * H * ((W + DW7_PIX - 1) / DW7_PIX), C / 8, 4, 16384);
 }
 static inline int dw7_check(int B, int H, int W, int C, const void* a, const void* b) {
     if (C <= 0 || C % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return SEGF_ERR_SHAPE;
