@@ -190,6 +190,9 @@ int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W, const voi
                      const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
                      const float* stats, const float* grad_out, void* dlogits, int64_t ldd, float* ws, void* stream);
 
+/* test hook: out[16] = column sums of in[64][16] through the loss kernels' transposing wave reduction */
+int segf_debug_wave_reduce16(const float* in, float* out, void* stream);
+
 /* ---- fused upsample + argmax + confusion matrix (engine.py:89-91; util/utils.py:99-109;
  * util/metrics.py:24-27).  mat: int64 [n][n] += counts where 0<=t<n; hist: int64 [n][n] += counts
  * where t != ignore_label (t>=n and != ignore is skipped and flagged in flag[0]).                  */

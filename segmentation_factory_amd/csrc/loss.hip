@@ -183,10 +183,185 @@ __device__ __forceinline__ void fwd_block_tail(float (&aI)[NS], float (&aP)[NS],
     }
 }
 
+// ---- 16 pixels of a cell at a time -----------------------------------------------------------------------------------
+// Per-pixel wave reductions (sum of exponentials, <G, p>) dominate the per-pixel form: 11 dependent instructions each.
+// Here a wave keeps the 16 pixels' class values in registers and reduces their 16 per-lane partial sums TOGETHER, as a
+// transposing reduction: v_permlane32_swap / v_permlane16_swap halve the number of live values while crossing the
+// 32- and 16-lane boundaries (8 + 4 swap-add pairs), four DPP butterflies finish the 16-lane rows for the remaining
+// 4 values, and 16 v_readlane turn the results into wave-uniform scalars: 56 instructions per 16 pixels instead of 176.
+// (inline asm: hipcc 7.2 miscompiles the two-result __builtin_amdgcn_permlane{16,32}_swap when both results feed
+// arithmetic -- it adds result 0 to itself; the s_nops cover the VALU-write -> permlane-read wait states, which hipcc does
+// not insert around asm statements)
+__device__ __forceinline__ float swap_add32(float a, float b) {      // [a.lo + a.hi | b.lo + b.hi]
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {      // rows: [a.r0+a.r1 | b.r0+b.r1 | a.r2+a.r3 | b.r2+b.r3]
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ void wave_reduce16(const float (&v)[16], float (&out)[16]) {
+    float u[8], t[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = swap_add32(v[i], v[i + 8]);     // lanes 0-31 keep pixel i, lanes 32-63 pixel i+8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = swap_add16(u[i], u[i + 4]);     // 16-lane row r keeps pixel i + 4*(r&1) + 8*(r>>1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t[i] += dpp_mov<DPP_XOR1>(t[i]); t[i] += dpp_mov<DPP_XOR2>(t[i]);
+        t[i] += dpp_mov<DPP_HALF_MIRROR>(t[i]); t[i] += dpp_mov<DPP_MIRROR>(t[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i + 4 * (r & 1) + 8 * (r >> 1)] = readlane_f(t[i], 16 * r);
+}
+
+// 8-value form (half the live registers of the 16-value form at the same cost per value): lanes 0-31 keep value i,
+// lanes 32-63 value i+4; 16-lane row r then keeps value i + 2*(r&1) + 4*(r>>1), i < 2.
+__device__ __forceinline__ void wave_reduce8(const float (&v)[8], float (&out)[8]) {
+    float u[4], t[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = swap_add32(v[i], v[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) t[i] = swap_add16(u[i], u[i + 2]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        t[i] += dpp_mov<DPP_XOR1>(t[i]); t[i] += dpp_mov<DPP_XOR2>(t[i]);
+        t[i] += dpp_mov<DPP_HALF_MIRROR>(t[i]); t[i] += dpp_mov<DPP_MIRROR>(t[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) out[i + 2 * (r & 1) + 4 * (r >> 1)] = readlane_f(t[i], 16 * r);
+}
+
+// Shared front end of the batched kernels: the cell's taps are brought into the "exp2 domain" once,
+//   u = (t - mb) * log2(e)        (mb = wave-uniform upper bound of every pixel's maximum logit; invalid class lanes: -1e30)
+// so that a pixel's exponent argument is a plain bilinear combination of the four u's (weights sum to one), evaluated
+// separably: one fma per row for the left / right columns and ONE fma per (pixel, class) for the column weight, with
+// the weights (k + 0.5) / SC folded into the instructions as literals.  exp2(-1e30) == 0 removes the class mask.
+#define LS_LOG2E 1.4426950408889634f
+#define LS_LN2 0.6931471805599453f
+template <int NS>
+__device__ __forceinline__ void cell_scaled_taps(float (&t00)[NS], float (&t01)[NS], float (&t10)[NS], float (&t11)[NS], float mb,
+                                                 int lane, int C, float (&d0)[NS], float (&d1)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool ok = lane + 64 * s < C;
+        t00[s] = ok ? (t00[s] - mb) * LS_LOG2E : -1e30f; t01[s] = ok ? (t01[s] - mb) * LS_LOG2E : -1e30f;
+        t10[s] = ok ? (t10[s] - mb) * LS_LOG2E : -1e30f; t11[s] = ok ? (t11[s] - mb) * LS_LOG2E : -1e30f;
+        d0[s] = t10[s] - t00[s]; d1[s] = t11[s] - t01[s];
+    }
+}
+
+// forward over cells, SC in {2, 4, 8}: batches of 16 pixels = 16/SC rows of the cell (SC == 2: the 4 pixels, 12 slots idle).
+// The pixel loops are branch-free: an ignored / out-of-image pixel runs with weight 0.  If the cell bound is ever too loose
+// for a valid pixel (its exponent sum underflows: needs a >88 logit spread between neighbouring taps of one class) the
+// wave raises *retry and the exact-maximum per-pixel kernel, launched right behind and idle otherwise, redoes the image set.
+template <typename T, int NS, int SC>
+__global__ void __launch_bounds__(LS_THREADS, 4) ce_dice_fwd_cells16_kernel(const T* __restrict__ logits, LossGeom g,
+                                                                          const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                          const float* __restrict__ cw, float* __restrict__ partial,
+                                                                          int* __restrict__ retry) {
+    constexpr int PB = 8;                                 // pixels per batch (one wave_reduce8)
+    constexpr int ROWS = SC >= 8 ? 1 : (SC == 4 ? 2 : SC);     // cell rows per batch
+    constexpr int COLS = SC >= 8 ? 8 : SC;                // pixels of a row per batch (SC == 8: a row is one batch)
+    constexpr int NPB = ROWS * COLS;                      // live pixels per batch (4 for SC == 2, else 8)
+    constexpr int NB = SC * SC / NPB;                     // batches per cell
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    constexpr int off = SC / 2;
+    const int ncx = g.w + 1, ncell = (g.h + 1) * ncx;
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * g.H * g.W;
+    float aI[NS], aP[NS], aT[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { aI[s] = 0.f; aP[s] = 0.f; aT[s] = 0.f; }
+    float cez = 0.f;                                   // per-lane: sum of wt * (exp2-domain logit of the label class) over owned pixels
+    float cel2 = 0.f, wsum = 0.f, nvalid = 0.f, bad = 0.f;       // wave-uniform
+    for (int cell = blockIdx.x * 4 + wave; cell < ncell; cell += gridDim.x * 4) {
+        const Cell c = make_cell(cell / ncx - 1, cell % ncx - 1, g.h, g.w, 1);
+        float t00[NS], t01[NS], t10[NS], t11[NS], d0[NS], d1[NS];
+        load_cell_taps<T, NS>(img, g, c, lane, t00, t01, t10, t11);
+        const int codes = cell_label_codes(tg, g, SC, off, c.cj, c.ck, lane, ignore_index);
+        const float mb = cell_max_bound<NS>(t00, t01, t10, t11, lane, g.C);
+        cell_scaled_taps<NS>(t00, t01, t10, t11, mb, lane, g.C, d0, d1);
+        if (__builtin_amdgcn_readfirstlane(__any(codes == -2))) bad = 1.f;
+#pragma unroll 1
+        for (int bi = 0; bi < NB; ++bi) {        // not unrolled: one batch's 24 exponentials + sums live at a time
+            // batch bi covers cell rows [row0, row0 + ROWS) x columns [col0, col0 + COLS)
+            constexpr int BPR = SC / COLS;                // batches per cell row (1 unless SC > 8)
+            const int row0 = (bi / BPR) * ROWS, col0 = (bi % BPR) * COLS;
+            float e[PB][NS], ps[PB], tot[PB];
+#pragma unroll
+            for (int i = NPB; i < PB; ++i) ps[i] = 0.f;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const float ly = (float)(row0 + r + 0.5f) / (float)SC;
+                float L[NS], D[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    L[s] = fmaf(ly, d0[s], t00[s]);
+                    D[s] = fmaf(ly, d1[s], t01[s]) - L[s];
+                }
+#pragma unroll
+                for (int q = 0; q < COLS; ++q) {
+                    const int i = r * COLS + q;
+                    const float lx = (float)(col0 + q + 0.5f) / (float)SC;
+                    const int t = __builtin_amdgcn_readlane(codes, (row0 + r) * SC + col0 + q);
+                    const int tt = t < 0 ? 0 : t;
+                    const float wt = t < 0 ? 0.f : (cw ? cw[tt] : 1.f);          // wave-uniform; 0 for ignored pixels
+                    float sum = 0.f, zt = 0.f;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const float zq = fmaf(lx, D[s], L[s]);
+                        e[i][s] = __builtin_amdgcn_exp2f(zq);
+                        sum += e[i][s];
+                        zt = lane + 64 * s == tt ? zq : zt;                    // the lane that owns the label class
+                    }
+                    ps[i] = sum;
+                    cez = fmaf(wt, zt, cez);
+                }
+            }
+            wave_reduce8(ps, tot);
+            unsigned slow = 0;
+#pragma unroll
+            for (int i = 0; i < NPB; ++i) {
+                const int t = __builtin_amdgcn_readlane(codes, (row0 + i / COLS) * SC + col0 + i % COLS);
+                const int tt = t < 0 ? 0 : t;
+                const bool under = !(tot[i] > 1e-30f);
+                if (t >= 0 && under) slow |= 1u << i;                 // scalar
+                const float okf = (t >= 0 && !under) ? 1.f : 0.f;
+                const float wt = okf * (cw ? cw[tt] : 1.f);
+                const float inv = okf * __builtin_amdgcn_rcpf(fmaxf(tot[i], 1e-30f));
+                cel2 = fmaf(wt, __builtin_amdgcn_logf(fmaxf(tot[i], 1e-30f)), cel2);
+                nvalid += okf; wsum += wt;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const float pr = e[i][s] * inv;
+                    aP[s] += pr;
+                    const bool own = lane + 64 * s == tt;
+                    aI[s] += own ? pr : 0.f;
+                    aT[s] += own ? okf : 0.f;
+                }
+            }
+            if (slow && lane == 0) atomicOr(retry, 1);
+        }
+    }
+    // CE = sum wt (lse - z_t) = ln2 * sum wt (log2(tot) - zq_t): the bound mb cancels
+    const float ce = LS_LN2 * (cel2 - wave_sum_all(cez));
+    fwd_block_tail<NS>(aI, aP, aT, ce, wsum, nvalid, bad, lane, wave, g.C,
+                       partial + ((int64_t)blockIdx.x * g.B + b) * (3 * g.C + 4));
+}
+
 template <typename T, int NS>
 __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_cells_kernel(const T* __restrict__ logits, LossGeom g, int sc,
                                                                         const int64_t* __restrict__ target, int64_t ignore_index,
-                                                                        const float* __restrict__ cw, float* __restrict__ partial) {
+                                                                        const float* __restrict__ cw, float* __restrict__ partial,
+                                                                        const int* __restrict__ run_if) {
+    if (run_if && *run_if == 0) return;          // retry pass behind the batched kernel: idle unless it raised the flag
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -491,19 +666,45 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_kernel(const T* __rest
     }
 }
 
+// test hook: out[i] = sum over the 64 rows of in[row][i], through the transposing wave reduction used by the loss kernels
+__global__ void wave_reduce16_test_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    float v[16], o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = in[threadIdx.x * 16 + i];
+    wave_reduce16(v, o);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[i] = o[i];
+    }
+}
+extern "C" int segf_debug_wave_reduce16(const float* in, float* out, void* stream) {
+    hipLaunchKernelGGL(wave_reduce16_test_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int64_t segf_ce_dice_stats_floats(int B, int C) {
-    return (int64_t)B * (3 * C + 4) + 4 + (int64_t)LS_NBLK * B * (3 * C + 4);
+    return (int64_t)B * (3 * C + 4) + 4 + (int64_t)LS_NBLK * B * (3 * C + 4) + 4;      // + retry flags
 }
 
 #define LS_NS_DISPATCH(ns, CALL) do { if ((ns) == 1) { CALL(1); } else if ((ns) == 2) { CALL(2); } else { CALL(3); } } while (0)
 
 template <typename T>
 static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
-                       int64_t ignore_index, const float* cw, float* partial) {
+                       int64_t ignore_index, const float* cw, float* partial, int* retry) {
 #define CALL(NS)                                                                                                                \
     do {                                                                                                                        \
-        if (sc) hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,     \
-                                   ignore_index, cw, partial);                                                                  \
+        if (sc >= 2) {                                                                                                          \
+            if (sc == 4) hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 4>), grid, dim3(LS_THREADS), 0, st, logits, g,    \
+                                            target, ignore_index, cw, partial, retry);                                          \
+            else if (sc == 2) hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 2>), grid, dim3(LS_THREADS), 0, st, logits,  \
+                                                 g, target, ignore_index, cw, partial, retry);                                  \
+            else hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 8>), grid, dim3(LS_THREADS), 0, st, logits, g, target,    \
+                                    ignore_index, cw, partial, retry);                                                          \
+            hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,         \
+                               ignore_index, cw, partial, (const int*)retry);                                                   \
+        } else if (sc) hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc,       \
+                                          target, ignore_index, cw, partial, (const int*)nullptr);                              \
         else hipLaunchKernelGGL((ce_dice_fwd_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index,    \
                                 cw, partial);                                                                                   \
     } while (0)
@@ -537,7 +738,12 @@ extern "C" int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W
     const int ns = (C + 63) / 64;
     const int sc = pow2_scale(h, w, H, W);
     const dim3 grid(LS_NBLK, B);
-    SEGF_DISPATCH_DT(dt, T, { fwd_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, partial); })
+    int* retry = reinterpret_cast<int*>(partial + (int64_t)LS_NBLK * B * (3 * C + 4));
+    if (sc >= 2) {
+        const hipError_t e = hipMemsetAsync(retry, 0, 16, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    SEGF_DISPATCH_DT(dt, T, { fwd_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, partial, retry); })
     SEGF_CHECK_LAUNCH();
     colreduce_finalize_launch(partial, LS_NBLK, (int64_t)B * (3 * C + 4), stats, st);
     SEGF_CHECK_LAUNCH();

@@ -60,6 +60,7 @@ _PROTOS = {
     'segf_ce_dice_fwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p]),
     'segf_ce_dice_bwd_ws': (_l, [_i, _i, _i, _i, _i, _i, _i]),
     'segf_ce_dice_bwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p, _l, _p, _p]),
+    'segf_debug_wave_reduce16': (_i, [_p, _p, _p]),
     'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
     'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),

@@ -525,3 +525,13 @@ def test_grn(dtype):
     _close(xd.grad, xr.grad.reshape(-1, C), dtype, fac=2)
     _close(gd.grad, gr.grad, dtype, fac=4)
     _close(bd.grad, br.grad, dtype, fac=4)
+
+
+def test_wave_reduce16_transposing_reduction(hipmod):
+    """The permlane32/16-swap + DPP reduction the loss kernels use for 16 pixels at a time (exact integer data)."""
+    x = torch.randint(-50, 50, (64, 16)).float()
+    out = torch.empty(16, device='cuda')
+    xd = x.cuda()
+    rc = hipmod.lib().segf_debug_wave_reduce16(xd.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(out.cpu(), x.sum(0))
