@@ -65,7 +65,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (BASELINE.json does not fix it; 64 x 512^2 uses ~60 of 288 GB)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward+loss+backward only')
