@@ -78,9 +78,13 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (there is no CPU fallback)'
+    # SEGFAC_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses duplicate devices): used to exercise the N>1 code
+    # path on a 1-GPU box; the driver's multi-GPU runs use the default 'nccl' (= RCCL on ROCm), one rank per GPU
+    backend = os.environ.get('SEGFAC_DIST_BACKEND', 'nccl')
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', init_method='env://')     # 'nccl' is RCCL on ROCm
+        dist.init_process_group(backend, init_method='env://')
     dev = torch.device('cuda', local)
 
     from segmentation_factory_amd import SegmentationModel, criterion_lowres, hip

@@ -62,7 +62,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: RCCL's watchdog thread polls events while we capture; in the default global mode that aborts the capture
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.loss = self.loss_fn(self.model, *self.static_inputs)
             self.loss.backward()
             self.opt.gather_grads()

@@ -274,3 +274,36 @@ def test_train_gpu_cli_synthetic(tmp_path, graph):
     assert (out / 'model.txt').exists() and (out / 'args.txt').exists()
     r2 = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0 and 'Loading local checkpoint' in r2.stdout, r2.stdout[-2000:] + r2.stderr[-2000:]
+
+
+@pytest.mark.parametrize('backbone,head', [('MiT-B2', 'SegFormerHead'), ('convnextv2_nano', 'UPerHead'), ('MiT-B1', 'UPerHead')])
+def test_other_variants_fp32_vs_oracle(backbone, head):
+    """Variants without a committed golden (BASELINE cfg4's MiT-B2: head_dim 64; a ConvNeXtV2 width that is not T; a MiT +
+    UPerHead pairing): exact-fp32 HIP path vs the (reference-pinned) CPU oracle -- low-res logits, loss, a few gradients."""
+    from segmentation_factory_amd import criterion_lowres
+    nc, B, H, W, seed = 11, 2, 64, 96, 21
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    x, y = OW.synthetic_batch(B, H, W, nc, seed)
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var')))
+           for k, v in sd.items()}
+    o, _ = ON.model_forward(sdg, x, backbone, head, training=True, lowres=True)
+    up = torch.nn.functional.interpolate(o, size=(H, W), mode='bilinear', align_corners=False)
+    ref_loss = OL.criterion_closed_form(up, y, None, num_classes=nc, dice=True, ignore_index=255)
+    ref_loss.backward()
+    model = _build(backbone, head, nc, sd, torch.float32, B).train()
+    lo = model.forward_lowres(x.cuda())
+    loss = criterion_lowres(lo, y.cuda(), (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+    loss.backward()
+    got = lo.nchw().float().cpu()
+    assert (got - o.detach()).abs().max() <= 1e-3 * o.detach().abs().max()
+    assert abs(loss.item() - ref_loss.item()) <= 2e-4 * abs(ref_loss.item())
+    params = dict(model.named_parameters())
+    gmax = max(v.grad.abs().max().item() for v in sdg.values() if v.grad is not None)
+    checked = 0
+    for k, v in sdg.items():
+        if v.grad is None or k not in params:
+            continue
+        g, r = params[k].grad.float().cpu(), v.grad
+        assert (g - r).abs().max().item() <= 2e-2 * (r.abs().max().item() + 0.05 * gmax), k
+        checked += 1
+    assert checked > 50
