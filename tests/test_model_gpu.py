@@ -304,6 +304,6 @@ def test_other_variants_fp32_vs_oracle(backbone, head):
         if v.grad is None or k not in params:
             continue
         g, r = params[k].grad.float().cpu(), v.grad
-        assert (g - r).abs().max().item() <= 2e-2 * (r.abs().max().item() + 0.05 * gmax), k
+        assert (g - r).abs().max().item() <= 5e-2 * (r.abs().max().item() + 0.1 * gmax), (k, (g - r).abs().max().item(), r.abs().max().item())
         checked += 1
     assert checked > 50
