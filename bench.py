@@ -29,6 +29,9 @@ MFMA_BF16_PEAK = 2.5e15       # dense bf16 MFMA peak, FLOP/s (MI355X_MICROARCH.m
 HBM_PEAK = 8.0e12             # HBM3E peak, B/s (MI355X_MICROARCH.md; ~6.3e12 achievable)
 FWD_GFLOP_PER_IMG = 89.05     # reference graph as written, forward
 NC, H, W = 150, 512, 512
+# BASELINE.json configs: backbone, head, classes, height, width
+CONFIGS = {'cfg2': ('MiT-B0', 'SegFormerHead', 150, 512, 512), 'cfg3': ('ConvNeXt', 'UPerHead', 150, 512, 512),
+           'cfg4': ('MiT-B2', 'SegFormerHead', 19, 1024, 2048), 'cfg5': ('convnextv2_large', 'UPerHead', 171, 640, 640)}
 
 
 def synthetic_batch(batch, seed):
@@ -69,8 +72,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward+loss+backward only')
-    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg3'],
-                    help='cfg2 = SegFormer-B0 (headline); cfg3 = ConvNeXt-T + UPerHead, both 150 classes at 512x512')
+    ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS),
+                    help='BASELINE.json configs as the reference builds them; cfg2 = SegFormer-B0 (headline)')
     ap.add_argument('--eager', action='store_true', help='per-kernel launches + torch DDP instead of the hipGraph step')
     args = ap.parse_args()
 
@@ -94,7 +97,8 @@ def main():
     from segmentation_factory_amd.graph import GraphedTrainStep
     torch.manual_seed(1234)          # identical initial weights on every rank (rank 0's are broadcast anyway)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    bb_name, head_name = ('MiT-B0', 'SegFormerHead') if args.config == 'cfg2' else ('ConvNeXt', 'UPerHead')
+    global NC, H, W
+    bb_name, head_name, NC, H, W = CONFIGS[args.config]
     core = SegmentationModel(bb_name, num_classes=NC, seg_head=head_name, compute_dtype=dtype).to(dev).train()
     opt = FusedAGCAdamW(param_groups_weight_decay(core, 0.025), lr=2e-4)
     x, y = synthetic_batch(args.batch, seed=rank)
@@ -188,8 +192,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("SegFormer-B0 (MiT-B0 + 768-wide SegFormerHead as the reference builds it)" if args.config == 'cfg2'
-                                    else "ConvNeXt-T + 768-wide UPerHead (BASELINE cfg3 model, single GPU)") +
-                                   ", ADE20K-shape 150 classes, 512x512, " +
+                                    else f"{bb_name} + 768-wide {head_name} (BASELINE {args.config} model)") +
+                                   f", {NC} classes, {H}x{W}, " +
                                    ("full train step (zero_grad+fwd+CE/Dice+bwd+AGC/AdamW)" if with_opt else "forward+loss+backward only"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "init": "random (reference initialisers)", "loss_after": round(final_loss, 4),

@@ -208,9 +208,14 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int
         for (int r = 0; r < nv; ++r) stf<OutT>(dst + r, v[r]);
 }
 
-template <int LAYOUT, typename OutT, bool TR, bool CONV = false>
+// NBUF = 2: double-buffered K loop (64 KB LDS, 2 workgroups per CU).  NBUF = 1: launches whose K fits one 64-deep step
+// (the stage-1 MiT linears and the folded head products, K = 32 / 64) need no second buffer; 34 KB of LDS lets 4 workgroups
+// share a CU, which is what hides the load -> MFMA -> store latency chain of these purely HBM-bound launches.
+template <int LAYOUT, typename OutT, bool TR, bool CONV = false, int NBUF = 2>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GB_TILE_BYTES];
+    constexpr int SMEM_BYTES = NBUF == 2 ? 4 * GB_TILE_BYTES : (64 * GB_STG_LD * 4 > 2 * GB_TILE_BYTES ? 64 * GB_STG_LD * 4 : 2 * GB_TILE_BYTES);
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+    unsigned char (*smem)[2][GB_TILE_BYTES] = reinterpret_cast<unsigned char (*)[2][GB_TILE_BYTES]>(smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the hardware id is
@@ -490,9 +495,11 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
     if (dt == SEGF_BF16) {
         dim3 grid((unsigned)cdiv64(N, GB_BN), (unsigned)cdiv64(M, GB_BM), (unsigned)split_k);
         if (grid.y > 65535u) return SEGF_ERR_SHAPE;
+        const bool one_step = kchunk <= GB_BK && layout != 2;     // single K step: the 34 KB single-buffer variant
 #define LAUNCH_B(L, OT)                                                                                      \
     do {                                                                                                     \
-        if (L == 0 || a.use_tr) hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, true>), grid, dim3(256), 0, st, a); \
+        if (one_step && L != 2) hipLaunchKernelGGL((gemm_bf16_kernel<(L == 2 ? 0 : L), OT, true, false, 1>), grid, dim3(256), 0, st, a); \
+        else if (L == 0 || a.use_tr) hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, true>), grid, dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, false>), grid, dim3(256), 0, st, a);                 \
     } while (0)
         if (c_dt == SEGF_F32 || a.ws) {
