@@ -16,6 +16,7 @@
 // gradient of the LOW-resolution logits directly: no full-resolution tensor exists in either direction.
 // Non-power-of-two ratios fall back to the per-pixel kernels + segf_bilinear_bwd (still HIP).
 // Deterministic: per-block partials + fixed-order finalize, no float atomics.
+#include <stdlib.h>
 #include "colreduce.h"
 
 #define LS_NBLK 128         // workgroups per image in the forward / eval kernels
@@ -361,7 +362,9 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_cells_kernel(const T* 
                                                                         const int64_t* __restrict__ target, int64_t ignore_index,
                                                                         const float* __restrict__ cw, float* __restrict__ partial,
                                                                         const int* __restrict__ run_if) {
-    if (run_if && *run_if == 0) return;          // retry pass behind the batched kernel: idle unless it raised the flag
+    // retry pass behind the batched kernel: idle unless it raised the flag.  Agent-scope atomic load (L2): a plain load is a
+    // scalar-cache read, and inside a replayed hipGraph that cache can still hold the word from an earlier tenant of the buffer
+    if (run_if && __hip_atomic_load(run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -689,6 +692,10 @@ extern "C" int64_t segf_ce_dice_stats_floats(int B, int C) {
 
 #define LS_NS_DISPATCH(ns, CALL) do { if ((ns) == 1) { CALL(1); } else if ((ns) == 2) { CALL(2); } else { CALL(3); } } while (0)
 
+__global__ void zero_ints_kernel(int* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+
 template <typename T>
 static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                        int64_t ignore_index, const float* cw, float* partial, int* retry) {
@@ -701,6 +708,7 @@ static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logit
                                                  g, target, ignore_index, cw, partial, retry);                                  \
             else hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 8>), grid, dim3(LS_THREADS), 0, st, logits, g, target,    \
                                     ignore_index, cw, partial, retry);                                                          \
+            if (!getenv("SEGFAC_LOSS_NO_RETRY"))                                                                                \
             hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,         \
                                ignore_index, cw, partial, (const int*)retry);                                                   \
         } else if (sc) hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc,       \
@@ -739,9 +747,9 @@ extern "C" int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W
     const int sc = pow2_scale(h, w, H, W);
     const dim3 grid(LS_NBLK, B);
     int* retry = reinterpret_cast<int*>(partial + (int64_t)LS_NBLK * B * (3 * C + 4));
-    if (sc >= 2) {
-        const hipError_t e = hipMemsetAsync(retry, 0, 16, st);
-        if (e != hipSuccess) return (int)e;
+    if (sc >= 2) {      // a kernel node rather than hipMemsetAsync: inside a captured graph the 16-byte memset node did not take effect
+        hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, 4);
+        SEGF_CHECK_LAUNCH();
     }
     SEGF_DISPATCH_DT(dt, T, { fwd_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, partial, retry); })
     SEGF_CHECK_LAUNCH();
