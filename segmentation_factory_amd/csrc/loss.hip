@@ -540,7 +540,8 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_cells_kernel(const T* 
                                                                         const float* __restrict__ cw, int dice,
                                                                         const float* __restrict__ stats,
                                                                         const float* __restrict__ grad_out, T* __restrict__ dlow,
-                                                                        int64_t ldd) {
+                                                                        int64_t ldd, const int* __restrict__ run_if) {
+    if (run_if && __hip_atomic_load(run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // idle retry pass
     __shared__ float accum[LS_TILE * LS_TILE][64 * NS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -601,6 +602,151 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_cells_kernel(const T* 
                 }
             }
             // taps of this cell that belong to the tile (the others are recomputed by the neighbouring workgroups)
+            const int ly0 = c.y0 - ty0, ly1 = c.y1 - ty0, lx0 = c.x0 - tx0, lx1 = c.x1 - tx0;
+            const bool vy0 = ly0 >= 0 && ly0 < LS_TILE, vy1 = ly1 >= 0 && ly1 < LS_TILE;
+            const bool vx0 = lx0 >= 0 && lx0 < LS_TILE, vx1 = lx1 >= 0 && lx1 < LS_TILE;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int cc = lane + 64 * s;
+                if (vy0 && vx0) accum[ly0 * LS_TILE + lx0][cc] += A00[s];
+                if (vy0 && vx1) accum[ly0 * LS_TILE + lx1][cc] += A01[s];
+                if (vy1 && vx0) accum[ly1 * LS_TILE + lx0][cc] += A10[s];
+                if (vy1 && vx1) accum[ly1 * LS_TILE + lx1][cc] += A11[s];
+            }
+        }
+        __syncthreads();
+    }
+    for (int tap = wave; tap < LS_TILE * LS_TILE; tap += 4) {
+        const int y = ty0 + tap / LS_TILE, x = tx0 + tap % LS_TILE;
+        if (y >= g.h || x >= g.w) continue;
+        T* drow = dlow + (((int64_t)b * g.h + y) * g.w + x) * ldd;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cc = lane + 64 * s;
+            if (cc < ldd) stf<T>(drow + cc, cc < g.C ? accum[tap][cc] : 0.f);
+        }
+    }
+}
+
+// Batched backward, SC in {2, 4, 8}: same tile / colour structure as ce_dice_bwd_cells_kernel, but a cell's pixels are
+// processed 8 at a time in the exp2 domain with two transposing reductions per batch (sum of exponentials, <G, e>) instead
+// of three per-pixel reductions, branch-free pixel loops, and the tap scatter done separably (column weights per pixel,
+// row weights once per cell row).  A too-loose cell bound raises *retry; the exact kernel behind redoes the image set.
+template <typename T, int NS, int SC>
+__global__ void __launch_bounds__(LS_THREADS, 4) ce_dice_bwd_cells8_kernel(const T* __restrict__ logits, LossGeom g,
+                                                                            const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                            const float* __restrict__ cw, int dice,
+                                                                            const float* __restrict__ stats,
+                                                                            const float* __restrict__ grad_out, T* __restrict__ dlow,
+                                                                            int64_t ldd, int* __restrict__ retry) {
+    constexpr int PB = 8;
+    constexpr int ROWS = SC >= 8 ? 1 : (SC == 4 ? 2 : SC);
+    constexpr int COLS = SC >= 8 ? 8 : SC;
+    constexpr int NPB = ROWS * COLS;
+    constexpr int NB = SC * SC / NPB;
+    constexpr int BPR = SC / COLS;
+    constexpr int off = SC / 2;
+    __shared__ float accum[LS_TILE * LS_TILE][64 * NS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int tiles_x = (g.w + LS_TILE - 1) / LS_TILE;
+    const int ty0 = (blockIdx.x / tiles_x) * LS_TILE, tx0 = (blockIdx.x % tiles_x) * LS_TILE;
+    for (int i = threadIdx.x; i < LS_TILE * LS_TILE * 64 * NS; i += LS_THREADS) (&accum[0][0])[i] = 0.f;
+    float gI[NS], gP[NS];
+    dice_coefs<NS>(stats, b, g.B, g.C, dice, lane, gI, gP);
+    const float go = grad_out ? grad_out[0] : 1.f;
+    const float invW = 1.f / stats[(int64_t)g.B * (3 * g.C + 4) + 1];
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * g.H * g.W;
+    __syncthreads();
+    constexpr int ncl = LS_TILE + 1;
+    for (int col = 0; col < 4; ++col) {
+        const int pj = col >> 1, pk = col & 1;
+        const int nj = (ncl - pj + 1) / 2, nk = (ncl - pk + 1) / 2;
+        for (int idx = wave; idx < nj * nk; idx += 4) {
+            const int lj = 2 * (idx / nk) + pj, lk = 2 * (idx % nk) + pk;
+            const int cj = ty0 - 1 + lj, ck = tx0 - 1 + lk;
+            if (cj > g.h - 1 || ck > g.w - 1) continue;
+            const Cell c = make_cell(cj, ck, g.h, g.w, 1);
+            float t00[NS], t01[NS], t10[NS], t11[NS], d0[NS], d1[NS], A00[NS], A01[NS], A10[NS], A11[NS];
+            load_cell_taps<T, NS>(img, g, c, lane, t00, t01, t10, t11);
+            const int codes = cell_label_codes(tg, g, SC, off, cj, ck, lane, ignore_index);      // -1 / -2: no gradient
+            const float mb = cell_max_bound<NS>(t00, t01, t10, t11, lane, g.C);
+            cell_scaled_taps<NS>(t00, t01, t10, t11, mb, lane, g.C, d0, d1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { A00[s] = 0.f; A01[s] = 0.f; A10[s] = 0.f; A11[s] = 0.f; }
+            unsigned slow = 0;
+#pragma unroll 1
+            for (int bi = 0; bi < NB; ++bi) {
+                const int row0 = (bi / BPR) * ROWS, col0 = (bi % BPR) * COLS;
+                float e[PB][NS], ps[PB], dp[PB], tot[PB], dtot[PB];
+#pragma unroll
+                for (int i = NPB; i < PB; ++i) { ps[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const float ly = (float)(row0 + r + 0.5f) / (float)SC;
+                    float L[NS], D[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        L[s] = fmaf(ly, d0[s], t00[s]);
+                        D[s] = fmaf(ly, d1[s], t01[s]) - L[s];
+                    }
+#pragma unroll
+                    for (int q = 0; q < COLS; ++q) {
+                        const int i = r * COLS + q;
+                        const float lx = (float)(col0 + q + 0.5f) / (float)SC;
+                        const int t = __builtin_amdgcn_readlane(codes, (row0 + r) * SC + col0 + q);
+                        const int tt = t < 0 ? 0 : t;
+                        float sum = 0.f, dsum = 0.f;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            e[i][s] = __builtin_amdgcn_exp2f(fmaf(lx, D[s], L[s]));
+                            sum += e[i][s];
+                            const float G = gP[s] + (lane + 64 * s == tt ? gI[s] : 0.f);
+                            dsum = fmaf(G, e[i][s], dsum);
+                        }
+                        ps[i] = sum; dp[i] = dsum;
+                    }
+                }
+                wave_reduce8(ps, tot);
+                wave_reduce8(dp, dtot);
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const float ly = (float)(row0 + r + 0.5f) / (float)SC;
+                    float Rl[NS], Rr[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { Rl[s] = 0.f; Rr[s] = 0.f; }
+#pragma unroll
+                    for (int q = 0; q < COLS; ++q) {
+                        const int i = r * COLS + q;
+                        const float lx = (float)(col0 + q + 0.5f) / (float)SC;
+                        const int t = __builtin_amdgcn_readlane(codes, (row0 + r) * SC + col0 + q);
+                        const int tt = t < 0 ? 0 : t;
+                        const bool under = !(tot[i] > 1e-30f);
+                        if (t >= 0 && under) slow |= 1u;
+                        const float okf = (t >= 0 && !under) ? 1.f : 0.f;
+                        const float inv = okf * __builtin_amdgcn_rcpf(fmaxf(tot[i], 1e-30f));
+                        const float wce = okf * (cw ? cw[tt] : 1.f) * invW;
+                        const float c1 = go * inv, k = wce - dtot[i] * inv, c2 = go * wce;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            const bool own = lane + 64 * s == tt;
+                            const float G = gP[s] + (own ? gI[s] : 0.f);
+                            const float dz = fmaf(c1 * e[i][s], G + k, own ? -c2 : 0.f);      // go * (p (G - <G,p>) + wce (p - [c==t]))
+                            Rl[s] = fmaf(1.f - lx, dz, Rl[s]);
+                            Rr[s] = fmaf(lx, dz, Rr[s]);
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        A00[s] = fmaf(1.f - ly, Rl[s], A00[s]); A10[s] = fmaf(ly, Rl[s], A10[s]);
+                        A01[s] = fmaf(1.f - ly, Rr[s], A01[s]); A11[s] = fmaf(ly, Rr[s], A11[s]);
+                    }
+                }
+            }
+            if (slow && lane == 0) atomicOr(retry, 1);
+            // the taps live in the exp2 domain: d zq / d logit = log2(e) is NOT wanted -- dz above is already d loss / d logit
             const int ly0 = c.y0 - ty0, ly1 = c.y1 - ty0, lx0 = c.x0 - tx0, lx1 = c.x1 - tx0;
             const bool vy0 = ly0 >= 0 && ly0 < LS_TILE, vy1 = ly1 >= 0 && ly1 < LS_TILE;
             const bool vx0 = lx0 >= 0 && lx0 < LS_TILE, vx1 = lx1 >= 0 && lx1 < LS_TILE;
@@ -722,8 +868,21 @@ static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logit
 template <typename T>
 static void bwd_cells_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                              int64_t ignore_index, const float* cw, int dice, const float* stats, const float* grad_out,
-                             T* dlow, int64_t ldd) {
-#define CALL(NS) hipLaunchKernelGGL((ce_dice_bwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target, ignore_index, cw, dice, stats, grad_out, dlow, ldd)
+                             T* dlow, int64_t ldd, int* retry) {
+#define CALL(NS)                                                                                                                \
+    do {                                                                                                                        \
+        if (sc >= 2) {                                                                                                          \
+            hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, 4);                                           \
+            if (sc == 4) hipLaunchKernelGGL((ce_dice_bwd_cells8_kernel<T, NS, 4>), grid, dim3(LS_THREADS), 0, st, logits, g,     \
+                                            target, ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry);                 \
+            else if (sc == 2) hipLaunchKernelGGL((ce_dice_bwd_cells8_kernel<T, NS, 2>), grid, dim3(LS_THREADS), 0, st, logits,   \
+                                                 g, target, ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry);         \
+            else hipLaunchKernelGGL((ce_dice_bwd_cells8_kernel<T, NS, 8>), grid, dim3(LS_THREADS), 0, st, logits, g, target,     \
+                                    ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry);                                 \
+        }                                                                                                                       \
+        hipLaunchKernelGGL((ce_dice_bwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,             \
+                           ignore_index, cw, dice, stats, grad_out, dlow, ldd, sc >= 2 ? (const int*)retry : (const int*)nullptr); \
+    } while (0)
     LS_NS_DISPATCH(ns, CALL);
 #undef CALL
 }
@@ -782,7 +941,9 @@ extern "C" int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W
     const int sc = pow2_scale(h, w, H, W);
     if (sc) {
         const dim3 grid(((h + LS_TILE - 1) / LS_TILE) * ((w + LS_TILE - 1) / LS_TILE), B);
-        SEGF_DISPATCH_DT(dt, T, { bwd_cells_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)dlogits, ldd); })
+        // the retry word shares the forward's flag slot at the end of the stats buffer (the forward has long consumed it)
+        int* retry = reinterpret_cast<int*>(const_cast<float*>(stats) + segf_ce_dice_stats_floats(B, C) - 4);
+        SEGF_DISPATCH_DT(dt, T, { bwd_cells_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)dlogits, ldd, retry); })
         SEGF_CHECK_LAUNCH();
         return 0;
     }
