@@ -362,6 +362,283 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
     }
 }
 
+// ---- 256 x 256 x 64 tile variant (8 waves: 2 along m x 4 along n, wave tile 128 x 64 = 8 x 4 MFMA tiles) ----------------
+// Twice the operand reuse of the 128^2 tile: each staged byte feeds twice the MFMA work, and a skinny dimension (e.g. the
+// 152-wide classifier) fits ONE tile, so the large operand is streamed once instead of once per 128 columns.  Same LDS
+// images and fragment algebra as the 128^2 kernel (ds_read_b64_tr_b16 for reduction-major operands), 128 KB LDS
+// (double-buffered), one workgroup per CU.
+#define GG_B 256
+#define GG_THREADS 512
+#define GG_TILE_BYTES 32768
+#define GG_STG_LD 260
+template <int T> __device__ __forceinline__ void gload_kc_t(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax,
+                                                            int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const int64_t k = k0 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + r + (T / 8) * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < rmax && k < kend) {
+            const bf16_t* p = base + row * ld + k;
+            if (vec && k + 8 <= kend) v = *reinterpret_cast<const uint4*>(p);
+            else v = ld8_bf16_guard(p, (int)(kend - k < 8 ? kend - k : 8));
+        }
+        reg[i] = v;
+    }
+}
+template <int T> __device__ __forceinline__ void swrite_kc_t(unsigned char* tile, const uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = r + (T / 8) * i;
+        *reinterpret_cast<uint4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = reg[i];
+    }
+}
+template <int T> __device__ __forceinline__ void gload_kc_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax,
+                                                                 int64_t k0, int64_t kend, const GemmArgs& a, const int (&ry)[4],
+                                                                 const int (&rx)[4], uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const int64_t k = k0 + c * 8;
+    const int tap = (int)(k / a.cC);
+    const int ci = (int)(k - (int64_t)tap * a.cC);
+    const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + r + (T / 8) * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int yy = ry[i] + dy, xx = rx[i] + dx;
+        if (row < rmax && k < kend && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
+            v = *reinterpret_cast<const uint4*>(base + (row + (int64_t)dy * a.cW + dx) * ld + ci);
+        reg[i] = v;
+    }
+}
+// reduction-major operand, tile = 64 k rows x R columns (R*2 bytes per row)
+template <int R, int T> __device__ __forceinline__ void gload_rm_t(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax,
+                                                                   int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
+    constexpr int CPR = R / 8;
+    const int c = threadIdx.x % CPR, r = threadIdx.x / CPR;
+    const int64_t col = col0 + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + r + (T / CPR) * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < kend && col < cmax) {
+            const bf16_t* p = base + k * ld + col;
+            if (vec && col + 8 <= cmax) v = *reinterpret_cast<const uint4*>(p);
+            else v = ld8_bf16_guard(p, (int)(cmax - col < 8 ? cmax - col : 8));
+        }
+        reg[i] = v;
+    }
+}
+template <int R, int T> __device__ __forceinline__ void gload_rm_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t col0,
+                                                                        int64_t cmax, int64_t k0, int64_t kend, const GemmArgs& a,
+                                                                        uint4 (&reg)[4]) {
+    constexpr int CPR = R / 8;
+    const int c = threadIdx.x % CPR, r = threadIdx.x / CPR;
+    const int64_t col = col0 + c * 8;
+    const int tap = (int)(col / a.cC);
+    const int ci = (int)(col - (int64_t)tap * a.cC);
+    const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + r + (T / CPR) * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < kend && col < cmax) {
+            const int x = (int)(k % a.cW);
+            const int y = (int)((k / a.cW) % a.cH);
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
+                v = *reinterpret_cast<const uint4*>(base + (k + (int64_t)dy * a.cW + dx) * ld + ci);
+        }
+        reg[i] = v;
+    }
+}
+template <int R, int T> __device__ __forceinline__ void swrite_rm_t(unsigned char* tile, const uint4 (&reg)[4]) {
+    constexpr int CPR = R / 8;
+    const int c = threadIdx.x % CPR, r = threadIdx.x / CPR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int krow = r + (T / CPR) * i;
+        *reinterpret_cast<uint4*>(tile + krow * (R * 2) + ((c ^ rm_swz(krow)) << 4)) = reg[i];
+    }
+}
+template <int R> __device__ __forceinline__ bf16x8 frag_rm_tr_t(const unsigned char* tile, int cb, int s, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int u = (cb >> 2) + p;
+    const int chunk = u >> 1, half = u & 1;
+    s16x4 lo, hi;
+    {
+        const int krow = 32 * s + 8 * g + q;
+        const unsigned char* a = tile + krow * (R * 2) + ((chunk ^ rm_swz(krow)) << 4) + half * 8;
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    }
+    {
+        const int krow = 32 * s + 8 * g + 4 + q;
+        const unsigned char* a = tile + krow * (R * 2) + ((chunk ^ rm_swz(krow)) << 4) + half * 8;
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    }
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int LAYOUT, typename OutT, bool CONV>
+__global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GG_TILE_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;              // wave tile: rows [128 wm, +128), columns [64 wn, +64)
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
+    const unsigned wgid = LAYOUT == 2 ? orig : (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
+    const unsigned bx = wgid % gx, by = (wgid / gx) % gy, bz = wgid / (gx * gy);
+    const int64_t m0 = (int64_t)by * GG_B, n0 = (int64_t)bx * GG_B;
+    const int64_t kbeg = (int64_t)bz * a.kchunk;
+    const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
+
+    f32x4 acc[4][8];   // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    int ry[4], rx[4];
+    if (CONV && LAYOUT == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = m0 + (threadIdx.x >> 3) + (GG_THREADS / 8) * i;
+            rx[i] = (int)(row % a.cW);
+            ry[i] = (int)((row / a.cW) % a.cH);
+        }
+    }
+    auto gload = [&](int64_t k0) {
+        if (LAYOUT == 2) gload_rm_t<GG_B, GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
+        else if (CONV) gload_kc_conv_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
+        else gload_kc_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
+        if (LAYOUT == 0) gload_kc_t<GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
+        else if (CONV && LAYOUT == 2) gload_rm_conv_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a, rb);
+        else gload_rm_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
+    };
+    auto swrite = [&](int buf) {
+        if (LAYOUT == 2) swrite_rm_t<GG_B, GG_THREADS>(smem[buf][0], ra); else swrite_kc_t<GG_THREADS>(smem[buf][0], ra);
+        if (LAYOUT == 0) swrite_kc_t<GG_THREADS>(smem[buf][1], rb); else swrite_rm_t<GG_B, GG_THREADS>(smem[buf][1], rb);
+    };
+
+    const int nk = (int)((kend - kbeg + GB_BK - 1) / GB_BK);
+    if (nk > 0) {
+        gload(kbeg);
+        swrite(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * GB_BK);
+        const unsigned char* ta = smem[buf][0];
+        const unsigned char* tb = smem[buf][1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int nb = wn * 64 + t * 16;
+                fb[t] = LAYOUT == 0 ? frag_kc(tb, nb, s, lane) : frag_rm_tr_t<GG_B>(tb, nb, s, lane);
+            }
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm) {           // the 8 row tiles in two groups of 4: 8 live fragments instead of 12
+                bf16x8 fa[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int mb = wm * 128 + (hm * 4 + t) * 16;
+                    fa[t] = LAYOUT == 2 ? frag_rm_tr_t<GG_B>(ta, mb, s, lane) : frag_kc(ta, mb, s, lane);
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[tn][hm * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[t], acc[tn][hm * 4 + t], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) swrite(buf ^ 1);
+        __syncthreads();
+    }
+    if (sizeof(OutT) == 2 && !a.ws && a.c_vec16) {
+        float* stg = reinterpret_cast<float*>(&smem[0][0][0]);     // [64][GG_STG_LD] floats = 66.5 KB
+        const int tchunk = threadIdx.x & 31, trow = threadIdx.x >> 5;
+        const int64_t ncol = n0 + tchunk * 8;
+        float bs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bs[j] = (a.bias && ncol + j < a.N) ? a.bias[ncol + j] : 0.f;
+        const bool full = ncol + 8 <= a.N;
+        for (int pass = 0; pass < 4; ++pass) {              // 64 rows per pass
+            if (pass) __syncthreads();
+            if (wm == (pass >> 1)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        *reinterpret_cast<f32x4*>(stg + (t * 16 + (lane & 15)) * GG_STG_LD + wn * 64 + tn * 16 + 4 * (lane >> 4)) =
+                            acc[tn][(pass & 1) * 4 + t];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = trow + 16 * i;
+                const int64_t m = m0 + pass * 64 + r;
+                if (m >= a.M || ncol >= a.N) continue;
+                float v[8];
+                const float4 lo = *reinterpret_cast<const float4*>(stg + r * GG_STG_LD + tchunk * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(stg + r * GG_STG_LD + tchunk * 8 + 4);
+                v[0] = lo.x + bs[0]; v[1] = lo.y + bs[1]; v[2] = lo.z + bs[2]; v[3] = lo.w + bs[3];
+                v[4] = hi.x + bs[4]; v[5] = hi.y + bs[5]; v[6] = hi.z + bs[6]; v[7] = hi.w + bs[7];
+                if (a.residual) {
+                    const float sc = a.rscale ? a.rscale[m / a.rpg] : 1.f;
+                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(a.residual) + m * a.ldr + ncol;
+                    float rv[8];
+                    if (full && a.r_vec) load8<bf16_t>(rp, rv);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rv[j] = ncol + j < a.N ? bf2f(rp[j]) : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = rv[j] + sc * v[j];
+                }
+                bf16_t* dst = reinterpret_cast<bf16_t*>(a.C) + m * a.ldc + ncol;
+                if (full) store8<bf16_t>(dst, v);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (ncol + j < a.N) dst[j] = f2bf(v[j]);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+        const int64_t m = m0 + wm * 128 + tm * 16 + (lane & 15);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int64_t n = n0 + wn * 64 + tn * 16 + 4 * (lane >> 4);
+            float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
+            gemm_epilogue4<bf16_t, OutT>(a, m, n, v, bz);
+        }
+    }
+}
+
+// one decision for both the launcher and the split-K / workspace sizing: the 256^2 tile when both dimensions exceed one
+// 128 tile, K spans more than one step, and the launch still has enough workgroups for 256 CUs
+static inline bool gemm_use_big(int layout, int64_t M, int64_t N, int64_t K) {
+    if (getenv("SEGFAC_GEMM_NO_BIG")) return false;
+    if (M <= 128 || N <= 128 || K <= GB_BK) return false;
+    const int64_t tiles = cdiv64(M, GG_B) * cdiv64(N, GG_B);
+    if (layout == 2) return K >= 16384;                       // token-count K: split-K supplies the parallelism
+    return tiles >= 192;
+}
+
 // ---- exact fp32 FMA kernel ---------------------------------------------------------------------------
 #define GF_BM 64
 #define GF_BN 64
@@ -450,8 +727,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 
 extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     // layout 2 (weight gradient): K = token count.  Aim for >= 512 workgroups, >= 4 K-steps per slice.
-    const int64_t tiles = cdiv64(M, GB_BM) * cdiv64(N, GB_BN);
-    int64_t s = cdiv64(512, tiles);
+    const bool big = gemm_use_big(2, M, N, K);
+    const int64_t tiles = big ? cdiv64(M, GG_B) * cdiv64(N, GG_B) : cdiv64(M, GB_BM) * cdiv64(N, GB_BN);
+    int64_t s = cdiv64(big ? 256 : 512, tiles);
     const int64_t maxs = K / (4 * GB_BK);
     if (s > maxs) s = maxs;
     if (s > 512) s = 512;
@@ -493,6 +771,20 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
         a.use_tr = (e && e[0] == '1') ? 0 : 1;
     }
     if (dt == SEGF_BF16) {
+        if (gemm_use_big(layout, M, N, K) && a.use_tr) {
+            dim3 gridb((unsigned)cdiv64(N, GG_B), (unsigned)cdiv64(M, GG_B), (unsigned)split_k);
+            if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
+            const bool f32o = c_dt == SEGF_F32 || a.ws;
+#define LAUNCH_G(L)                                                                                              \
+    do {                                                                                                         \
+        if (f32o) hipLaunchKernelGGL((gemm_bf16_big_kernel<L, float, false>), gridb, dim3(GG_THREADS), 0, st, a);  \
+        else hipLaunchKernelGGL((gemm_bf16_big_kernel<L, bf16_t, false>), gridb, dim3(GG_THREADS), 0, st, a);      \
+    } while (0)
+            if (layout == 0) LAUNCH_G(0); else if (layout == 1) LAUNCH_G(1); else LAUNCH_G(2);
+#undef LAUNCH_G
+            SEGF_CHECK_LAUNCH();
+            goto reduce;
+        }
         dim3 grid((unsigned)cdiv64(N, GB_BN), (unsigned)cdiv64(M, GB_BM), (unsigned)split_k);
         if (grid.y > 65535u) return SEGF_ERR_SHAPE;
         const bool one_step = kchunk <= GB_BK && layout != 2;     // single K step: the 34 KB single-buffer variant
@@ -516,6 +808,7 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
         else hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, st, a);
     }
     SEGF_CHECK_LAUNCH();
+reduce:
     if (a.ws) {
         const int64_t total = M * N;
         const unsigned blocks = (unsigned)cdiv64(total, 16);
@@ -563,9 +856,23 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     const size_t csz = y_dt == SEGF_BF16 ? 2 : 4;
     a.c_vec = ((uintptr_t)y % (4 * csz) == 0) && ((ldy * csz) % (4 * csz) == 0);
     a.c_vec16 = ((uintptr_t)y % 16 == 0) && ((ldy * csz) % 16 == 0);
+    const bool f32out = y_dt == SEGF_F32 || a.ws;
+    if (gemm_use_big(layout, a.M, a.N, a.K)) {
+        dim3 gridb((unsigned)cdiv64(a.N, GG_B), (unsigned)cdiv64(a.M, GG_B), (unsigned)split_k);
+        if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
+        if (layout == 0) {
+            if (f32out) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, float, true>), gridb, dim3(GG_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, true>), gridb, dim3(GG_THREADS), 0, st, a);
+        } else {
+            if (f32out) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, true>), gridb, dim3(GG_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((gemm_bf16_big_kernel<2, bf16_t, true>), gridb, dim3(GG_THREADS), 0, st, a);
+        }
+        SEGF_CHECK_LAUNCH();
+        goto reduce3;
+    }
+    {
     dim3 grid((unsigned)cdiv64(a.N, GB_BN), (unsigned)cdiv64(a.M, GB_BM), (unsigned)split_k);
     if (grid.y > 65535u) return SEGF_ERR_SHAPE;
-    const bool f32out = y_dt == SEGF_F32 || a.ws;
     if (layout == 0) {
         if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<0, float, true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_bf16_kernel<0, bf16_t, true, true>), grid, dim3(256), 0, st, a);
@@ -574,6 +881,8 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
         else hipLaunchKernelGGL((gemm_bf16_kernel<2, bf16_t, true, true>), grid, dim3(256), 0, st, a);
     }
     SEGF_CHECK_LAUNCH();
+    }
+reduce3:
     if (a.ws) {
         const unsigned blocks = (unsigned)cdiv64(a.M * a.N, 16);
         if (y_dt == SEGF_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (float*)y, ldy);

@@ -422,7 +422,8 @@ def test_dwconv7x7(dtype, geom):
     _close(bd.grad, br.grad, dtype, fac=4)
 
 
-@pytest.mark.parametrize('cfg', [(2, 8, 8, 16, 24), (1, 5, 7, 64, 8), (2, 16, 12, 128, 136), (1, 1, 1, 8, 8)])
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 16, 24), (1, 5, 7, 64, 8), (2, 16, 12, 128, 136), (1, 1, 1, 8, 8),
+                                 (3, 128, 128, 136, 264)])      # the last one runs on the 256x256 tile kernel in all three modes
 def test_conv3x3_implicit_gemm(cfg):
     """bf16 implicit-GEMM 3x3 conv (forward, data gradient, weight gradient) vs F.conv2d on bf16-rounded inputs; the input
     is a column slice of a wider buffer as in the UPerNet concat."""
@@ -535,3 +536,32 @@ def test_wave_reduce16_transposing_reduction(hipmod):
     rc = hipmod.lib().segf_debug_wave_reduce16(xd.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert torch.equal(out.cpu(), x.sum(0))
+
+
+@pytest.mark.parametrize('layout', [0, 1, 2])
+def test_gemm_big_tile_variant(hipmod, layout):
+    """256x256 tile kernel (chosen for M, N > 128 with many tiles / token-count K): odd sizes, bias + residual epilogue,
+    split-K, against a float64 product of the bf16-rounded operands."""
+    g = torch.Generator().manual_seed(30 + layout)
+    if layout == 2:
+        M, N, K, sk = 200, 392, 20000, 5
+    else:
+        M, N, K, sk = 256 * 12 + 72, 256 * 17 - 40, 200, 1
+    a = torch.randn((K, M) if layout == 2 else (M, K), generator=g)
+    b = torch.randn((N, K) if layout == 0 else (K, N), generator=g)
+    aq, bq = a.bfloat16().double(), b.bfloat16().double()
+    A = aq.t() if layout == 2 else aq
+    Bm = bq.t() if layout == 0 else bq
+    ref = A @ Bm
+    ad, bd = a.bfloat16().cuda(), b.bfloat16().cuda()
+    if layout == 2:
+        out = hipmod.gemm(2, ad, bd, M, N, K, out_dtype=torch.float32, split_k=sk)
+        err = (out.double().cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item()
+    else:
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g)
+        out = hipmod.gemm(layout, ad, bd, M, N, K, bias=bias.cuda(), residual=res.bfloat16().cuda())
+        full = ref + bias.double() + res.bfloat16().double()
+        err = (out.double().cpu() - full).abs().max().item()
+        assert err <= 1.2e-2 * full.abs().max().item()       # one bf16 rounding of the output
