@@ -488,9 +488,9 @@ def ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, d
     dt = dt_of(logits)
     nws = lib().segf_ce_dice_bwd_ws(dt, B, Cc, h, w, H, W)
     ws = _f32(nws, logits.device) if nws else None
-    _chk(lib().segf_ce_dice_bwd(dt, B, Cc, h, w, H, W, _ptr(logits), ld, _ptr(target), int(ignore_index),
-                                _ptr(class_weight), int(dice), _ptr(stats), _ptr(grad_out), _ptr(dlow), ld, _ptr(ws),
-                                _stream()), 'segf_ce_dice_bwd')
+    _chk(_timed(('ce_dice_bwd', B, Cc, h, w, H, W), lambda: lib().segf_ce_dice_bwd(
+        dt, B, Cc, h, w, H, W, _ptr(logits), ld, _ptr(target), int(ignore_index), _ptr(class_weight), int(dice), _ptr(stats),
+        _ptr(grad_out), _ptr(dlow), ld, _ptr(ws), _stream())), 'segf_ce_dice_bwd')
     return dlow
 
 
