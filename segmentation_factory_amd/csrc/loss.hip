@@ -773,6 +773,346 @@ __global__ void __launch_bounds__(LS_THREADS, 4) ce_dice_bwd_cells8_kernel(const
     }
 }
 
+// ---- MFMA form of the cell kernels (SC == 4) ---------------------------------------------------------------------------
+// The two contractions of the fused loss run on the matrix pipe in exact f32 (v_mfma_f32_16x16x4_f32 == an fmaf chain):
+//   interpolation  Z[pixel][class] = sum_tap W[pixel][tap] * U[tap][class]      (K = the cell's 4 taps, M = its 16 pixels)
+//   tap scatter    dU[tap][class]  = sum_pix W[pixel][tap] * dZ[pixel][class]   (K = pixels, 4 per instruction)
+// and the VALU is left with what only it can do: one exp2 per (pixel, class) and a handful of multiplies.
+// Lane = (class column c = lane & 15 of a 16-class tile, row group gq = lane >> 4); the accumulator layout puts pixel
+// 4 gq + r = (cell row gq, cell column r) in register r, so the softmax sums are NT register adds plus one 16-lane DPP row
+// reduction per pixel, and the dZ registers feed the scatter MFMA as its B operand without any lane movement (register r of
+// all four row groups = pixels {r, 4+r, 8+r, 12+r} = the four k-slices of one instruction; A carries the matching weights).
+// The label class of a pixel is handled on the side by a "label path" in which the wave's lanes are (tap = c & 3,
+// pixel = 4 gq + (c >> 2)): one gathered tap value per lane and a quad reduction give the label logit; I / T (forward) and
+// the [c == t] terms of the gradient (backward) go through shared-memory float adds, where only lanes of ONE instruction
+// ever collide (a wave owns its histogram / its colour's taps), so the summation order is fixed.
+typedef float lossf4 __attribute__((ext_vector_type(4)));
+typedef __bf16 lossbf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float tap_weight(int k, float ly, float lx) {      // k = 2 * (row tap) + (column tap)
+    return ((k >> 1) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ float sel4(const float (&v)[4], int r) {
+    return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3]));
+}
+
+// Front end shared by forward and backward, split in two so that the loads of the NEXT cell are in flight while the current
+// one is evaluated: issue() = this lane's tap row (MFMA operand) + its label; finish() = label-class gather (issued before
+// the next cell's loads so that waiting for it does not drain them), exp2-domain operands, Z tiles -> exponentials.
+template <typename T, int NT>
+struct MfmaCellLoads {
+    Cell cc;
+    float u[NT];
+    int64_t traw;
+    bool inside;
+    __device__ __forceinline__ void issue(const T* __restrict__ img, const int64_t* __restrict__ tg, const LossGeom& g, int cj, int ck,
+                                          int c, int gq) {
+        cc = make_cell(cj, ck, g.h, g.w, 1);
+        const T* pk = img + ((int64_t)((gq >> 1) ? cc.y1 : cc.y0) * g.w + ((gq & 1) ? cc.x1 : cc.x0)) * g.ldl;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int cls = 16 * t + c;
+            u[t] = ldf<T>(pk + (cls < g.C ? cls : g.C - 1));
+        }
+        const int Y = 4 * cj + 2 + gq, X = 4 * ck + 2 + (c >> 2);
+        inside = Y >= 0 && Y < g.H && X >= 0 && X < g.W;
+        traw = tg[(int64_t)(Y < 0 ? 0 : (Y >= g.H ? g.H - 1 : Y)) * g.W + (X < 0 ? 0 : (X >= g.W ? g.W - 1 : X))];
+    }
+};
+template <typename T, int NT>
+struct MfmaCell {
+    int code, tt;            // label path: this lane's pixel label code (>= 0 class, -1 skip, -2 out of range) and max(code, 0)
+    float ulraw, ul, mb;     // label path: tap value of class tt at tap (c & 3): raw, and in the exp2 domain
+    lossf4 e[NT];            // e[t][r] = exp2(zq) of class 16 t + c at pixel (gq, r)
+    float s[4];              // per pixel r: sum over classes of e  (uniform over the 16 lanes of the row group)
+    __device__ __forceinline__ void gather(const T* __restrict__ img, const LossGeom& g, const MfmaCellLoads<T, NT>& L, int c,
+                                           int64_t skip_label) {
+        const int kl = c & 3;
+        const T* pl = img + ((int64_t)((kl >> 1) ? L.cc.y1 : L.cc.y0) * g.w + ((kl & 1) ? L.cc.x1 : L.cc.x0)) * g.ldl;
+        code = (!L.inside || L.traw == skip_label) ? -1 : ((L.traw < 0 || L.traw >= g.C) ? -2 : (int)L.traw);
+        tt = code < 0 ? 0 : code;
+        ulraw = ldf<T>(pl + tt);
+    }
+    __device__ __forceinline__ void finish(const LossGeom& g, const MfmaCellLoads<T, NT>& L, int c, float wA) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mx = 16 * t + c < g.C ? fmaxf(mx, L.u[t]) : mx;
+        mb = wave_max_all(mx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float ut = 16 * t + c < g.C ? (L.u[t] - mb) * LS_LOG2E : -1e30f;
+            const lossf4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, ut, lossf4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { e[t][r] = __builtin_amdgcn_exp2f(z[r]); s[r] += e[t][r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = row_sum16(s[r]);
+        ul = (ulraw - mb) * LS_LOG2E;
+    }
+};
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_mfma4_kernel(const T* __restrict__ logits, LossGeom g,
+                                                                       const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                       const float* __restrict__ cw, float* __restrict__ partial,
+                                                                       int* __restrict__ retry) {
+    __shared__ float hI[4][NT * 16], hT[4][NT * 16], redP[4][NT * 16], redS[4][4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, gq = lane >> 4;
+    const int b = blockIdx.y;
+    for (int i = lane; i < NT * 16; i += 64) { hI[wave][i] = 0.f; hT[wave][i] = 0.f; }
+    // A operand of the interpolation: lane = (pixel p = c -> cell row c >> 2, column c & 3; tap k = gq)
+    const float wA = tap_weight(gq, ((c >> 2) + 0.5f) * 0.25f, ((c & 3) + 0.5f) * 0.25f);
+    // label path: lane = (tap c & 3; pixel = cell row gq, column c >> 2)
+    const float wL = tap_weight(c & 3, (gq + 0.5f) * 0.25f, ((c >> 2) + 0.5f) * 0.25f);
+    const int ncx = g.w + 1, ncell = (g.h + 1) * ncx;
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * g.H * g.W;
+    float aP[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) aP[t] = 0.f;
+    float cel = 0.f, wsum = 0.f, nvalid = 0.f;      // per lane (quad leaders)
+    bool bad = false, slow = false;
+    const int stride = gridDim.x * 4;
+    int cell = blockIdx.x * 4 + wave;
+    MfmaCellLoads<T, NT> nx;
+    if (cell < ncell) nx.issue(img, tg, g, cell / ncx - 1, cell % ncx - 1, c, gq);
+    while (cell < ncell) {
+        const MfmaCellLoads<T, NT> cur = nx;
+        MfmaCell<T, NT> m;
+        m.gather(img, g, cur, c, ignore_index);
+        cell += stride;
+        if (cell < ncell) nx.issue(img, tg, g, cell / ncx - 1, cell % ncx - 1, c, gq);
+        m.finish(g, cur, c, wA);
+        // validity of the pixels of my accumulator rows: pixel (gq, r) is the label-path pixel of lanes 16 gq + 4 r ..
+        const unsigned long long okm = __ballot(m.code >= 0);
+        const unsigned okrow = (unsigned)(okm >> (16 * gq)) & 0xffffu;
+        float inv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) inv[r] = ((okrow >> (4 * r)) & 1u) ? __builtin_amdgcn_rcpf(fmaxf(m.s[r], 1e-30f)) : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) aP[t] += (m.e[t][0] * inv[0] + m.e[t][1] * inv[1]) + (m.e[t][2] * inv[2] + m.e[t][3] * inv[3]);
+        // label path
+        float zt = wL * m.ul;
+        zt += dpp_mov<DPP_XOR1>(zt); zt += dpp_mov<DPP_XOR2>(zt);
+        const float tot = sel4(m.s, c >> 2);
+        const bool valid = m.code >= 0, under = valid && !(tot > 1e-30f);
+        bad |= m.code == -2; slow |= under;
+        if (valid && !under && (c & 3) == 0) {
+            const float wt = cw ? cw[m.tt] : 1.f;
+            atomicAdd(&hI[wave][m.tt], __builtin_amdgcn_exp2f(zt) * __builtin_amdgcn_rcpf(tot));
+            atomicAdd(&hT[wave][m.tt], 1.f);
+            cel = fmaf(wt, __builtin_amdgcn_logf(tot) - zt, cel);
+            wsum += wt; nvalid += 1.f;
+        }
+    }
+    if (__any(slow) && lane == 0) atomicOr(retry, 1);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float v = aP[t];
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (gq == 0) redP[wave][16 * t + c] = v;
+    }
+    const float ce = LS_LN2 * wave_sum_all(cel), ws = wave_sum_all(wsum), nv = wave_sum_all(nvalid);
+    if (lane == 0) { redS[wave][0] = ce; redS[wave][1] = ws; redS[wave][2] = nv; redS[wave][3] = __any(bad) ? 1.f : 0.f; }
+    __syncthreads();
+    float* dst = partial + ((int64_t)blockIdx.x * g.B + b) * (3 * g.C + 4);
+    for (int i = threadIdx.x; i < NT * 16; i += LS_THREADS) {
+        if (i < g.C) {
+            dst[i] = (hI[0][i] + hI[1][i]) + (hI[2][i] + hI[3][i]);
+            dst[g.C + i] = (redP[0][i] + redP[1][i]) + (redP[2][i] + redP[3][i]);
+            dst[2 * g.C + i] = (hT[0][i] + hT[1][i]) + (hT[2][i] + hT[3][i]);
+        }
+    }
+    if (threadIdx.x < 4) dst[3 * g.C + threadIdx.x] = (redS[0][threadIdx.x] + redS[1][threadIdx.x]) + (redS[2][threadIdx.x] + redS[3][threadIdx.x]);
+}
+
+__device__ __forceinline__ void dice_coef_one(const float* __restrict__ stats, int b, int B, int C, int dice, int cls, float& gI, float& gP) {
+    gI = 0.f; gP = 0.f;
+    if (cls < C && dice) {
+        const float* st = stats + (int64_t)b * (3 * C + 4);
+        const float I = st[cls], P = st[C + cls], Tt = st[2 * C + cls];
+        const float sets = P + Tt;
+        if (sets != 0.f) {
+            const float nbc = 1.f / (float)(B * C);
+            gI = -nbc * 2.f / (sets + LS_EPS);
+            gP = nbc * (2.f * I + LS_EPS) / ((sets + LS_EPS) * (sets + LS_EPS));
+        }
+    }
+}
+
+// Backward: workgroup = LS_TILE x LS_TILE low-res taps (+ the halo cells), four parity colours as in the VALU kernels.  A wave
+// walks its cells of all four colours as one sequence so that the next cell's loads overlap the current cell's arithmetic
+// also across the colour barriers.  The scatter MFMA puts tap j in product row 4 j, i.e. in register 0 of row group j: every
+// lane then owns one (tap, class) element per class tile and the tile update is one full-wave LDS read-add-write per class
+// tile (taps outside the tile go to a scratch row).
+template <typename T, int NT>
+__global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_mfma4_kernel(const T* __restrict__ logits, LossGeom g,
+                                                                       const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                       const float* __restrict__ cw, int dice,
+                                                                       const float* __restrict__ stats,
+                                                                       const float* __restrict__ grad_out, T* __restrict__ dlow,
+                                                                       int64_t ldd, int* __restrict__ retry) {
+    constexpr int NTAP = LS_TILE * LS_TILE;
+    __shared__ float accum[NTAP + 1][NT * 16];       // row NTAP: scratch
+    __shared__ float gIs[NT * 16];
+    __shared__ __attribute__((aligned(16))) float c1s[4][16], cks[4][16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, gq = lane >> 4;
+    const int b = blockIdx.y;
+    const int tiles_x = (g.w + LS_TILE - 1) / LS_TILE;
+    const int ty0 = (blockIdx.x / tiles_x) * LS_TILE, tx0 = (blockIdx.x % tiles_x) * LS_TILE;
+    for (int i = threadIdx.x; i < (NTAP + 1) * NT * 16; i += LS_THREADS) (&accum[0][0])[i] = 0.f;
+    float gP[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float gi;
+        dice_coef_one(stats, b, g.B, g.C, dice, 16 * t + c, gi, gP[t]);
+        if (wave == 0 && gq == 0) gIs[16 * t + c] = gi;
+    }
+    const float wA = tap_weight(gq, ((c >> 2) + 0.5f) * 0.25f, ((c & 3) + 0.5f) * 0.25f);
+    const float wL = tap_weight(c & 3, (gq + 0.5f) * 0.25f, ((c >> 2) + 0.5f) * 0.25f);
+    // A operand of the scatter for accumulator register r: lane = (product row c, k = gq); row 4 j carries tap j, the weight
+    // is the one of tap j at pixel (gq, r)
+    // At the clamped image border two taps of a cell coincide: the first of the pair then takes the whole weight and the
+    // second is parked on the scratch row (two row groups must never update one LDS word in the same instruction).
+    const int kB = c >> 2;
+    const float wBy = (c & 3) == 0 ? ((kB >> 1) ? (gq + 0.5f) * 0.25f : 1.f - (gq + 0.5f) * 0.25f) : 0.f;
+    const float wByc = (c & 3) == 0 ? ((kB >> 1) ? 0.f : 1.f) : 0.f;
+    float wBx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wBx[r] = (kB & 1) ? (r + 0.5f) * 0.25f : 1.f - (r + 0.5f) * 0.25f;
+    const float wBxc = (kB & 1) ? 0.f : 1.f;
+    const float go = grad_out ? grad_out[0] : 1.f;
+    const float invW = 1.f / stats[(int64_t)g.B * (3 * g.C + 4) + 1];
+    const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * g.H * g.W;
+    __syncthreads();
+    constexpr int ncl = LS_TILE + 1;
+    bool slow = false;
+    // the wave's cell sequence: colour col, i-th cell of that colour for this wave
+    int col = 0, idx = wave;
+    auto cell_of = [&](int col_, int idx_, int& cj, int& ck) {
+        const int pj = col_ >> 1, pk = col_ & 1;
+        const int nk = (ncl - pk + 1) / 2;
+        cj = ty0 - 1 + 2 * (idx_ / nk) + pj; ck = tx0 - 1 + 2 * (idx_ % nk) + pk;
+    };
+    auto count_of = [&](int col_) { return ((ncl - (col_ >> 1) + 1) / 2) * ((ncl - (col_ & 1) + 1) / 2); };
+    MfmaCellLoads<T, NT> nx;
+    int cj, ck;
+    cell_of(col, idx, cj, ck);
+    nx.issue(img, tg, g, cj > g.h - 1 ? g.h - 1 : cj, ck > g.w - 1 ? g.w - 1 : ck, c, gq);
+    bool nx_ok = cj <= g.h - 1 && ck <= g.w - 1;
+    while (col < 4) {
+        const MfmaCellLoads<T, NT> cur = nx;
+        const bool cur_ok = nx_ok;
+        MfmaCell<T, NT> m;
+        m.gather(img, g, cur, c, ignore_index);
+        int ncol = col, nidx = idx + 4;
+        if (nidx >= count_of(col)) { ++ncol; nidx = wave; }
+        if (ncol < 4) {
+            cell_of(ncol, nidx, cj, ck);
+            nx_ok = cj <= g.h - 1 && ck <= g.w - 1;
+            nx.issue(img, tg, g, cj > g.h - 1 ? g.h - 1 : cj, ck > g.w - 1 ? g.w - 1 : ck, c, gq);
+        }
+        if (cur_ok) {
+            const Cell& cc = cur.cc;
+            m.finish(g, cur, c, wA);
+            float dp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[r] = fmaf(gP[t], m.e[t][r], dp[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[r] = row_sum16(dp[r]);
+            // label path: per-pixel coefficients, the [c == t] part of the gradient, and c1 / c1*k for the class lanes
+            float zt = wL * m.ul;
+            zt += dpp_mov<DPP_XOR1>(zt); zt += dpp_mov<DPP_XOR2>(zt);
+            const float tot = sel4(m.s, c >> 2), dpm = sel4(dp, c >> 2);
+            const bool valid = m.code >= 0, under = valid && !(tot > 1e-30f);
+            slow |= under;
+            const float okf = (valid && !under) ? 1.f : 0.f;
+            const float inv = okf * __builtin_amdgcn_rcpf(fmaxf(tot, 1e-30f));
+            const float wce = okf * (cw ? cw[m.tt] : 1.f) * invW;
+            const float et = __builtin_amdgcn_exp2f(zt), git = gIs[m.tt];
+            const float c1 = go * inv;
+            const float k = wce - (dpm + git * et) * inv;                  // wce - <G, p>
+            const float dlt = okf * (c1 * et * git - go * wce);            // extra d loss / d z of the label class
+            if ((c & 3) == 0) { c1s[wave][4 * gq + (c >> 2)] = c1; cks[wave][4 * gq + (c >> 2)] = c1 * k; }
+            __builtin_amdgcn_wave_barrier();
+            const float4 c1r = *reinterpret_cast<const float4*>(&c1s[wave][4 * gq]);
+            const float4 ckr = *reinterpret_cast<const float4*>(&cks[wave][4 * gq]);
+            __builtin_amdgcn_wave_barrier();
+            const float c1v[4] = {c1r.x, c1r.y, c1r.z, c1r.w}, ckv[4] = {ckr.x, ckr.y, ckr.z, ckr.w};
+            // tile row of a tap of this cell (taps outside the tile are recomputed by the neighbouring workgroups -> scratch row)
+            const bool ycol = cc.y0 == cc.y1, xcol = cc.x0 == cc.x1;
+            auto tap_row = [&](int kk) {
+                const int ly = ((kk >> 1) ? cc.y1 : cc.y0) - ty0, lx = ((kk & 1) ? cc.x1 : cc.x0) - tx0;
+                return (ly >= 0 && ly < LS_TILE && lx >= 0 && lx < LS_TILE) ? ly * LS_TILE + lx : NTAP;
+            };
+            const bool dup = ((gq >> 1) && ycol) || ((gq & 1) && xcol);
+            float* arow = &accum[dup ? NTAP : tap_row(gq)][c];
+            const float wy = ycol ? wByc : wBy;
+            float wB[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wB[r] = wy * (xcol ? wBxc : wBx[r]);
+            float upd[NT];
+            if constexpr (sizeof(T) == 2) {
+                // bf16 activations: the gradient is rounded to bf16 on store anyway, so the scatter runs as ONE
+                // v_mfma_f32_16x16x32_bf16 per class tile (k-slot 8 gq + j = pixel (gq, j), j < 4; slots 4..7 empty) instead of
+                // four f32 instructions; the weights (odd multiples of 1/64) are exact in bf16
+                union { uint32_t u[4]; lossbf8 v; } A, Bv;
+                A.u[0] = pack2bf(wB[0], wB[1]); A.u[1] = pack2bf(wB[2], wB[3]); A.u[2] = 0u; A.u[3] = 0u;
+                Bv.u[2] = 0u; Bv.u[3] = 0u;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float dz[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz[r] = m.e[t][r] * fmaf(c1v[r], gP[t], ckv[r]);
+                    Bv.u[0] = pack2bf(dz[0], dz[1]); Bv.u[1] = pack2bf(dz[2], dz[3]);
+                    const lossf4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.v, Bv.v, lossf4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    upd[t] = acc[0];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    lossf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dz = m.e[t][r] * fmaf(c1v[r], gP[t], ckv[r]);      // go * p * (gP - <G,p> + wce)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[r], dz, acc, 0, 0, 0);
+                    }
+                    upd[t] = acc[0];          // product row 4 gq = tap gq, class 16 t + c
+                }
+            }
+            float old[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) old[t] = arow[16 * t];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) arow[16 * t] = old[t] + upd[t];
+            // label class: every lane adds its tap's share for its pixel (same-wave LDS operations execute in order)
+            atomicAdd(&accum[tap_row(c & 3)][m.tt], wL * dlt);
+        }
+        if (ncol != col) __syncthreads();
+        col = ncol; idx = nidx;
+    }
+    if (__any(slow) && lane == 0) atomicOr(retry, 1);
+    for (int tap = wave; tap < NTAP; tap += 4) {
+        const int y = ty0 + tap / LS_TILE, x = tx0 + tap % LS_TILE;
+        if (y >= g.h || x >= g.w) continue;
+        T* drow = dlow + (((int64_t)b * g.h + y) * g.w + x) * ldd;
+        for (int cls = lane; cls < ldd; cls += 64) stf<T>(drow + cls, cls < g.C ? accum[tap][cls] : 0.f);
+    }
+}
+
 // generic ratio: full-resolution gradient, one wave per pixel at a time; segf_bilinear_bwd follows
 template <typename T, int NS>
 __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_kernel(const T* __restrict__ logits, LossGeom g,
@@ -842,13 +1182,23 @@ __global__ void zero_ints_kernel(int* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
 }
 
+#define LS_NT_DISPATCH(C, CALL) do { const int nt_ = ((C) + 15) / 16;                                                             \
+        if (nt_ <= 2) { CALL(2); } else if (nt_ <= 4) { CALL(4); } else if (nt_ <= 10) { CALL(10); } else { CALL(12); } } while (0)
+static bool loss_use_mfma(int sc) { return sc == 4 && !getenv("SEGFAC_LOSS_NO_MFMA"); }
+
 template <typename T>
 static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                        int64_t ignore_index, const float* cw, float* partial, int* retry) {
+    if (loss_use_mfma(sc)) {
+#define CALLM(NT) hipLaunchKernelGGL((ce_dice_fwd_mfma4_kernel<T, NT>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, partial, retry)
+        LS_NT_DISPATCH(g.C, CALLM);
+#undef CALLM
+    }
 #define CALL(NS)                                                                                                                \
     do {                                                                                                                        \
         if (sc >= 2) {                                                                                                          \
-            if (sc == 4) hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 4>), grid, dim3(LS_THREADS), 0, st, logits, g,    \
+            if (loss_use_mfma(sc)) {}                                                                                           \
+            else if (sc == 4) hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 4>), grid, dim3(LS_THREADS), 0, st, logits, g, \
                                             target, ignore_index, cw, partial, retry);                                          \
             else if (sc == 2) hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 2>), grid, dim3(LS_THREADS), 0, st, logits,  \
                                                  g, target, ignore_index, cw, partial, retry);                                  \
@@ -869,11 +1219,17 @@ template <typename T>
 static void bwd_cells_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                              int64_t ignore_index, const float* cw, int dice, const float* stats, const float* grad_out,
                              T* dlow, int64_t ldd, int* retry) {
+    if (sc >= 2) hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, 4);
+    if (loss_use_mfma(sc)) {
+#define CALLM(NT) hipLaunchKernelGGL((ce_dice_bwd_mfma4_kernel<T, NT>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry)
+        LS_NT_DISPATCH(g.C, CALLM);
+#undef CALLM
+    }
 #define CALL(NS)                                                                                                                \
     do {                                                                                                                        \
         if (sc >= 2) {                                                                                                          \
-            hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, 4);                                           \
-            if (sc == 4) hipLaunchKernelGGL((ce_dice_bwd_cells8_kernel<T, NS, 4>), grid, dim3(LS_THREADS), 0, st, logits, g,     \
+            if (loss_use_mfma(sc)) {}                                                                                           \
+            else if (sc == 4) hipLaunchKernelGGL((ce_dice_bwd_cells8_kernel<T, NS, 4>), grid, dim3(LS_THREADS), 0, st, logits, g, \
                                             target, ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry);                 \
             else if (sc == 2) hipLaunchKernelGGL((ce_dice_bwd_cells8_kernel<T, NS, 2>), grid, dim3(LS_THREADS), 0, st, logits,   \
                                                  g, target, ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry);         \

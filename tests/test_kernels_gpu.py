@@ -300,7 +300,8 @@ def test_loss_golden_cases(golden_dir):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('cfg', [(2, 19, 8, 8, 32, 32), (2, 150, 6, 10, 24, 40), (1, 2, 5, 5, 20, 20), (3, 65, 4, 4, 4, 4)])
+@pytest.mark.parametrize('cfg', [(2, 19, 8, 8, 32, 32), (2, 150, 6, 10, 24, 40), (1, 2, 5, 5, 20, 20), (3, 65, 4, 4, 4, 4),
+                                 (2, 171, 9, 7, 36, 28), (2, 21, 8, 8, 16, 16), (1, 40, 4, 6, 32, 48)])
 def test_upsample_ce_dice_vs_oracle(dtype, cfg):
     from oracle import loss as OL
     from segmentation_factory_amd import functional as Fh
@@ -323,6 +324,34 @@ def test_upsample_ce_dice_vs_oracle(dtype, cfg):
     loss.backward()
     assert abs(loss.item() - ref.item()) < (1e-5 if dtype == torch.float32 else 2e-3) * max(1, abs(ref.item()))
     _close(tok.grad, lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C), dtype, fac=2 if dtype == torch.float32 else 6)
+
+
+def test_upsample_ce_dice_retry_and_reproducible():
+    """Logit spreads far beyond exp's range make the cell bound underflow: the batched / MFMA kernels must hand over to
+    the exact-maximum pass (retry flag) and still match the oracle; two runs must agree bitwise."""
+    from oracle import loss as OL
+    from segmentation_factory_amd import functional as Fh
+    B, C, h, w, H, W = 2, 150, 8, 8, 32, 32
+    g = torch.Generator().manual_seed(12)
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    t[:, :1] = 255
+    for scale, expect_retry in ((2.0, 0), (150.0, 1)):
+        lo = torch.randn(B, C, h, w, generator=g) * scale
+        lr = lo.clone().requires_grad_(True)
+        up = F.interpolate(lr, size=(H, W), mode='bilinear', align_corners=False)
+        ref = OL.criterion_closed_form(up, t, None, num_classes=C, dice=True, ignore_index=255)
+        ref.backward()
+        outs = []
+        for _ in range(2):
+            tok = lo.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous().cuda().requires_grad_(True)
+            loss, parts, stats = Fh.upsample_ce_dice(tok, t.cuda(), (B, C, h, w, H, W), 255, None, True)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((loss.detach().clone(), tok.grad.clone()))
+        assert int(stats[-4:].view(torch.int32)[0].item() != 0) == expect_retry
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert abs(outs[0][0].item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+        _close(outs[0][1], lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C), torch.float32, fac=2)
 
 
 def test_argmax_confmat_and_metrics_golden(golden_dir):
