@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(AM_THREADS) attn_mfma_bwd_dq_kernel(const bf16
 // grid (key blocks of 256, query chunks, B*heads); wave w owns keys [256*bx + 64w, +64): its K / V fragments (B operands)
 // stay in registers; Q / dO tiles of 32 queries pass through LDS.  Output: fp32 slab[z][b*Nkv + key][2C] partial sums.
 template <int HD>
-__global__ void __launch_bounds__(AM_THREADS) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+__global__ void __launch_bounds__(AM_THREADS, HD == 32 ? 2 : 1) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                         const bf16_t* __restrict__ k, int64_t ldk,
                                                                         const bf16_t* __restrict__ v, int64_t ldv,
                                                                         const bf16_t* __restrict__ dO, int64_t lddo,

@@ -725,6 +725,122 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
+// ---- streaming kernel for huge-M, small-K, small-N products (stage-1/2 linears, the head's stage-1 projection) ------------
+// y = x W^T with M ~ 10^6 tokens and K, N <= 128 is pure HBM streaming: one 64..256-byte row in, one out.  The tiled
+// kernels above stage both operands through LDS in 128-wide tiles and waste most of a tile on N = 32.  Here the weight
+// fragments live in registers for the whole launch (NT * KS <= 16 fragments), a wave walks 16-token groups, and the product
+// is computed transposed (C^T = W X^T): the activation rows ARE the MFMA B operand as they lie in memory
+// (lane (m = l & 15, g = l >> 4) loads the 16 bytes x[m][32 s + 8 g ..]), no LDS at all; the accumulator rows (features)
+// are permuted through the weight-row order so that every lane ends up with runs of 8 consecutive output features of one
+// token and stores them with 16-byte writes that tile whole 64-byte segments.  N > 16*NT is covered by blockIdx.y chunks (x is re-read from L2, it is the small side).
+template <int LAYOUT, int KS, int NT>
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mi = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * (16 * NT);
+    const bf16_t* __restrict__ A = static_cast<const bf16_t*>(a.A);
+    const bf16_t* __restrict__ B = static_cast<const bf16_t*>(a.B);
+    bf16_t* __restrict__ C = static_cast<bf16_t*>(a.C);
+    const bf16_t* __restrict__ R = static_cast<const bf16_t*>(a.residual);
+    // weight fragments: MFMA row i of tile nt carries feature n0 + 32 (nt >> 1) + 8 (i >> 2) + 4 (nt & 1) + (i & 3): the tile
+    // pair (2q, 2q+1) gives lane group g the 8 consecutive features 32 q + 8 g .. + 7, so one 16-byte store instruction covers
+    // whole 64-byte row segments
+    bf16x8 Wf[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + 32 * (nt >> 1) + 8 * (mi >> 2) + 4 * (nt & 1) + (mi & 3);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (LAYOUT == 0) {
+                Wf[nt][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(B + (int64_t)n * a.ldb + 32 * s + 8 * g));
+            } else {
+                s16x8 w;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[j] = (short)B[(int64_t)(32 * s + 8 * g + j) * a.ldb + n];
+                Wf[nt][s] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+    }
+    float bv[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[nt][r] = a.bias ? a.bias[n0 + 32 * (nt >> 1) + 8 * g + 4 * (nt & 1) + r] : 0.f;
+    const int64_t ngroups = (a.M + 15) / 16, gstride = (int64_t)gridDim.x * 4;
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    uint4 xa[KS], xb[KS];
+    auto load_rows = [&](int64_t gp, uint4 (&x)[KS]) {
+        int64_t m = gp * 16 + mi;
+        m = m < a.M ? m : a.M - 1;
+        const bf16_t* p = A + m * a.lda + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) x[s] = *reinterpret_cast<const uint4*>(p + 32 * s);
+    };
+    if (grp < ngroups) load_rows(grp, xa);
+    for (; grp < ngroups; grp += gstride) {
+        const int64_t nxt = grp + gstride;
+        if (nxt < ngroups) load_rows(nxt, xb);
+        const int64_t m = grp * 16 + mi;
+        const bool mok = m < a.M;
+        uint4 rres[(NT + 1) / 2];
+        if (R) {
+            const bf16_t* rp = R + (mok ? m : a.M - 1) * a.ldr + n0 + 8 * g;
+#pragma unroll
+            for (int q = 0; q < (NT + 1) / 2; ++q) rres[q] = *reinterpret_cast<const uint4*>(rp + 32 * q);
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], __builtin_bit_cast(bf16x8, xa[s]), acc[nt], 0, 0, 0);
+        }
+        const float rs = a.rscale ? a.rscale[(mok ? m : 0) / a.rpg] : 1.f;
+        bf16_t* cp = C + m * a.ldc + n0 + 8 * g;
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][r] + bv[2 * q][r]; v[4 + r] = acc[2 * q + 1][r] + bv[2 * q + 1][r]; }
+            if (R) {
+                const uint4 u = rres[q];
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[2 * j] = __uint_as_float(w[j] << 16) + rs * v[2 * j];
+                    v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u) + rs * v[2 * j + 1];
+                }
+            }
+            if (mok) {
+                uint4 o;
+                o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+                *reinterpret_cast<uint4*>(cp + 32 * q) = o;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xa[s] = xb[s];
+    }
+}
+
+// shapes the streaming kernel takes: bf16 in/out, layouts 0/1, K in {32, 64, 128}, N a multiple of the chunk width,
+// 16-byte aligned rows on every operand, enough tokens to amortise the register-resident weights
+static int gemm_skinny_nt(int layout, int64_t M, int64_t N, int64_t K) {
+    if (layout > 1 || M < 16384 || (K != 32 && K != 64 && K != 128)) return 0;
+    const int ks = (int)(K / 32);
+    int nt = 16 / ks;                       // NT * KS <= 16 fragments
+    if (nt > 8) nt = 8;
+    while (nt >= 2 && N % (16 * nt)) nt >>= 1;
+    return nt >= 2 ? nt : 0;
+}
+template <int LAYOUT>
+static bool gemm_skinny_launch(int ks, int nt, dim3 grid, hipStream_t st, const GemmArgs& a) {
+#define SK(KS_, NT_) if (ks == KS_ && nt == NT_) { hipLaunchKernelGGL((gemm_skinny_kernel<LAYOUT, KS_, NT_>), grid, dim3(256), 0, st, a); return true; }
+    SK(1, 2) SK(1, 4) SK(1, 8) SK(2, 2) SK(2, 4) SK(2, 8) SK(4, 2) SK(4, 4)
+#undef SK
+    return false;
+}
+
 extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     // layout 2 (weight gradient): K = token count.  Aim for >= 512 workgroups, >= 4 K-steps per slice.
     const bool big = gemm_use_big(2, M, N, K);
@@ -771,6 +887,19 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
         a.use_tr = (e && e[0] == '1') ? 0 : 1;
     }
     if (dt == SEGF_BF16) {
+        if (c_dt == SEGF_BF16 && split_k == 1 && a.a_vec && a.c_vec16 && (!residual || a.r_vec) &&
+            (layout == 1 || a.b_vec) && !getenv("SEGFAC_GEMM_NO_SKINNY")) {
+            const int nt = gemm_skinny_nt(layout, M, N, K);
+            if (nt) {
+                const int64_t groups = cdiv64(M, 16);
+                int64_t gx = cdiv64(groups, 4 * 4);           // >= 4 token groups per wave
+                if (gx > 2048) gx = 2048;
+                const dim3 grid((unsigned)gx, (unsigned)(N / (16 * nt)));
+                const bool ok = layout == 0 ? gemm_skinny_launch<0>((int)(K / 32), nt, grid, st, a)
+                                            : gemm_skinny_launch<1>((int)(K / 32), nt, grid, st, a);
+                if (ok) { SEGF_CHECK_LAUNCH(); return 0; }
+            }
+        }
         if (gemm_use_big(layout, M, N, K) && a.use_tr) {
             dim3 gridb((unsigned)cdiv64(N, GG_B), (unsigned)cdiv64(M, GG_B), (unsigned)split_k);
             if (gridb.y > 65535u) return SEGF_ERR_SHAPE;

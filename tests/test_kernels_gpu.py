@@ -594,3 +594,39 @@ def test_gemm_big_tile_variant(hipmod, layout):
         full = ref + bias.double() + res.bfloat16().double()
         err = (out.double().cpu() - full).abs().max().item()
         assert err <= 1.2e-2 * full.abs().max().item()       # one bf16 rounding of the output
+
+
+@pytest.mark.parametrize('layout', [0, 1])
+@pytest.mark.parametrize('shape', [(16391, 32, 32), (20000, 128, 32), (16400, 32, 128), (16384, 64, 64), (16390, 768, 32),
+                                   (16384, 256, 64), (16392, 64, 128)])
+def test_gemm_streaming_variant(hipmod, layout, shape):
+    """Register-resident-weight streaming kernel (huge token count, K and N small): ragged token counts, bias + residual +
+    per-row-group scale epilogue, strided operands, against a float64 product of the bf16-rounded operands; and the same
+    call with the variant switched off must agree to bf16 rounding."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(40 + layout)
+    a = torch.randn(M, K + 8, generator=g)[:, :K]                  # row stride K + 8
+    b = torch.randn((N, K) if layout == 0 else (K, N), generator=g) / K ** 0.5
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    rpg = 4099
+    rs = torch.rand((M + rpg - 1) // rpg, generator=g) * 2
+    aq, bq = a.bfloat16().double(), b.bfloat16().double()
+    ref = res.bfloat16().double() + rs.double().repeat_interleave(rpg)[:M, None] * (aq @ (bq.t() if layout == 0 else bq) + bias.double())
+    ad = torch.randn(M, K + 8).bfloat16().cuda()
+    ad[:, :K] = a.bfloat16().cuda()
+    outs = []
+    for off in ('0', '1'):
+        os.environ['SEGFAC_GEMM_NO_SKINNY'] = off
+        try:
+            out = torch.zeros(M, N + 8, dtype=torch.bfloat16, device='cuda')
+            hipmod.gemm(layout, ad[:, :K], b.bfloat16().cuda(), M, N, K, out=out[:, :N], bias=bias.cuda(),
+                        residual=res.bfloat16().cuda(), rscale=rs.cuda(), rows_per_group=rpg)
+        finally:
+            os.environ.pop('SEGFAC_GEMM_NO_SKINNY', None)
+        assert out[:, N:].abs().max().item() == 0
+        err = (out[:, :N].double().cpu() - ref).abs().max().item()
+        assert err <= 1.2e-2 * ref.abs().max().item()
+        outs.append(out)
+    assert (outs[0].float() - outs[1].float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    plain = hipmod.gemm(layout, ad[:, :K], b.bfloat16().cuda(), M, N, K)
+    assert (plain.double().cpu() - aq @ (bq.t() if layout == 0 else bq)).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
