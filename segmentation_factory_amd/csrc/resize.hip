@@ -72,6 +72,83 @@ __global__ void __launch_bounds__(256) upsample_add_kernel(const T* __restrict__
     }
 }
 
+// The SegFormer head's case: three sources at exactly 1/2, 1/4 and 1/8 of the output grid (align_corners=False).  The generic
+// kernel issues 13 16-byte loads per 16-byte store and is bound by the L1 / address path, not by HBM.  Here a thread owns a
+// strip of four output pixels (X = 4k .. 4k+3) of one row: their horizontal taps are the static sets {2k-1..2k+2},
+// {k-1..k+1} and {(k-1)>>1, +1} with literal weights, the vertical blend is done once per tap column, and the strip needs
+// 22 loads for 4 stores.  Clamped border taps reproduce bilinear_src exactly (both taps of a clamped pair coincide).
+template <typename T, int NT>
+__device__ __forceinline__ void load_vblend(const T* __restrict__ sb, const UpSrc& s, int y0, int y1, float ly, int xfirst,
+                                            float (&tv)[NT][8]) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int x = xfirst + j;
+        x = x < 0 ? 0 : (x > s.w - 1 ? s.w - 1 : x);
+        float a[8], b[8];
+        load8<T>(sb + ((int64_t)y0 * s.w + x) * s.ld, a);
+        load8<T>(sb + ((int64_t)y1 * s.w + x) * s.ld, b);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tv[j][c] = fmaf(ly, b[c] - a[c], a[c]);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) upsample_add_248_kernel(const T* __restrict__ base, int64_t ldb, UpSrc s0, UpSrc s1, UpSrc s2,
+                                                                T* __restrict__ out, int64_t ldo, int B, int H, int W, int C) {
+    const int nch = C / 8, nst = W / 4;
+    const int64_t total = (int64_t)B * H * nst * nch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % nch);
+        int64_t t = idx / nch;
+        const int k = (int)(t % nst); t /= nst;
+        const int Y = (int)(t % H);
+        const int64_t b = t / H;
+        const int c0 = ch * 8;
+        const int64_t pix0 = (b * H + Y) * W + 4 * k;
+        float acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load8<T>(base + (pix0 + i) * ldb + c0, acc[i]);
+        int y0, y1; float ly;
+        {   // 1/2-resolution source
+            bilinear_src(Y, s0.h, H, 0, y0, y1, ly);
+            float tv[4][8];
+            load_vblend<T, 4>(reinterpret_cast<const T*>(s0.p) + b * s0.h * s0.w * s0.ld + c0, s0, y0, y1, ly, 2 * k - 1, tv);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc[0][c] += 0.25f * tv[0][c] + 0.75f * tv[1][c];
+                acc[1][c] += 0.75f * tv[1][c] + 0.25f * tv[2][c];
+                acc[2][c] += 0.25f * tv[1][c] + 0.75f * tv[2][c];
+                acc[3][c] += 0.75f * tv[2][c] + 0.25f * tv[3][c];
+            }
+        }
+        {   // 1/4
+            bilinear_src(Y, s1.h, H, 0, y0, y1, ly);
+            float tv[3][8];
+            load_vblend<T, 3>(reinterpret_cast<const T*>(s1.p) + b * s1.h * s1.w * s1.ld + c0, s1, y0, y1, ly, k - 1, tv);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc[0][c] += 0.375f * tv[0][c] + 0.625f * tv[1][c];
+                acc[1][c] += 0.125f * tv[0][c] + 0.875f * tv[1][c];
+                acc[2][c] += 0.875f * tv[1][c] + 0.125f * tv[2][c];
+                acc[3][c] += 0.625f * tv[1][c] + 0.375f * tv[2][c];
+            }
+        }
+        {   // 1/8: strip k lies inside one source cell
+            bilinear_src(Y, s2.h, H, 0, y0, y1, ly);
+            float tv[2][8];
+            load_vblend<T, 2>(reinterpret_cast<const T*>(s2.p) + b * s2.h * s2.w * s2.ld + c0, s2, y0, y1, ly, (k - 1) >> 1, tv);
+            const float l0 = (k & 1) ? 0.0625f : 0.5625f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float lx = l0 + 0.125f * i;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[i][c] += fmaf(lx, tv[1][c] - tv[0][c], tv[0][c]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store8<T>(out + (pix0 + i) * ldo + c0, acc[i]);
+    }
+}
+
 extern "C" int segf_upsample_add(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
                                  const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
                                  const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
@@ -87,8 +164,18 @@ extern "C" int segf_upsample_add(int dt, int B, int H, int W, int C, const void*
     for (int i = 0; i < nsrc; ++i)
         if (hs[i] <= 0 || ws[i] <= 0) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = (int)imin64(cdiv64((int64_t)B * H * W * (C / 8), 256), 16384);
     UpSrc s0{src0, h0, w0, ld0}, s1{src1, h1, w1, ld1}, s2{src2, h2, w2, ld2};
+    if (nsrc == 3 && !align_corners && W % 8 == 0 && H % 8 == 0 && h0 * 2 == H && w0 * 2 == W && h1 * 4 == H && w1 * 4 == W &&
+        h2 * 8 == H && w2 * 8 == W && !getenv("SEGFAC_UPADD_GENERIC")) {
+        const int blocks4 = (int)imin64(cdiv64((int64_t)B * H * (W / 4) * (C / 8), 256), 16384);
+        SEGF_DISPATCH_DT(dt, T, {
+            hipLaunchKernelGGL((upsample_add_248_kernel<T>), dim3(blocks4), dim3(256), 0, st, (const T*)base, ldb, s0, s1, s2,
+                               (T*)out, ldo, B, H, W, C);
+        })
+        SEGF_CHECK_LAUNCH();
+        return 0;
+    }
+    const int blocks = (int)imin64(cdiv64((int64_t)B * H * W * (C / 8), 256), 16384);
     SEGF_DISPATCH_DT(dt, T, {
         hipLaunchKernelGGL((upsample_add_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)base, ldb, s0, s1, s2, nsrc, (T*)out,
                            ldo, B, H, W, C, align_corners);

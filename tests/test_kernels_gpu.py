@@ -630,3 +630,26 @@ def test_gemm_streaming_variant(hipmod, layout, shape):
     assert (outs[0].float() - outs[1].float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
     plain = hipmod.gemm(layout, ad[:, :K], b.bfloat16().cuda(), M, N, K)
     assert (plain.double().cpu() - aq @ (bq.t() if layout == 0 else bq)).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('geom', [(2, 16, 24, 16), (1, 8, 8, 40), (1, 12, 20, 8)])
+def test_upsample_add_multi_scale(hipmod, dtype, geom):
+    """out = base + sum_k bilinear_up(src_k) on the stride-4 grid (folded SegFormer head, heads/segformer.py:44-56): the
+    specialised 1/2-1/4-1/8 strip kernel and the generic kernel against F.interpolate; (12, 20) is not a multiple of 8 and
+    takes the generic kernel either way."""
+    B, H, W, C = geom
+    g = torch.Generator().manual_seed(50)
+    base = torch.randn(B, C, H, W, generator=g)
+    sizes = [(max(H // r, 1), max(W // r, 1)) for r in (2, 4, 8)]
+    srcs = [torch.randn(B, C, h, w, generator=g) for (h, w) in sizes]
+    ref = _q(base, dtype) + sum(F.interpolate(_q(s, dtype), size=(H, W), mode='bilinear', align_corners=False) for s in srcs)
+    tok = lambda t: _dev(t.permute(0, 2, 3, 1).reshape(-1, C).contiguous(), dtype)
+    for generic in ('', '1'):
+        if generic:
+            os.environ['SEGFAC_UPADD_GENERIC'] = '1'
+        try:
+            out = hipmod.upsample_add(tok(base), [(tok(s), h, w) for s, (h, w) in zip(srcs, sizes)], B, H, W, C)
+        finally:
+            os.environ.pop('SEGFAC_UPADD_GENERIC', None)
+        _close(out, ref.permute(0, 2, 3, 1).reshape(-1, C), dtype)
