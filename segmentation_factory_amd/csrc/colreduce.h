@@ -105,24 +105,36 @@ __global__ void __launch_bounds__(CR_THREADS) colreduce_kernel(F f, int64_t rows
     if (active) {
         typename F::Col col;
         f.init(c0, nvalid, col);
-        // two rows per iteration: both rows' loads are issued before either is consumed (memory-level parallelism)
-        int64_t r = r0 + ty;
-        for (; r + rl < r1; r += 2 * rl) {
-            float v[NOUT][8], w[NOUT][8];
-            f(col, r, c0, nvalid, v);
-            f(col, r + rl, c0, nvalid, w);
+        // two rows per iteration: both rows' loads are issued before either is consumed (memory-level parallelism).
+        // The row loop exists twice, under `full chunk and 16-byte aligned rows` and under its negation: inside the first copy
+        // the functor's guarded loads fold to plain vector loads (a guard left inside the loop is a divergent branch per load,
+        // and each such branch ends in s_waitcnt vmcnt(0): the loads of one iteration would run one after the other).
+        auto row_loop = [&](const int nv, const F& ff) {
+            int64_t r = r0 + ty;
+            for (; r + rl < r1; r += 2 * rl) {
+                float v[NOUT][8], w[NOUT][8];
+                ff(col, r, c0, nv, v);
+                ff(col, r + rl, c0, nv, w);
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o)
+                for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[o][j] += v[o][j] + w[o][j];
-        }
-        if (r < r1) {
-            float v[NOUT][8];
-            f(col, r, c0, nvalid, v);
+                    for (int j = 0; j < 8; ++j) acc[o][j] += v[o][j] + w[o][j];
+            }
+            if (r < r1) {
+                float v[NOUT][8];
+                ff(col, r, c0, nv, v);
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o)
+                for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[o][j] += v[o][j];
+                    for (int j = 0; j < 8; ++j) acc[o][j] += v[o][j];
+            }
+        };
+        if (nvalid >= 8 && f.vec) {
+            F ff = f;
+            ff.vec = true;
+            row_loop(8, ff);
+        } else {
+            row_loop(nvalid, f);
         }
     }
     colreduce_block_tail<NOUT>(acc, active, ty == 0 && nvalid > 0, tx, ch, rl, c0, nvalid, C, partial, red);

@@ -34,6 +34,23 @@ static inline int colfixed_blocks(int64_t units, int nchunk, int units_per_threa
     return (int)blocks;
 }
 
+// exact unsigned 32-bit division by a launch-constant divisor (Granlund-Montgomery): 5 integer ops instead of the ~80 of a
+// 64-bit software division in per-row index arithmetic (sample index = row / rows_per_sample)
+struct FastDivU32 { uint32_t m, sh1, sh2; };
+static inline FastDivU32 fastdiv_make(uint32_t d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDivU32 f;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l - f.sh1;
+    return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, FastDivU32 f) {
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
     // plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)

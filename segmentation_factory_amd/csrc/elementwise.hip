@@ -103,23 +103,27 @@ __global__ void ew2d_kernel(const T* __restrict__ a, int64_t lda, const T* __res
     const int64_t nchunk = (cols + 7) / 8;
     const int64_t total = rows * nchunk;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t r = i / nchunk;
-        const int c0 = (int)(i - r * nchunk) * 8;
-        const int nv = (int)(cols - c0 < 8 ? cols - c0 : 8);
-        float va[8], vb[8];
-        load8_guard<T>(a + r * lda + c0, nv, vec, va);
-        if (MODE == 0) {
-            const float s = scale[r / rpg];
+    auto body = [&](const bool full) {      // full: every chunk complete and 16-byte aligned -> guard-free vector accesses
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+            const int64_t r = i / nchunk;
+            const int c0 = (int)(i - r * nchunk) * 8;
+            const int nv = full ? 8 : (int)(cols - c0 < 8 ? cols - c0 : 8);
+            const bool vv = full ? true : vec;
+            float va[8], vb[8];
+            load8_guard<T>(a + r * lda + c0, nv, vv, va);
+            if (MODE == 0) {
+                const float s = scale[r / rpg];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) va[j] *= s;
-        } else {
-            load8_guard<T>(b + r * ldb + c0, nv, vec, vb);
+                for (int j = 0; j < 8; ++j) va[j] *= s;
+            } else {
+                load8_guard<T>(b + r * ldb + c0, nv, vv, vb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) va[j] += vb[j];
+                for (int j = 0; j < 8; ++j) va[j] += vb[j];
+            }
+            store8_guard<T>(y + r * ldy + c0, nv, vv, va);
         }
-        store8_guard<T>(y + r * ldy + c0, nv, vec, va);
-    }
+    };
+    if (vec && cols % 8 == 0) body(true); else body(false);
 }
 
 extern "C" int segf_scale_rows(int dt, const void* x, int64_t ldx, void* y, int64_t ldy, const float* scale,

@@ -298,7 +298,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int act, const float* __restrict__ cscale,
-                                                        int64_t rps, T* __restrict__ y, int64_t rows, int C, bool vec) {
+                                                        FastDivU32 rps, T* __restrict__ y, int64_t rows, int C, bool vec) {
     const int nchunk = (C + 7) / 8;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t T_ = (int64_t)gridDim.x * 256;
@@ -313,20 +313,25 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
         a[j] = gamma[c] * rstd[c];
         b[j] = beta[c] - mean[c] * a[j];
     }
+    // the row loop is instantiated under `full 16-byte-aligned chunk` and under its negation, so that the guarded accesses of
+    // the first copy fold to plain vector loads / stores (see colreduce_kernel)
+    auto row_loop = [&](const int nvv, const bool vv) {
 #pragma unroll 2
-    for (int64_t r = g / nchunk; r < rows; r += rstep) {
-        float v[8];
-        load8_guard<T>(x + r * C + c0, nv, vec, v);
+        for (int64_t r = g / nchunk; r < rows; r += rstep) {
+            float v[8];
+            load8_guard<T>(x + r * C + c0, nvv, vv, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bn_act(fmaf(v[j], a[j], b[j]), act);
-        if (cscale) {
-            float cs[8];
-            load8_guard<float>(cscale + (r / rps) * C + c0, nv, vec, cs);
+            for (int j = 0; j < 8; ++j) v[j] = bn_act(fmaf(v[j], a[j], b[j]), act);
+            if (cscale) {
+                float cs[8];
+                load8_guard<float>(cscale + (int64_t)fastdiv((uint32_t)r, rps) * C + c0, nvv, vv, cs);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= cs[j];
+                for (int j = 0; j < 8; ++j) v[j] *= cs[j];
+            }
+            store8_guard<T>(y + r * C + c0, nvv, vv, v);
         }
-        store8_guard<T>(y + r * C + c0, nv, vec, v);
-    }
+    };
+    if (nv >= 8 && vec) row_loop(8, true); else row_loop(nv, vec);
 }
 
 extern "C" int segf_bn_apply(int dt, int64_t rows, int C, const void* x, const float* mean, const float* rstd,
@@ -339,7 +344,7 @@ extern "C" int segf_bn_apply(int dt, int64_t rows, int C, const void* x, const f
     SEGF_DISPATCH_DT(dt, T, {
         const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(y, C) && (C % 8 == 0);
         hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, mean, rstd, gamma, beta, act,
-                           chan_scale, rows_per_sample > 0 ? rows_per_sample : 1, (T*)y, rows, C, vec);
+                           chan_scale, fastdiv_make((uint32_t)(rows_per_sample > 0 ? rows_per_sample : 1)), (T*)y, rows, C, vec);
     })
     SEGF_CHECK_LAUNCH();
     return 0;
@@ -358,14 +363,14 @@ __device__ __forceinline__ void bn_col_init(const float* mean, const float* rstd
 }
 template <typename T> struct BnBwdF {
     const T* x; const T* dy; const float* mean; const float* rstd; const float* gamma; const float* beta;
-    const float* cscale; int64_t rps; int C; int act; bool vec;
+    const float* cscale; FastDivU32 rps; int C; int act; bool vec;
     typedef BnCol Col;
     __device__ void init(int c0, int nv, Col& col) const { bn_col_init(mean, rstd, gamma, beta, c0, nv, col); }
     __device__ void operator()(const Col& col, int64_t r, int c0, int nv, float (&v)[2][8]) const {
         float xv[8], dv[8], cs[8];
         load8_guard<T>(x + r * C + c0, nv, vec, xv);
         load8_guard<T>(dy + r * C + c0, nv, vec, dv);
-        if (cscale) load8_guard<float>(cscale + (r / rps) * C + c0, nv, vec, cs);
+        if (cscale) load8_guard<float>(cscale + (int64_t)fastdiv((uint32_t)r, rps) * C + c0, nv, vec, cs);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xh = (xv[j] - col.mean[j]) * col.rstd[j];
@@ -381,7 +386,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-                                                            const float* __restrict__ cscale, int64_t rps,
+                                                            const float* __restrict__ cscale, FastDivU32 rps,
                                                             const float* __restrict__ sums /*[2][C]: dbeta, dgamma*/,
                                                             int eval_mode, T* __restrict__ dx, int64_t rows, int C, bool vec) {
     const int nchunk = (C + 7) / 8;
@@ -402,21 +407,24 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
         k2[j] = eval_mode ? 0.f : sums[C + c] * invn;
         gr[j] = col.a[j] * col.rstd[j];
     }
+    auto row_loop = [&](const int nvv, const bool vv) {
 #pragma unroll 2
-    for (int64_t r = g / nchunk; r < rows; r += rstep) {
-        float xv[8], dv[8], cs[8];
-        load8_guard<T>(x + r * C + c0, nv, vec, xv);
-        load8_guard<T>(dy + r * C + c0, nv, vec, dv);
-        if (cscale) load8_guard<float>(cscale + (r / rps) * C + c0, nv, vec, cs);
+        for (int64_t r = g / nchunk; r < rows; r += rstep) {
+            float xv[8], dv[8], cs[8];
+            load8_guard<T>(x + r * C + c0, nvv, vv, xv);
+            load8_guard<T>(dy + r * C + c0, nvv, vv, dv);
+            if (cscale) load8_guard<float>(cscale + (int64_t)fastdiv((uint32_t)r, rps) * C + c0, nvv, vv, cs);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = (xv[j] - col.mean[j]) * col.rstd[j];
-            float d = dv[j] * bn_act_mask(fmaf(xh, col.a[j], col.b[j]), act);
-            if (cscale) d *= cs[j];
-            xv[j] = gr[j] * (d - k1[j] - xh * k2[j]);
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xv[j] - col.mean[j]) * col.rstd[j];
+                float d = dv[j] * bn_act_mask(fmaf(xh, col.a[j], col.b[j]), act);
+                if (cscale) d *= cs[j];
+                xv[j] = gr[j] * (d - k1[j] - xh * k2[j]);
+            }
+            store8_guard<T>(dx + r * C + c0, nvv, vv, xv);
         }
-        store8_guard<T>(dx + r * C + c0, nv, vec, xv);
-    }
+    };
+    if (nv >= 8 && vec) row_loop(8, true); else row_loop(nv, vec);
 }
 
 // dgamma = sums[1], dbeta = sums[0] are produced in-place: caller passes dbeta = ws-resident [C], dgamma [C]
@@ -435,7 +443,8 @@ extern "C" int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const voi
     if (chan_scale && rows_per_sample <= 0) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     float* sums = ws + cr_ws_floats(rows, C, 2);
-    const int64_t rps = rows_per_sample > 0 ? rows_per_sample : 1;
+    if (rows > 0xffffffffll) return SEGF_ERR_SHAPE;
+    const FastDivU32 rps = fastdiv_make((uint32_t)(rows_per_sample > 0 ? rows_per_sample : 1));
     const int blocks = colfixed_blocks(rows, (C + 7) / 8, 4, 8192);
     SEGF_DISPATCH_DT(dt, T, {
         const bool vec = vec_ok_host<T>(x, C) && vec_ok_host<T>(dy, C) && vec_ok_host<T>(dx, C) && (C % 8 == 0);
@@ -519,7 +528,7 @@ __global__ void __launch_bounds__(256) grn_coef_kernel(const float* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(256) grn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ a,
                                                          const float* __restrict__ k, const float* __restrict__ beta, T* __restrict__ y,
-                                                         int64_t rows, int64_t rps, int C) {
+                                                         int64_t rows, FastDivU32 rps, int C) {
     const int nchunk = C / 8;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t rstep = ((int64_t)gridDim.x * 256) / nchunk;
@@ -528,7 +537,7 @@ __global__ void __launch_bounds__(256) grn_apply_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int j = 0; j < 8; ++j) bt[j] = beta ? beta[c0 + j] : 0.f;
     for (int64_t r = g / nchunk; r < rows; r += rstep) {
-        const int64_t b = r / rps;
+        const int64_t b = fastdiv((uint32_t)r, rps);
         float v[8], av[8];
         load8<T>(x + r * C + c0, v);
         load8f(a + b * C + c0, av);
@@ -575,7 +584,7 @@ extern "C" int segf_grn_fwd(int dt, int B, int64_t rows_per_sample, int C, const
         hipLaunchKernelGGL(grn_coef_kernel, dim3(B), dim3(256), 0, st, sumsq, gamma, C, a_out, g_out, (const float*)nullptr,
                            (float*)nullptr, (float*)nullptr);
         hipLaunchKernelGGL((grn_apply_kernel<T>), dim3(colfixed_blocks(rows, C / 8, 4, 8192)), dim3(256), 0, st, (const T*)x,
-                           (const T*)nullptr, a_out, (const float*)nullptr, beta, (T*)y, rows, rows_per_sample, C);
+                           (const T*)nullptr, a_out, (const float*)nullptr, beta, (T*)y, rows, fastdiv_make((uint32_t)rows_per_sample), C);
     })
     SEGF_CHECK_LAUNCH();
     return 0;
@@ -597,7 +606,7 @@ extern "C" int segf_grn_bwd(int dt, int B, int64_t rows_per_sample, int C, const
         // dg_part reuses the front of the (now consumed) partial workspace
         hipLaunchKernelGGL(grn_coef_kernel, dim3(B), dim3(256), 0, st, g_saved, gamma, C, a, (float*)nullptr, S, K, ws);
         hipLaunchKernelGGL((grn_apply_kernel<T>), dim3(colfixed_blocks(rows, C / 8, 4, 8192)), dim3(256), 0, st, (const T*)dy,
-                           (const T*)x, a, K, (const float*)nullptr, (T*)dx, rows, rows_per_sample, C);
+                           (const T*)x, a, K, (const float*)nullptr, (T*)dx, rows, fastdiv_make((uint32_t)rows_per_sample), C);
     })
     SEGF_CHECK_LAUNCH();
     hipLaunchKernelGGL(grn_param_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, S, B, C, dgamma, dbeta);

@@ -9,27 +9,33 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ in, int64_t ldi, T* __
                                     int C, int H, int W, int ac, bool vec) {
     const int nch = (C + 7) / 8;
     const int64_t total = (int64_t)B * H * W * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % nch);
-        int64_t t = idx / nch;
-        const int X = (int)(t % W); t /= W;
-        const int Y = (int)(t % H);
-        const int64_t b = t / H;
-        const int c0 = ch * 8, nv = C - c0 < 8 ? C - c0 : 8;
-        int y0, y1, x0, x1; float ly, lx;
-        bilinear_src(Y, h, H, ac, y0, y1, ly);
-        bilinear_src(X, w, W, ac, x0, x1, lx);
-        float v00[8], v01[8], v10[8], v11[8], o[8];
-        const T* base = in + b * h * w * ldi + c0;
-        load8_guard<T>(base + ((int64_t)y0 * w + x0) * ldi, nv, vec, v00);
-        load8_guard<T>(base + ((int64_t)y0 * w + x1) * ldi, nv, vec, v01);
-        load8_guard<T>(base + ((int64_t)y1 * w + x0) * ldi, nv, vec, v10);
-        load8_guard<T>(base + ((int64_t)y1 * w + x1) * ldi, nv, vec, v11);
-        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    // two copies of the loop (all chunks full and aligned / general): in the first the four tap loads are plain vector loads
+    // in flight together; a per-load guard inside the loop would serialise them (branch + s_waitcnt per load)
+    auto body = [&](const bool full) {
+        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+            const int ch = (int)(idx % nch);
+            int64_t t = idx / nch;
+            const int X = (int)(t % W); t /= W;
+            const int Y = (int)(t % H);
+            const int64_t b = t / H;
+            const int c0 = ch * 8, nv = full ? 8 : (C - c0 < 8 ? C - c0 : 8);
+            const bool vv = full ? true : vec;
+            int y0, y1, x0, x1; float ly, lx;
+            bilinear_src(Y, h, H, ac, y0, y1, ly);
+            bilinear_src(X, w, W, ac, x0, x1, lx);
+            float v00[8], v01[8], v10[8], v11[8], o[8];
+            const T* base = in + b * h * w * ldi + c0;
+            load8_guard<T>(base + ((int64_t)y0 * w + x0) * ldi, nv, vv, v00);
+            load8_guard<T>(base + ((int64_t)y0 * w + x1) * ldi, nv, vv, v01);
+            load8_guard<T>(base + ((int64_t)y1 * w + x0) * ldi, nv, vv, v10);
+            load8_guard<T>(base + ((int64_t)y1 * w + x1) * ldi, nv, vv, v11);
+            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = w00 * v00[j] + w01 * v01[j] + w10 * v10[j] + w11 * v11[j];
-        store8_guard<T>(out + ((b * H + Y) * W + X) * ldo + c0, nv, vec, o);
-    }
+            for (int j = 0; j < 8; ++j) o[j] = w00 * v00[j] + w01 * v01[j] + w10 * v10[j] + w11 * v11[j];
+            store8_guard<T>(out + ((b * H + Y) * W + X) * ldo + c0, nv, vv, o);
+        }
+    };
+    if (vec && C % 8 == 0) body(true); else body(false);
 }
 
 // out = base + sum_k bilinear_up(src_k): the folded SegFormerHead (heads/segformer.py:44-56).  Because bilinear
