@@ -79,6 +79,35 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
     v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
     v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
+// Two-phase form for loops that want several rows in flight: issue every load8_raw of the iteration, SEGF_LOADS_ISSUED(),
+// then unpack8 + arithmetic.  hipcc's scheduler otherwise keeps `load, s_waitcnt vmcnt(0), convert` together per load8
+// (it minimises live registers), which turns an iteration's independent loads into a dependent chain of HBM latencies;
+// the scheduling barrier pins the loads above the first use, and the waits then count down (vmcnt(N-1), vmcnt(N-2), ...).
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<bf16_t> { uint4 u; };
+template <typename T> __device__ __forceinline__ Raw8<T> load8_raw(const T* p);
+template <> __device__ __forceinline__ Raw8<float> load8_raw<float>(const float* p) {
+    Raw8<float> r;
+    r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
+    return r;
+}
+template <> __device__ __forceinline__ Raw8<bf16_t> load8_raw<bf16_t>(const bf16_t* p) {
+    Raw8<bf16_t> r;
+    r.u = *reinterpret_cast<const uint4*>(p);
+    return r;
+}
+__device__ __forceinline__ void unpack8(const Raw8<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void unpack8(const Raw8<bf16_t>& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.u.x << 16); v[1] = __uint_as_float(r.u.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.u.y << 16); v[3] = __uint_as_float(r.u.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.u.z << 16); v[5] = __uint_as_float(r.u.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.u.w << 16); v[7] = __uint_as_float(r.u.w & 0xffff0000u);
+}
+#define SEGF_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
 template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);

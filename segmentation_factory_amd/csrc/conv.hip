@@ -154,14 +154,29 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_kernel(const T* __restric
             const int yy = t % H;
             const int b = t / H;
             const int x0 = xg * DW_PIX;
-            float g[DW_PIX][8];
+            // all loads of the strip (its gradient pixels and the 3 x (DW_PIX + 2) input window) are issued before the
+            // first use (see SEGF_LOADS_ISSUED in common.h)
+            Raw8<T> graw[DW_PIX], vraw[3][DW_PIX + 2];
 #pragma unroll
             for (int p = 0; p < DW_PIX; ++p) {
                 const int xp = x0 + p < W ? x0 + p : W - 1;
-                load8<T>(du + (((int64_t)b * H + yy) * W + xp) * C + c0, g[p]);
+                graw[p] = load8_raw<T>(du + (((int64_t)b * H + yy) * W + xp) * C + c0);
             }
 #pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = yy + ky - 1;
+                const T* row = x + (((int64_t)b * H + ((iy >= 0 && iy < H) ? iy : yy)) * W) * C + c0;
+#pragma unroll
+                for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                    const int ix = x0 + cx - 1;
+                    vraw[ky][cx] = load8_raw<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C);
+                }
+            }
+            SEGF_LOADS_ISSUED();
+            float g[DW_PIX][8];
+#pragma unroll
             for (int p = 0; p < DW_PIX; ++p) {
+                unpack8(graw[p], g[p]);
                 const bool ok = x0 + p < W;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { g[p][j] = ok ? g[p][j] : 0.f; acc[9][j] += g[p][j]; }
@@ -170,17 +185,12 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_kernel(const T* __restric
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = yy + ky - 1;
                 const bool vy = iy >= 0 && iy < H;
-                const T* row = x + (((int64_t)b * H + (vy ? iy : yy)) * W) * C + c0;
                 float v[DW_PIX + 2][8];
 #pragma unroll
                 for (int cx = 0; cx < DW_PIX + 2; ++cx) {
                     const int ix = x0 + cx - 1;
-                    load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[cx]);
-                }
-#pragma unroll
-                for (int cx = 0; cx < DW_PIX + 2; ++cx) {
-                    const int ix = x0 + cx - 1;
                     const bool ok = vy && ix >= 0 && ix < W;
+                    unpack8(vraw[ky][cx], v[cx]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[cx][j] = ok ? v[cx][j] : 0.f;
 #pragma unroll

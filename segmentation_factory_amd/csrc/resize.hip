@@ -272,23 +272,25 @@ __global__ void __launch_bounds__(256) bilinear_bwd_int_kernel(T* __restrict__ d
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         const T* src = dout + (b * H * W) * ldo + c0;
+        // every load is unconditional (out-of-window rows / columns are clamped and carry weight 0): a row's 2R loads are
+        // in flight together; a `skip if weight == 0` branch around each load would end in s_waitcnt vmcnt(0) per load
         for (int i = 0; i < WIN; ++i) {
-            const int Y = Y0 + i;
-            if (Y >= H) break;
+            const int Y = Y0 + i, Yc = Y < H ? Y : H - 1;
             int y0, y1; float ly;
-            bilinear_src(Y, h, H, 0, y0, y1, ly);
-            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
-            if (wy == 0.f) continue;
-            const T* row = src + ((int64_t)Y * W + X0) * ldo;
+            bilinear_src(Yc, h, H, 0, y0, y1, ly);
+            const float wy = Y < H ? (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f) : 0.f;
+            const T* row = src + (int64_t)Yc * W * ldo;
+            Raw8<T> raw[WIN];
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) raw[j] = load8_raw<T>(row + (int64_t)(X0 + j < W ? X0 + j : W - 1) * ldo);
+            SEGF_LOADS_ISSUED();
 #pragma unroll
             for (int j = 0; j < WIN; ++j) {
-                if (wx[j] != 0.f) {
-                    float v[8];
-                    load8<T>(row + (int64_t)j * ldo, v);
-                    const float ww = wy * wx[j];
+                float v[8];
+                unpack8(raw[j], v);
+                const float ww = wy * wx[j];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(ww, v[q], acc[q]);
-                }
+                for (int q = 0; q < 8; ++q) acc[q] = fmaf(ww, v[q], acc[q]);
             }
         }
         store8<T>(din + ((b * h + y) * w + x) * ldi + c0, acc);
