@@ -494,34 +494,44 @@ __global__ void im2col_nhwc_kernel(const T* __restrict__ x, T* __restrict__ col,
 }
 // fp32 NCHW image input (Cin small, e.g. 3): a thread builds 8 consecutive columns of one im2col row (scalar gathers from
 // the image, which stays L2-resident) and issues ONE 16-byte store; pad columns [K, ldcol) are zeroed.  ldcol % 8 == 0.
+// Column-fixed threads: the (channel, ky, kx) of a thread's eight columns are decoded once; per row the eight gathers are
+// unconditional (clamped address, masked value) and issued together.
 template <typename T>
-__global__ void im2col_nchw_kernel(const float* __restrict__ x, T* __restrict__ col, int64_t ldcol, int B, int H, int W, int Cin,
-                                   int kh, int kw, int stride, int pad, int Ho, int Wo) {
+__global__ void __launch_bounds__(256) im2col_nchw_kernel(const float* __restrict__ x, T* __restrict__ col, int64_t ldcol, int B,
+                                                           int H, int W, int Cin, int kh, int kw, int stride, int pad, int Ho,
+                                                           int Wo) {
     const int nch = (int)(ldcol / 8);
-    const int64_t total = (int64_t)B * Ho * Wo * nch;
+    const int64_t rows = (int64_t)B * Ho * Wo;
     const int K = kh * kw * Cin;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % nch);
-        const int64_t m = idx / nch;
-        const int ox = (int)(m % Wo);
-        const int64_t t2 = m / Wo;
-        const int oy = (int)(t2 % Ho);
-        const int64_t b = t2 / Ho;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rstep = ((int64_t)gridDim.x * 256) / nch;
+    const int ch = (int)(g % nch);
+    int kyj[8], kxj[8], cij[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int kcol = ch * 8 + j;
+        const int kk = kcol / Cin;
+        cij[j] = kcol < K ? kcol % Cin : -1;
+        kxj[j] = kk % kw; kyj[j] = kk / kw;
+    }
+    for (int64_t m = g / nch; m < rows; m += rstep) {
+        const uint32_t t2 = (uint32_t)m / (uint32_t)Wo;       // rows < 2^31 (checked on the host)
+        const int ox = (int)((uint32_t)m - t2 * (uint32_t)Wo);
+        const int64_t b = t2 / (uint32_t)Ho;
+        const int oy = (int)(t2 - (uint32_t)b * (uint32_t)Ho);
         const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
         float v[8];
+        bool ok[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int kcol = ch * 8 + j;
-            float val = 0.f;
-            if (kcol < K) {
-                const int ci = kcol % Cin;
-                const int kk = kcol / Cin;
-                const int kx = kk % kw, ky = kk / kw;
-                const int iy = iy0 + ky, ix = ix0 + kx;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = x[((b * Cin + ci) * H + iy) * W + ix];
-            }
-            v[j] = val;
+            const int iy = iy0 + kyj[j], ix = ix0 + kxj[j];
+            ok[j] = cij[j] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            v[j] = x[((b * Cin + (cij[j] < 0 ? 0 : cij[j])) * H + iyc) * W + ixc];
         }
+        SEGF_LOADS_ISSUED();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ok[j] ? v[j] : 0.f;
         store8<T>(col + m * ldcol + ch * 8, v);
     }
 }
@@ -543,10 +553,11 @@ extern "C" int segf_im2col(int dt, int in_nchw_f32, int B, int H, int W, int Cin
     if (ldcol < K || stride <= 0) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * Ho * Wo;
+    if (rows >= (1ll << 31)) return SEGF_ERR_SHAPE;
     if (in_nchw_f32) {
         const int64_t esz0 = dt == SEGF_BF16 ? 2 : 4;
         if (ldcol % 8 || ((uintptr_t)col % 16) || ((ldcol * esz0) % 16)) return SEGF_ERR_SHAPE;
-        const int blocks = (int)imin64(cdiv64(rows * (ldcol / 8), 256), 16384);
+        const int blocks = colfixed_blocks(rows, (int)(ldcol / 8), 4, 16384);
         SEGF_DISPATCH_DT(dt, T, {
             hipLaunchKernelGGL((im2col_nchw_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)x, (T*)col, ldcol, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
         })
