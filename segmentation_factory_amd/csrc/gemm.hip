@@ -24,6 +24,7 @@ struct GemmArgs {
     int64_t kchunk;          // K range per grid.z slice
     float* ws;               // split-K partials [z][M][N] (nullptr when split_k == 1)
     int a_vec, b_vec, c_vec, r_vec, use_tr;
+    int fast;                // uniform guard-free tile loads for full K steps (debug switch SEGFAC_GEMM_NO_FASTLOAD)
     int c_vec16;             // C rows allow 16-byte stores (bf16 output, LDS-staged epilogue)
     // implicit 3x3 convolution (stride 1, pad 1) over an NHWC operand [B][cH][cW][ld >= cC]: the gathered operand's K (layout 0,
     // operand A) or N (layout 2, operand B) axis is (tap = ky*3+kx, channel); csign = +1 reads pixel + offset(tap) (forward,
@@ -52,6 +53,17 @@ __device__ __forceinline__ void gload_kc(const bf16_t* __restrict__ base, int64_
                                          int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
     const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
     const int64_t k = k0 + c * 8;
+    if ((vec & 2) && k0 + GB_BK <= kend) {
+        // whole K step in range (workgroup-uniform): four plain vector loads in flight together.  Rows past the operand are
+        // clamped, not zeroed: they only feed output rows / columns that are never stored.  (A per-load `if (in range)`
+        // costs a divergent branch and an s_waitcnt vmcnt(0) per load, i.e. 8 serialised HBM latencies per K step.)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + r + 32 * i;
+            reg[i] = *reinterpret_cast<const uint4*>(base + (row < rmax ? row : rmax - 1) * ld + k);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + r + 32 * i;
@@ -78,6 +90,12 @@ __device__ __forceinline__ void gload_rm(const bf16_t* __restrict__ base, int64_
                                          int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
     const int64_t col = col0 + c * 8;
+    if ((vec & 2) && k0 + GB_BK <= kend && (cmax & 7) == 0) {      // see gload_kc: uniform fast path, clamped columns
+        const bf16_t* p = base + (k0 + r) * ld + (col < cmax ? col : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reg[i] = *reinterpret_cast<const uint4*>(p + (int64_t)(16 * i) * ld);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t k = k0 + r + 16 * i;
@@ -375,6 +393,14 @@ template <int T> __device__ __forceinline__ void gload_kc_t(const bf16_t* __rest
                                                             int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
     const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
     const int64_t k = k0 + c * 8;
+    if ((vec & 2) && k0 + GB_BK <= kend) {      // see gload_kc
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + r + (T / 8) * i;
+            reg[i] = *reinterpret_cast<const uint4*>(base + (row < rmax ? row : rmax - 1) * ld + k);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + r + (T / 8) * i;
@@ -419,6 +445,12 @@ template <int R, int T> __device__ __forceinline__ void gload_rm_t(const bf16_t*
     constexpr int CPR = R / 8;
     const int c = threadIdx.x % CPR, r = threadIdx.x / CPR;
     const int64_t col = col0 + c * 8;
+    if ((vec & 2) && k0 + GB_BK <= kend && (cmax & 7) == 0) {      // see gload_kc
+        const bf16_t* p = base + (k0 + r) * ld + (col < cmax ? col : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reg[i] = *reinterpret_cast<const uint4*>(p + (int64_t)((T / CPR) * i) * ld);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t k = k0 + r + (T / CPR) * i;
@@ -878,6 +910,10 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
     const size_t esz = dt == SEGF_BF16 ? 2 : 4, csz = c_dt == SEGF_BF16 ? 2 : 4;
     a.a_vec = ((uintptr_t)A % 16 == 0) && ((lda * esz) % 16 == 0);
     a.b_vec = ((uintptr_t)B % 16 == 0) && ((ldb * esz) % 16 == 0);
+    a.fast = getenv("SEGFAC_GEMM_NO_FASTLOAD") ? 0 : 1;
+    // bit 0: vector loads allowed, bit 1: guard-free full-K-step loads.  Layouts 0 / 1 gain 25-45 % from the latter; the split-K
+    // weight-gradient launches (layout 2) measured 8-15 % SLOWER with every load in flight, so they keep the guarded loads
+    if (a.fast && (layout != 2 || getenv("SEGFAC_GEMM_FASTLOAD_L2"))) { a.a_vec *= 3; a.b_vec *= 3; }
     a.c_vec = ((uintptr_t)C % (4 * csz) == 0) && ((ldc * csz) % (4 * csz) == 0);
     a.r_vec = residual ? (((uintptr_t)residual % 16 == 0) && ((ldr * esz) % 16 == 0)) : 0;
     a.c_vec16 = ((uintptr_t)C % 16 == 0) && ((ldc * csz) % 16 == 0);
