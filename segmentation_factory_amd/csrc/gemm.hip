@@ -877,7 +877,9 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     // layout 2 (weight gradient): K = token count.  Aim for >= 512 workgroups, >= 4 K-steps per slice.
     const bool big = gemm_use_big(2, M, N, K);
     const int64_t tiles = big ? cdiv64(M, GG_B) * cdiv64(N, GG_B) : cdiv64(M, GB_BM) * cdiv64(N, GB_BN);
-    int64_t s = cdiv64(big ? 256 : 512, tiles);
+    // one wave of workgroups: 256 CUs x (1 big-tile | 2 small-tile) resident workgroups.  Rounded DOWN: 3 tiles x 86 slices =
+    // 258 workgroups would run as two rounds (256 + 2) and take twice as long as 3 x 85
+    int64_t s = getenv("SEGFAC_SPLITK_CEIL") ? cdiv64(big ? 256 : 512, tiles) : (big ? 256 : 512) / tiles;
     const int64_t maxs = K / (4 * GB_BK);
     if (s > maxs) s = maxs;
     if (s > 512) s = 512;
