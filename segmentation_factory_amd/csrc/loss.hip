@@ -842,17 +842,20 @@ struct MfmaCell {
 #pragma unroll
         for (int t = 0; t < NT; ++t) mx = 16 * t + c < g.C ? fmaxf(mx, L.u[t]) : mx;
         mb = wave_max_all(mx);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = 0.f;
+        // the elementwise work is written on 4-vectors so that it lowers to packed fp32 instructions (v_pk_add/mul/fma_f32:
+        // two lanes' worth of flops per issue slot) -- these kernels are bound by VALU issue, not by memory
+        lossf4 s4 = {0.f, 0.f, 0.f, 0.f};
+        const float nmb = -mb * LS_LOG2E;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float ut = 16 * t + c < g.C ? (L.u[t] - mb) * LS_LOG2E : -1e30f;
+            const float ut = 16 * t + c < g.C ? fmaf(L.u[t], LS_LOG2E, nmb) : -1e30f;
             const lossf4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(wA, ut, lossf4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { e[t][r] = __builtin_amdgcn_exp2f(z[r]); s[r] += e[t][r]; }
+            e[t] = lossf4{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1]), __builtin_amdgcn_exp2f(z[2]),
+                          __builtin_amdgcn_exp2f(z[3])};
+            s4 += e[t];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = row_sum16(s[r]);
+        for (int r = 0; r < 4; ++r) s[r] = row_sum16(s4[r]);
         ul = (ulraw - mb) * LS_LOG2E;
     }
 };
@@ -875,9 +878,9 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_mfma4_kernel(const T* 
     const int ncx = g.w + 1, ncell = (g.h + 1) * ncx;
     const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
     const int64_t* tg = target + (int64_t)b * g.H * g.W;
-    float aP[NT];
+    lossf4 aP[NT];                                  // per pixel row r separately (packed fma); summed over r at the end
 #pragma unroll
-    for (int t = 0; t < NT; ++t) aP[t] = 0.f;
+    for (int t = 0; t < NT; ++t) aP[t] = lossf4{0.f, 0.f, 0.f, 0.f};
     float cel = 0.f, wsum = 0.f, nvalid = 0.f;      // per lane (quad leaders)
     bool bad = false, slow = false;
     const int stride = gridDim.x * 4;
@@ -894,11 +897,11 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_mfma4_kernel(const T* 
         // validity of the pixels of my accumulator rows: pixel (gq, r) is the label-path pixel of lanes 16 gq + 4 r ..
         const unsigned long long okm = __ballot(m.code >= 0);
         const unsigned okrow = (unsigned)(okm >> (16 * gq)) & 0xffffu;
-        float inv[4];
+        lossf4 inv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) inv[r] = ((okrow >> (4 * r)) & 1u) ? __builtin_amdgcn_rcpf(fmaxf(m.s[r], 1e-30f)) : 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) aP[t] += (m.e[t][0] * inv[0] + m.e[t][1] * inv[1]) + (m.e[t][2] * inv[2] + m.e[t][3] * inv[3]);
+        for (int t = 0; t < NT; ++t) aP[t] += m.e[t] * inv;
         // label path
         float zt = wL * m.ul;
         zt += dpp_mov<DPP_XOR1>(zt); zt += dpp_mov<DPP_XOR2>(zt);
@@ -916,7 +919,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_mfma4_kernel(const T* 
     if (__any(slow) && lane == 0) atomicOr(retry, 1);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float v = aP[t];
+        float v = (aP[t][0] + aP[t][1]) + (aP[t][2] + aP[t][3]);
         v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
         if (gq == 0) redP[wave][16 * t + c] = v;
     }
@@ -1026,13 +1029,12 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_mfma4_kernel(const T* 
         if (cur_ok) {
             const Cell& cc = cur.cc;
             m.finish(g, cur, c, wA);
-            float dp[4] = {0.f, 0.f, 0.f, 0.f};
+            lossf4 dp4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t) dp4 += gP[t] * m.e[t];
+            float dp[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dp[r] = fmaf(gP[t], m.e[t][r], dp[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dp[r] = row_sum16(dp[r]);
+            for (int r = 0; r < 4; ++r) dp[r] = row_sum16(dp4[r]);
             // label path: per-pixel coefficients, the [c == t] part of the gradient, and c1 / c1*k for the class lanes
             float zt = wL * m.ul;
             zt += dpp_mov<DPP_XOR1>(zt); zt += dpp_mov<DPP_XOR2>(zt);
@@ -1051,7 +1053,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_mfma4_kernel(const T* 
             const float4 c1r = *reinterpret_cast<const float4*>(&c1s[wave][4 * gq]);
             const float4 ckr = *reinterpret_cast<const float4*>(&cks[wave][4 * gq]);
             __builtin_amdgcn_wave_barrier();
-            const float c1v[4] = {c1r.x, c1r.y, c1r.z, c1r.w}, ckv[4] = {ckr.x, ckr.y, ckr.z, ckr.w};
+            const lossf4 c1v = {c1r.x, c1r.y, c1r.z, c1r.w}, ckv = {ckr.x, ckr.y, ckr.z, ckr.w};
             // tile row of a tap of this cell (taps outside the tile are recomputed by the neighbouring workgroups -> scratch row)
             const bool ycol = cc.y0 == cc.y1, xcol = cc.x0 == cc.x1;
             auto tap_row = [&](int kk) {
@@ -1074,9 +1076,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_mfma4_kernel(const T* 
                 Bv.u[2] = 0u; Bv.u[3] = 0u;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    float dz[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dz[r] = m.e[t][r] * fmaf(c1v[r], gP[t], ckv[r]);
+                    const lossf4 dz = m.e[t] * (c1v * gP[t] + ckv);          // go * p * (gP - <G,p> + wce)
                     Bv.u[0] = pack2bf(dz[0], dz[1]); Bv.u[1] = pack2bf(dz[2], dz[3]);
                     const lossf4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.v, Bv.v, lossf4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     upd[t] = acc[0];
@@ -1085,11 +1085,9 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_bwd_mfma4_kernel(const T* 
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     lossf4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const lossf4 dz = m.e[t] * (c1v * gP[t] + ckv);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dz = m.e[t][r] * fmaf(c1v[r], gP[t], ckv[r]);      // go * p * (gP - <G,p> + wce)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[r], dz, acc, 0, 0, 0);
-                    }
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[r], dz[r], acc, 0, 0, 0);
                     upd[t] = acc[0];          // product row 4 gq = tap gq, class 16 t + c
                 }
             }
