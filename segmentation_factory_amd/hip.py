@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsegfac_hip.so')
+# SEGFAC_HIP_LIB: another build of the same library (same-box A/B of kernel changes, tools/ab_bench.sh); default in-tree
+LIB_PATH = os.environ.get('SEGFAC_HIP_LIB') or os.path.join(_HERE, 'libsegfac_hip.so')
 F32, BF16 = 0, 1
 _lib = None
 
