@@ -68,6 +68,13 @@ int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K,
               const float* rscale, int64_t rows_per_group,
               int split_k, float* ws, void* stream);
 int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K);
+/* Weight gradient and bias gradient of nn.Linear / 1x1 conv in ONE pass over dy (mit.py:45,52,58,98-99 backward):
+ *   C[M,N] = sum_k A(k,m) B(k,n)  (layout 2: A = dy [K tokens][M], B = x [K tokens][N]),  dbias[m] = sum_k A(k,m)  (fp32).
+ * The column sums ride on the matrix pipe (an all-ones operand) inside the GEMM; shapes that take the 256x256-tile or fp32
+ * kernels run a separate column reduction behind the product.  ws >= segf_gemm_dw_db_ws(M, N, K, split_k) floats. */
+int64_t segf_gemm_dw_db_ws(int64_t M, int64_t N, int64_t K, int split_k);
+int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    void* C, int c_dt, int64_t ldc, int split_k, float* ws, float* dbias, void* stream);
 
 /* ---- LayerNorm over the last dim (nn.LayerNorm eps 1e-5 in mit.py:107,136-140,178-190; ConvNeXt's
  * channels-first LayerNorm, convnext.py:8-23, is the same kernel on NHWC rows) ---------------------- */

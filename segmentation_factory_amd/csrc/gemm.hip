@@ -10,7 +10,7 @@
 //   of one output row m -> 8-byte (bf16) / 16-byte (f32) row-contiguous stores.
 // f32 path: exact-fp32 FMA kernel (64x64x16 tile, 4x4 per thread) used by the parity mode.
 #include <stdlib.h>
-#include "common.h"
+#include "colreduce.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -30,6 +30,9 @@ struct GemmArgs {
     // operand A) or N (layout 2, operand B) axis is (tap = ky*3+kx, channel); csign = +1 reads pixel + offset(tap) (forward,
     // weight gradient), -1 reads pixel - offset(tap) (data gradient = correlation of dy with the transposed weights)
     int cH, cW, cC, csign;
+    // layout 2 only: colsum[m] = sum_k A(k, m) (the bias gradient next to the weight gradient): the first unused column of the
+    // last column tile is staged as all-ones, so its accumulators are the column sums; colsum_ws = split-K partials [z][M]
+    float* colsum; float* colsum_ws;
 };
 
 #define GB_BM 128
@@ -206,6 +209,8 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 template <typename InT, typename OutT>
 __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int64_t n0, float (&v)[4], unsigned zslice) {
     // v[r] is the accumulator of C[m][n0 + r]
+    if (a.colsum && m < a.M && n0 <= a.N && a.N < n0 + 4)      // the all-ones column (layout 2, see gemm_bf16_kernel)
+        (a.colsum_ws ? a.colsum_ws + (int64_t)zslice * a.M : a.colsum)[m] = v[a.N - n0];
     if (m >= a.M || n0 >= a.N) return;
     const int nv = (int)(a.N - n0 < 4 ? a.N - n0 : 4);
     if (a.ws) {   // split-K partial: raw accumulators, fp32, ld = N
@@ -259,6 +264,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient riding on the weight gradient (layout 2, a.colsum): the first unused column of the last column tile is
+    // staged as all-ones, so its accumulator column is sum_k A(k, m); csn = that column's index inside this tile (or -1)
+    const int csn = (LAYOUT == 2 && !CONV && a.colsum != nullptr && a.N >= n0 && a.N < n0 + GB_BN) ? (int)(a.N - n0) : -1;
     uint4 ra[4], rb[4];
     int ry[4], rx[4];
     if (CONV && LAYOUT == 0) {       // output pixel of each of this thread's 4 tile rows
@@ -276,6 +284,19 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
         if (LAYOUT == 0) gload_kc(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
         else if (CONV && LAYOUT == 2) gload_rm_conv(B, a.ldb, n0, a.N, k0, kend, a, rb);
         else gload_rm(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
+        if (LAYOUT == 2 && csn >= 0 && (int)(threadIdx.x & 15) == (csn >> 3)) {      // this thread stages the ones column
+            const uint32_t sh = 16u * (csn & 1), one = 0x3f80u << sh, keep = ~(0xffffu << sh);
+            const int wsel = (csn & 7) >> 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (k0 + (int)(threadIdx.x >> 4) + 16 * i < kend) {
+                    if (wsel == 0) rb[i].x = (rb[i].x & keep) | one;
+                    else if (wsel == 1) rb[i].y = (rb[i].y & keep) | one;
+                    else if (wsel == 2) rb[i].z = (rb[i].z & keep) | one;
+                    else rb[i].w = (rb[i].w & keep) | one;
+                }
+            }
+        }
     };
     auto swrite = [&](int buf) {
         if (LAYOUT == 2) swrite_rm(smem[buf][0], ra); else swrite_kc(smem[buf][0], ra);
@@ -887,9 +908,44 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     return (int)s;
 }
 
+static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                     int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
+                     const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream);
+
 extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                          int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
                          const float* rscale, int64_t rows_per_group, int split_k, float* ws, void* stream) {
+    return gemm_impl(dt, layout, M, N, K, A, lda, B, ldb, C, c_dt, ldc, bias, residual, ldr, rscale, rows_per_group, split_k, ws,
+                     nullptr, stream);
+}
+
+extern "C" int segf_colsum(int dt, const void* x, int64_t ldx, int64_t rows, int64_t cols, float* out, float* ws, void* stream);
+extern "C" int64_t segf_colsum_ws(int64_t rows, int64_t cols);
+
+// weight gradient + bias gradient in one pass over dy:  C[M,N] = A^T B (layout 2),  dbias[m] = sum_k A(k, m)
+extern "C" int64_t segf_gemm_dw_db_ws(int64_t M, int64_t N, int64_t K, int split_k) {
+    if (split_k < 1) split_k = 1;
+    const int64_t g = split_k > 1 ? (int64_t)split_k * M * N : 0;
+    const int64_t c1 = (int64_t)split_k * M, c2 = segf_colsum_ws(K, M);
+    return g + (c1 > c2 ? c1 : c2);
+}
+extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                               void* C, int c_dt, int64_t ldc, int split_k, float* ws, float* dbias, void* stream) {
+    if (!dbias || !ws) return SEGF_ERR_WORKSPACE;
+    if (split_k < 1) split_k = 1;
+    const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (N % GB_BN) != 0 && !gemm_use_big(2, M, N, K) &&
+                       !getenv("SEGFAC_GEMM_NO_FUSED_DB");
+    if (!fused) {       // big-tile / fp32 kernels: separate column reduction (still one C-ABI call)
+        const int rc = gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, nullptr, stream);
+        if (rc) return rc;
+        return segf_colsum(dt, A, lda, K, M, dbias, ws + (split_k > 1 ? (int64_t)split_k * M * N : 0), stream);
+    }
+    return gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, dbias, stream);
+}
+
+static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                     int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
+                     const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K < 0 || layout < 0 || layout > 2) return SEGF_ERR_SHAPE;
     if (dt != SEGF_F32 && dt != SEGF_BF16) return SEGF_ERR_DTYPE;
@@ -920,6 +976,8 @@ extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, co
     a.r_vec = residual ? (((uintptr_t)residual % 16 == 0) && ((ldr * esz) % 16 == 0)) : 0;
     a.c_vec16 = ((uintptr_t)C % 16 == 0) && ((ldc * csz) % 16 == 0);
     a.cH = a.cW = a.cC = 0; a.csign = 1;
+    a.colsum = colsum;
+    a.colsum_ws = (colsum && split_k > 1) ? ws + (int64_t)split_k * M * N : nullptr;
     {   // debugging switch: SEGFAC_GEMM_NO_TR=1 reads transposed fragments with scalar LDS loads instead of ds_read_b64_tr_b16
         const char* e = getenv("SEGFAC_GEMM_NO_TR");
         a.use_tr = (e && e[0] == '1') ? 0 : 1;
@@ -984,6 +1042,10 @@ reduce:
         else
             hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (bf16_t*)C, ldc);
         SEGF_CHECK_LAUNCH();
+        if (a.colsum_ws) {
+            colreduce_finalize_launch(a.colsum_ws, split_k, M, a.colsum, st);     // 16 slices in parallel per output, fixed order
+            SEGF_CHECK_LAUNCH();
+        }
     }
     return 0;
 }
@@ -1007,6 +1069,7 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     a.bias = bias; a.residual = nullptr; a.rscale = nullptr; a.ldr = 0; a.rpg = 1;
     a.a_vec = 1; a.b_vec = 1; a.r_vec = 0; a.use_tr = 1;
     a.cH = H; a.cW = W; a.csign = mode == 1 ? -1 : 1;
+    a.colsum = nullptr; a.colsum_ws = nullptr;
     int layout;
     if (mode == 0) { layout = 0; a.M = P; a.N = Cout; a.K = 9 * (int64_t)Cin; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cin; }
     else if (mode == 1) { layout = 0; a.M = P; a.N = Cin; a.K = 9 * (int64_t)Cout; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cout; }

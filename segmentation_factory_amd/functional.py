@@ -67,20 +67,28 @@ class LinearFn(Function):
             dyp = dy.as_strided((M, Np), (Np, 1))
             dx = hip.gemm(1, dyp, w, M, K, Np) if ctx.needs_input_grad[0] else None
             dw = db = None
-            if ctx.needs_input_grad[1]:
-                dw = hip.gemm(2, dyp, x, Np, K, M, out_dtype=torch.float32, split_k=_splitk(Np, K, M))[:N].view(wshape)
-            if has_bias and ctx.needs_input_grad[2]:
-                db = hip.colsum(dyp)[:N]
+            if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
+                dw, db = hip.gemm_dw_db(dyp, x, Np, K, M, split_k=_splitk(Np, K, M))
+                dw, db = dw[:N].view(wshape), db[:N]
+            else:
+                if ctx.needs_input_grad[1]:
+                    dw = hip.gemm(2, dyp, x, Np, K, M, out_dtype=torch.float32, split_k=_splitk(Np, K, M))[:N].view(wshape)
+                if has_bias and ctx.needs_input_grad[2]:
+                    db = hip.colsum(dyp)[:N]
             return dx, dw, db, None, None, None, None
         wv = w[:N] if Np > N else w
         dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = hip.gemm(1, dys, wv, M, K, N)
-        if ctx.needs_input_grad[1]:
-            dw = hip.gemm(2, dys, x, N, K, M, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = hip.colsum(dys)
+        if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
+            dw, db = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M))      # one pass over dy for both gradients
+            dw = dw.view(wshape)
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = hip.gemm(2, dys, x, N, K, M, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dys)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None
 
@@ -144,11 +152,15 @@ class ConvPatchFn(Function):
         M = B * Ho * Wo
         dy = _rowmajor(dy)
         dx = dw = db = None
-        if ctx.needs_input_grad[1]:
-            dwm = hip.gemm(2, dy, col, O, K, M, out_dtype=torch.float32, split_k=_splitk(O, K, M))   # [O][(ky,kx)][ci]
+        if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
+            dwm, db = hip.gemm_dw_db(dy, col, O, K, M, split_k=_splitk(O, K, M))                      # [O][(ky,kx)][ci]
             dw = hip.permute021(dwm, O, k * k, Cin, torch.float32).view(wshape)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = hip.colsum(dy)
+        else:
+            if ctx.needs_input_grad[1]:
+                dwm = hip.gemm(2, dy, col, O, K, M, out_dtype=torch.float32, split_k=_splitk(O, K, M))
+                dw = hip.permute021(dwm, O, k * k, Cin, torch.float32).view(wshape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dy)
         if ctx.needs_input_grad[0] and not image:
             dcol = hip.gemm(1, dy, wmat, M, K, O)
             dx = hip.col2im(dcol, B, H, W, Cin, k, k, stride, pad, Ho, Wo)
@@ -350,7 +362,8 @@ class SegformerFoldedFuseFn(Function):
         B, H1, W1 = geoms[0]
         dy = _rowmajor(dy)
         dev = dy.device
-        dbeta = hip.colsum(dy)               # [E] fp32; colsum(resize^T(dy)) == colsum(dy): the resize weights sum to one
+        dbeta = None                         # [E] fp32 = colsum(dy) (colsum(resize^T(dy)) == colsum(dy): the resize weights sum
+                                             # to one); it rides along with the stage-1 weight-gradient product below
         dwf = torch.empty((E, 4 * E), dtype=torch.float32, device=dev)
         dxs, dws, dbs = [], [], []
         for i in range(4):
@@ -360,7 +373,10 @@ class SegformerFoldedFuseFn(Function):
             dt = dy if i == 0 else hip.bilinear_bwd(dy, B, h, w, E, H1, W1, align_corners=False)
             dxs.append(hip.gemm(1, dt, G, M, Ci, E) if ctx.needs_input_grad[1 + i] else None)
             dGp = torch.zeros((E, Ci + 8), dtype=torch.float32, device=dev)                 # d [G_i | beta_i | 0]
-            hip.gemm(2, dt, x, E, Ci, M, out=dGp[:, :Ci], split_k=_splitk(E, Ci, M))
+            if i == 0:
+                _, dbeta = hip.gemm_dw_db(dt, x, E, Ci, M, split_k=_splitk(E, Ci, M), out=dGp[:, :Ci])
+            else:
+                hip.gemm(2, dt, x, E, Ci, M, out=dGp[:, :Ci], split_k=_splitk(E, Ci, M))
             hip.cast2d(dbeta.unsqueeze(1), dGp[:, Ci:Ci + 1])
             dGc = _w(dGp, dtype)
             Fi = wfc[:, (3 - i) * E:(4 - i) * E]
@@ -482,8 +498,7 @@ class LinearLayerScaleFn(Function):
         dy = _rowmajor(dy)
         dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
         dx = hip.gemm(1, dys, wc, M, K, N) if ctx.needs_input_grad[0] else None
-        dws = hip.gemm(2, dys, x, N, K, M, out_dtype=torch.float32, split_k=_splitk(N, K, M))        # d W'
-        dbs = hip.colsum(dys)                                                                       # d b'
+        dws, dbs = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M))                         # d W', d b'
         dw = hip.scale_rows(dws, g32, 1)
         db = hip.scale_rows(dbs.view(N, 1), g32, 1).view(N)
         dg = hip.rowdot(dws, w32 if w32.is_contiguous() else w32.contiguous(), dbs, b32)

@@ -27,6 +27,8 @@ _PROTOS = {
     'segf_colsum': (_i, [_i, _p, _l, _l, _l, _p, _p, _p]),
     'segf_gemm': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _p, _l, _p, _l, _i, _p, _p]),
     'segf_gemm_pick_splitk': (_i, [_l, _l, _l]),
+    'segf_gemm_dw_db_ws': (_l, [_l, _l, _l, _i]),
+    'segf_gemm_dw_db': (_i, [_i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _i, _p, _p, _p]),
     'segf_layernorm_fwd': (_i, [_i, _l, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     'segf_layernorm_bwd_ws': (_l, [_l, _i]),
     'segf_layernorm_bwd': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -203,6 +205,20 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, 
         _ptr(residual), residual.stride(0) if residual is not None else 0, _ptr(rscale), rows_per_group, split_k, _ptr(ws),
         _stream())), 'segf_gemm')
     return out
+
+
+def gemm_dw_db(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, split_k=1, out=None):
+    """(dW [M,N] fp32, db [M] fp32) = (dy^T x, column sums of dy) in one pass over dy [K,M]; x is [K,N]."""
+    _need_cuda(dy, x)
+    assert dy.stride(-1) == 1 and x.stride(-1) == 1 and dt_of(dy) == dt_of(x)
+    dw = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dy.device)
+    assert dw.stride(-1) == 1
+    db = torch.empty(M, dtype=torch.float32, device=dy.device)
+    ws = _f32(lib().segf_gemm_dw_db_ws(M, N, K, split_k), dy.device)
+    _chk(_timed(('gemm', 2, M, N, K), lambda: lib().segf_gemm_dw_db(
+        dt_of(dy), M, N, K, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dt_of(dw), dw.stride(0), split_k, _ptr(ws),
+        _ptr(db), _stream())), 'segf_gemm_dw_db')
+    return dw, db
 
 
 class KernelTimer:

@@ -653,3 +653,26 @@ def test_upsample_add_multi_scale(hipmod, dtype, geom):
         finally:
             os.environ.pop('SEGFAC_UPADD_GENERIC', None)
         _close(out, ref.permute(0, 2, 3, 1).reshape(-1, C), dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(32, 32, 20000), (150, 64, 4097), (768, 40, 30000), (200, 392, 20000), (128, 130, 777)])
+def test_gemm_dw_db(hipmod, dtype, shape):
+    """Weight gradient + bias gradient in one pass (column sums on the matrix pipe inside the layout-2 GEMM; the 256-tile and
+    fp32 kernels fall back to a column reduction behind the product): against float64 on the rounded operands, with and
+    without split-K, and with the fused path switched off."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(60)
+    dy, x = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    dyq, xq = _q(dy, dtype).double(), _q(x, dtype).double()
+    rw, rb = dyq.t() @ xq, dyq.sum(0)
+    for sk in (1, hipmod.pick_splitk(M, N, K)):
+        for off in ('', '1'):
+            if off:
+                os.environ['SEGFAC_GEMM_NO_FUSED_DB'] = '1'
+            try:
+                dw, db = hipmod.gemm_dw_db(_dev(dy, dtype), _dev(x, dtype), M, N, K, split_k=sk)
+            finally:
+                os.environ.pop('SEGFAC_GEMM_NO_FUSED_DB', None)
+            assert (dw.double().cpu() - rw).abs().max().item() <= 2e-3 * rw.abs().max().item()
+            assert (db.double().cpu() - rb).abs().max().item() <= 1e-4 * max(1.0, rb.abs().max().item())
