@@ -34,6 +34,15 @@ static inline int colfixed_blocks(int64_t units, int nchunk, int units_per_threa
     return (int)blocks;
 }
 
+// XCD-aware logical workgroup id for 1-D grids.  The hardware deals workgroups round-robin over the 8 XCDs, each with its own
+// L2: neighbouring workgroups of a spatial kernel (the rows above / below a depthwise-conv strip, the four taps that share a
+// gradient pixel in a transposed resize) land on different L2s and each re-fetches the shared lines (measured with
+// FETCH_SIZE: 2-3x the algorithmic bytes).  The bijection below gives every XCD a CONTIGUOUS range of logical ids.
+__device__ __forceinline__ unsigned xcd_block() {
+    const unsigned n = gridDim.x, o = blockIdx.x, q = n >> 3, r8 = n & 7, x = o & 7;
+    return (x < r8 ? x * (q + 1) : r8 * (q + 1) + (x - r8) * q) + (o >> 3);
+}
+
 // exact unsigned 32-bit division by a launch-constant divisor (Granlund-Montgomery): 5 integer ops instead of the ~80 of a
 // 64-bit software division in per-row index arithmetic (sample index = row / rows_per_sample)
 struct FastDivU32 { uint32_t m, sh1, sh2; };

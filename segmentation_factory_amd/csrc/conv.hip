@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
     const int nchunk = C / 8;
     const int wg = (W + DW_PIX - 1) / DW_PIX;
     const int units = B * H * wg;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
     const int ustep = (int)(((int64_t)gridDim.x * 256) / nchunk);
     const int c0 = (int)(g % nchunk) * 8;
     float wk[9][8], bs[8];
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_kernel(const T* __restric
     for (int o = 0; o < 10; ++o)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
-    const int u0 = blockIdx.x * units_per_blk;
+    const int u0 = xcd_block() * units_per_blk;
     const int u1 = u0 + units_per_blk < units ? u0 + units_per_blk : units;
     if (active) {
         for (int u = u0 + ty; u < u1; u += rl) {
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) dwconv7x7_kernel(const T* __restrict__ x,
     const int nchunk = C / 8;
     const int wg = (W + DW7_PIX - 1) / DW7_PIX;
     const int units = B * H * wg;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
     const int ustep = (int)(((int64_t)gridDim.x * 256) / nchunk);
     const int c0 = (int)(g % nchunk) * 8;
     float bs[8];
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restric
     for (int o = 0; o < 8; ++o)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
-    const int u0 = blockIdx.x * units_per_blk;
+    const int u0 = xcd_block() * units_per_blk;
     const int u1 = u0 + units_per_blk < units ? u0 + units_per_blk : units;
     if (active) {
         for (int u = u0 + ty; u < u1; u += rl) {
@@ -472,7 +472,7 @@ __global__ void im2col_nhwc_kernel(const T* __restrict__ x, T* __restrict__ col,
                                    int kh, int kw, int stride, int pad, int Ho, int Wo) {
     const int nch = Cin / 8;
     const int64_t total = (int64_t)B * Ho * Wo * kh * kw * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % nch);
         int64_t t = idx / nch;
         const int kx = (int)(t % kw); t /= kw;
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) im2col_nchw_kernel(const float* __restric
     const int nch = (int)(ldcol / 8);
     const int64_t rows = (int64_t)B * Ho * Wo;
     const int K = kh * kw * Cin;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
     const int64_t rstep = ((int64_t)gridDim.x * 256) / nch;
     const int ch = (int)(g % nch);
     int kyj[8], kxj[8], cij[8];
@@ -583,7 +583,7 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, int64_t ldcol, T* __re
                               int kw, int stride, int pad, int Ho, int Wo) {
     const int nch = Cin / 8;
     const int64_t total = (int64_t)B * H * W * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % nch);
         int64_t t = idx / nch;
         const int ix = (int)(t % W); t /= W;

@@ -12,7 +12,7 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ in, int64_t ldi, T* __
     // two copies of the loop (all chunks full and aligned / general): in the first the four tap loads are plain vector loads
     // in flight together; a per-load guard inside the loop would serialise them (branch + s_waitcnt per load)
     auto body = [&](const bool full) {
-        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
             const int ch = (int)(idx % nch);
             int64_t t = idx / nch;
             const int X = (int)(t % W); t /= W;
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) upsample_add_kernel(const T* __restrict__
                                                             int ac) {
     const int nch = C / 8;
     const int64_t total = (int64_t)B * H * W * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % nch);
         int64_t t = idx / nch;
         const int X = (int)(t % W); t /= W;
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) upsample_add_248_kernel(const T* __restri
                                                                 T* __restrict__ out, int64_t ldo, int B, int H, int W, int C) {
     const int nch = C / 8, nst = W / 4;
     const int64_t total = (int64_t)B * H * nst * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % nch);
         int64_t t = idx / nch;
         const int k = (int)(t % nst); t /= nst;
@@ -207,7 +207,7 @@ __global__ void bilinear_bwd_kernel(T* __restrict__ din, int64_t ldi, const T* _
                                     int C, int H, int W, int ac, bool vec) {
     const int nch = (C + 7) / 8;
     const int64_t total = (int64_t)B * h * w * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % nch);
         int64_t t = idx / nch;
         const int x = (int)(t % w); t /= w;
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) bilinear_bwd_int_kernel(T* __restrict__ d
     const int H = R * h, W = R * w, off = R / 2;
     const int nch = C / 8;
     const int64_t total = (int64_t)B * h * w * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ch = (int)(idx % nch);
         int64_t t = idx / nch;
         const int x = (int)(t % w); t /= w;
@@ -339,7 +339,7 @@ template <typename T>
 __global__ void bilinear_to_nchw_kernel(const T* __restrict__ in, int64_t ldi, float* __restrict__ out, int B, int h, int w, int C,
                                         int H, int W) {
     const int64_t total = (int64_t)B * C * H * W;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int X = (int)(idx % W);
         int64_t t = idx / W;
         const int Y = (int)(t % H); t /= H;
@@ -374,7 +374,7 @@ template <typename T, bool BWD>   // BWD: din[pix] = sum over bins containing pi
 __global__ void adaptive_pool_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int S) {
     const int nch = C / 8;
     const int64_t total = BWD ? (int64_t)B * H * W * nch : (int64_t)B * S * S * nch;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(idx % nch) * 8;
         int64_t t = idx / nch;
         float acc[8];
