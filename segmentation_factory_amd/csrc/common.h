@@ -115,6 +115,13 @@ __device__ __forceinline__ void unpack8(const Raw8<bf16_t>& r, float (&v)[8]) {
     v[4] = __uint_as_float(r.u.z << 16); v[5] = __uint_as_float(r.u.z & 0xffff0000u);
     v[6] = __uint_as_float(r.u.w << 16); v[7] = __uint_as_float(r.u.w & 0xffff0000u);
 }
+// zero a raw chunk (padding taps): on the packed words, i.e. 4 selects for 8 bf16 values instead of 8 after unpacking
+__device__ __forceinline__ void zero_unless(Raw8<bf16_t>& r, bool keep) {
+    r.u.x = keep ? r.u.x : 0u; r.u.y = keep ? r.u.y : 0u; r.u.z = keep ? r.u.z : 0u; r.u.w = keep ? r.u.w : 0u;
+}
+__device__ __forceinline__ void zero_unless(Raw8<float>& r, bool keep) {
+    if (!keep) { r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = make_float4(0.f, 0.f, 0.f, 0.f); }
+}
 #define SEGF_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
 
 template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
@@ -213,6 +220,75 @@ __device__ __forceinline__ float erf_fast(float x) {
     p = fmaf(p, t, 0.254829592f);
     const float y = 1.f - p * t * __expf(-ax * ax);
     return copysignf(y, x);
+}
+// Two-channel forms: the same arithmetic on float2 vectors lowers to packed fp32 instructions (v_pk_mul / v_pk_fma_f32, two
+// channels per issue slot); only the transcendentals and the sign transfer stay per element.  Same polynomial, same accuracy.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t erf_fast2(f32x2_t z, f32x2_t e /* exp(-z*z) */) {
+    const f32x2_t az = __builtin_elementwise_abs(z);
+    const f32x2_t d = az * 0.3275911f + 1.f;
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2_t p = t * 1.061405429f + -1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t + -0.284496736f;
+    p = p * t + 0.254829592f;
+    const f32x2_t y = 1.f - p * t * e;
+    return f32x2_t{copysignf(y.x, z.x), copysignf(y.y, z.y)};
+}
+__device__ __forceinline__ f32x2_t exp_neg_half_sq2(f32x2_t x) {          // exp(-x*x/2), the Gaussian both GELU forms need
+    const f32x2_t a = x * x * -0.72134752044448170368f;                    // -0.5 * log2(e)
+    return f32x2_t{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+}
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+    const f32x2_t h = x * 0.5f;
+    return h * erf_fast2(x * 0.70710678118654752440f, exp_neg_half_sq2(x)) + h;
+}
+__device__ __forceinline__ f32x2_t gelu_erf_grad2(f32x2_t x) {
+    const f32x2_t e = exp_neg_half_sq2(x);
+    const f32x2_t cdf = erf_fast2(x * 0.70710678118654752440f, e) * 0.5f + 0.5f;
+    return x * e * 0.39894228040143267794f + cdf;
+}
+// Eight channels at a time, stage by stage (all reciprocals, then all polynomials, ...): the transcendental unit has a
+// multi-cycle result latency, and element-at-a-time code makes the compiler pad every rcp / exp with s_nop
+template <bool GRAD>
+__device__ __forceinline__ void gelu_erf8(f32x2_t (&a)[4], const f32x2_t* __restrict__ gy) {
+    f32x2_t e[4], t[4], p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t q = a[i] * a[i] * -0.72134752044448170368f;
+        const f32x2_t d = __builtin_elementwise_abs(a[i]) * (0.3275911f * 0.70710678118654752440f) + 1.f;
+        e[i] = f32x2_t{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+        t[i] = f32x2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = t[i] * 1.061405429f + -1.453152027f;
+        p[i] = p[i] * t[i] + 1.421413741f;
+        p[i] = p[i] * t[i] + -0.284496736f;
+        p[i] = p[i] * t[i] + 0.254829592f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t y = 1.f - p[i] * t[i] * e[i];                               // erf(|x| / sqrt2)
+        const f32x2_t er = {copysignf(y.x, a[i].x), copysignf(y.y, a[i].y)};
+        if (GRAD) a[i] = gy[i] * (a[i] * e[i] * 0.39894228040143267794f + (er * 0.5f + 0.5f));
+        else { const f32x2_t h = a[i] * 0.5f; a[i] = h * er + h; }
+    }
+}
+// 8 consecutive elements as 4 channel pairs
+template <typename T> __device__ __forceinline__ void unpack8v(const Raw8<T>& r, f32x2_t (&v)[4]);
+template <> __device__ __forceinline__ void unpack8v<float>(const Raw8<float>& r, f32x2_t (&v)[4]) {
+    v[0] = f32x2_t{r.a.x, r.a.y}; v[1] = f32x2_t{r.a.z, r.a.w}; v[2] = f32x2_t{r.b.x, r.b.y}; v[3] = f32x2_t{r.b.z, r.b.w};
+}
+template <> __device__ __forceinline__ void unpack8v<bf16_t>(const Raw8<bf16_t>& r, f32x2_t (&v)[4]) {
+    v[0] = f32x2_t{__uint_as_float(r.u.x << 16), __uint_as_float(r.u.x & 0xffff0000u)};
+    v[1] = f32x2_t{__uint_as_float(r.u.y << 16), __uint_as_float(r.u.y & 0xffff0000u)};
+    v[2] = f32x2_t{__uint_as_float(r.u.z << 16), __uint_as_float(r.u.z & 0xffff0000u)};
+    v[3] = f32x2_t{__uint_as_float(r.u.w << 16), __uint_as_float(r.u.w & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ void store8v(T* p, const f32x2_t (&v)[4]) {
+    const float f[8] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
+    store8<T>(p, f);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -22,12 +22,17 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
     const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
     const int ustep = (int)(((int64_t)gridDim.x * 256) / nchunk);
     const int c0 = (int)(g % nchunk) * 8;
-    float wk[9][8], bs[8];
+    // channel PAIRS as float2 vectors: the 36 tap products per pixel and the GELU polynomial issue as packed fp32 instructions
+    // (these kernels are bound by VALU issue -- the tap fmas plus ~25 operations of GELU per element -- not by HBM)
+    f32x2_t wk[9][4], bs[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-        for (int kk = 0; kk < 9; ++kk) wk[kk][j] = w[(c0 + j) * 9 + (MODE == 1 ? 8 - kk : kk)];
-        bs[j] = (MODE != 1 && bias) ? bias[c0 + j] : 0.f;
+        for (int kk = 0; kk < 9; ++kk) {
+            const int ks = MODE == 1 ? 8 - kk : kk;
+            wk[kk][jj] = f32x2_t{w[(c0 + 2 * jj) * 9 + ks], w[(c0 + 2 * jj + 1) * 9 + ks]};
+        }
+        bs[jj] = (MODE != 1 && bias) ? f32x2_t{bias[c0 + 2 * jj], bias[c0 + 2 * jj + 1]} : f32x2_t{0.f, 0.f};
     }
     for (int u = (int)(g / nchunk); u < units; u += ustep) {
         const int xg = u % wg;
@@ -35,36 +40,47 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
         const int yy = t % H;
         const int b = t / H;
         const int x0 = xg * DW_PIX;
-        float acc[DW_PIX][8];
+        f32x2_t acc[DW_PIX][4];
 #pragma unroll
         for (int p = 0; p < DW_PIX; ++p)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
-        // every tap load is unconditional (clamped address, value masked afterwards): a conditional load costs a branch plus a
-        // full s_waitcnt per load, which serialises the 18 loads of a strip behind each other's memory latency
+            for (int jj = 0; jj < 4; ++jj) acc[p][jj] = bs[jj];
+        // every tap load is unconditional (clamped address, value masked afterwards) and all 18 (+ the 4 gradient pixels of
+        // MODE 2) are issued before the first use: a conditional load costs a branch plus a full s_waitcnt per load
+        Raw8<T> raw[3][DW_PIX + 2], graw[DW_PIX];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = yy + ky - 1;
+            const T* row = x + (((int64_t)b * H + ((iy >= 0 && iy < H) ? iy : yy)) * W) * C + c0;
+#pragma unroll
+            for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                const int ix = x0 + cx - 1;
+                raw[ky][cx] = load8_raw<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C);
+            }
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int p = 0; p < DW_PIX; ++p)
+                graw[p] = load8_raw<T>(dy + (((int64_t)b * H + yy) * W + (x0 + p < W ? x0 + p : W - 1)) * C + c0);
+        }
+        SEGF_LOADS_ISSUED();
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = yy + ky - 1;
             const bool vy = iy >= 0 && iy < H;
-            const T* row = x + (((int64_t)b * H + (vy ? iy : yy)) * W) * C + c0;
-            float v[DW_PIX + 2][8];
-#pragma unroll
-            for (int cx = 0; cx < DW_PIX + 2; ++cx) {
-                const int ix = x0 + cx - 1;
-                load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[cx]);
-            }
 #pragma unroll
             for (int cx = 0; cx < DW_PIX + 2; ++cx) {
                 const int ix = x0 + cx - 1;
                 const bool ok = vy && ix >= 0 && ix < W;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[cx][j] = ok ? v[cx][j] : 0.f;
+                f32x2_t v[4];
+                zero_unless(raw[ky][cx], ok);
+                unpack8v<T>(raw[ky][cx], v);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int p = cx - kx;            // output pixel that sees this column through tap kx
                     if (p >= 0 && p < DW_PIX) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wk[ky * 3 + kx][j], v[cx][j], acc[p][j]);
+                        for (int jj = 0; jj < 4; ++jj) acc[p][jj] = wk[ky * 3 + kx][jj] * v[jj] + acc[p][jj];
                     }
                 }
             }
@@ -73,17 +89,17 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
         for (int p = 0; p < DW_PIX; ++p) {
             if (x0 + p < W) {
                 const int64_t off = (((int64_t)b * H + yy) * W + x0 + p) * C + c0;
-                if (MODE == 0 && apply_gelu) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[p][j] = gelu_erf(acc[p][j]);
-                }
+                if (MODE == 0 && apply_gelu) gelu_erf8<false>(acc[p], nullptr);
                 if (MODE == 2) {
-                    float gy[8];
-                    load8<T>(dy + off, gy);
+                    f32x2_t gy[4];
+                    unpack8v<T>(graw[p], gy);
+                    if (apply_gelu) gelu_erf8<true>(acc[p], gy);
+                    else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[p][j] = apply_gelu ? gy[j] * gelu_erf_grad(acc[p][j]) : gy[j];
+                        for (int jj = 0; jj < 4; ++jj) acc[p][jj] = gy[jj];
+                    }
                 }
-                store8<T>(y + off, acc[p]);
+                store8v<T>(y + off, acc[p]);
             }
         }
     }
