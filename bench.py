@@ -68,7 +68,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='per-GPU batch (BASELINE.json does not fix it; 64 x 512^2 uses ~60 of 288 GB)')
+    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (BASELINE.json does not fix it; 128 x 512^2 uses ~120 of 288 GB; 64: -8 %%)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward+loss+backward only')
@@ -193,6 +193,17 @@ def main():
     gemm_bytes = esz * (M * K + ld * K + M * ld)
     del A_, W_, lo_
 
+    # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command,
+    # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/): reported only for the batch it was measured at
+    traffic = {}
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_b128.json')) as fh:
+            pmc = json.load(fh)
+        if pmc.get('batch') == args.batch and args.config == 'cfg2' and args.dtype == 'bf16':
+            for kname, v in pmc['kernels'].items():
+                traffic[kname.split('<')[0] + ('<0' if kname.startswith('gemm_bf16_big_kernel<0') else '')] = v['total_bytes']
+    except (OSError, ValueError):
+        pass
     if rank == 0:
         summ = kt.summary()
         nl, avg_ms = summ.get(loss_key, (0, float('nan')))
@@ -217,14 +228,15 @@ def main():
             "roofline": {"kernel": "ce_dice_bwd_mfma4_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
                                    "backward, low-res logits [B,128,128,152] -> d logits, labels int64 [B,512,512]",
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": None,
+                         "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('ce_dice_bwd_mfma4_kernel'),
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
                          "note": "transcendental-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~6 VALU "
                                  "ops; interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
             "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0> heaviest GEMM launch: classifier 1x1 conv [B*128*128,768]x[768,152]",
                               "bound": "hbm", "achieved": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                              "unit": "GB/s", "frac": round(gemm_bytes / (gemm_ms * 1e-3) / HBM_PEAK, 4), "launches_timed": ng,
+                              "unit": "GB/s", "frac": round(gemm_bytes / (gemm_ms * 1e-3) / HBM_PEAK, 4),
+                              "traffic": traffic.get('gemm_bf16_big_kernel<0'), "launches_timed": ng,
                               "avg_launch_ms": round(gemm_ms, 4), "algorithmic_bytes_per_launch": gemm_bytes,
                               "flops_per_launch": 2.0 * M * ld * K},
         }

@@ -1,0 +1,36 @@
+"""Index-width check at the large default batch: in eval mode (BatchNorm on running statistics, no dropout / drop-path) samples
+are independent, so a batch of 2n images made of two copies of n images must give the same low-res logits per sample and the
+same parameter gradients (mean-reduced loss) as the n-image batch -- any 32-bit offset overflow at > 2^31 bytes per tensor
+would show up here.  Usage: python tools/check_large_batch.py [n=64]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from segmentation_factory_amd import SegmentationModel, functional as Fh
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+NC, H, W = 150, 512, 512
+torch.manual_seed(0)
+m = SegmentationModel('MiT-B0', num_classes=NC, seg_head='SegFormerHead').cuda().eval()
+x, y = bench.synthetic_batch(n, 0)
+x, y = x.cuda(), y.cuda()
+
+
+def run(xx, yy):
+    for p in m.parameters():
+        p.grad = None
+    B = xx.shape[0]
+    lo = m.forward_lowres(xx)
+    loss, _, _ = Fh.upsample_ce_dice(lo.data, yy, (B, NC, lo.H, lo.W, H, W), 255, None, False)     # CE only: mean over pixels
+    loss.backward()
+    torch.cuda.synchronize()
+    return lo.data.detach().float().clone(), loss.item(), {k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+lo1, l1, g1 = run(x, y)
+lo2, l2, g2 = run(torch.cat([x, x]), torch.cat([y, y]))
+rows = lo1.shape[0]
+e_fwd = max((lo2[:rows] - lo1).abs().max().item(), (lo2[rows:] - lo1).abs().max().item())
+e_g = max(((g2[k] - g1[k]).abs().max() / (g1[k].abs().max() + 1e-12)).item() for k in g1)
+print(f'n={n}: logits max |diff| {e_fwd:.3e} (scale {lo1.abs().max().item():.2f}), loss {l1:.6f} vs {l2:.6f}, worst relative grad diff {e_g:.3e}')
+assert e_fwd <= 1e-6 * max(1.0, lo1.abs().max().item()) and abs(l1 - l2) <= 1e-5 * abs(l1) and e_g < 2e-2, 'MISMATCH'
+print('OK')
