@@ -121,45 +121,58 @@ __device__ __forceinline__ void swrite_rm(unsigned char* tile, const uint4 (&reg
 }
 
 // implicit-im2col variants: the 128 tile rows are output pixels (ry, rx precomputed per thread), k = tap * C + channel
-__device__ __forceinline__ void gload_kc_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax, int64_t k0,
-                                              int64_t kend, const GemmArgs& a, const int (&ry)[4], const int (&rx)[4],
-                                              uint4 (&reg)[4]) {
+__device__ __forceinline__ unsigned gload_kc_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax, int64_t k0,
+                                                  int64_t kend, const GemmArgs& a, const int (&ry)[4], const int (&rx)[4],
+                                                  uint4 (&reg)[4]) {
+    // Every gather is unconditional: padding taps / rows past the end read a clamped in-range address and are zeroed at the
+    // LDS write through the returned validity bits (a branch per load would serialise the four loads, see gload_kc)
     const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
     const int64_t k = k0 + c * 8;
-    const int tap = (int)(k / a.cC);
-    const int ci = (int)(k - (int64_t)tap * a.cC);
+    const bool kok = k < kend;
+    const int64_t kc = kok ? k : 0;
+    const int tap = (int)(kc / a.cC);
+    const int ci = (int)(kc - (int64_t)tap * a.cC);
     const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + r + 32 * i;
-        uint4 v = make_uint4(0, 0, 0, 0);
         const int yy = ry[i] + dy, xx = rx[i] + dx;
-        if (row < rmax && k < kend && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
-            v = *reinterpret_cast<const uint4*>(base + (row + (int64_t)dy * a.cW + dx) * ld + ci);
-        reg[i] = v;
+        const bool ok = row < rmax && kok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
+        okm |= ok ? 1u << i : 0u;
+        const int64_t src = ok ? row + (int64_t)dy * a.cW + dx : (row < rmax ? row : rmax - 1);
+        reg[i] = *reinterpret_cast<const uint4*>(base + src * ld + ci);
     }
+    return okm;
 }
 // reduction-major gathered operand: tile rows are pixels k, tile columns are (tap, channel); the thread's column chunk is fixed
-__device__ __forceinline__ void gload_rm_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax, int64_t k0,
-                                              int64_t kend, const GemmArgs& a, uint4 (&reg)[4]) {
+__device__ __forceinline__ unsigned gload_rm_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax, int64_t k0,
+                                                  int64_t kend, const GemmArgs& a, uint4 (&reg)[4]) {
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
     const int64_t col = col0 + c * 8;
-    const int tap = (int)(col / a.cC);
-    const int ci = (int)(col - (int64_t)tap * a.cC);
+    const bool cok = col < cmax;
+    const int64_t cc = cok ? col : 0;
+    const int tap = (int)(cc / a.cC);
+    const int ci = (int)(cc - (int64_t)tap * a.cC);
     const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t k = k0 + r + 16 * i;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (k < kend && col < cmax) {
-            const int x = (int)(k % a.cW);
-            const int y = (int)((k / a.cW) % a.cH);
-            const int yy = y + dy, xx = x + dx;
-            if (yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
-                v = *reinterpret_cast<const uint4*>(base + (k + (int64_t)dy * a.cW + dx) * ld + ci);
-        }
-        reg[i] = v;
+        const int64_t kc = k < kend ? k : kend - 1;
+        const int x = (int)(kc % a.cW);
+        const int y = (int)((kc / a.cW) % a.cH);
+        const int yy = y + dy, xx = x + dx;
+        const bool ok = k < kend && cok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
+        okm |= ok ? 1u << i : 0u;
+        reg[i] = *reinterpret_cast<const uint4*>(base + (ok ? kc + (int64_t)dy * a.cW + dx : kc) * ld + ci);
     }
+    return okm;
+}
+__device__ __forceinline__ void zero_invalid(uint4 (&reg)[4], unsigned okm) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (!((okm >> i) & 1u)) reg[i] = make_uint4(0, 0, 0, 0);
 }
 
 // fragment for mfma_f32_16x16x32_bf16: lane l holds X[idx = l&15][k = 8*(l>>4) + j], j = 0..7 of k-step s
@@ -277,12 +290,13 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
             ry[i] = (int)((row / a.cW) % a.cH);
         }
     }
+    unsigned oka = 0xfu, okb = 0xfu;          // validity bits of the gathered (implicit-conv) operand's four loads
     auto gload = [&](int64_t k0) {
         if (LAYOUT == 2) gload_rm(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
-        else if (CONV) gload_kc_conv(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
+        else if (CONV) oka = gload_kc_conv(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
         else gload_kc(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
         if (LAYOUT == 0) gload_kc(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
-        else if (CONV && LAYOUT == 2) gload_rm_conv(B, a.ldb, n0, a.N, k0, kend, a, rb);
+        else if (CONV && LAYOUT == 2) okb = gload_rm_conv(B, a.ldb, n0, a.N, k0, kend, a, rb);
         else gload_rm(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
         if (LAYOUT == 2 && csn >= 0 && (int)(threadIdx.x & 15) == (csn >> 3)) {      // this thread stages the ones column
             const uint32_t sh = 16u * (csn & 1), one = 0x3f80u << sh, keep = ~(0xffffu << sh);
@@ -299,6 +313,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
         }
     };
     auto swrite = [&](int buf) {
+        if (CONV) {
+            SEGF_LOADS_ISSUED();                 // keep the zeroing selects (and with them the wait for the gathers) down here
+            if (LAYOUT != 2) zero_invalid(ra, oka); else zero_invalid(rb, okb);
+        }
         if (LAYOUT == 2) swrite_rm(smem[buf][0], ra); else swrite_kc(smem[buf][0], ra);
         if (LAYOUT == 0) swrite_kc(smem[buf][1], rb); else swrite_rm(smem[buf][1], rb);
     };
@@ -442,23 +460,27 @@ template <int T> __device__ __forceinline__ void swrite_kc_t(unsigned char* tile
         *reinterpret_cast<uint4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = reg[i];
     }
 }
-template <int T> __device__ __forceinline__ void gload_kc_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax,
-                                                                 int64_t k0, int64_t kend, const GemmArgs& a, const int (&ry)[4],
-                                                                 const int (&rx)[4], uint4 (&reg)[4]) {
+template <int T> __device__ __forceinline__ unsigned gload_kc_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t row0,
+                                                                     int64_t rmax, int64_t k0, int64_t kend, const GemmArgs& a,
+                                                                     const int (&ry)[4], const int (&rx)[4], uint4 (&reg)[4]) {
     const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
     const int64_t k = k0 + c * 8;
-    const int tap = (int)(k / a.cC);
-    const int ci = (int)(k - (int64_t)tap * a.cC);
+    const bool kok = k < kend;
+    const int64_t kc = kok ? k : 0;
+    const int tap = (int)(kc / a.cC);
+    const int ci = (int)(kc - (int64_t)tap * a.cC);
     const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t row = row0 + r + (T / 8) * i;
-        uint4 v = make_uint4(0, 0, 0, 0);
         const int yy = ry[i] + dy, xx = rx[i] + dx;
-        if (row < rmax && k < kend && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
-            v = *reinterpret_cast<const uint4*>(base + (row + (int64_t)dy * a.cW + dx) * ld + ci);
-        reg[i] = v;
+        const bool ok = row < rmax && kok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
+        okm |= ok ? 1u << i : 0u;
+        const int64_t src = ok ? row + (int64_t)dy * a.cW + dx : (row < rmax ? row : rmax - 1);
+        reg[i] = *reinterpret_cast<const uint4*>(base + src * ld + ci);
     }
+    return okm;
 }
 // reduction-major operand, tile = 64 k rows x R columns (R*2 bytes per row)
 template <int R, int T> __device__ __forceinline__ void gload_rm_t(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax,
@@ -484,28 +506,30 @@ template <int R, int T> __device__ __forceinline__ void gload_rm_t(const bf16_t*
         reg[i] = v;
     }
 }
-template <int R, int T> __device__ __forceinline__ void gload_rm_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t col0,
-                                                                        int64_t cmax, int64_t k0, int64_t kend, const GemmArgs& a,
-                                                                        uint4 (&reg)[4]) {
+template <int R, int T> __device__ __forceinline__ unsigned gload_rm_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t col0,
+                                                                            int64_t cmax, int64_t k0, int64_t kend, const GemmArgs& a,
+                                                                            uint4 (&reg)[4]) {
     constexpr int CPR = R / 8;
     const int c = threadIdx.x % CPR, r = threadIdx.x / CPR;
     const int64_t col = col0 + c * 8;
-    const int tap = (int)(col / a.cC);
-    const int ci = (int)(col - (int64_t)tap * a.cC);
+    const bool cok = col < cmax;
+    const int64_t cc = cok ? col : 0;
+    const int tap = (int)(cc / a.cC);
+    const int ci = (int)(cc - (int64_t)tap * a.cC);
     const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t k = k0 + r + (T / CPR) * i;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (k < kend && col < cmax) {
-            const int x = (int)(k % a.cW);
-            const int y = (int)((k / a.cW) % a.cH);
-            const int yy = y + dy, xx = x + dx;
-            if (yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW)
-                v = *reinterpret_cast<const uint4*>(base + (k + (int64_t)dy * a.cW + dx) * ld + ci);
-        }
-        reg[i] = v;
+        const int64_t kc = k < kend ? k : kend - 1;
+        const int x = (int)(kc % a.cW);
+        const int y = (int)((kc / a.cW) % a.cH);
+        const int yy = y + dy, xx = x + dx;
+        const bool ok = k < kend && cok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
+        okm |= ok ? 1u << i : 0u;
+        reg[i] = *reinterpret_cast<const uint4*>(base + (ok ? kc + (int64_t)dy * a.cW + dx : kc) * ld + ci);
     }
+    return okm;
 }
 template <int R, int T> __device__ __forceinline__ void swrite_rm_t(unsigned char* tile, const uint4 (&reg)[4]) {
     constexpr int CPR = R / 8;
@@ -568,15 +592,20 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
             ry[i] = (int)((row / a.cW) % a.cH);
         }
     }
+    unsigned oka = 0xfu, okb = 0xfu;
     auto gload = [&](int64_t k0) {
         if (LAYOUT == 2) gload_rm_t<GG_B, GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
-        else if (CONV) gload_kc_conv_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
+        else if (CONV) oka = gload_kc_conv_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
         else gload_kc_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
         if (LAYOUT == 0) gload_kc_t<GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
-        else if (CONV && LAYOUT == 2) gload_rm_conv_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a, rb);
+        else if (CONV && LAYOUT == 2) okb = gload_rm_conv_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a, rb);
         else gload_rm_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
     };
     auto swrite = [&](int buf) {
+        if (CONV) {
+            SEGF_LOADS_ISSUED();
+            if (LAYOUT != 2) zero_invalid(ra, oka); else zero_invalid(rb, okb);
+        }
         if (LAYOUT == 2) swrite_rm_t<GG_B, GG_THREADS>(smem[buf][0], ra); else swrite_kc_t<GG_THREADS>(smem[buf][0], ra);
         if (LAYOUT == 0) swrite_kc_t<GG_THREADS>(smem[buf][1], rb); else swrite_rm_t<GG_B, GG_THREADS>(smem[buf][1], rb);
     };
