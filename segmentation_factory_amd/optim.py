@@ -3,7 +3,7 @@
 
 timm is not available in the build image and no reference test covers this arithmetic, so AGC / AdamW are
 restated from timm 0.9.2 + torch.optim.AdamW semantics ("parity unpinned") and checked against
-hand-derived known answers (tests/test_optim.py).  The step itself is one HIP kernel over flat buffers.
+the CPU restatement oracle/optim.py (tests/test_kernels_gpu.py::test_agc_adamw_known_answers).  The step itself is one HIP kernel over flat buffers.
 """
 import torch
 

@@ -164,3 +164,29 @@ def test_train_gpu_cli_flags_and_scheduler_quirk():
     img, lbl = ds[1]
     assert img.shape == (3, 32, 32) and img.dtype == torch.float32 and lbl.dtype == torch.int64 and int(lbl[0, 0]) == 255
     assert int(lbl[2:].max()) < 7
+
+
+def test_oracle_optimizer_restatement_properties():
+    """oracle/optim.py (AGC + AdamW, parity unpinned): unit-wise clipping bound, no-op below the bound, eps floor for tiny
+    parameters, and agreement of the AdamW restatement with torch.optim.AdamW itself (which IS available here)."""
+    import torch
+    from oracle import optim as OO
+    g = torch.Generator().manual_seed(5)
+    p, gr = torch.randn(7, 3, 3, generator=g), torch.randn(7, 3, 3, generator=g) * 10
+    c = OO.adaptive_clip_grad_(p, gr, 0.02)
+    pn, cn = p.flatten(1).norm(dim=1), c.flatten(1).norm(dim=1)
+    assert torch.all(cn <= 0.02 * pn.clamp(min=1e-3) * (1 + 1e-5))
+    small = gr * 1e-6
+    assert torch.equal(OO.adaptive_clip_grad_(p, small, 0.02), small)
+    tiny = torch.zeros(4, 5)
+    ct = OO.adaptive_clip_grad_(tiny, torch.ones(4, 5), 0.02)
+    assert torch.allclose(ct.norm(dim=1), torch.full((4,), 0.02 * 1e-3), rtol=1e-5)
+    w = torch.nn.Parameter(torch.randn(5, 4, generator=g))
+    ref = torch.optim.AdamW([w], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    pw, m, v = w.detach().clone(), torch.zeros(5, 4), torch.zeros(5, 4)
+    for step in range(1, 5):
+        grad = torch.randn(5, 4, generator=g)
+        w.grad = grad.clone()
+        ref.step()
+        OO.adamw_step_(pw, grad, m, v, step, 3e-3, weight_decay=0.05)
+        assert torch.allclose(w.detach(), pw, rtol=1e-6, atol=1e-7)

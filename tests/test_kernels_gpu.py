@@ -395,8 +395,10 @@ def test_argmax_confmat_fused_upsample():
 
 
 def test_agc_adamw_known_answers(hipmod):
-    """Hand-restated timm-0.9.2 AGC + torch AdamW arithmetic (parity unpinned: timm is not installed)."""
-    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler
+    """Fused AGC + AdamW kernel against the CPU restatement in oracle/optim.py (timm-0.9.2 adaptive_clip_grad + torch AdamW;
+    parity unpinned: timm is not installed in this image)."""
+    from oracle import optim as OO
+    from segmentation_factory_amd.optim import FusedAGCAdamW
     g = torch.Generator().manual_seed(11)
     w = torch.nn.Parameter(torch.randn(6, 10, generator=g).cuda())
     b = torch.nn.Parameter(torch.randn(6, generator=g).cuda())
@@ -408,19 +410,8 @@ def test_agc_adamw_known_answers(hipmod):
         w.grad, b.grad = gw.cuda(), gb.cuda()
         opt.agc_clip = 0.02
         opt.step()
-        # reference arithmetic
-        def agc(p, gr):
-            pn = p.norm(2, dim=tuple(range(1, p.ndim)), keepdim=True) if p.ndim > 1 else p.norm(2)
-            gn = gr.norm(2, dim=tuple(range(1, p.ndim)), keepdim=True) if p.ndim > 1 else gr.norm(2)
-            mx = pn.clamp(min=1e-3) * 0.02
-            return torch.where(gn < mx, gr, gr * (mx / gn.clamp(min=1e-6)))
         for (p, gr, m_, v_, wd) in ((pw, gw, mw, vw, 0.05), (pb, gb, mb, vb, 0.)):
-            gr = agc(p, gr)
-            p.mul_(1 - 1e-2 * wd)
-            m_.mul_(0.9).add_(gr, alpha=0.1)
-            v_.mul_(0.999).addcmul_(gr, gr, value=0.001)
-            denom = v_.sqrt() / (1 - 0.999 ** step) ** 0.5 + 1e-8
-            p.addcdiv_(m_, denom, value=-1e-2 / (1 - 0.9 ** step))
+            OO.adamw_step_(p, OO.adaptive_clip_grad_(p, gr, 0.02), m_, v_, step, 1e-2, weight_decay=wd)
         assert (w.detach().cpu() - pw).abs().max() < 1e-5
         assert (b.detach().cpu() - pb).abs().max() < 1e-5
 
