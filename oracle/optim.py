@@ -4,8 +4,9 @@
     -> timm.utils.NativeScaler.__call__ -> dispatch_clip_grad(mode='agc') -> timm.utils.agc.adaptive_clip_grad
     -> torch.optim.AdamW.step   (train_gpu.py:243-247 builds it through timm.optim.create_optimizer)
 
-PARITY UNPINNED: timm (pinned 0.9.2 in the reference's requirements) is not installed in this image and is not vendored
-under /root/reference, so nothing here could be checked against the real implementation.  The arithmetic below restates
+PARITY UNPINNED for the AGC half: timm (pinned 0.9.2 in the reference's requirements) is not installed in this image and
+is not vendored under /root/reference, so `adaptive_clip_grad_` could not be checked against the real implementation.  The
+AdamW half IS pinned: tests/test_host_cpu.py checks `adamw_step_` against torch.optim.AdamW itself.  The arithmetic below restates
 the published algorithm (Brock et al. 2021, "High-Performance Large-Scale Image Recognition Without Normalization", eq. 3:
 unit-wise gradient clipping with the parameter norm floored at eps = 1e-3) and torch.optim.AdamW's documented update
 (decoupled weight decay, bias-corrected moments, eps added to the corrected second-moment root).
