@@ -68,6 +68,20 @@ int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K,
               const float* rscale, int64_t rows_per_group,
               int split_k, float* ws, void* stream);
 int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K);
+/* Product whose ACTIVATION operand is normalised on the way into LDS: ConvModule's BatchNorm2d + ReLU and the Dropout2d
+ * channel scale in front of SegFormerHead.linear_pred (heads/segformer.py:21-29,40,57-58), folded into per-(sample, channel)
+ * tables by segf_bn_affine_table, so that the normalised [B*H*W, C] tensor is never written or re-read:
+ *   layout 0:  C[M,N] = act(A s + t) B^T + bias      (A [M tokens][K], B [N][K]; bf16 out)
+ *   layout 2:  C[M,N] = A^T act(B s + t)             (A = dy [K tokens][M], B = x [K tokens][N]; fp32 out, split-K)
+ * s, t: fp32 [tokens / rows_per_group][features] (features = K in layout 0, N in layout 2); act 0 none / 1 ReLU / 2 ReLU6
+ * (ReLU6 only with unit channel scale).  Implemented by the 256x256-tile kernel only: segf_gemm_pro_supported() tells
+ * whether a shape qualifies (the caller otherwise materialises the normalised tensor with segf_bn_apply). */
+int segf_gemm_pro_supported(int dt, int layout, int64_t M, int64_t N, int64_t K, int64_t rows_per_group);
+int segf_gemm_pro(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                  void* C, int c_dt, int64_t ldc, const float* bias, int split_k, float* ws, const float* pro_scale,
+                  const float* pro_shift, int64_t rows_per_group, int act, void* stream);
+int segf_bn_affine_table(const float* mean, const float* rstd, const float* gamma, const float* beta, const float* chan_scale,
+                         int groups, int C, float* scale, float* shift, void* stream);
 /* Weight gradient and bias gradient of nn.Linear / 1x1 conv in ONE pass over dy (mit.py:45,52,58,98-99 backward):
  *   C[M,N] = sum_k A(k,m) B(k,n)  (layout 2: A = dy [K tokens][M], B = x [K tokens][N]),  dbias[m] = sum_k A(k,m)  (fp32).
  * The column sums ride on the matrix pipe (an all-ones operand) inside the GEMM; shapes that take the 256x256-tile or fp32

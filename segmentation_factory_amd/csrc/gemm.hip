@@ -33,6 +33,10 @@ struct GemmArgs {
     // layout 2 only: colsum[m] = sum_k A(k, m) (the bias gradient next to the weight gradient): the first unused column of the
     // last column tile is staged as all-ones, so its accumulators are the column sums; colsum_ws = split-K partials [z][M]
     float* colsum; float* colsum_ws;
+    // operand prologue (256-tile kernel, layouts 0 / 2): the ACTIVATION operand (A in layout 0, B in layout 2) is read as
+    // act(x * pro_scale[g][f] + pro_shift[g][f]), g = token / pro_rpg, f = feature -- BatchNorm(+ReLU)(+Dropout2d scale) of
+    // the producer applied on the way into LDS, so the normalised tensor is never materialised
+    const float* pro_scale; const float* pro_shift; int64_t pro_rpg; int64_t pro_ld; int pro_act;
 };
 
 #define GB_BM 128
@@ -559,7 +563,22 @@ template <int R> __device__ __forceinline__ bf16x8 frag_rm_tr_t(const unsigned c
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int LAYOUT, typename OutT, bool CONV>
+__device__ __forceinline__ void pro_apply(uint4& r, const float (&sc)[8], const float (&sh)[8], int act) {
+    float v[8];
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = fmaf(v[j], sc[j], sh[j]);
+        if (act >= 1) v[j] = fmaxf(v[j], 0.f);
+        if (act == 2) v[j] = fminf(v[j], 6.f);
+    }
+    r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
+}
+
+template <int LAYOUT, typename OutT, bool CONV, bool PRO = false>
 __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GG_TILE_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -593,6 +612,7 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         }
     }
     unsigned oka = 0xfu, okb = 0xfu;
+    float psc[8], psh[8];
     auto gload = [&](int64_t k0) {
         if (LAYOUT == 2) gload_rm_t<GG_B, GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
         else if (CONV) oka = gload_kc_conv_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
@@ -600,11 +620,23 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         if (LAYOUT == 0) gload_kc_t<GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
         else if (CONV && LAYOUT == 2) okb = gload_rm_conv_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a, rb);
         else gload_rm_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
+        if (PRO) {      // affine of this thread's 8 features for the tile in flight (group = sample of the tile's tokens)
+            const int64_t grp = (LAYOUT == 0 ? m0 : k0) / a.pro_rpg;
+            int64_t f0 = LAYOUT == 0 ? k0 + (threadIdx.x & 7) * 8 : n0 + (threadIdx.x % (GG_B / 8)) * 8;
+            f0 = f0 + 8 <= a.pro_ld ? f0 : a.pro_ld - 8;
+            load8f(a.pro_scale + grp * a.pro_ld + f0, psc);
+            load8f(a.pro_shift + grp * a.pro_ld + f0, psh);
+        }
     };
     auto swrite = [&](int buf) {
         if (CONV) {
             SEGF_LOADS_ISSUED();
             if (LAYOUT != 2) zero_invalid(ra, oka); else zero_invalid(rb, okb);
+        }
+        if (PRO) {
+            SEGF_LOADS_ISSUED();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pro_apply(LAYOUT == 0 ? ra[i] : rb[i], psc, psh, a.pro_act);
         }
         if (LAYOUT == 2) swrite_rm_t<GG_B, GG_THREADS>(smem[buf][0], ra); else swrite_kc_t<GG_THREADS>(smem[buf][0], ra);
         if (LAYOUT == 0) swrite_kc_t<GG_THREADS>(smem[buf][1], rb); else swrite_rm_t<GG_B, GG_THREADS>(smem[buf][1], rb);
@@ -938,9 +970,11 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     return (int)s;
 }
 
+struct GemmPro { const float* scale; const float* shift; int64_t rpg; int64_t ld; int act; };
 static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                      int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
-                     const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream);
+                     const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream,
+                     const GemmPro* pro = nullptr);
 
 extern "C" int segf_gemm(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                          int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
@@ -973,9 +1007,31 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
     return gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, dbias, stream);
 }
 
+// Product whose activation operand is normalised on the way in (BatchNorm + ReLU + Dropout2d scale of ConvModule, heads/
+// segformer.py:21-29,40, folded into per-(sample, channel) scale / shift tables): layout 0 = y = act(x s + t) W^T,
+// layout 2 = dW = dy^T act(x s + t).  Only the 256-tile kernel implements it: ask segf_gemm_pro_supported first.
+extern "C" int segf_gemm_pro_supported(int dt, int layout, int64_t M, int64_t N, int64_t K, int64_t rows_per_group) {
+    if (dt != SEGF_BF16 || (layout != 0 && layout != 2) || rows_per_group <= 0) return 0;
+    if (!gemm_use_big(layout, M, N, K) || K % GB_BK) return 0;
+    { const char* e = getenv("SEGFAC_GEMM_NO_TR"); if (e && e[0] == '1') return 0; }
+    if (getenv("SEGFAC_GEMM_NO_PRO")) return 0;
+    if (layout == 0) return (rows_per_group % GG_B == 0 && K % 8 == 0) ? 1 : 0;
+    return (rows_per_group % GB_BK == 0 && N % 8 == 0) ? 1 : 0;
+}
+extern "C" int segf_gemm_pro(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                             int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, int split_k, float* ws,
+                             const float* pro_scale, const float* pro_shift, int64_t rows_per_group, int act, void* stream) {
+    if (!pro_scale || !pro_shift || !segf_gemm_pro_supported(dt, layout, M, N, K, rows_per_group)) return SEGF_ERR_SHAPE;
+    if ((uintptr_t)pro_scale % 16 || (uintptr_t)pro_shift % 16) return SEGF_ERR_SHAPE;
+    if ((layout == 0) != (c_dt == SEGF_BF16)) return SEGF_ERR_DTYPE;       // forward writes bf16, weight gradient fp32
+    const GemmPro pro{pro_scale, pro_shift, rows_per_group, layout == 0 ? K : N, act};
+    return gemm_impl(dt, layout, M, N, K, A, lda, B, ldb, C, c_dt, ldc, bias, nullptr, 0, nullptr, 1, split_k, ws, nullptr, stream, &pro);
+}
+
 static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                      int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
-                     const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream) {
+                     const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream,
+                     const GemmPro* pro) {
     if (M <= 0 || N <= 0) return 0;
     if (K < 0 || layout < 0 || layout > 2) return SEGF_ERR_SHAPE;
     if (dt != SEGF_F32 && dt != SEGF_BF16) return SEGF_ERR_DTYPE;
@@ -1008,12 +1064,14 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     a.cH = a.cW = a.cC = 0; a.csign = 1;
     a.colsum = colsum;
     a.colsum_ws = (colsum && split_k > 1) ? ws + (int64_t)split_k * M * N : nullptr;
+    a.pro_scale = pro ? pro->scale : nullptr; a.pro_shift = pro ? pro->shift : nullptr;
+    a.pro_rpg = pro ? pro->rpg : 1; a.pro_ld = pro ? pro->ld : 0; a.pro_act = pro ? pro->act : 0;
     {   // debugging switch: SEGFAC_GEMM_NO_TR=1 reads transposed fragments with scalar LDS loads instead of ds_read_b64_tr_b16
         const char* e = getenv("SEGFAC_GEMM_NO_TR");
         a.use_tr = (e && e[0] == '1') ? 0 : 1;
     }
     if (dt == SEGF_BF16) {
-        if (c_dt == SEGF_BF16 && split_k == 1 && a.a_vec && a.c_vec16 && (!residual || a.r_vec) &&
+        if (!pro && c_dt == SEGF_BF16 && split_k == 1 && a.a_vec && a.c_vec16 && (!residual || a.r_vec) &&
             (layout == 1 || a.b_vec) && !getenv("SEGFAC_GEMM_NO_SKINNY")) {
             const int nt = gemm_skinny_nt(layout, M, N, K);
             if (nt) {
@@ -1035,11 +1093,17 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
         if (f32o) hipLaunchKernelGGL((gemm_bf16_big_kernel<L, float, false>), gridb, dim3(GG_THREADS), 0, st, a);  \
         else hipLaunchKernelGGL((gemm_bf16_big_kernel<L, bf16_t, false>), gridb, dim3(GG_THREADS), 0, st, a);      \
     } while (0)
+            if (a.pro_scale) {
+                if (layout == 0 && !f32o) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
+                else if (layout == 2 && f32o) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
+                else return SEGF_ERR_SHAPE;
+            } else
             if (layout == 0) LAUNCH_G(0); else if (layout == 1) LAUNCH_G(1); else LAUNCH_G(2);
 #undef LAUNCH_G
             SEGF_CHECK_LAUNCH();
             goto reduce;
         }
+        if (pro) return SEGF_ERR_SHAPE;            // only the 256-tile kernel applies operand prologues
         dim3 grid((unsigned)cdiv64(N, GB_BN), (unsigned)cdiv64(M, GB_BM), (unsigned)split_k);
         if (grid.y > 65535u) return SEGF_ERR_SHAPE;
         const bool one_step = kchunk <= GB_BK && layout != 2;     // single K step: the 34 KB single-buffer variant
@@ -1099,7 +1163,7 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     a.bias = bias; a.residual = nullptr; a.rscale = nullptr; a.ldr = 0; a.rpg = 1;
     a.a_vec = 1; a.b_vec = 1; a.r_vec = 0; a.use_tr = 1;
     a.cH = H; a.cW = W; a.csign = mode == 1 ? -1 : 1;
-    a.colsum = nullptr; a.colsum_ws = nullptr;
+    a.colsum = nullptr; a.colsum_ws = nullptr; a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_rpg = 1; a.pro_ld = 0; a.pro_act = 0;
     int layout;
     if (mode == 0) { layout = 0; a.M = P; a.N = Cout; a.K = 9 * (int64_t)Cin; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cin; }
     else if (mode == 1) { layout = 0; a.M = P; a.N = Cin; a.K = 9 * (int64_t)Cout; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cout; }

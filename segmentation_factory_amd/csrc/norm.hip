@@ -350,6 +350,28 @@ extern "C" int segf_bn_apply(int dt, int64_t rows, int C, const void* x, const f
     return 0;
 }
 
+// BatchNorm (+ Dropout2d channel scale) as per-(sample, channel) affine tables for segf_gemm_pro:
+//   scale[g][c] = gamma rstd cs[g][c],  shift[g][c] = (beta - mean gamma rstd) cs[g][c]
+// cs >= 0, so ReLU(a x + b) cs == ReLU(cs a x + cs b): the consumer applies the activation after the scaled affine.
+__global__ void bn_affine_table_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, const float* __restrict__ cs, int G, int C,
+                                       float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int c = i % C;
+    const float a = gamma[c] * rstd[c], s = cs ? cs[i] : 1.f;
+    scale[i] = a * s;
+    shift[i] = (beta[c] - mean[c] * a) * s;
+}
+extern "C" int segf_bn_affine_table(const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                    const float* chan_scale, int groups, int C, float* scale, float* shift, void* stream) {
+    if (groups <= 0 || C <= 0) return SEGF_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_affine_table_kernel, dim3((groups * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, rstd, gamma,
+                       beta, chan_scale, groups, C, scale, shift);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 // backward sums: [0] = sum dyr, [1] = sum dyr * xhat, where dyr = dy * chan_scale * act'(pre)
 struct BnCol { float mean[8], rstd[8], a[8], b[8]; };
 __device__ __forceinline__ void bn_col_init(const float* mean, const float* rstd, const float* gamma, const float* beta, int c0,

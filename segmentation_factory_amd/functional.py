@@ -260,6 +260,67 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
                                 rows_per_sample)
 
 
+class BnActLinearFn(Function):
+    """ConvModule's BatchNorm2d + ReLU, the Dropout2d channel scale and the following 1x1 conv (heads/segformer.py:21-29,40,
+    57-58: linear_fuse.bn/activate -> dropout -> linear_pred) as ONE product: the normalisation is folded into per-(sample,
+    channel) scale / shift tables and applied while the GEMM stages its activation operand, in the forward product and again in
+    the weight-gradient product, so the normalised [B*H*W, E] tensor is never written.  Same arithmetic as
+    BatchNormActFn + LinearFn (bf16 rounding of the normalised value included)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rps, weight, bias, Np):
+        x = x if x.is_contiguous() else x.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            mean, rstd = hip.bn_stats(x, running_mean, running_var, momentum, eps)
+        else:
+            mean = running_mean.detach().clone()
+            rstd = torch.rsqrt(running_var.detach() + eps)
+        scale, shift = hip.bn_affine_table(mean, rstd, g, b, chan_scale, M // rps, K)
+        w = torch.zeros((Np, K), dtype=x.dtype, device=x.device)
+        hip.cast2d(weight.detach().reshape(N, -1), w[:N])
+        bp = None
+        if bias is not None:
+            bp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+            hip.cast2d(bias.detach().unsqueeze(1), bp[:N].unsqueeze(1))
+        y = hip.gemm_pro(0, x, w, M, Np, K, scale, shift, rps, act, bias=bp)[:, :N]
+        ctx.save_for_backward(x, mean, rstd, g, b, chan_scale, scale, shift, w)
+        ctx.meta = (M, N, K, Np, act, rps, not training, bias is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, g, b, chan_scale, scale, shift, w = ctx.saved_tensors
+        M, N, K, Np, act, rps, eval_mode, has_bias, wshape = ctx.meta
+        if dy.stride(-1) == 1 and dy.stride(0) == Np:
+            dyp = dy.as_strided((M, Np), (Np, 1))           # the producer zero-fills the pad columns (segfac.h)
+        else:
+            dyp = torch.zeros((M, Np), dtype=x.dtype, device=x.device)
+            dyp[:, :N] = dy
+        da = hip.gemm(1, dyp, w, M, K, Np)                   # gradient w.r.t. the (never materialised) normalised tensor
+        dw = hip.gemm_pro(2, dyp, x, Np, K, M, scale, shift, rps, act, split_k=_splitk(Np, K, M))[:N].view(wshape)
+        db = hip.colsum(dyp)[:N] if has_bias else None
+        dx, dg, dbeta = hip.bn_bwd(x, da, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
+        return dx, dg, dbeta, None, None, None, None, None, None, None, None, dw, db, None
+
+
+def bn_act_linear(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample, weight,
+                  bias, pad_to=None):
+    """batch_norm_act followed by linear; fused into the GEMM operand load when the shape takes the 256-tile kernel."""
+    M, K = x.shape
+    N = weight.shape[0]
+    Np = pad_to if (pad_to and pad_to > N) else N
+    rps = rows_per_sample or M
+    if (x.dtype == torch.bfloat16 and act in (0, 1) and M % rps == 0 and hip.gemm_pro_supported(x.dtype, 0, M, Np, K, rps)
+            and hip.gemm_pro_supported(x.dtype, 2, Np, K, M, rps)):
+        return BnActLinearFn.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rps,
+                                   weight, bias, Np)
+    y = batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample)
+    return linear(y, weight, bias, pad_to=pad_to)
+
+
 class SegformerProjectConcatFn(Function):
     """The front half of SegFormerHead.forward (heads/segformer.py:42-50): per-scale Linear(C_i -> E),
     bilinear resize to the stride-4 grid, channel concat in the order [c4, c3, c2, c1].  Every branch writes

@@ -73,11 +73,10 @@ class SegFormerHead(nn.Module):
             x = Fh.linear(cat, self.linear_fuse.conv.weight)                   # 1x1 conv 4E -> E, no bias
         bn = self.linear_fuse.bn
         drop = dropout2d_scale(self.training and self.dropout.p > 0, B, E, x.device, self.stochastic_override)
-        x = Fh.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps,
-                              act=1, chan_scale=drop, rows_per_sample=H1 * W1)
+        logits = Fh.bn_act_linear(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, 1,
+                                  drop, H1 * W1, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 7) // 8 * 8)
         if self.training:
             bn.num_batches_tracked += 1
-        logits = Fh.linear(x, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 7) // 8 * 8)
         return TokenMap(logits, B, H1, W1)
 
     def forward(self, features):

@@ -28,6 +28,9 @@ _PROTOS = {
     'segf_gemm': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _p, _l, _p, _l, _i, _p, _p]),
     'segf_gemm_pick_splitk': (_i, [_l, _l, _l]),
     'segf_gemm_dw_db_ws': (_l, [_l, _l, _l, _i]),
+    'segf_gemm_pro_supported': (_i, [_i, _i, _l, _l, _l, _l]),
+    'segf_gemm_pro': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _i, _p, _p, _p, _l, _i, _p]),
+    'segf_bn_affine_table': (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     'segf_gemm_dw_db': (_i, [_i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _i, _p, _p, _p]),
     'segf_layernorm_fwd': (_i, [_i, _l, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     'segf_layernorm_bwd_ws': (_l, [_l, _i]),
@@ -219,6 +222,33 @@ def gemm_dw_db(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, split_
         dt_of(dy), M, N, K, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dt_of(dw), dw.stride(0), split_k, _ptr(ws),
         _ptr(db), _stream())), 'segf_gemm_dw_db')
     return dw, db
+
+
+def gemm_pro_supported(dtype, layout, M, N, K, rows_per_group):
+    return bool(lib().segf_gemm_pro_supported(BF16 if dtype == torch.bfloat16 else F32, layout, M, N, K, rows_per_group))
+
+
+def bn_affine_table(mean, rstd, gamma, beta, chan_scale, groups, Cc):
+    """(scale, shift) fp32 [groups, C]: BatchNorm (+ Dropout2d channel scale) as the affine segf_gemm_pro applies."""
+    _need_cuda(mean, rstd, gamma, beta)
+    scale = torch.empty((groups, Cc), dtype=torch.float32, device=mean.device)
+    shift = torch.empty_like(scale)
+    _chk(lib().segf_bn_affine_table(_ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(chan_scale), groups, Cc, _ptr(scale),
+                                    _ptr(shift), _stream()), 'segf_bn_affine_table')
+    return scale, shift
+
+
+def gemm_pro(layout, A, B, M, N, K, scale, shift, rows_per_group, act, bias=None, split_k=1, out=None):
+    """segf_gemm with the activation operand read as act(x * scale[g] + shift[g]) (layout 0: A, bf16 out; layout 2: B, fp32 out)."""
+    _need_cuda(A, B, scale, shift)
+    assert A.stride(-1) == 1 and B.stride(-1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype if layout == 0 else torch.float32, device=A.device)
+    ws = _f32(split_k * M * N, A.device) if split_k > 1 else None
+    _chk(_timed(('gemm', layout, M, N, K), lambda: lib().segf_gemm_pro(
+        dt_of(A), layout, M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), dt_of(out), out.stride(0), _ptr(bias),
+        split_k, _ptr(ws), _ptr(scale), _ptr(shift), rows_per_group, act, _stream())), 'segf_gemm_pro')
+    return out
 
 
 class KernelTimer:

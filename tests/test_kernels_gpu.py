@@ -667,3 +667,43 @@ def test_gemm_dw_db(hipmod, dtype, shape):
                 os.environ.pop('SEGFAC_GEMM_NO_FUSED_DB', None)
             assert (dw.double().cpu() - rw).abs().max().item() <= 2e-3 * rw.abs().max().item()
             assert (db.double().cpu() - rb).abs().max().item() <= 1e-4 * max(1.0, rb.abs().max().item())
+
+
+def test_bn_act_linear_fused_into_gemm(hipmod):
+    """BatchNorm + ReLU + Dropout2d scale applied while the GEMM stages its activation operand (segf_gemm_pro, forward and
+    weight-gradient products) against the unfused batch_norm_act -> linear pair of this library, and against fp64 torch."""
+    from segmentation_factory_amd import functional as Fh
+    B, hw, K, N = 5, 16384, 256, 150
+    M, Np = B * hw, 152
+    g = torch.Generator().manual_seed(70)
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.3).bfloat16().cuda()
+    gam, bet = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.1 * torch.randn(K, generator=g)).cuda()
+    w, bb = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    cs = ((torch.rand(B, K, generator=g) > 0.1).float() / 0.9).cuda()
+    dy = torch.randn(M, N, generator=g).bfloat16().cuda()
+    assert hipmod.gemm_pro_supported(torch.bfloat16, 0, M, Np, K, hw) and hipmod.gemm_pro_supported(torch.bfloat16, 2, Np, K, M, hw)
+    outs = []
+    for fused in (True, False):
+        if not fused:
+            os.environ['SEGFAC_GEMM_NO_PRO'] = '1'
+        try:
+            xs = x.clone().requires_grad_(True)
+            ps = [t.clone().requires_grad_(True) for t in (gam, bet, w, bb)]
+            rm, rv = torch.zeros(K, device='cuda'), torch.ones(K, device='cuda')
+            y = Fh.bn_act_linear(xs, ps[0], ps[1], rm, rv, True, 0.1, 1e-5, 1, cs, hw, ps[2], ps[3], pad_to=Np)
+            y.backward(dy)
+        finally:
+            os.environ.pop('SEGFAC_GEMM_NO_PRO', None)
+        outs.append((y.detach().float(), xs.grad.float(), [p.grad.float() for p in ps], rm, rv))
+    (y1, dx1, gp1, rm1, rv1), (y2, dx2, gp2, rm2, rv2) = outs
+    assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+    assert (y1 - y2).abs().max().item() <= 2e-2 * y2.abs().max().item()
+    assert (dx1 - dx2).abs().max().item() <= 2e-2 * dx2.abs().max().item()
+    for a, b in zip(gp1, gp2):
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+    # float64 reference of the forward on the bf16-rounded input
+    xd = x.double()
+    mu, var = xd.mean(0), xd.var(0, unbiased=False)
+    a = torch.relu((xd - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()) * cs.double().repeat_interleave(hw, 0)
+    ref = a.bfloat16().double() @ w.bfloat16().double().t() + bb.double()
+    assert (y1.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
