@@ -44,6 +44,12 @@ static inline CRPlan cr_plan(int64_t rows, int C) {
     CRPlan p;
     const int nchunk = (C + 7) / 8;
     p.ch = nchunk < CR_THREADS ? nchunk : CR_THREADS;
+    // a chunk count that does not divide the block (96 chunks of C = 768 -> 192 of 256 threads busy): take channel slabs of a
+    // power-of-two width instead when one divides the chunk count
+    if (CR_THREADS % p.ch) {
+        for (int c2 = 64; c2 >= 8; c2 >>= 1)
+            if (nchunk % c2 == 0) { p.ch = c2; break; }
+    }
     p.rl = CR_THREADS / p.ch;
     p.slabs = (nchunk + p.ch - 1) / p.ch;
     int64_t want = cdiv64(rows, (int64_t)p.rl * 32);
