@@ -284,10 +284,12 @@ __global__ void __launch_bounds__(AM_THREADS) attn_mfma_bwd_dq_kernel(const bf16
 }
 
 // ---- backward, key side: dV = P^T dO, dK = scale * (P o (dP - D))^T Q, summed over one query chunk ------------------------
-// grid (key blocks of 256, query chunks, B*heads); wave w owns keys [256*bx + 64w, +64): its K / V fragments (B operands)
+// grid (key blocks of 64 KW, query chunks, B*heads); wave w owns 16 KW keys: its K / V fragments (B operands)
 // stay in registers; Q / dO tiles of 32 queries pass through LDS.  Output: fp32 slab[z][b*Nkv + key][2C] partial sums.
-template <int HD>
-__global__ void __launch_bounds__(AM_THREADS, HD == 32 ? 2 : 1) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+// KW = 16-key tiles per wave: 4 (64 keys) at head dim 32; 2 at head dim 64, where 64 keys per wave need ~300 registers (one
+// wave per SIMD, nothing to overlap the Q / dO staging with) and 32 keys fit two waves per SIMD
+template <int HD, int KW = (HD == 32 ? 4 : 2)>
+__global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                         const bf16_t* __restrict__ k, int64_t ldk,
                                                                         const bf16_t* __restrict__ v, int64_t ldv,
                                                                         const bf16_t* __restrict__ dO, int64_t lddo,
@@ -302,27 +304,27 @@ __global__ void __launch_bounds__(AM_THREADS, HD == 32 ? 2 : 1) attn_mfma_bwd_dk
     const int g = lane >> 4, c = lane & 15;
     const int bh = blockIdx.z, b = bh / heads, h = bh - b * heads;
     const int z = blockIdx.y;
-    const int key0 = blockIdx.x * 256 + wave * 64;
+    const int key0 = blockIdx.x * (64 * KW) + wave * (16 * KW);
     const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
     const bf16_t* dOb = dO + (int64_t)b * N * lddo + h * HD;
     const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
     const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
     const float* lb = lse + ((int64_t)b * heads + h) * N;
     const float* Db = Dbuf + ((int64_t)b * heads + h) * N;
-    bf16x8 Kf[4][KS], Vf[4][KS];
+    bf16x8 Kf[KW][KS], Vf[KW][KS];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < KW; ++kt)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int key = key0 + 16 * kt + c;
             Kf[kt][s] = ld_frag_global(Kb + (int64_t)key * ldk + 32 * s + 8 * g, key < Nkv);
             Vf[kt][s] = ld_frag_global(Vb + (int64_t)key * ldv + 32 * s + 8 * g, key < Nkv);
         }
-    f32x4 dK[DT][4], dV[DT][4];
+    f32x4 dK[DT][KW], dV[DT][KW];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { dK[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < KW; ++kt) { dK[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int qbeg = z * qchunk, qend = qbeg + qchunk < N ? qbeg + qchunk : N;
     for (int qt0 = qbeg; qt0 < qend; qt0 += 32) {
         __syncthreads();
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(AM_THREADS, HD == 32 ? 2 : 1) attn_mfma_bwd_dk
         }
         __syncthreads();
         if (key0 >= Nkv) continue;
-        float P[2][4][4], dS[2][4][4];
+        float P[2][KW][4], dS[2][KW][4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             bf16x8 Qa[KS], dOa[KS];
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(AM_THREADS, HD == 32 ? 2 : 1) attn_mfma_bwd_dk
 #pragma unroll
             for (int r = 0; r < 4; ++r) { lr[r] = Ls[16 * qt + 4 * g + r]; dr[r] = Ds[16 * qt + 4 * g + r]; }
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < KW; ++kt) {
                 f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
@@ -370,7 +372,7 @@ __global__ void __launch_bounds__(AM_THREADS, HD == 32 ? 2 : 1) attn_mfma_bwd_dk
             QT[d] = ld_frag_tr<HD>(Qs, 4 * g, 16 + 4 * g, 16 * d, lane);
         }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < KW; ++kt) {
             const bf16x8 Pf = pack_acc(P[0][kt], P[1][kt]);
             const bf16x8 dSf = pack_acc(dS[0][kt], dS[1][kt]);
 #pragma unroll
@@ -384,7 +386,7 @@ __global__ void __launch_bounds__(AM_THREADS, HD == 32 ? 2 : 1) attn_mfma_bwd_dk
     const int C = heads * HD;
     float* sb = slab + (int64_t)z * B * Nkv * 2 * C;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < KW; ++kt) {
         const int key = key0 + 16 * kt + c;
         if (key < Nkv) {
             float* row = sb + ((int64_t)b * Nkv + key) * 2 * C + h * HD;
@@ -402,7 +404,7 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
                   const float* lse, void* dq, int64_t lddq, float* Dbuf, float* slab, int nchunk, int qchunk, hipStream_t st) {
     constexpr int QW = 2;
     dim3 g1((unsigned)cdiv64(N, 4 * 16 * QW), heads, B);
-    dim3 g2((unsigned)cdiv64(Nkv, 256), nchunk, B * heads);
+    dim3 g2((unsigned)cdiv64(Nkv, hd == 32 ? 256 : 128), nchunk, B * heads);      // keys per workgroup = 4 waves x 16 KW
     const bf16_t* Q = (const bf16_t*)q; const bf16_t* K = (const bf16_t*)k; const bf16_t* V = (const bf16_t*)v;
     const bf16_t* O = (const bf16_t*)o; const bf16_t* DO = (const bf16_t*)d_o;
     if (hd == 32) {
