@@ -221,6 +221,10 @@ int segf_argmax_confmat(int dt, int B, int C, int h, int w, int H, int W, const 
                         const int64_t* target, int64_t ignore_label, int64_t* mat, int64_t* hist,
                         int32_t* flag, int64_t* pred_out /*nullable [B][H][W]*/, void* stream);
 
+/* out[r] = argmax_c x[r][c] (lowest index on ties): the prediction step of single-image inference
+ * (estimate_model.py:104-106, softmax(dim=1).argmax(dim=1) -- softmax is monotonic).  x: [rows][ld >= C], C <= 192. */
+int segf_argmax_rows(int dt, int64_t rows, int C, const void* x, int64_t ld, int64_t* out, void* stream);
+
 /* ConfusionMatrix.update(a, b) on explicit int64 (ground truth, prediction) pairs (util/utils.py:99-109) and
  * the Metrics.update bincount (util/metrics.py:24-27); mat / hist nullable.  flag bit0: label >= n that is not
  * ignore_label, bit1: prediction out of range.                                                      */

@@ -1454,6 +1454,39 @@ extern "C" int segf_argmax_confmat(int dt, int B, int C, int h, int w, int H, in
     return 0;
 }
 
+// ---- argmax over the class row of NHWC logits (inference: estimate_model.py:104-106 softmax(dim=1).argmax(dim=1); softmax is
+// monotonic, so the arg max of the logits is the prediction; lowest index on ties like torch.argmax) -----------------------
+template <typename T, int NS>
+__global__ void __launch_bounds__(LS_THREADS) argmax_rows_kernel(const T* __restrict__ x, int64_t ld, int64_t rows, int C,
+                                                                  int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+        float z[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = lane + 64 * s;
+            const float v = ldf<T>(x + r * ld + (c < C ? c : C - 1));
+            z[s] = c < C ? v : -INFINITY;
+        }
+        const int best = wave_argmax<NS>(z, lane, C);
+        if (lane == 0) out[r] = best;
+    }
+}
+extern "C" int segf_argmax_rows(int dt, int64_t rows, int C, const void* x, int64_t ld, int64_t* out, void* stream) {
+    if (rows <= 0) return 0;
+    if (C <= 0 || C > 192 || ld < C) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = (C + 63) / 64;
+    const dim3 grid((unsigned)(rows / 4 + 1 < 16384 ? rows / 4 + 1 : 16384));
+#define CALL(NS) SEGF_DISPATCH_DT(dt, T, { hipLaunchKernelGGL((argmax_rows_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, (const T*)x, ld, rows, C, out); })
+    LS_NS_DISPATCH(ns, CALL);
+#undef CALL
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+
 // ---- confusion matrix from explicit (ground truth, prediction) pairs: ConfusionMatrix.update(a, b)
 // (util/utils.py:99-109) and the bincount of Metrics.update (util/metrics.py:24-27) ------------------------------
 __global__ void confmat_pairs_kernel(const int64_t* __restrict__ gt, const int64_t* __restrict__ pred, int64_t n, int C,

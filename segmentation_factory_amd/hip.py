@@ -27,6 +27,7 @@ _PROTOS = {
     'segf_colsum': (_i, [_i, _p, _l, _l, _l, _p, _p, _p]),
     'segf_gemm': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _p, _l, _p, _l, _i, _p, _p]),
     'segf_gemm_pick_splitk': (_i, [_l, _l, _l]),
+    'segf_argmax_rows': (_i, [_i, _l, _i, _p, _l, _p, _p]),
     'segf_gemm_dw_db_ws': (_l, [_l, _l, _l, _i]),
     'segf_gemm_pro_supported': (_i, [_i, _i, _l, _l, _l, _l]),
     'segf_gemm_pro': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _i, _p, _p, _p, _l, _i, _p]),
@@ -483,6 +484,14 @@ def bilinear_fwd(x, B, h, w, Cc, H, W, out, align_corners=False):
     """x: [B*h*w, >=C] view; out: [B*H*W, >=C] view (may be a column slice of a concat buffer)."""
     _chk(lib().segf_bilinear_fwd(dt_of(x), B, h, w, Cc, _ptr(x), x.stride(0), H, W, _ptr(out), out.stride(0),
                                  int(align_corners), _stream()), 'segf_bilinear_fwd')
+    return out
+
+
+def argmax_rows(x, Cc):
+    """int64 [rows]: arg max over the first Cc columns of x [rows, >= Cc] (lowest index on ties)."""
+    _need_cuda(x)
+    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    _chk(lib().segf_argmax_rows(dt_of(x), x.shape[0], Cc, _ptr(x), x.stride(0), _ptr(out), _stream()), 'segf_argmax_rows')
     return out
 
 

@@ -307,3 +307,38 @@ def test_other_variants_fp32_vs_oracle(backbone, head):
         assert (g - r).abs().max().item() <= 5e-2 * (r.abs().max().item() + 0.1 * gmax), (k, (g - r).abs().max().item(), r.abs().max().item())
         checked += 1
     assert checked > 50
+
+
+@pytest.mark.gpu
+def test_single_image_inference_matches_reference_pipeline():
+    """inference.SemSeg (estimate_model.py:53-123 restated for tensors): HIP resizes + arg max against the reference's op
+    sequence on this library's own full-resolution logits: F.interpolate(align_corners=True) -> softmax -> argmax."""
+    import torch.nn.functional as F
+    from segmentation_factory_amd import SegmentationModel
+    from segmentation_factory_amd.inference import SemSeg
+    torch.manual_seed(3)
+    m = SegmentationModel('MiT-B0', num_classes=19, seg_head='SegFormerHead').cuda().eval()
+    pal = torch.randint(0, 255, (19, 3), dtype=torch.uint8)
+    ss = SemSeg(m, img_size=128, palette=pal)
+    img = torch.randint(0, 256, (3, 150, 200), dtype=torch.uint8)
+    assert ss.inference_size(150, 200) == (128, 192)
+    seg, col = ss.predict(img, overlay=False)
+    assert seg.shape == (150, 200) and seg.dtype == torch.int64 and col.shape == (150, 200, 3)
+    x = ss.preprocess(img)
+    with torch.inference_mode():
+        logits = m(x)                                                    # fp32 NCHW at the network input size
+        ref = F.interpolate(logits, size=(150, 200), mode='bilinear', align_corners=True).softmax(dim=1).argmax(dim=1)[0]
+    agree = (seg == ref).float().mean().item()
+    assert agree >= 0.999, agree
+    assert torch.equal(col, pal.cuda()[seg])
+
+
+@pytest.mark.gpu
+def test_argmax_rows_kernel():
+    from segmentation_factory_amd import hip
+    g = torch.Generator().manual_seed(4)
+    for C, ld, dt in ((19, 24, torch.float32), (150, 152, torch.bfloat16), (171, 176, torch.float32), (2, 8, torch.bfloat16)):
+        x = torch.randn(1000, ld, generator=g).to(dt).cuda()
+        x[5, :C] = 1.0                                                   # ties -> lowest index
+        out = hip.argmax_rows(x, C)
+        assert torch.equal(out, x[:, :C].float().argmax(dim=1))
