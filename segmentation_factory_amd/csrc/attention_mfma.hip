@@ -13,6 +13,7 @@
 //   dq  : S^T form again, dS^T feeds dQ^T += K^T dS^T directly from the accumulators
 //   dkv : S form (rows = queries), each wave owns 64 keys whose K/V fragments stay in registers for the whole kernel;
 //         Q / dO tiles go through LDS; dV^T += dO^T P and dK^T += Q^T dS take P / dS from the accumulators.
+#include <stdlib.h>
 #include "attention_mfma.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -20,7 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-#define AM_KC 256      // keys per LDS stage
+#define AM_KC_OF(HD) ((HD) == 64 ? 128 : 256)      // keys per LDS stage: 32 KB of K + V either way (3+ workgroups per CU)
 #define AM_THREADS 256
 
 __device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* __restrict__ p, bool valid) {
@@ -71,6 +72,7 @@ __global__ void __launch_bounds__(AM_THREADS) attn_mfma_fwd_kernel(const bf16_t*
                                                                     const bf16_t* __restrict__ v, int64_t ldv,
                                                                     bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
                                                                     int heads, int N, int Nkv, float scale) {
+    constexpr int AM_KC = AM_KC_OF(HD);
     __shared__ __attribute__((aligned(16))) bf16_t Ks[AM_KC * HD];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[AM_KC * HD];
     constexpr int KS = HD / 32, DT = HD / 16;
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(AM_THREADS) attn_mfma_fwd_kernel(const bf16_t*
 int attn_mfma_fwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64_t ldq, const void* k, int64_t ldk,
                   const void* v, int64_t ldv, float scale, void* o, int64_t ldo, float* lse, hipStream_t st) {
     constexpr int QW = 2;
-    dim3 grid((unsigned)cdiv64(N, 4 * 16 * QW), heads, B);
+    dim3 grid((unsigned)cdiv64(N, 4 * 16 * QW), heads, B);      // (one query tile per wave measured 2 % slower at head dim 64)
     if (hd == 32)
         hipLaunchKernelGGL((attn_mfma_fwd_kernel<32, QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
                            (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
@@ -190,6 +192,7 @@ __global__ void __launch_bounds__(AM_THREADS) attn_mfma_bwd_dq_kernel(const bf16
                                                                        const float* __restrict__ lse, bf16_t* __restrict__ dq,
                                                                        int64_t lddq, float* __restrict__ Dbuf, int heads, int N,
                                                                        int Nkv, float scale) {
+    constexpr int AM_KC = AM_KC_OF(HD);
     __shared__ __attribute__((aligned(16))) bf16_t Ks[AM_KC * HD];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[AM_KC * HD];
     constexpr int KS = HD / 32, DT = HD / 16;
