@@ -67,7 +67,7 @@ __device__ __forceinline__ void stage_rows(bf16_t* tile, const bf16_t* __restric
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
 template <int HD, int QW>
-__global__ void __launch_bounds__(AM_THREADS) attn_mfma_fwd_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+__global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                     const bf16_t* __restrict__ k, int64_t ldk,
                                                                     const bf16_t* __restrict__ v, int64_t ldv,
                                                                     bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
@@ -184,7 +184,7 @@ int attn_mfma_fwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
 
 // ---- backward, query side: D = rowsum(dO * O), dQ = scale * (P o (dP - D)) K ---------------------------------------------
 template <int HD, int QW>
-__global__ void __launch_bounds__(AM_THREADS) attn_mfma_bwd_dq_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+__global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                        const bf16_t* __restrict__ k, int64_t ldk,
                                                                        const bf16_t* __restrict__ v, int64_t ldv,
                                                                        const bf16_t* __restrict__ o, int64_t ldo,
