@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         }
     }
     unsigned oka = 0xfu, okb = 0xfu;
-    float psc[8], psh[8];
+    int64_t pro_k0 = 0;
     auto gload = [&](int64_t k0) {
         if (LAYOUT == 2) gload_rm_t<GG_B, GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
         else if (CONV) oka = gload_kc_conv_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
@@ -620,13 +620,7 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         if (LAYOUT == 0) gload_kc_t<GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
         else if (CONV && LAYOUT == 2) okb = gload_rm_conv_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a, rb);
         else gload_rm_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
-        if (PRO) {      // affine of this thread's 8 features for the tile in flight (group = sample of the tile's tokens)
-            const int64_t grp = (LAYOUT == 0 ? m0 : k0) / a.pro_rpg;
-            int64_t f0 = LAYOUT == 0 ? k0 + (threadIdx.x & 7) * 8 : n0 + (threadIdx.x % (GG_B / 8)) * 8;
-            f0 = f0 + 8 <= a.pro_ld ? f0 : a.pro_ld - 8;
-            load8f(a.pro_scale + grp * a.pro_ld + f0, psc);
-            load8f(a.pro_shift + grp * a.pro_ld + f0, psh);
-        }
+        if (PRO) pro_k0 = k0;
     };
     auto swrite = [&](int buf) {
         if (CONV) {
@@ -634,7 +628,15 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
             if (LAYOUT != 2) zero_invalid(ra, oka); else zero_invalid(rb, okb);
         }
         if (PRO) {
+            // affine of this thread's 8 features for the staged tile (group = sample of the tile's tokens); fetched here, after
+            // the MFMA phase, from L1 / L2 (the tables are a few hundred KB): held across the MFMAs the 16 values spill
             SEGF_LOADS_ISSUED();
+            float psc[8], psh[8];
+            const int64_t grp = (LAYOUT == 0 ? m0 : pro_k0) / a.pro_rpg;
+            int64_t f0 = LAYOUT == 0 ? pro_k0 + (threadIdx.x & 7) * 8 : n0 + (threadIdx.x % (GG_B / 8)) * 8;
+            f0 = f0 + 8 <= a.pro_ld ? f0 : a.pro_ld - 8;
+            load8f(a.pro_scale + grp * a.pro_ld + f0, psc);
+            load8f(a.pro_shift + grp * a.pro_ld + f0, psh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) pro_apply(LAYOUT == 0 ? ra[i] : rb[i], psc, psh, a.pro_act);
         }
