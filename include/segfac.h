@@ -188,6 +188,18 @@ int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, int64_t ldi
 int segf_upsample_add(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
                       const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
                       const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners, void* stream);
+/* The same, also returning sums[2][C] = per-channel (sum, sum of squares) of the stored result over all B*H*W rows: the
+ * BatchNorm batch statistics of the ConvModule that consumes it (heads/segformer.py:21-29), so no separate pass over the
+ * [B*H*W, C] tensor is needed; segf_bn_stats_from_sums turns them into mean / rstd / running statistics.  Fused only for the
+ * folded SegFormerHead geometry (three sources at 1/2, 1/4, 1/8 of the grid, align_corners = 0): SEGF_ERR_SHAPE otherwise
+ * (use segf_upsample_add + segf_bn_stats).  ws >= segf_upsample_add_stats_ws(B, H, W, C) floats. */
+int64_t segf_upsample_add_stats_ws(int B, int H, int W, int C);
+int segf_upsample_add_stats(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
+                            const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
+                            const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
+                            float* sums, float* ws, void* stream);
+int segf_bn_stats_from_sums(const float* sums, int64_t rows, int C, float* mean, float* rstd, float* running_mean,
+                            float* running_var, float momentum, float eps, void* stream);
 /* out (fp32 NCHW [B][C][H][W]) = bilinear(in NHWC [B][h][w][ldi]) -- materialised logits for API parity */
 int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, const void* in, int64_t ldi,
                               int H, int W, float* out, void* stream);

@@ -282,6 +282,16 @@ extern "C" int segf_bn_stats(int dt, int64_t rows, int C, const void* x, float* 
     return 0;
 }
 
+// mean / rstd / running statistics from per-channel sums [2][C] = (sum x, sum x^2) produced elsewhere (segf_upsample_add_stats)
+extern "C" int segf_bn_stats_from_sums(const float* sums, int64_t rows, int C, float* mean, float* rstd, float* running_mean,
+                                       float* running_var, float momentum, float eps, void* stream) {
+    if (rows <= 0 || C <= 0 || !sums) return SEGF_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, (double)rows, eps,
+                       momentum, mean, rstd, running_mean, running_var);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 __device__ __forceinline__ float bn_act(float v, int act) {
     if (act == 1) return fmaxf(v, 0.f);
     if (act == 2) return fminf(fmaxf(v, 0.f), 6.f);

@@ -97,14 +97,25 @@ __device__ __forceinline__ void load_vblend(const T* __restrict__ sb, const UpSr
         for (int c = 0; c < 8; ++c) tv[j][c] = fmaf(ly, b[c] - a[c], a[c]);
     }
 }
-template <typename T>
+// STATS: the kernel also returns the per-channel sum and sum of squares of what it stores (the BatchNorm statistics of the
+// following ConvModule, heads/segformer.py:21-29), as per-workgroup partials [blk][2][C] for colreduce_finalize: the separate
+// statistics pass over the [B*H*W, C] tensor disappears.  Column-fixed threads (the grid makes the thread count a multiple of
+// the chunk count), sums over the ROUNDED stored values, fixed-order reduction inside the workgroup.
+template <typename T, bool STATS>
 __global__ void __launch_bounds__(256) upsample_add_248_kernel(const T* __restrict__ base, int64_t ldb, UpSrc s0, UpSrc s1, UpSrc s2,
-                                                                T* __restrict__ out, int64_t ldo, int B, int H, int W, int C) {
+                                                                T* __restrict__ out, int64_t ldo, int B, int H, int W, int C,
+                                                                float* __restrict__ partial) {
+    __shared__ float red[STATS ? 256 * 16 : 1];
     const int nch = C / 8, nst = W / 4;
-    const int64_t total = (int64_t)B * H * nst * nch;
-    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % nch);
-        int64_t t = idx / nch;
+    const int64_t units = (int64_t)B * H * nst;
+    const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
+    const int64_t ustep = ((int64_t)gridDim.x * 256) / nch;
+    const int ch = (int)(g % nch);
+    float sm1[8], sm2[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sm1[c] = 0.f; sm2[c] = 0.f; }
+    for (int64_t u = g / nch; u < units; u += ustep) {
+        int64_t t = u;
         const int k = (int)(t % nst); t /= nst;
         const int Y = (int)(t % H);
         const int64_t b = t / H;
@@ -151,14 +162,76 @@ __global__ void __launch_bounds__(256) upsample_add_248_kernel(const T* __restri
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) store8<T>(out + (pix0 + i) * ldo + c0, acc[i]);
+        for (int i = 0; i < 4; ++i) {
+            store8<T>(out + (pix0 + i) * ldo + c0, acc[i]);
+            if (STATS) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float r = sizeof(T) == 2 ? bf2f(f2bf(acc[i][c])) : acc[i][c];
+                    sm1[c] += r; sm2[c] = fmaf(r, r, sm2[c]);
+                }
+            }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { red[threadIdx.x * 16 + c] = sm1[c]; red[threadIdx.x * 16 + 8 + c] = sm2[c]; }
+        __syncthreads();
+        if ((int)threadIdx.x < nch) {          // first thread of each chunk in this workgroup adds the later ones in order
+            float a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = red[threadIdx.x * 16 + c];
+            for (int o = threadIdx.x + nch; o < 256; o += nch)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] += red[o * 16 + c];
+            float* dst = partial + (int64_t)blockIdx.x * 2 * C + ch * 8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { dst[c] = a[c]; dst[C + c] = a[8 + c]; }
+        }
     }
 }
 
+static bool upsample_add_is_248(int H, int W, int C, int nsrc, int h0, int w0, int h1, int w1, int h2, int w2, int align_corners) {
+    return nsrc == 3 && !align_corners && W % 8 == 0 && H % 8 == 0 && h0 * 2 == H && w0 * 2 == W && h1 * 4 == H && w1 * 4 == W &&
+           h2 * 8 == H && w2 * 8 == W && C % 8 == 0 && !getenv("SEGFAC_UPADD_GENERIC");
+}
+static int upsample_add_248_blocks(int B, int H, int W, int C) {
+    return colfixed_blocks((int64_t)B * H * (W / 4), C / 8, 2, 16384);
+}
+static int upsample_add_impl(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
+                             const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
+                             const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
+                             float* partial, void* stream);
 extern "C" int segf_upsample_add(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
                                  const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
                                  const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
                                  void* stream) {
+    return upsample_add_impl(dt, B, H, W, C, base, ldb, nsrc, src0, h0, w0, ld0, src1, h1, w1, ld1, src2, h2, w2, ld2, out, ldo,
+                             align_corners, nullptr, stream);
+}
+// Same, plus sums[2][C] = per-channel (sum, sum of squares) of `out` over all B*H*W rows (BatchNorm statistics of the consumer);
+// ws >= segf_upsample_add_stats_ws(...) floats.  Returns SEGF_ERR_SHAPE when the geometry is not the 1/2-1/4-1/8 case
+// (the caller then runs segf_bn_stats on the result).
+extern "C" int64_t segf_upsample_add_stats_ws(int B, int H, int W, int C) {
+    return (int64_t)upsample_add_248_blocks(B, H, W, C) * 2 * C;
+}
+extern "C" int segf_upsample_add_stats(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
+                                       const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
+                                       const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
+                                       float* sums, float* ws, void* stream) {
+    if (!sums || !ws) return SEGF_ERR_WORKSPACE;
+    if (!upsample_add_is_248(H, W, C, nsrc, h0, w0, h1, w1, h2, w2, align_corners) || C / 8 > 256) return SEGF_ERR_SHAPE;
+    const int rc = upsample_add_impl(dt, B, H, W, C, base, ldb, nsrc, src0, h0, w0, ld0, src1, h1, w1, ld1, src2, h2, w2, ld2, out,
+                                     ldo, align_corners, ws, stream);
+    if (rc) return rc;
+    colreduce_finalize_launch(ws, upsample_add_248_blocks(B, H, W, C), 2 * (int64_t)C, sums, (hipStream_t)stream);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+static int upsample_add_impl(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
+                             const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
+                             const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
+                             float* partial, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
     if (nsrc < 0 || nsrc > 3 || C % 8 != 0 || ldb < C || ldo < C) return SEGF_ERR_SHAPE;
     const int64_t esz = dt == SEGF_BF16 ? 2 : 4;
@@ -171,16 +244,18 @@ extern "C" int segf_upsample_add(int dt, int B, int H, int W, int C, const void*
         if (hs[i] <= 0 || ws[i] <= 0) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     UpSrc s0{src0, h0, w0, ld0}, s1{src1, h1, w1, ld1}, s2{src2, h2, w2, ld2};
-    if (nsrc == 3 && !align_corners && W % 8 == 0 && H % 8 == 0 && h0 * 2 == H && w0 * 2 == W && h1 * 4 == H && w1 * 4 == W &&
-        h2 * 8 == H && w2 * 8 == W && !getenv("SEGFAC_UPADD_GENERIC")) {
-        const int blocks4 = (int)imin64(cdiv64((int64_t)B * H * (W / 4) * (C / 8), 256), 16384);
+    if (upsample_add_is_248(H, W, C, nsrc, h0, w0, h1, w1, h2, w2, align_corners)) {
+        const int blocks4 = upsample_add_248_blocks(B, H, W, C);
         SEGF_DISPATCH_DT(dt, T, {
-            hipLaunchKernelGGL((upsample_add_248_kernel<T>), dim3(blocks4), dim3(256), 0, st, (const T*)base, ldb, s0, s1, s2,
-                               (T*)out, ldo, B, H, W, C);
+            if (partial) hipLaunchKernelGGL((upsample_add_248_kernel<T, true>), dim3(blocks4), dim3(256), 0, st, (const T*)base, ldb,
+                                            s0, s1, s2, (T*)out, ldo, B, H, W, C, partial);
+            else hipLaunchKernelGGL((upsample_add_248_kernel<T, false>), dim3(blocks4), dim3(256), 0, st, (const T*)base, ldb, s0,
+                                    s1, s2, (T*)out, ldo, B, H, W, C, partial);
         })
         SEGF_CHECK_LAUNCH();
         return 0;
     }
+    if (partial) return SEGF_ERR_SHAPE;
     const int blocks = (int)imin64(cdiv64((int64_t)B * H * W * (C / 8), 256), 16384);
     SEGF_DISPATCH_DT(dt, T, {
         hipLaunchKernelGGL((upsample_add_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)base, ldb, s0, s1, s2, nsrc, (T*)out,

@@ -232,10 +232,13 @@ class BatchNormActFn(Function):
     heads/segformer.py:40,57.  Training uses batch statistics and updates the running buffers in place."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample,
+                pre_sums=None):
         x = x if x.is_contiguous() else x.contiguous()
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        if training:
+        if training and pre_sums is not None:
+            mean, rstd = hip.bn_stats_from_sums(pre_sums, x.shape[0], running_mean, running_var, momentum, eps)
+        elif training:
             mean, rstd = hip.bn_stats(x, running_mean, running_var, momentum, eps)
         else:
             mean = running_mean.detach().clone()
@@ -251,13 +254,13 @@ class BatchNormActFn(Function):
         act, rps, eval_mode = ctx.meta
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx, dg, db = hip.bn_bwd(x, dy, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
-        return dx, dg, db, None, None, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, act=1, chan_scale=None,
-                   rows_per_sample=None):
+                   rows_per_sample=None, pre_sums=None):
     return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale,
-                                rows_per_sample)
+                                rows_per_sample, pre_sums)
 
 
 class BnActLinearFn(Function):
@@ -268,12 +271,15 @@ class BnActLinearFn(Function):
     BatchNormActFn + LinearFn (bf16 rounding of the normalised value included)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rps, weight, bias, Np):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rps, weight, bias, Np,
+                pre_sums):
         x = x if x.is_contiguous() else x.contiguous()
         M, K = x.shape
         N = weight.shape[0]
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        if training:
+        if training and pre_sums is not None:       # the producer already summed x and x^2 per channel
+            mean, rstd = hip.bn_stats_from_sums(pre_sums, M, running_mean, running_var, momentum, eps)
+        elif training:
             mean, rstd = hip.bn_stats(x, running_mean, running_var, momentum, eps)
         else:
             mean = running_mean.detach().clone()
@@ -303,12 +309,13 @@ class BnActLinearFn(Function):
         dw = hip.gemm_pro(2, dyp, x, Np, K, M, scale, shift, rps, act, split_k=_splitk(Np, K, M))[:N].view(wshape)
         db = hip.colsum(dyp)[:N] if has_bias else None
         dx, dg, dbeta = hip.bn_bwd(x, da, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
-        return dx, dg, dbeta, None, None, None, None, None, None, None, None, dw, db, None
+        return dx, dg, dbeta, None, None, None, None, None, None, None, None, dw, db, None, None
 
 
 def bn_act_linear(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample, weight,
-                  bias, pad_to=None):
-    """batch_norm_act followed by linear; fused into the GEMM operand load when the shape takes the 256-tile kernel."""
+                  bias, pad_to=None, pre_sums=None):
+    """batch_norm_act followed by linear; fused into the GEMM operand load when the shape takes the 256-tile kernel.
+    pre_sums: optional fp32 [2, C] (sum, sum of squares) of x per channel from its producer (replaces the statistics pass)."""
     M, K = x.shape
     N = weight.shape[0]
     Np = pad_to if (pad_to and pad_to > N) else N
@@ -316,8 +323,9 @@ def bn_act_linear(x, gamma, beta, running_mean, running_var, training, momentum,
     if (x.dtype == torch.bfloat16 and act in (0, 1) and M % rps == 0 and hip.gemm_pro_supported(x.dtype, 0, M, Np, K, rps)
             and hip.gemm_pro_supported(x.dtype, 2, Np, K, M, rps)):
         return BnActLinearFn.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rps,
-                                   weight, bias, Np)
-    y = batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample)
+                                   weight, bias, Np, pre_sums)
+    y = batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample,
+                       pre_sums=pre_sums)
     return linear(y, weight, bias, pad_to=pad_to)
 
 
@@ -410,13 +418,16 @@ class SegformerFoldedFuseFn(Function):
             _, h, w = geoms[i]
             ts.append(hip.gemm(0, x, G, B * h * w, E, Ci, bias=beta_i))   # a constant row passes through the resize unchanged
             saved += [x, G, Wp]
-        y = hip.upsample_add(ts[0], [(ts[i], geoms[i][1], geoms[i][2]) for i in range(1, 4)], B, H1, W1, E)
+        y, sums = hip.upsample_add_stats(ts[0], [(ts[i], geoms[i][1], geoms[i][2]) for i in range(1, 4)], B, H1, W1, E)
+        if sums is None:
+            sums = torch.empty(0, device=y.device)          # geometry without the fused statistics: the consumer runs its own pass
+        ctx.mark_non_differentiable(sums)
         ctx.save_for_backward(wfc, *saved)
         ctx.meta = (geoms, E, dtype)
-        return y
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsums=None):
         geoms, E, dtype = ctx.meta
         sv = ctx.saved_tensors
         wfc = sv[0]
@@ -449,7 +460,10 @@ class SegformerFoldedFuseFn(Function):
 
 
 def segformer_folded_fuse(feats, weights, biases, fuse_weight, geoms):
-    return SegformerFoldedFuseFn.apply(tuple(geoms), *feats, *weights, *biases, fuse_weight)
+    """-> (y [B*H1*W1, E], sums): sums = fp32 [2, E] per-channel (sum, sum of squares) of y for the BatchNorm that follows, or
+    None when the geometry did not take the fused kernel."""
+    y, sums = SegformerFoldedFuseFn.apply(tuple(geoms), *feats, *weights, *biases, fuse_weight)
+    return y, (sums if sums.numel() else None)
 
 
 class DWConv7Fn(Function):

@@ -66,15 +66,17 @@ class SegFormerHead(nn.Module):
         lins = [getattr(self, f'linear_c{i + 1}').proj for i in range(4)]
         geoms = [(f.B, f.H, f.W) for f in feats]
         if self.fold and all(f.data.shape[1] % 8 == 0 for f in feats) and E % 8 == 0:
-            x = Fh.segformer_folded_fuse([f.data for f in feats], [l.weight for l in lins], [l.bias for l in lins],
-                                         self.linear_fuse.conv.weight, geoms)
+            x, pre = Fh.segformer_folded_fuse([f.data for f in feats], [l.weight for l in lins], [l.bias for l in lins],
+                                              self.linear_fuse.conv.weight, geoms)
         else:                                                                  # the reference's literal op order
             cat = Fh.segformer_project_concat([f.data for f in feats], [l.weight for l in lins], [l.bias for l in lins], geoms)
             x = Fh.linear(cat, self.linear_fuse.conv.weight)                   # 1x1 conv 4E -> E, no bias
+            pre = None
         bn = self.linear_fuse.bn
         drop = dropout2d_scale(self.training and self.dropout.p > 0, B, E, x.device, self.stochastic_override)
         logits = Fh.bn_act_linear(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, 1,
-                                  drop, H1 * W1, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 7) // 8 * 8)
+                                  drop, H1 * W1, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 7) // 8 * 8,
+                                  pre_sums=pre if self.training else None)
         if self.training:
             bn.num_batches_tracked += 1
         return TokenMap(logits, B, H1, W1)

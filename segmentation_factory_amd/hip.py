@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGFAC_HIP_LIB: another build of the same library (same-box A/B of kernel changes, tools/ab_bench.sh); default in-tree
 LIB_PATH = os.environ.get('SEGFAC_HIP_LIB') or os.path.join(_HERE, 'libsegfac_hip.so')
 F32, BF16 = 0, 1
+ERR_SHAPE = -1          # SEGF_ERR_SHAPE
 _lib = None
 
 _i, _l, _f, _p = C.c_int, C.c_int64, C.c_float, C.c_void_p
@@ -62,6 +63,9 @@ _PROTOS = {
     'segf_bilinear_fwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
     'segf_bilinear_bwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
     'segf_upsample_add': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p]),
+    'segf_upsample_add_stats_ws': (_l, [_i, _i, _i, _i]),
+    'segf_upsample_add_stats': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p, _p, _p]),
+    'segf_bn_stats_from_sums': (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p]),
     'segf_bilinear_to_nchw_f32': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p]),
     'segf_ce_dice_stats_floats': (_l, [_i, _i]),
     'segf_ce_dice_fwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p]),
@@ -518,6 +522,36 @@ def upsample_add(base, srcs, B, H, W, Cc, align_corners=False):
     _chk(lib().segf_upsample_add(dt_of(base), B, H, W, Cc, _ptr(base), base.stride(0), len(srcs), *a, _ptr(out), Cc,
                                  int(align_corners), _stream()), 'segf_upsample_add')
     return out
+
+
+def upsample_add_stats(base, srcs, B, H, W, Cc):
+    """upsample_add that also returns sums fp32 [2, C] = per-channel (sum, sum of squares) of the stored result (the BatchNorm
+    statistics of the consumer); None for the sums when the geometry is not the fused 1/2-1/4-1/8 case."""
+    out = torch.empty((B * H * W, Cc), dtype=base.dtype, device=base.device)
+    a = []
+    for k in range(3):
+        if k < len(srcs):
+            t, h, w = srcs[k]
+            a += [_ptr(t), h, w, t.stride(0)]
+        else:
+            a += [None, 0, 0, 0]
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=base.device)
+    ws = _f32(max(1, lib().segf_upsample_add_stats_ws(B, H, W, Cc)), base.device)
+    rc = lib().segf_upsample_add_stats(dt_of(base), B, H, W, Cc, _ptr(base), base.stride(0), len(srcs), *a, _ptr(out), Cc, 0,
+                                       _ptr(sums), _ptr(ws), _stream())
+    if rc == ERR_SHAPE:
+        return upsample_add(base, srcs, B, H, W, Cc), None
+    _chk(rc, 'segf_upsample_add_stats')
+    return out, sums
+
+
+def bn_stats_from_sums(sums, rows, running_mean, running_var, momentum, eps):
+    Cc = sums.shape[1]
+    mean = torch.empty(Cc, dtype=torch.float32, device=sums.device)
+    rstd = torch.empty(Cc, dtype=torch.float32, device=sums.device)
+    _chk(lib().segf_bn_stats_from_sums(_ptr(sums), rows, Cc, _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
+                                       momentum, eps, _stream()), 'segf_bn_stats_from_sums')
+    return mean, rstd
 
 
 def bilinear_to_nchw_f32(x, B, h, w, Cc, H, W):

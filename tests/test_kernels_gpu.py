@@ -707,3 +707,30 @@ def test_bn_act_linear_fused_into_gemm(hipmod):
     a = torch.relu((xd - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()) * cs.double().repeat_interleave(hw, 0)
     ref = a.bfloat16().double() @ w.bfloat16().double().t() + bb.double()
     assert (y1.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_upsample_add_with_batchnorm_statistics(hipmod, dtype):
+    """segf_upsample_add_stats: same result as segf_upsample_add plus per-channel (sum, sum of squares) of the STORED values,
+    against torch on the kernel's own output; segf_bn_stats_from_sums against segf_bn_stats."""
+    B, H, W, C = 3, 16, 24, 104
+    g = torch.Generator().manual_seed(80)
+    base = torch.randn(B * H * W, C, generator=g)
+    sizes = [(H // r, W // r) for r in (2, 4, 8)]
+    srcs = [torch.randn(B * h * w, C, generator=g) for (h, w) in sizes]
+    args = (_dev(base, dtype), [(_dev(s, dtype), h, w) for s, (h, w) in zip(srcs, sizes)], B, H, W, C)
+    ref = hipmod.upsample_add(*args)
+    out, sums = hipmod.upsample_add_stats(*args)
+    assert sums is not None and (out.float() - ref.float()).abs().max().item() <= 1e-5 * ref.float().abs().max().item()
+    o64 = out.double()
+    assert torch.allclose(sums[0].double(), o64.sum(0), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(sums[1].double(), (o64 * o64).sum(0), rtol=1e-5, atol=1e-3)
+    rm1, rv1, rm2, rv2 = (torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros(C, device='cuda'),
+                          torch.ones(C, device='cuda'))
+    m1, r1 = hipmod.bn_stats(out, rm1, rv1, 0.1, 1e-5)
+    m2, r2 = hipmod.bn_stats_from_sums(sums, B * H * W, rm2, rv2, 0.1, 1e-5)
+    assert torch.allclose(m1, m2, rtol=1e-5, atol=1e-6) and torch.allclose(r1, r2, rtol=1e-4)
+    assert torch.allclose(rm1, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv1, rv2, rtol=1e-4)
+    # a geometry outside the fused case reports "no sums"
+    out2, sums2 = hipmod.upsample_add_stats(_dev(base, dtype), [(_dev(srcs[0], dtype), *sizes[0])], B, H, W, C)
+    assert sums2 is None and out2.shape == out.shape
