@@ -68,7 +68,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (BASELINE.json does not fix it; 128 x 512^2 uses ~120 of 288 GB; 64: -8 %%)')
+    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (BASELINE.json does not fix it; 128 x 512^2 peaks at ~22 of 288 GB; 64: -8 %%, 192: +0.3 %%)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward+loss+backward only')
@@ -223,6 +223,7 @@ def main():
                        "init": "random (reference initialisers)", "loss_after": round(final_loss, 4),
                        "launch": "eager" if args.eager else "hipGraph(zero_grad+fwd+loss+bwd+grad gather) + RCCL all-reduce + fused AGC/AdamW"},
             "images_per_sec_per_gpu": round(ips / world, 2),
+            "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "fwd_loss_bwd_only_images_per_sec": round(world * args.batch * args.steps / fb, 2),
             "reference_graph_tflops_equivalent": round(3 * FWD_GFLOP_PER_IMG * 1e9 * ips / 1e12, 1) if args.config == 'cfg2' else None,
             "roofline": {"kernel": "ce_dice_bwd_mfma4_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
