@@ -124,52 +124,80 @@ __device__ __forceinline__ void swrite_rm(unsigned char* tile, const uint4 (&reg
     }
 }
 
-// implicit-im2col variants: the 128 tile rows are output pixels (ry, rx precomputed per thread), k = tap * C + channel
-__device__ __forceinline__ unsigned gload_kc_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax, int64_t k0,
-                                                  int64_t kend, const GemmArgs& a, const int (&ry)[4], const int (&rx)[4],
-                                                  uint4 (&reg)[4]) {
+// implicit-im2col variants: the tile rows are output pixels, k = tap * C + channel.  All index arithmetic that does not change
+// from one K step to the next lives in a per-thread ConvState set up once per workgroup (the tap / channel split and the pixel
+// coordinates are integer divisions -- 64-bit ones cost ~80 instructions each, and the loaders used to redo up to nine of them
+// per K step); the loaders then only advance the state by one K step.
+struct ConvState {
+    int ry[4], rx[4];      // K-contiguous gather (layout 0, operand A): output pixel of each of the thread's four tile rows
+    int tap, ci;           //   tap / channel of the thread's 8-column chunk at the CURRENT K step
+    int dyc, dxc, cci;     // reduction-major gather (layout 2, operand B): tap offset and channel of the thread's fixed column chunk
+    int py[4], px[4];      //   pixel coordinates of the thread's four K rows at the current K step
+};
+// rows: row index of the thread's i-th tile row = row0 + rbase + rstride * i
+__device__ __forceinline__ void conv_state_init_kc(ConvState& st, const GemmArgs& a, int64_t row0, int rbase, int rstride, int64_t k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + rbase + rstride * i;
+        st.rx[i] = (int)(row % a.cW);
+        st.ry[i] = (int)((row / a.cW) % a.cH);
+    }
+    st.tap = (int)(k / a.cC);
+    st.ci = (int)(k - (int64_t)st.tap * a.cC);
+}
+__device__ __forceinline__ void conv_state_init_rm(ConvState& st, const GemmArgs& a, int64_t col, int64_t cmax, int64_t k0, int rbase,
+                                                   int rstride) {
+    const int64_t cc = col < cmax ? col : 0;
+    const int tap = (int)(cc / a.cC);
+    st.cci = (int)(cc - (int64_t)tap * a.cC);
+    st.dyc = a.csign * (tap / 3 - 1); st.dxc = a.csign * (tap % 3 - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + rbase + rstride * i;
+        st.px[i] = (int)(k % a.cW);
+        st.py[i] = (int)((k / a.cW) % a.cH);
+    }
+}
+// K-contiguous gather; advances (tap, ci) by one K step afterwards
+__device__ __forceinline__ unsigned gload_kc_conv_s(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax, int64_t k0,
+                                                    int64_t kend, const GemmArgs& a, ConvState& st, int rbase, int rstride,
+                                                    uint4 (&reg)[4]) {
     // Every gather is unconditional: padding taps / rows past the end read a clamped in-range address and are zeroed at the
     // LDS write through the returned validity bits (a branch per load would serialise the four loads, see gload_kc)
-    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
-    const int64_t k = k0 + c * 8;
+    const int64_t k = k0 + (threadIdx.x & 7) * 8;
     const bool kok = k < kend;
-    const int64_t kc = kok ? k : 0;
-    const int tap = (int)(kc / a.cC);
-    const int ci = (int)(kc - (int64_t)tap * a.cC);
+    const int tap = kok ? st.tap : 0, ci = kok ? st.ci : 0;
     const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
     unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t row = row0 + r + 32 * i;
-        const int yy = ry[i] + dy, xx = rx[i] + dx;
+        const int64_t row = row0 + rbase + rstride * i;
+        const int yy = st.ry[i] + dy, xx = st.rx[i] + dx;
         const bool ok = row < rmax && kok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
         okm |= ok ? 1u << i : 0u;
         const int64_t src = ok ? row + (int64_t)dy * a.cW + dx : (row < rmax ? row : rmax - 1);
         reg[i] = *reinterpret_cast<const uint4*>(base + src * ld + ci);
     }
+    st.ci += GB_BK;
+    while (st.ci >= a.cC) { st.ci -= a.cC; ++st.tap; }
     return okm;
 }
-// reduction-major gathered operand: tile rows are pixels k, tile columns are (tap, channel); the thread's column chunk is fixed
-__device__ __forceinline__ unsigned gload_rm_conv(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax, int64_t k0,
-                                                  int64_t kend, const GemmArgs& a, uint4 (&reg)[4]) {
-    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
-    const int64_t col = col0 + c * 8;
+// reduction-major gather (tile rows = pixels k, columns = (tap, channel)); advances the pixel coordinates by one K step
+__device__ __forceinline__ unsigned gload_rm_conv_s(const bf16_t* __restrict__ base, int64_t ld, int64_t col, int64_t cmax, int64_t k0,
+                                                    int64_t kend, const GemmArgs& a, ConvState& st, int rbase, int rstride,
+                                                    uint4 (&reg)[4]) {
     const bool cok = col < cmax;
-    const int64_t cc = cok ? col : 0;
-    const int tap = (int)(cc / a.cC);
-    const int ci = (int)(cc - (int64_t)tap * a.cC);
-    const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
     unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t k = k0 + r + 16 * i;
+        const int64_t k = k0 + rbase + rstride * i;
         const int64_t kc = k < kend ? k : kend - 1;
-        const int x = (int)(kc % a.cW);
-        const int y = (int)((kc / a.cW) % a.cH);
-        const int yy = y + dy, xx = x + dx;
+        const int yy = st.py[i] + st.dyc, xx = st.px[i] + st.dxc;
         const bool ok = k < kend && cok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
         okm |= ok ? 1u << i : 0u;
-        reg[i] = *reinterpret_cast<const uint4*>(base + (ok ? kc + (int64_t)dy * a.cW + dx : kc) * ld + ci);
+        reg[i] = *reinterpret_cast<const uint4*>(base + (ok ? kc + (int64_t)st.dyc * a.cW + st.dxc : kc) * ld + st.cci);
+        st.px[i] += GB_BK;
+        while (st.px[i] >= a.cW) { st.px[i] -= a.cW; if (++st.py[i] == a.cH) st.py[i] = 0; }
     }
     return okm;
 }
@@ -285,22 +313,16 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
     // staged as all-ones, so its accumulator column is sum_k A(k, m); csn = that column's index inside this tile (or -1)
     const int csn = (LAYOUT == 2 && !CONV && a.colsum != nullptr && a.N >= n0 && a.N < n0 + GB_BN) ? (int)(a.N - n0) : -1;
     uint4 ra[4], rb[4];
-    int ry[4], rx[4];
-    if (CONV && LAYOUT == 0) {       // output pixel of each of this thread's 4 tile rows
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t row = m0 + (threadIdx.x >> 3) + 32 * i;
-            rx[i] = (int)(row % a.cW);
-            ry[i] = (int)((row / a.cW) % a.cH);
-        }
-    }
+    ConvState cst;
+    if (CONV && LAYOUT == 0) conv_state_init_kc(cst, a, m0, threadIdx.x >> 3, 32, kbeg + (threadIdx.x & 7) * 8);
+    if (CONV && LAYOUT == 2) conv_state_init_rm(cst, a, n0 + (threadIdx.x & 15) * 8, a.N, kbeg, threadIdx.x >> 4, 16);
     unsigned oka = 0xfu, okb = 0xfu;          // validity bits of the gathered (implicit-conv) operand's four loads
     auto gload = [&](int64_t k0) {
         if (LAYOUT == 2) gload_rm(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
-        else if (CONV) oka = gload_kc_conv(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
+        else if (CONV) oka = gload_kc_conv_s(A, a.lda, m0, a.M, k0, kend, a, cst, threadIdx.x >> 3, 32, ra);
         else gload_kc(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
         if (LAYOUT == 0) gload_kc(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
-        else if (CONV && LAYOUT == 2) okb = gload_rm_conv(B, a.ldb, n0, a.N, k0, kend, a, rb);
+        else if (CONV && LAYOUT == 2) okb = gload_rm_conv_s(B, a.ldb, n0 + (threadIdx.x & 15) * 8, a.N, k0, kend, a, cst, threadIdx.x >> 4, 16, rb);
         else gload_rm(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
         if (LAYOUT == 2 && csn >= 0 && (int)(threadIdx.x & 15) == (csn >> 3)) {      // this thread stages the ones column
             const uint32_t sh = 16u * (csn & 1), one = 0x3f80u << sh, keep = ~(0xffffu << sh);
@@ -464,28 +486,6 @@ template <int T> __device__ __forceinline__ void swrite_kc_t(unsigned char* tile
         *reinterpret_cast<uint4*>(tile + row * 128 + ((c ^ (row & 7)) << 4)) = reg[i];
     }
 }
-template <int T> __device__ __forceinline__ unsigned gload_kc_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t row0,
-                                                                     int64_t rmax, int64_t k0, int64_t kend, const GemmArgs& a,
-                                                                     const int (&ry)[4], const int (&rx)[4], uint4 (&reg)[4]) {
-    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
-    const int64_t k = k0 + c * 8;
-    const bool kok = k < kend;
-    const int64_t kc = kok ? k : 0;
-    const int tap = (int)(kc / a.cC);
-    const int ci = (int)(kc - (int64_t)tap * a.cC);
-    const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
-    unsigned okm = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t row = row0 + r + (T / 8) * i;
-        const int yy = ry[i] + dy, xx = rx[i] + dx;
-        const bool ok = row < rmax && kok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
-        okm |= ok ? 1u << i : 0u;
-        const int64_t src = ok ? row + (int64_t)dy * a.cW + dx : (row < rmax ? row : rmax - 1);
-        reg[i] = *reinterpret_cast<const uint4*>(base + src * ld + ci);
-    }
-    return okm;
-}
 // reduction-major operand, tile = 64 k rows x R columns (R*2 bytes per row)
 template <int R, int T> __device__ __forceinline__ void gload_rm_t(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax,
                                                                    int64_t k0, int64_t kend, int vec, uint4 (&reg)[4]) {
@@ -509,31 +509,6 @@ template <int R, int T> __device__ __forceinline__ void gload_rm_t(const bf16_t*
         }
         reg[i] = v;
     }
-}
-template <int R, int T> __device__ __forceinline__ unsigned gload_rm_conv_t(const bf16_t* __restrict__ base, int64_t ld, int64_t col0,
-                                                                            int64_t cmax, int64_t k0, int64_t kend, const GemmArgs& a,
-                                                                            uint4 (&reg)[4]) {
-    constexpr int CPR = R / 8;
-    const int c = threadIdx.x % CPR, r = threadIdx.x / CPR;
-    const int64_t col = col0 + c * 8;
-    const bool cok = col < cmax;
-    const int64_t cc = cok ? col : 0;
-    const int tap = (int)(cc / a.cC);
-    const int ci = (int)(cc - (int64_t)tap * a.cC);
-    const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
-    unsigned okm = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t k = k0 + r + (T / CPR) * i;
-        const int64_t kc = k < kend ? k : kend - 1;
-        const int x = (int)(kc % a.cW);
-        const int y = (int)((kc / a.cW) % a.cH);
-        const int yy = y + dy, xx = x + dx;
-        const bool ok = k < kend && cok && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
-        okm |= ok ? 1u << i : 0u;
-        reg[i] = *reinterpret_cast<const uint4*>(base + (ok ? kc + (int64_t)dy * a.cW + dx : kc) * ld + ci);
-    }
-    return okm;
 }
 template <int R, int T> __device__ __forceinline__ void swrite_rm_t(unsigned char* tile, const uint4 (&reg)[4]) {
     constexpr int CPR = R / 8;
@@ -602,23 +577,20 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[4], rb[4];
-    int ry[4], rx[4];
-    if (CONV && LAYOUT == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t row = m0 + (threadIdx.x >> 3) + (GG_THREADS / 8) * i;
-            rx[i] = (int)(row % a.cW);
-            ry[i] = (int)((row / a.cW) % a.cH);
-        }
-    }
+    ConvState cst;
+    if (CONV && LAYOUT == 0) conv_state_init_kc(cst, a, m0, threadIdx.x >> 3, GG_THREADS / 8, kbeg + (threadIdx.x & 7) * 8);
+    if (CONV && LAYOUT == 2)
+        conv_state_init_rm(cst, a, n0 + (threadIdx.x % (GG_B / 8)) * 8, a.N, kbeg, threadIdx.x / (GG_B / 8), GG_THREADS / (GG_B / 8));
     unsigned oka = 0xfu, okb = 0xfu;
     int64_t pro_k0 = 0;
     auto gload = [&](int64_t k0) {
         if (LAYOUT == 2) gload_rm_t<GG_B, GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
-        else if (CONV) oka = gload_kc_conv_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a, ry, rx, ra);
+        else if (CONV) oka = gload_kc_conv_s(A, a.lda, m0, a.M, k0, kend, a, cst, threadIdx.x >> 3, GG_THREADS / 8, ra);
         else gload_kc_t<GG_THREADS>(A, a.lda, m0, a.M, k0, kend, a.a_vec, ra);
         if (LAYOUT == 0) gload_kc_t<GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
-        else if (CONV && LAYOUT == 2) okb = gload_rm_conv_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a, rb);
+        else if (CONV && LAYOUT == 2)
+            okb = gload_rm_conv_s(B, a.ldb, n0 + (threadIdx.x % (GG_B / 8)) * 8, a.N, k0, kend, a, cst, threadIdx.x / (GG_B / 8),
+                                  GG_THREADS / (GG_B / 8), rb);
         else gload_rm_t<GG_B, GG_THREADS>(B, a.ldb, n0, a.N, k0, kend, a.b_vec, rb);
         if (PRO) pro_k0 = k0;
     };
