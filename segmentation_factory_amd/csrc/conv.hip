@@ -3,6 +3,7 @@
 //   DWConv + GELU : reference models/backbones/mit.py:62-71 (DWConv), :98-99 (F.gelu(self.dwconv(self.fc1(x))))
 //   PatchEmbed    : mit.py:105,127 (Conv2d k7 s4 p3 / k3 s2 p1);  sr conv: mit.py:21,48 (Conv2d k=s=sr)
 // All HBM-bound: channel-contiguous 16-B lane accesses, fp32 math.
+#include <stdlib.h>
 #include "colreduce.h"
 
 #define DW_PIX 4   // output pixels per thread along W (sliding 3x(PIX+2) window in registers)
@@ -593,6 +594,54 @@ extern "C" int segf_im2col(int dt, int in_nchw_f32, int B, int H, int W, int Cin
     return 0;
 }
 
+// Fast form for kernel <= NC * stride per axis (every conv of the path: k = s -> NC 1; k3 s2, k7 s4 -> NC 2): an input pixel is
+// covered by at most NC x NC windows, ky = (iy + pad) % stride + j * stride.  The NC*NC candidate loads are unconditional
+// (clamped address, masked value) and in flight together; the generic kernel below walks all kh x kw taps with a branch each.
+template <typename T, int NC>
+__global__ void __launch_bounds__(256) col2im_nc_kernel(const T* __restrict__ dcol, int64_t ldcol, T* __restrict__ dx, int B, int H,
+                                                         int W, int Cin, int kh, int kw, int stride, int pad, int Ho, int Wo) {
+    const int nch = Cin / 8;
+    const int64_t total = (int64_t)B * H * W * nch;
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t i32 = (uint32_t)idx;                    // total < 2^32 (checked on the host)
+        const uint32_t tq = i32 / (uint32_t)nch;
+        const int ch = (int)(i32 - tq * (uint32_t)nch);
+        const uint32_t t2 = tq / (uint32_t)W;
+        const int ix = (int)(tq - t2 * (uint32_t)W);
+        const int64_t b = t2 / (uint32_t)H;
+        const int iy = (int)(t2 - (uint32_t)b * (uint32_t)H);
+        const int ky0 = (iy + pad) % stride, kx0 = (ix + pad) % stride;
+        Raw8<T> raw[NC][NC];
+        bool ok[NC][NC];
+#pragma unroll
+        for (int jy = 0; jy < NC; ++jy) {
+            const int ky = ky0 + jy * stride, oy = (iy + pad - ky) / stride;
+            const bool vy = ky < kh && iy + pad - ky >= 0 && oy < Ho;
+#pragma unroll
+            for (int jx = 0; jx < NC; ++jx) {
+                const int kx = kx0 + jx * stride, ox = (ix + pad - kx) / stride;
+                ok[jy][jx] = vy && kx < kw && ix + pad - kx >= 0 && ox < Wo;
+                const int oyc = ok[jy][jx] ? oy : 0, oxc = ok[jy][jx] ? ox : 0, tap = ok[jy][jx] ? ky * kw + kx : 0;
+                raw[jy][jx] = load8_raw<T>(dcol + ((b * Ho + oyc) * Wo + oxc) * ldcol + (int64_t)tap * Cin + ch * 8);
+            }
+        }
+        SEGF_LOADS_ISSUED();
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int jy = 0; jy < NC; ++jy)
+#pragma unroll
+            for (int jx = 0; jx < NC; ++jx) {
+                float v[8];
+                unpack8(raw[jy][jx], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += ok[jy][jx] ? v[j] : 0.f;
+            }
+        store8<T>(dx + ((b * H + iy) * W + ix) * Cin + ch * 8, acc);
+    }
+}
+
 // dx[b][iy][ix][ci] = sum over (ky,kx) with (iy+pad-ky) % stride == 0 ... of dcol[(b,oy,ox)][(ky,kx,ci)]  (gather form, no atomics)
 template <typename T>
 __global__ void col2im_kernel(const T* __restrict__ dcol, int64_t ldcol, T* __restrict__ dx, int B, int H, int W, int Cin, int kh,
@@ -637,8 +686,15 @@ extern "C" int segf_col2im(int dt, int B, int H, int W, int Cin, int kh, int kw,
         return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)imin64(cdiv64((int64_t)B * H * W * (Cin / 8), 256), 8192);
+    const int nc = (kh > kw ? kh : kw) <= stride ? 1 : ((kh > kw ? kh : kw) <= 2 * stride ? 2 : 0);
+    const bool small = (int64_t)B * H * W * (Cin / 8) < (1ll << 32) && !getenv("SEGFAC_COL2IM_GENERIC");
     SEGF_DISPATCH_DT(dt, T, {
-        hipLaunchKernelGGL((col2im_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)dcol, ldcol, (T*)dx, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
+        if (nc == 1 && small)
+            hipLaunchKernelGGL((col2im_nc_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)dcol, ldcol, (T*)dx, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
+        else if (nc == 2 && small)
+            hipLaunchKernelGGL((col2im_nc_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const T*)dcol, ldcol, (T*)dx, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
+        else
+            hipLaunchKernelGGL((col2im_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)dcol, ldcol, (T*)dx, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
     })
     SEGF_CHECK_LAUNCH();
     return 0;

@@ -229,7 +229,7 @@ def test_dwconv3x3_gelu(dtype, geom):
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('cfg', [(2, 3, 32, 40, 32, 7, 4, 3, True), (2, 32, 16, 12, 64, 3, 2, 1, False),
                                  (1, 64, 16, 16, 64, 4, 4, 0, False), (2, 160, 7, 9, 256, 3, 2, 1, False),
-                                 (1, 32, 16, 24, 32, 8, 8, 0, False)])
+                                 (1, 32, 16, 24, 32, 8, 8, 0, False), (1, 16, 9, 11, 24, 5, 2, 2, False)])
 def test_conv_patch(dtype, cfg):
     from segmentation_factory_amd import functional as Fh
     B, Cin, H, W, O, k, s, p, image = cfg
