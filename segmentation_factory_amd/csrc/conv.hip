@@ -281,49 +281,56 @@ __global__ void __launch_bounds__(256) dwconv7x7_kernel(const T* __restrict__ x,
     const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
     const int ustep = (int)(((int64_t)gridDim.x * 256) / nchunk);
     const int c0 = (int)(g % nchunk) * 8;
-    float bs[8];
+    // channel pairs on float2 vectors -> packed fp32 fmas (49 taps x 8 pixels per strip: the kernel is VALU-bound)
+    f32x2_t bs[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bs[j] = (!FLIP && bias) ? bias[c0 + j] : 0.f;
+    for (int jj = 0; jj < 4; ++jj) bs[jj] = (!FLIP && bias) ? f32x2_t{bias[c0 + 2 * jj], bias[c0 + 2 * jj + 1]} : f32x2_t{0.f, 0.f};
     for (int u = (int)(g / nchunk); u < units; u += ustep) {
         const int xg = u % wg;
         const int t = u / wg;
         const int yy = t % H;
         const int b = t / H;
         const int x0 = xg * DW7_PIX;
-        float acc[DW7_PIX][8];
+        f32x2_t acc[DW7_PIX][4];
 #pragma unroll
         for (int p = 0; p < DW7_PIX; ++p)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[p][j] = bs[j];
+            for (int jj = 0; jj < 4; ++jj) acc[p][jj] = bs[jj];
         for (int ky = 0; ky < 7; ++ky) {
             const int iy = yy + ky - 3;
             if (iy < 0 || iy >= H) continue;            // wave-divergent only at the image border rows
-            float wk[7][8];
+            f32x2_t wk[7][4];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) load8f(wt + (int64_t)(FLIP ? 48 - (ky * 7 + kx) : ky * 7 + kx) * C + c0, wk[kx]);
+            for (int kx = 0; kx < 7; ++kx) {
+                const float* wp = wt + (int64_t)(FLIP ? 48 - (ky * 7 + kx) : ky * 7 + kx) * C + c0;
+                const float4 wa = *reinterpret_cast<const float4*>(wp), wb = *reinterpret_cast<const float4*>(wp + 4);
+                wk[kx][0] = f32x2_t{wa.x, wa.y}; wk[kx][1] = f32x2_t{wa.z, wa.w};
+                wk[kx][2] = f32x2_t{wb.x, wb.y}; wk[kx][3] = f32x2_t{wb.z, wb.w};
+            }
             const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
-            // unconditional, clamped loads in two batches of 7 columns (a branch per load would serialise their latencies)
+            // unconditional, clamped loads in two batches of 7 columns, all issued before the first use
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                float v[7][8];
+                Raw8<T> raw[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
                     const int ix = x0 + half * 7 + q - 3;
-                    load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[q]);
+                    raw[q] = load8_raw<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C);
                 }
+                SEGF_LOADS_ISSUED();
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
                     const int cx = half * 7 + q;
                     const int ix = x0 + cx - 3;
-                    const bool ok = ix >= 0 && ix < W;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[q][j] = ok ? v[q][j] : 0.f;
+                    f32x2_t v[4];
+                    zero_unless(raw[q], ix >= 0 && ix < W);
+                    unpack8v<T>(raw[q], v);
 #pragma unroll
                     for (int kx = 0; kx < 7; ++kx) {
                         const int p = cx - kx;
                         if (p >= 0 && p < DW7_PIX) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[p][j] = fmaf(wk[kx][j], v[q][j], acc[p][j]);
+                            for (int jj = 0; jj < 4; ++jj) acc[p][jj] = wk[kx][jj] * v[jj] + acc[p][jj];
                         }
                     }
                 }
@@ -331,7 +338,7 @@ __global__ void __launch_bounds__(256) dwconv7x7_kernel(const T* __restrict__ x,
         }
 #pragma unroll
         for (int p = 0; p < DW7_PIX; ++p)
-            if (x0 + p < W) store8<T>(y + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, acc[p]);
+            if (x0 + p < W) store8v<T>(y + (((int64_t)b * H + yy) * W + x0 + p) * C + c0, acc[p]);
     }
 }
 
