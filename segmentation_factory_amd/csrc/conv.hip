@@ -370,11 +370,11 @@ __global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restric
     const int ky = blockIdx.z;
     const int wg = (W + DW7_PIX - 1) / DW7_PIX;
     const int units = B * H * wg;
-    float acc[8][8];
+    f32x2_t ap[8][4];          // channel pairs: packed fp32 fmas
 #pragma unroll
     for (int o = 0; o < 8; ++o)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+        for (int jj = 0; jj < 4; ++jj) ap[o][jj] = f32x2_t{0.f, 0.f};
     const int u0 = xcd_block() * units_per_blk;
     const int u1 = u0 + units_per_blk < units ? u0 + units_per_blk : units;
     if (active) {
@@ -385,48 +385,56 @@ __global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restric
             const int b = t / H;
             const int x0 = xg * DW7_PIX;
             const int iy = yy + ky - 3;
-            float gq[DW7_PIX][8];
+            Raw8<T> graw[DW7_PIX];
+#pragma unroll
+            for (int p = 0; p < DW7_PIX; ++p)
+                graw[p] = load8_raw<T>(dy + (((int64_t)b * H + yy) * W + (x0 + p < W ? x0 + p : W - 1)) * C + c0);
+            SEGF_LOADS_ISSUED();
+            f32x2_t gq[DW7_PIX][4];
 #pragma unroll
             for (int p = 0; p < DW7_PIX; ++p) {
-                load8<T>(dy + (((int64_t)b * H + yy) * W + (x0 + p < W ? x0 + p : W - 1)) * C + c0, gq[p]);
-                if (!(x0 + p < W)) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) gq[p][j] = 0.f;
-                }
+                zero_unless(graw[p], x0 + p < W);
+                unpack8v<T>(graw[p], gq[p]);
                 if (ky == 3) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[7][j] += gq[p][j];
+                    for (int jj = 0; jj < 4; ++jj) ap[7][jj] += gq[p][jj];
                 }
             }
             if (iy < 0 || iy >= H) continue;
             const T* row = x + (((int64_t)b * H + iy) * W) * C + c0;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                float v[7][8];
+                Raw8<T> raw[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
                     const int ix = x0 + half * 7 + q - 3;
-                    load8<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C, v[q]);
+                    raw[q] = load8_raw<T>(row + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C);
                 }
+                SEGF_LOADS_ISSUED();
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
                     const int cx = half * 7 + q;
                     const int ix = x0 + cx - 3;
-                    const bool ok = ix >= 0 && ix < W;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[q][j] = ok ? v[q][j] : 0.f;
+                    f32x2_t v[4];
+                    zero_unless(raw[q], ix >= 0 && ix < W);
+                    unpack8v<T>(raw[q], v);
 #pragma unroll
                     for (int kx = 0; kx < 7; ++kx) {
                         const int p = cx - kx;
                         if (p >= 0 && p < DW7_PIX) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[kx][j] = fmaf(gq[p][j], v[q][j], acc[kx][j]);
+                            for (int jj = 0; jj < 4; ++jj) ap[kx][jj] = gq[p][jj] * v[jj] + ap[kx][jj];
                         }
                     }
                 }
             }
         }
     }
+    float acc[8][8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { acc[o][2 * jj] = ap[o][jj].x; acc[o][2 * jj + 1] = ap[o][jj].y; }
     // partial[(ky * nblk + blk)][8][C]
     float* pz = partial + (int64_t)ky * gridDim.x * 8 * C;
     colreduce_block_tail<8>(acc, active, ty == 0 && c0 < C, tx, ch, rl, c0, 8, C, pz, red);
