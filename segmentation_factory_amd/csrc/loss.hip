@@ -838,9 +838,11 @@ struct MfmaCell {
         ulraw = ldf<T>(pl + tt);
     }
     __device__ __forceinline__ void finish(const LossGeom& g, const MfmaCellLoads<T, NT>& L, int c, float wA) {
-        float mx = -INFINITY;
+        // lanes past the last class hold a duplicate of class C-1 (clamped load), so they can take part in the maximum as they
+        // are; plain v_max_f32 (fmaxf would first canonicalise each operand with a second v_max)
+        float mx = L.u[0];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mx = 16 * t + c < g.C ? fmaxf(mx, L.u[t]) : mx;
+        for (int t = 1; t < NT; ++t) asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(L.u[t]));
         mb = wave_max_all(mx);
         // the elementwise work is written on 4-vectors so that it lowers to packed fp32 instructions (v_pk_add/mul/fma_f32:
         // two lanes' worth of flops per issue slot) -- these kernels are bound by VALU issue, not by memory
