@@ -567,6 +567,48 @@ __global__ void __launch_bounds__(256) im2col_nchw_kernel(const float* __restric
         store8<T>(col + m * ldcol + ch * 8, v);
     }
 }
+// Row-staged form of the same: a workgroup owns one output row (b, oy).  Its kh input rows of all Cin planes are read once,
+// coalesced, into LDS (as T); the row's Wo x ldcol/8 chunks are then assembled from LDS and stored with 16-byte writes.  The
+// gather form above reads every image element ~k*k/stride^2 times through uncoalesced 4-byte loads and runs at ~2 TB/s of
+// output; this one is bound by the 16-byte stores.  Needs kh * Cin * W * sizeof(T) of LDS (21 KB for the 7x7 stride-4 stem).
+template <typename T>
+__global__ void __launch_bounds__(256) im2col_nchw_rows_kernel(const float* __restrict__ x, T* __restrict__ col, int64_t ldcol, int B,
+                                                                int H, int W, int Cin, int kh, int kw, int stride, int pad, int Ho,
+                                                                int Wo) {
+    extern __shared__ unsigned char im2col_lds[];
+    T* rows = reinterpret_cast<T*>(im2col_lds);                 // [ky][ci][W]
+    const int bo = xcd_block();
+    const int oy = bo % Ho, b = bo / Ho;
+    const int iy0 = oy * stride - pad;
+    const int nrow = kh * Cin;
+    for (int i = threadIdx.x; i < nrow * (W / 4); i += 256) {           // W % 4 == 0 (checked on the host)
+        const int rr = i / (W / 4), x4 = (i - rr * (W / 4)) * 4;
+        const int ky = rr / Cin, ci = rr - ky * Cin;
+        const int iy = iy0 + ky;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy >= 0 && iy < H) v = *reinterpret_cast<const float4*>(x + (((int64_t)b * Cin + ci) * H + iy) * W + x4);
+        T* dst = rows + (int64_t)rr * W + x4;
+        stf<T>(dst, v.x); stf<T>(dst + 1, v.y); stf<T>(dst + 2, v.z); stf<T>(dst + 3, v.w);
+    }
+    __syncthreads();
+    const int nch = (int)(ldcol / 8), K = kh * kw * Cin;
+    T* out = col + ((int64_t)b * Ho + oy) * Wo * ldcol;
+    for (int i = threadIdx.x; i < Wo * nch; i += 256) {
+        const int ox = i / nch, ch = i - ox * nch;
+        const int ix0 = ox * stride - pad;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kcol = ch * 8 + j;
+            const int kk = kcol / Cin, ci = kcol - kk * Cin;
+            const int ky = kk / kw, kx = kk - ky * kw;
+            const int ix = ix0 + kx;
+            const bool ok = kcol < K && ix >= 0 && ix < W;
+            v[j] = ok ? ldf<T>(rows + (int64_t)(ky * Cin + ci) * W + ix) : 0.f;
+        }
+        store8<T>(out + (int64_t)ox * ldcol + ch * 8, v);
+    }
+}
 // pad columns [K, ldcol) of the NHWC im2col matrix
 template <typename T>
 __global__ void zero_cols_kernel(T* __restrict__ col, int64_t ldcol, int64_t rows, int k0) {
@@ -589,6 +631,16 @@ extern "C" int segf_im2col(int dt, int in_nchw_f32, int B, int H, int W, int Cin
     if (in_nchw_f32) {
         const int64_t esz0 = dt == SEGF_BF16 ? 2 : 4;
         if (ldcol % 8 || ((uintptr_t)col % 16) || ((ldcol * esz0) % 16)) return SEGF_ERR_SHAPE;
+        const int64_t lds_bytes = (int64_t)kh * Cin * W * esz0;
+        if (W % 4 == 0 && ((uintptr_t)x % 16) == 0 && lds_bytes <= 64 * 1024 && (int64_t)B * Ho <= 0x7fffffff &&
+            !getenv("SEGFAC_IM2COL_GATHER")) {
+            SEGF_DISPATCH_DT(dt, T, {
+                hipLaunchKernelGGL((im2col_nchw_rows_kernel<T>), dim3((unsigned)(B * Ho)), dim3(256), (size_t)lds_bytes, st,
+                                   (const float*)x, (T*)col, ldcol, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
+            })
+            SEGF_CHECK_LAUNCH();
+            return 0;
+        }
         const int blocks = colfixed_blocks(rows, (int)(ldcol / 8), 4, 16384);
         SEGF_DISPATCH_DT(dt, T, {
             hipLaunchKernelGGL((im2col_nchw_kernel<T>), dim3(blocks), dim3(256), 0, st, (const float*)x, (T*)col, ldcol, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
