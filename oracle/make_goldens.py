@@ -218,6 +218,48 @@ def train_loop_case():
     np.savez_compressed(os.path.join(OUT, 'train_loop_segformer_b0.npz'), **out)
 
 
+def train_overfit_case():
+    """SURVEY.md Appendix D `train_loop_overfit` -- the mIoU-parity fixture on DECISIVE logits: the reference's
+    engine.train_one_epoch (engine.py:18-70) run for 6 epochs x 10 steps of AdamW on one learnable batch (labels = block
+    pattern, image colour = function of the label), then engine.evaluate (engine.py:74-104) + Metrics.compute_iou
+    (util/metrics.py:30-35) on the training batch and on a held-out batch drawn the same way."""
+    ref = ref_shim.load()
+    backbone, head, nc, B, H, Wd, seed, epochs, per_epoch, lr, wd = 'MiT-B0', 'SegFormerHead', 8, 4, 128, 128, 2468, 6, 10, 1e-3, 0.01
+    sd = OW.make_state_dict(backbone, head, nc, seed, lively=True)
+    x, y = OW.learnable_batch(B, H, Wd, nc, seed)
+    xv, yv = OW.learnable_batch(B, H, Wd, nc, seed + 1)
+    model = ref_shim.build_reference_model(backbone, head, nc, sd)
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+    torch.cuda.synchronize = lambda *a, **k: None          # engine.py:56 (quirk Q14)
+    losses = []
+
+    class Rec:
+        def add_scalar(self, name, v, it=None):
+            if name == 'train_loss':
+                losses.append(float(v))
+    args = types.SimpleNamespace(nb_classes=nc, dice=True, ignore_index=255, ignore_label=255, local_rank=0, device='cpu')
+    out = dict(backbone=backbone, head=head, nc=nc, B=B, H=H, W=Wd, seed=seed, epochs=epochs, per_epoch=per_epoch, lr=lr, wd=wd)
+    mious = []
+    for ep in range(epochs):
+        ref.engine.train_one_epoch(model, opt, [(x, y)] * per_epoch, ep, 'cpu', 1, None, None, _PlainScaler(), Rec(), args)
+        _, m = ref.engine.evaluate(args, model, [(x, y)], 'cpu', 1, None)
+        mious.append(m.compute_iou()[1])
+    for tag, (xe, ye) in (('train', (x, y)), ('heldout', (xv, yv))):
+        confmat, metric = ref.engine.evaluate(args, model, [(xe, ye)], 'cpu', 1, None)
+        out[f'mat_{tag}'] = confmat.mat.numpy()
+        out[f'hist_{tag}'] = metric.hist.numpy()
+        out[f'iou_{tag}'] = np.array(metric.compute_iou()[0])
+        out[f'miou_{tag}'] = metric.compute_iou()[1]
+        out[f'mf1_{tag}'] = metric.compute_f1()[1]
+        out[f'macc_{tag}'] = metric.compute_pixel_acc()[1]
+    out['losses'] = np.array(losses)
+    out['miou_per_epoch'] = np.array(mious)
+    print('[train_overfit] losses', losses[:4], '...', losses[-1], 'mIoU/epoch', mious, 'final train', out['miou_train'],
+          'held-out', out['miou_heldout'])
+    assert out['miou_train'] > 99.0 and out['miou_heldout'] > 95.0       # the logits must be decisive for the fixture to mean anything
+    np.savez_compressed(os.path.join(OUT, 'train_overfit_segformer_b0.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -230,6 +272,7 @@ def main():
     e2e_case('convnext_uper_64', 'ConvNeXt', 'UPerHead', 19, 2, 64, 64)
     e2e_case('convnextv2_tiny_uper_64', 'convnextv2_tiny', 'UPerHead', 19, 2, 64, 64)
     train_loop_case()
+    train_overfit_case()
     print('goldens written to', OUT)
 
 

@@ -316,3 +316,20 @@ def synthetic_batch(batch: int, height: int, width: int, nc: int, seed: int = 12
     lbl[:, :band] = ignore_index
     lbl[rng.random((batch, height, width)) < ignore_frac] = ignore_index
     return torch.from_numpy(img), torch.from_numpy(lbl)
+
+
+def learnable_batch(batch: int, height: int, width: int, nc: int, seed: int = 1234, block: int = 16,
+                    ignore_index: int = 255, noise: float = 0.15):
+    """SURVEY.md section 8(d) / Appendix D `train_loop_overfit`: labels are a block pattern (block x block pixels per
+    cell, classes drawn per cell) and the image colour is a fixed function of the label (one RGB code per class) plus
+    noise, so a model can fit it and the logits become decisive.  Top band ignored (255) like synthetic_batch."""
+    rng = np.random.default_rng(seed)
+    gh, gw = (height + block - 1) // block, (width + block - 1) // block
+    coarse = rng.integers(0, nc, (batch, gh, gw), dtype=np.int64)
+    lbl = np.repeat(np.repeat(coarse, block, axis=1), block, axis=2)[:, :height, :width].copy()
+    codes = np.random.default_rng(977).uniform(-1.5, 1.5, (nc, 3)).astype(np.float32)       # class -> RGB code
+    img = codes[lbl].transpose(0, 3, 1, 2).copy()
+    img += rng.standard_normal(img.shape, dtype=np.float32) * noise
+    band = min(8, max(1, height // 16))
+    lbl[:, :band] = ignore_index
+    return torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)), torch.from_numpy(lbl)

@@ -55,10 +55,18 @@ class GraphedTrainStep:
         broadcast_flat_(self.opt.flat_params, 0, self.group)     # DDP's initial parameter broadcast from rank 0
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        # the warm-up passes run real train-mode forwards: snapshot every buffer (BatchNorm running_mean / running_var /
+        # num_batches_tracked) and put it back afterwards, so that the graphed path leaves the same eval-time statistics and
+        # checkpoint contents as the eager path and the reference (one momentum update per optimisation step, engine.py:41)
         with torch.cuda.stream(s):
+            saved_buffers = [(b, b.detach().clone()) for b in self.model.buffers()]
             for _ in range(warmup):             # allocator / lazy-init warm-up on a side stream (no optimizer step)
                 self.opt.zero_grad(set_to_none=True)
                 self.loss_fn(self.model, *self.static_inputs).backward()
+            with torch.no_grad():
+                for b, keep in saved_buffers:
+                    b.copy_(keep)
+            del saved_buffers
         torch.cuda.current_stream().wait_stream(s)
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
