@@ -200,6 +200,11 @@ int segf_upsample_add_stats(int dt, int B, int H, int W, int C, const void* base
                             float* sums, float* ws, void* stream);
 int segf_bn_stats_from_sums(const float* sums, int64_t rows, int C, float* mean, float* rstd, float* running_mean,
                             float* running_var, float momentum, float eps, void* stream);
+/* Nearest-neighbour upsampling by an integer factor on dense NHWC (F.interpolate mode='nearest': the top-down step of FPNHead,
+ * heads/fpn.py:31,35).  bwd=0: out[B][H][W][C] = in[B][h][w][C] replicated (+ base[B][H][W][C], nullable: the `out + lateral`
+ * of fpn.py:34 fused); bwd=1: out[B][h][w][C] = block sums of in[B][H][W][C].  H % h == 0, W % w == 0, C % 8 == 0. */
+int segf_nearest_up(int dt, int bwd, int B, int h, int w, int C, int H, int W, const void* in, const void* base, void* out,
+                    void* stream);
 /* out (fp32 NCHW [B][C][H][W]) = bilinear(in NHWC [B][h][w][ldi]) -- materialised logits for API parity */
 int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, const void* in, int64_t ldi,
                               int H, int W, float* out, void* stream);

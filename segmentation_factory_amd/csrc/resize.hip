@@ -511,3 +511,60 @@ extern "C" int segf_adaptive_avgpool(int dt, int bwd, int B, int H, int W, int C
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- nearest-neighbour upsampling by an integer factor on NHWC (F.interpolate mode='nearest', heads/fpn.py:31,35): the
+// top-down step of FPNHead, `out = nearest(out, size of lateral)`, `out = out + lateral`, `out = nearest(out, x2)`.
+// Forward (bwd=0): out[b][Y][X] = in[b][Y / ry][X / rx] (+ base[b][Y][X] when base != NULL); ry = H / h, rx = W / w exact.
+// Backward (bwd=1): out[b][y][x] = sum of in[b][y*ry .. y*ry+ry)[x*rx .. x*rx+rx) (gather form, deterministic).
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) nearest_up_kernel(const T* __restrict__ in, const T* __restrict__ base, T* __restrict__ out,
+                                                          int B, int h, int w, int C, int H, int W) {
+    const int nch = C / 8, ry = H / h, rx = W / w;
+    const int oh = BWD ? h : H, ow = BWD ? w : W;
+    const int64_t total = (int64_t)B * oh * ow * nch;
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(idx % nch) * 8;
+        int64_t t = idx / nch;
+        const int X = (int)(t % ow); t /= ow;
+        const int Y = (int)(t % oh);
+        const int64_t b = t / oh;
+        float acc[8];
+        if (!BWD) {
+            load8<T>(in + ((b * h + Y / ry) * w + X / rx) * C + c0, acc);
+            if (base) {
+                float v[8];
+                load8<T>(base + ((b * H + Y) * W + X) * C + c0, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            for (int dy = 0; dy < ry; ++dy)
+                for (int dx = 0; dx < rx; ++dx) {
+                    float v[8];
+                    load8<T>(in + ((b * H + Y * ry + dy) * W + X * rx + dx) * C + c0, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                }
+        }
+        store8<T>(out + ((b * oh + Y) * ow + X) * C + c0, acc);
+    }
+}
+
+extern "C" int segf_nearest_up(int dt, int bwd, int B, int h, int w, int C, int H, int W, const void* in, const void* base,
+                               void* out, void* stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return 0;
+    if (C % 8 != 0 || H < h || W < w || H % h != 0 || W % w != 0) return SEGF_ERR_SHAPE;
+    if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)base) % 16 != 0) return SEGF_ERR_SHAPE;
+    if (bwd && base) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * (bwd ? h : H) * (bwd ? w : W) * (C / 8);
+    const int blocks = (int)imin64(cdiv64(total, 256), 8192);
+    SEGF_DISPATCH_DT(dt, T, {
+        if (bwd) hipLaunchKernelGGL((nearest_up_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)nullptr, (T*)out, B, h, w, C, H, W);
+        else hipLaunchKernelGGL((nearest_up_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, C, H, W);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

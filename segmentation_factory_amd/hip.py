@@ -62,6 +62,7 @@ _PROTOS = {
     'segf_col2im': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p]),
     'segf_bilinear_fwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
     'segf_bilinear_bwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
+    'segf_nearest_up': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     'segf_upsample_add': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p]),
     'segf_upsample_add_stats_ws': (_l, [_i, _i, _i, _i]),
     'segf_upsample_add_stats': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p, _p, _p]),
@@ -507,6 +508,16 @@ def bilinear_bwd(dout, B, h, w, Cc, H, W, align_corners=False, ld_in=None):
     _chk(lib().segf_bilinear_bwd(dt_of(dout), B, h, w, Cc, _ptr(din), ld_in, H, W, _ptr(dout), dout.stride(0),
                                  int(align_corners), _stream()), 'segf_bilinear_bwd')
     return din
+
+
+def nearest_up(x, B, h, w, Cc, H, W, base=None, bwd=False):
+    """bwd=False: x [B*h*w, C] -> [B*H*W, C] replicated by the integer factors H/h, W/w (+ base); bwd=True: x = dout [B*H*W, C]
+    -> block sums [B*h*w, C]."""
+    _need_cuda(x, base)
+    assert x.is_contiguous() and (base is None or base.is_contiguous())
+    out = torch.empty(((B * h * w) if bwd else (B * H * W), Cc), dtype=x.dtype, device=x.device)
+    _chk(lib().segf_nearest_up(dt_of(x), int(bwd), B, h, w, Cc, H, W, _ptr(x), _ptr(base), _ptr(out), _stream()), 'segf_nearest_up')
+    return out
 
 
 def upsample_add(base, srcs, B, H, W, Cc, align_corners=False):
