@@ -31,7 +31,10 @@ def sample_indices(name, numel, k=SAMPLES_PER_TENSOR):
     return np.random.default_rng(seed).integers(0, numel, k)
 
 
-def e2e_case(tag, backbone, head, nc, B, H, Wd, seed=1234, dice=True):
+def e2e_case(tag, backbone, head, nc, B, H, Wd, seed=1234, dice=True, compact=False):
+    """compact=True (fixtures at sizes where the full-resolution logits would be several MB): the stored logits are the
+    reference's HEAD OUTPUT (captured with a forward hook on model.decode_head, i.e. before build_models.py:65's resize) plus a
+    strided sample of the full-resolution eval logits (rows 1::4, columns 2::4)."""
     ref = ref_shim.load()
     sd = OW.make_state_dict(backbone, head, nc, seed)
     x, y = OW.synthetic_batch(B, H, Wd, nc, seed)
@@ -43,6 +46,8 @@ def e2e_case(tag, backbone, head, nc, B, H, Wd, seed=1234, dice=True):
         assert tuple(rsd[k].shape) == tuple(sd[k].shape), (k, rsd[k].shape, sd[k].shape)
 
     out = {'backbone': backbone, 'head': head, 'nc': nc, 'B': B, 'H': H, 'W': Wd, 'seed': seed}
+    captured = []
+    hook = model.decode_head.register_forward_hook(lambda mod, inp, o: captured.append(o.detach().clone()))
     # eval-mode logits
     model.eval()
     with torch.no_grad():
@@ -51,7 +56,11 @@ def e2e_case(tag, backbone, head, nc, B, H, Wd, seed=1234, dice=True):
     e = rel_err(o_eval, logits_eval)
     print(f'[{tag}] eval logits oracle-vs-ref rel err {e:.2e}')
     assert e < 2e-5, e
-    out['logits_eval'] = logits_eval.numpy()
+    if compact:
+        out['lowres_eval'] = captured[-1].numpy()
+        out['logits_eval_sub'] = logits_eval[:, :, 1::4, 2::4].contiguous().numpy()
+    else:
+        out['logits_eval'] = logits_eval.numpy()
 
     # train-mode forward + criterion + backward
     model.train()
@@ -71,7 +80,11 @@ def e2e_case(tag, backbone, head, nc, B, H, Wd, seed=1234, dice=True):
     e = rel_err(o_tr.detach(), logits.detach())
     print(f'[{tag}] train logits rel err {e:.2e}; loss ref {loss.item():.6f} oracle {l2.item():.6f}')
     assert e < 2e-5 and abs(loss.item() - l2.item()) < 2e-5 * max(1, abs(loss.item()))
-    out['logits_train'] = logits.detach().numpy()
+    if compact:
+        out['lowres_train'] = captured[-1].numpy()
+    else:
+        out['logits_train'] = logits.detach().numpy()
+    hook.remove()
     out['loss'] = np.float64(loss.item())
     names, norms, samp = [], [], []
     worst = 0.
@@ -271,6 +284,10 @@ def main():
     e2e_case('mbv2_fpn_64', 'MobileNetV2', 'FPNHead', 21, 2, 64, 64)
     e2e_case('convnext_uper_64', 'ConvNeXt', 'UPerHead', 19, 2, 64, 64)
     e2e_case('convnextv2_tiny_uper_64', 'convnextv2_tiny', 'UPerHead', 19, 2, 64, 64)
+    # BatchNorm-well-conditioned sizes (>= 128 x 128, batch 4: every BatchNorm sees >= 64 samples except PPM's pooled maps)
+    e2e_case('convnext_uper_128', 'ConvNeXt', 'UPerHead', 19, 4, 128, 128, seed=77, compact=True)
+    e2e_case('convnextv2_tiny_uper_128', 'convnextv2_tiny', 'UPerHead', 19, 4, 128, 128, seed=78, compact=True)
+    e2e_case('mbv2_fpn_128', 'MobileNetV2', 'FPNHead', 21, 2, 128, 128, seed=79, compact=True)
     train_loop_case()
     train_overfit_case()
     print('goldens written to', OUT)

@@ -9,7 +9,8 @@ import torch
 from torch import nn
 
 from . import functional as Fh
-from .containers import ChannelsFirstLayerNormWeights, ConvWeights, LayerNormWeights, LinearWeights, init_mit_style
+from .containers import (BatchNormWeights, ChannelsFirstLayerNormWeights, ConvWeights, LayerNormWeights, LinearWeights,
+                         init_mit_style)
 
 # reference models/backbones/mit.py:149-156
 mit_settings = {
@@ -392,3 +393,93 @@ def convnextv2_large(**kw):
 
 def convnextv2_huge(**kw):
     return ConvNeXtV2(depths=[3, 3, 27, 3], dims=[352, 704, 1408, 2816], drop_path_rate=0.5, **kw)
+
+
+# ---- MobileNetV2 (models/backbones/mobilenetv2.py) ------------------------------------------------------------------------
+def _bn_act(x, bn, training, act):
+    """BatchNorm2d (+ReLU6) of mobilenetv2.ConvModule (mobilenetv2.py:5-11) / the bare BatchNorm2d of :29."""
+    y = Fh.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, act=act)
+    if training:
+        bn.num_batches_tracked += 1
+    return y
+
+
+class MBConvModule(nn.Sequential):
+    """Conv2d(bias=False) + BatchNorm2d + ReLU6 with the reference's keys `<name>.0.weight`, `<name>.1.*`
+    (mobilenetv2.py:5-11; the ReLU6 at index 2 has no parameters)."""
+
+    def __init__(self, c1, c2, k, s=1, p=0, g=1):
+        super().__init__(ConvWeights(c1, c2, k, s, p, 1, g, bias=False), BatchNormWeights(c2))
+        self.k, self.s, self.g = k, s, g
+
+
+class InvertedResidual(nn.Module):
+    """mobilenetv2.py:14-37: [1x1 expand + BN + ReLU6] -> 3x3 depthwise (stride s) + BN + ReLU6 -> 1x1 project + BN
+    (+ residual when s == 1 and c1 == c2)."""
+
+    def __init__(self, c1, c2, s, expand_ratio):
+        super().__init__()
+        ch = int(round(c1 * expand_ratio))
+        self.use_res_connect = s == 1 and c1 == c2
+        self.stride, self.ch, self.expand = s, ch, expand_ratio != 1
+        layers = []
+        if self.expand:
+            layers.append(MBConvModule(c1, ch, 1))
+        layers.extend([MBConvModule(ch, ch, 3, s, 1, g=ch), ConvWeights(ch, c2, 1, bias=False), BatchNormWeights(c2)])
+        self.conv = nn.Sequential(*layers)
+
+    def tokens(self, x, B, H, W, training):
+        h, li = x, 0
+        if self.expand:
+            m = self.conv[li]
+            h = _bn_act(Fh.linear(h, m[0].weight), m[1], training, 2)
+            li += 1
+        m = self.conv[li]
+        h = Fh.dwconv3x3_gelu(h, m[0].weight, None, B, H, W, False)           # depthwise 3x3, pad 1, no bias, no GELU
+        if self.stride > 1:
+            h = Fh.subsample(h, B, H, W, self.stride)
+            H, W = (H - 1) // self.stride + 1, (W - 1) // self.stride + 1
+        h = _bn_act(h, m[1], training, 2)
+        h = _bn_act(Fh.linear(h, self.conv[li + 1].weight), self.conv[li + 2], training, 0)
+        return (Fh.add(x, h) if self.use_res_connect else h), H, W
+
+
+class MobileNetV2(nn.Module):
+    """models/backbones/mobilenetv2.py:45-92 (width 1.0): Conv-BN-ReLU6 stem + 17 inverted residuals, feature taps after
+    features 3, 6, 13, 17 -> channels [24, 32, 96, 320] at strides 4 / 8 / 16 / 32."""
+
+    def __init__(self, variant: str = None):
+        super().__init__()
+        self.out_indices = [3, 6, 13, 17]
+        self.channels = [24, 32, 96, 320]
+        self.compute_dtype = torch.bfloat16
+        input_channel = 32
+        setting = [[1, 16, 1, 1], [6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1], [6, 160, 3, 2], [6, 320, 1, 1]]   # t, c, n, s
+        self.features = nn.ModuleList([MBConvModule(3, input_channel, 3, 2, 1)])
+        for t, c, n, s in setting:
+            for i in range(n):
+                self.features.append(InvertedResidual(input_channel, c, s if i == 0 else 1, t))
+                input_channel = c
+        for m in self.modules():                                # mobilenetv2.py:68-79
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward_tokens(self, x):
+        B, _, H, W = x.shape
+        tr = self.training
+        stem = self.features[0]
+        t = Fh.conv_patch(x, stem[0].weight, None, (B, H, W, 3, 3, 2, 1), image=True, dtype=self.compute_dtype)
+        H, W = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        t = _bn_act(t, stem[1], tr, 2)
+        outs = []
+        for i in range(1, len(self.features)):
+            t, H, W = self.features[i].tokens(t, B, H, W, tr)
+            if i in self.out_indices:
+                outs.append(TokenMap(t, B, H, W))
+        return outs
+
+    def forward(self, x):
+        return [tm.nchw() for tm in self.forward_tokens(x)]

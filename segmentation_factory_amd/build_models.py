@@ -16,11 +16,12 @@ from . import heads as _heads
 from .backbones import TokenMap, tokens_from_nchw
 
 # name -> constructor; the reference resolves names with eval() over models.backbones' namespace (:25-29)
-backbone_registry = {'MiT': _backbones.MiT, 'ConvNeXt': _backbones.ConvNeXt, 'ConvNeXtV2': _backbones.ConvNeXtV2}
+backbone_registry = {'MiT': _backbones.MiT, 'ConvNeXt': _backbones.ConvNeXt, 'ConvNeXtV2': _backbones.ConvNeXtV2,
+                     'MobileNetV2': _backbones.MobileNetV2}
 backbone_registry.update({n: getattr(_backbones, n) for n in (
     'convnextv2_atto', 'convnextv2_femto', 'convnext_pico', 'convnextv2_nano', 'convnextv2_tiny', 'convnextv2_base',
     'convnextv2_large', 'convnextv2_huge')})
-head_dict = {'SegFormerHead': _heads.SegFormerHead, 'UPerHead': _heads.UPerHead}
+head_dict = {'SegFormerHead': _heads.SegFormerHead, 'UPerHead': _heads.UPerHead, 'FPNHead': _heads.FPNHead}
 
 
 def register_backbone(name, ctor):

@@ -693,6 +693,73 @@ def resize_concat(feats, geoms, aligns, size):
     return ResizeConcatFn.apply(tuple(geoms), tuple(aligns), tuple(size), *feats)
 
 
+class AddFn(Function):
+    """x + y on token rows (the residual of mobilenetv2.InvertedResidual, mobilenetv2.py:33-35)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return hip.add(_rowmajor(a), _rowmajor(b))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class SubsampleFn(Function):
+    """x[:, ::s, ::s, :] on NHWC tokens, rows (oy, ox) <- (s*oy, s*ox): a stride-s convolution with padding 1 and kernel 3 equals
+    the stride-1 convolution sampled at every s-th position, which is how MobileNetV2's four stride-2 depthwise layers
+    (mobilenetv2.py:27, ConvModule(ch, ch, 3, s, 1, g=ch)) run on the stride-1 depthwise kernel.  Forward = im2col with a 1x1
+    window, backward = its col2im."""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W, stride):
+        x = x if x.is_contiguous() else x.contiguous()
+        Cc = x.shape[1]
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        ctx.meta = (B, H, W, Cc, stride, Ho, Wo)
+        return hip.im2col(x, x.dtype, False, B, H, W, Cc, 1, 1, stride, 0, Ho, Wo, Cc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Cc, stride, Ho, Wo = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        return hip.col2im(dy, B, H, W, Cc, 1, 1, stride, 0, Ho, Wo), None, None, None, None
+
+
+def subsample(x, B, H, W, stride):
+    return SubsampleFn.apply(x, B, H, W, stride)
+
+
+class NearestUpFn(Function):
+    """F.interpolate(x, mode='nearest') by integer factors (+ base): heads/fpn.py:31 (`size=`), :34-35 (`out + lateral`, then
+    `scale_factor=2.0`)."""
+
+    @staticmethod
+    def forward(ctx, x, base, geom):
+        B, h, w, H, W = geom
+        x = x if x.is_contiguous() else x.contiguous()
+        if base is not None:
+            base = base if base.is_contiguous() else base.contiguous()
+        ctx.meta = (geom, x.shape[1], base is not None)
+        return hip.nearest_up(x, B, h, w, x.shape[1], H, W, base=base)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (B, h, w, H, W), Cc, has_base = ctx.meta
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        dx = hip.nearest_up(dy, B, h, w, Cc, H, W, bwd=True) if ctx.needs_input_grad[0] else None
+        return dx, (dy if has_base else None), None
+
+
+def nearest_up(x, geom, base=None):
+    """geom = (B, h, w, H, W)."""
+    return NearestUpFn.apply(x, base, tuple(geom))
+
+
 class UpsampleCEDiceFn(Function):
     """criterion(F.interpolate(logits, size), target): build_models.py:65 + engine.py:10-15 +
     util/losses.py:126-177, without materialising full-resolution logits in the forward."""

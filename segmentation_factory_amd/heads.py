@@ -8,7 +8,7 @@ from . import functional as Fh
 from .backbones import TokenMap, tokens_from_nchw
 from .containers import BatchNormWeights, ConvWeights, LinearWeights
 
-__all__ = ['SegFormerHead', 'UPerHead']
+__all__ = ['SegFormerHead', 'UPerHead', 'FPNHead']
 
 DROPOUT2D_P = 0.1
 
@@ -167,6 +167,72 @@ class UPerHead(nn.Module):
         x = _bn_relu(Fh.conv3x3(cat, conv.weight, B, H1, W1), bn, tr, chan_scale=drop, rows_per_sample=H1 * W1)
         logits = Fh.linear(x, self.conv_seg.weight, self.conv_seg.bias, pad_to=(nc + 7) // 8 * 8)
         return TokenMap(logits, B, H1, W1)
+
+    def forward(self, features):
+        tms = [f if isinstance(f, TokenMap) else tokens_from_nchw(f, self.compute_dtype) for f in features]
+        return self.forward_tokens(tms).nchw()
+
+
+class FPNHead(nn.Module):
+    """Panoptic-FPN head (models/heads/fpn.py:9-38): 1x1 lateral ConvModules on the reversed features, nearest-neighbour
+    top-down path, one 3x3 ConvModule per merge, Dropout2d(0.1), 1x1 classifier at stride 2 of the finest feature.
+
+    Quirk Q3 reproduced: the reference EVALUATES `lateral_convs[i](features[i])` once more for the shape test (fpn.py:30) and
+    again for the `size=` argument when the shapes differ (:31) before the value that is used (:34), so in training the
+    lateral BatchNorms' running statistics advance 2 or 3 momentum steps per forward (`num_batches_tracked` likewise);
+    `output_convs[0]` is constructed but never called (its parameters get no gradient)."""
+
+    def __init__(self, in_channels, channel=128, num_classes=19):
+        super().__init__()
+        self.lateral_convs = nn.ModuleList([])
+        self.output_convs = nn.ModuleList([])
+        for ch in in_channels[::-1]:
+            self.lateral_convs.append(_conv_module(ch, channel, 1))
+            self.output_convs.append(_conv_module(channel, channel, 3, 1, 1))
+        self.conv_seg = ConvWeights(channel, num_classes, 1)
+        self.dropout = nn.Dropout2d(DROPOUT2D_P)
+        self.embed_dim, self.num_classes = channel, num_classes
+        self.compute_dtype = torch.bfloat16
+        self.stochastic_override = None               # tests: {'dropout2d': keep[B, channel]}
+
+    def _lateral(self, i, f: TokenMap, evaluations):
+        conv, bn = self.lateral_convs[i][0], self.lateral_convs[i][1]
+        z = Fh.linear(f.data, conv.weight)
+        if self.training:
+            with torch.no_grad():                      # the discarded evaluations: same batch statistics, extra momentum steps
+                for _ in range(evaluations - 1):
+                    Fh.hip.bn_stats(z.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+                    bn.num_batches_tracked += 1
+        return _bn_relu(z, bn, self.training)
+
+    def forward_tokens(self, feats):
+        feats = feats[::-1]
+        B = feats[0].B
+        ch, nc = self.embed_dim, self.num_classes
+        out = self._lateral(0, feats[0], 1)
+        H, W = feats[0].H, feats[0].W
+        n = len(feats)
+        x = None
+        for i in range(1, n):
+            f = feats[i]
+            resized = (f.H, f.W) != (H, W)
+            lat = self._lateral(i, f, 3 if resized else 2)
+            if resized:                                                        # fpn.py:30-31: nearest to the lateral's size
+                out = Fh.nearest_up(out, (B, H, W, f.H, f.W), base=lat)        # ... and fpn.py:34: out + lateral, fused
+            else:
+                out = Fh.add(out, lat)
+            H, W = f.H, f.W
+            out = Fh.nearest_up(out, (B, H, W, 2 * H, 2 * W))                  # fpn.py:35: scale_factor=2.0
+            H, W = 2 * H, 2 * W
+            conv, bn = self.output_convs[i][0], self.output_convs[i][1]
+            y = Fh.conv3x3(out, conv.weight, B, H, W)
+            if i == n - 1:                                                      # fpn.py:37: Dropout2d in front of the classifier
+                drop = dropout2d_scale(self.training and self.dropout.p > 0, B, ch, y.device, self.stochastic_override)
+                out = _bn_relu(y, bn, self.training, chan_scale=drop, rows_per_sample=H * W)
+            else:
+                out = _bn_relu(y, bn, self.training)
+        logits = Fh.linear(out, self.conv_seg.weight, self.conv_seg.bias, pad_to=(nc + 7) // 8 * 8)
+        return TokenMap(logits, B, H, W)
 
     def forward(self, features):
         tms = [f if isinstance(f, TokenMap) else tokens_from_nchw(f, self.compute_dtype) for f in features]
