@@ -248,9 +248,11 @@ class ConvNeXtBlock(nn.Module):
         self.dwconv = ConvWeights(dim, dim, 7, 1, 3, groups=dim)
         self.norm = LayerNormWeights(dim, eps=1e-6)
         self.pwconv1 = LinearWeights(dim, 4 * dim)
+        if v2:
+            self.grn = GRNWeights(4 * dim)           # registered between the linears, as in convnextv2.py:92-94 (state_dict order)
         self.pwconv2 = LinearWeights(4 * dim, dim)
         if v2:
-            self.grn = GRNWeights(4 * dim)
+            pass
         elif init_value > 0:
             self.gamma = nn.Parameter(init_value * torch.ones((dim)), requires_grad=True)
         self.drop_prob = float(dpr)

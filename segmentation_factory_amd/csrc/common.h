@@ -208,6 +208,17 @@ __device__ __forceinline__ void bilinear_src(int d, int in, int out, int align_c
     l = s - (float)i0;
 }
 
+// One bilinear sample in the operation order of ATen's CPU upsample_bilinear2d on a contiguous NCHW tensor (the reference's
+// evaluation path, build_models.py:65 on the CPU): four weight products wy*wx, then  v01*w01  and three fused multiply-adds
+// (v00, v10, v11).  Verified bit-identical against F.interpolate for power-of-two ratios and align_corners=True on small maps
+// (tests/test_kernels_gpu.py::test_argmax_tie_policy); ATen switches to differently associated vector loops for larger maps,
+// so beyond that this is "the same value up to the last fp32 rounding".  l = weight of the second tap (bilinear_src).
+__device__ __forceinline__ float bilinear_aten(float v00, float v01, float v10, float v11, float ly, float lx) {
+    const float wy0 = 1.f - ly, wx0 = 1.f - lx;
+    const float w00 = __fmul_rn(wy0, wx0), w01 = __fmul_rn(wy0, lx), w10 = __fmul_rn(ly, wx0), w11 = __fmul_rn(ly, lx);
+    return __fmaf_rn(v11, w11, __fmaf_rn(v10, w10, __fmaf_rn(v00, w00, __fmul_rn(v01, w01))));
+}
+
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) in ~13 branch-free instructions; libm's erff costs ~40 with two
 // divergent branches per element, which made the fused depthwise-conv + GELU kernels VALU-bound.  GELU only needs absolute
 // accuracy (gelu(x) = x/2 * (1 + erf(x/sqrt2))): the resulting error is <= 0.8e-7 * |x|.

@@ -46,7 +46,7 @@ __device__ __forceinline__ void load_tap(const T* __restrict__ p, int lane, int 
 }
 
 // z[s] = upsampled logit of class lane + 64*s at full-res pixel (Y, X); invalid class slots get -inf  (generic path)
-template <typename T, int NS>
+template <typename T, int NS, bool ATEN = false>
 __device__ __forceinline__ void pixel_logits(const T* __restrict__ img, const LossGeom& g, int Y, int X, int lane, float (&z)[NS]) {
     if (g.h == g.H && g.w == g.W) {
         const T* p = img + ((int64_t)Y * g.w + X) * g.ldl;
@@ -69,7 +69,8 @@ __device__ __forceinline__ void pixel_logits(const T* __restrict__ img, const Lo
     for (int s = 0; s < NS; ++s) {
         const int c = lane + 64 * s, ci = c < g.C ? c : g.C - 1;
         const float a = ldf<T>(p00 + ci), b = ldf<T>(p01 + ci), cc = ldf<T>(p10 + ci), d = ldf<T>(p11 + ci);
-        const float v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+        // ATEN (evaluation kernels): the operation order of the reference's CPU F.interpolate, so that arg max ties resolve alike
+        const float v = ATEN ? bilinear_aten(a, b, cc, d, ly, lx) : (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
         z[s] = c < g.C ? v : -INFINITY;
     }
 }
@@ -1178,6 +1179,9 @@ extern "C" int64_t segf_ce_dice_stats_floats(int B, int C) {
 
 #define LS_NS_DISPATCH(ns, CALL) do { if ((ns) == 1) { CALL(1); } else if ((ns) == 2) { CALL(2); } else { CALL(3); } } while (0)
 
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
 __global__ void zero_ints_kernel(int* p, int n) {
     if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
 }
@@ -1307,9 +1311,10 @@ extern "C" int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W
     const int64_t ldg = (C + 7) / 8 * 8;
     SEGF_DISPATCH_DT(dt, T, { bwd_generic_launch<T>(ns, dim3(LS_NBLK, B), st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)ws, ldg); })
     SEGF_CHECK_LAUNCH();
-    if (ldd > C) {
-        const hipError_t e = hipMemsetAsync(dlogits, 0, (size_t)B * h * w * ldd * (dt == SEGF_BF16 ? 2 : 4), st);
-        if (e != hipSuccess) return (int)e;
+    if (ldd > C) {      // a kernel node, not hipMemsetAsync: a captured memset node did not take effect in graph replay (see segf_ce_dice_fwd)
+        const int64_t nwords = ((int64_t)B * h * w * ldd * (dt == SEGF_BF16 ? 2 : 4) + 3) / 4;
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)imin64(cdiv64(nwords, 256), 4096)), dim3(256), 0, st, (uint32_t*)dlogits, nwords);
+        SEGF_CHECK_LAUNCH();
     }
     return segf_bilinear_bwd(dt, B, h, w, C, dlogits, ldd, H, W, ws, ldg, 0, stream);
 }
@@ -1364,24 +1369,23 @@ __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_cells_kernel(const 
         int codes = cell_label_codes(tg, g, sc, off, c.cj, c.ck, lane, INT64_MIN, &raw);
         if (codes == -2 && raw == ignore_label) codes = -3;
         int preds = 0;
+        // Tap weights as ATen's compute_source_index_and_lambda produces them: inside the image lambda1 = (a + 0.5) / sc (exact
+        // for the power-of-two ratios of this path); in the clamped top / left border cells (cj < 0 / ck < 0) the source index is
+        // clamped to 0, lambda1 = 0 and the first tap carries the whole weight; in the bottom / right border cells both taps are
+        // the last row / column and keep their fractional weights.  Value = bilinear_aten (ATen's operation order).
         for (int a = 0; a < sc; ++a) {
             const int Y = sc * c.cj + off + a;
             if (Y < 0 || Y >= g.H) continue;
-            const float ly = (a + 0.5f) * inv_sc * fhalo;
-            float L[NS], R[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                L[s] = (1.f - ly) * t00[s] + ly * t10[s];
-                R[s] = (1.f - ly) * t01[s] + ly * t11[s];
-            }
+            const float ly = c.cj < 0 ? 0.f : (a + 0.5f) * inv_sc * fhalo;
             for (int bb = 0; bb < sc; ++bb) {
                 const int t = __builtin_amdgcn_readlane(codes, a * sc + bb);     // wave-uniform
                 if (t == -1 || (t == -3 && !pred_out)) continue;
                 const int X = sc * c.ck + off + bb;
-                const float lx = (bb + 0.5f) * inv_sc * fhalo;
+                const float lx = c.ck < 0 ? 0.f : (bb + 0.5f) * inv_sc * fhalo;
                 float z[NS];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) z[s] = (lane + 64 * s) < g.C ? (1.f - lx) * L[s] + lx * R[s] : -INFINITY;
+                for (int s = 0; s < NS; ++s)
+                    z[s] = (lane + 64 * s) < g.C ? bilinear_aten(t00[s], t01[s], t10[s], t11[s], ly, lx) : -INFINITY;
                 const int best = wave_argmax<NS>(z, lane, g.C);
                 if (lane == a * sc + bb) preds = best;
             }
@@ -1417,7 +1421,7 @@ __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_kernel(const T* __r
         if (!pred_out && !(t >= 0 && t < g.C) && t == ignore_label) continue;
         const int Y = (int)(p / g.W), X = (int)(p - (int64_t)Y * g.W);
         float z[NS];
-        pixel_logits<T, NS>(img, g, Y, X, lane, z);
+        pixel_logits<T, NS, true>(img, g, Y, X, lane, z);
         const int best = wave_argmax<NS>(z, lane, g.C);
         if (lane == 0) {
             if (pred_out) pred_out[(int64_t)b * npix + p] = best;

@@ -181,14 +181,18 @@ template <typename T>
 static void ln_fwd_launch(int vpt, int blocks, hipStream_t st, const T* x, const float* gamma, const float* beta, T* y,
                           float* mean, float* rstd, int64_t rows, int C, float eps, int lpr_log2) {
 #define LN_F(V) hipLaunchKernelGGL((ln_fwd_kernel<T, V>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, C, eps, lpr_log2)
-    if (vpt == 1) LN_F(1); else if (vpt == 2) LN_F(2); else if (vpt == 3) LN_F(3); else LN_F(4);
+    if (vpt == 1) LN_F(1); else if (vpt == 2) LN_F(2); else if (vpt == 3) LN_F(3); else if (vpt == 4) LN_F(4); else if (vpt == 5) LN_F(5); else LN_F(6);
 #undef LN_F
 }
 template <typename T>
 static void ln_bwd_launch(int vpt, int blocks, size_t shm, hipStream_t st, const T* x, const T* dy, const float* gamma,
                           const float* mean, const float* rstd, T* dx, float* ws, int64_t rows, int C, int lpr_log2) {
 #define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, gamma, mean, rstd, dx, ws, rows, C, lpr_log2)
-    if (vpt == 1) LN_B(1); else if (vpt == 2) LN_B(2); else if (vpt == 3) LN_B(3); else LN_B(4);
+    // C in (2048, 3072] (convnextv2_huge's 2816-wide last stage): six chunks per lane and 96 KB of dynamic LDS -- above the 64 KB
+    // a kernel gets by default, so the limit is raised on the function first (160 KB per CU on gfx950)
+#define LN_B_BIG(V) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); LN_B(V); } while (0)
+    if (vpt == 1) LN_B(1); else if (vpt == 2) LN_B(2); else if (vpt == 3) LN_B(3); else if (vpt == 4) LN_B(4); else if (vpt == 5) LN_B_BIG(5); else LN_B_BIG(6);
+#undef LN_B_BIG
 #undef LN_B
 }
 
@@ -202,7 +206,7 @@ static inline int ln_plan(int C, int& lpr_log2) {
 extern "C" int segf_layernorm_fwd(int dt, int64_t rows, int C, const void* x, const float* gamma, const float* beta,
                                   float eps, void* y, float* mean, float* rstd, void* stream) {
     if (rows <= 0) return 0;
-    if (C <= 0 || C % 8 != 0 || C > 2048) return SEGF_ERR_SHAPE;
+    if (C <= 0 || C % 8 != 0 || C > 3072) return SEGF_ERR_SHAPE;
     if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)gamma % 16) || ((uintptr_t)beta % 16)) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     int lpr_log2;
@@ -226,7 +230,7 @@ extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, co
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                   float* ws, void* stream) {
     if (rows <= 0) return 0;
-    if (C <= 0 || C % 8 != 0 || C > 2048) return SEGF_ERR_SHAPE;
+    if (C <= 0 || C % 8 != 0 || C > 3072) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
     if (dbeta != dgamma + C) return SEGF_ERR_SHAPE;   // dgamma and dbeta are one [2][C] fp32 buffer
     hipStream_t st = (hipStream_t)stream;

@@ -431,7 +431,7 @@ __global__ void bilinear_to_nchw_kernel(const T* __restrict__ in, int64_t ldi, f
         const T* base = in + b * h * w * ldi + c;
         const float v00 = ldf<T>(base + ((int64_t)y0 * w + x0) * ldi), v01 = ldf<T>(base + ((int64_t)y0 * w + x1) * ldi);
         const float v10 = ldf<T>(base + ((int64_t)y1 * w + x0) * ldi), v11 = ldf<T>(base + ((int64_t)y1 * w + x1) * ldi);
-        out[idx] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        out[idx] = bilinear_aten(v00, v01, v10, v11, ly, lx);
     }
 }
 

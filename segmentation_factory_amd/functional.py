@@ -768,6 +768,16 @@ class UpsampleCEDiceFn(Function):
     def forward(ctx, logits, target, geom, ignore_index, class_weight, dice):
         B, Cc, h, w, H, W = geom
         logits = _rowmajor(logits)
+        # the kernel reads `target` as int64 [B, H, W] on the device: anything else would be silently reinterpreted
+        # (F.cross_entropy raises for non-Long targets, engine.py:12)
+        if not target.is_cuda or target.device != logits.device:
+            raise RuntimeError('criterion: target must be a device tensor on the logits\' device (no CPU fallback)')
+        if target.dtype != torch.int64:
+            raise RuntimeError(f'criterion: expected an int64 (Long) target, got {target.dtype}')
+        if target.numel() != B * H * W:
+            raise RuntimeError(f'criterion: target has {target.numel()} elements, expected B*H*W = {B * H * W}')
+        if logits.shape[0] != B * h * w or logits.shape[1] < Cc:
+            raise RuntimeError(f'criterion: logits {tuple(logits.shape)} do not match geometry {geom}')
         target = target.contiguous()
         loss, stats = hip.ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice)
         ctx.save_for_backward(logits, target, stats, class_weight)

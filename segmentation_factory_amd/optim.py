@@ -89,6 +89,15 @@ class FusedAGCAdamW(torch.optim.Optimizer):
     def apply_flat(self):
         """AGC + AdamW over the flat buffers: one kernel launch (bias corrections are host scalars of this step)."""
         g = self.param_groups[0]
+        # one kernel over the flat buffer: lr / betas / eps are launch scalars and weight decay is an on/off flag per unit, so
+        # every group must agree on them (timm's param_groups_weight_decay gives exactly {0, wd}); anything else would be
+        # silently ignored
+        for pg in self.param_groups[1:]:
+            if (pg['lr'], tuple(pg['betas']), pg['eps']) != (g['lr'], tuple(g['betas']), g['eps']):
+                raise NotImplementedError('FusedAGCAdamW: all parameter groups must share lr / betas / eps')
+        wds = {pg['weight_decay'] for pg in self.param_groups if pg['weight_decay'] > 0}
+        if len(wds) > 1:
+            raise NotImplementedError(f'FusedAGCAdamW: one non-zero weight decay for all decayed groups, got {sorted(wds)}')
         wd = max(pg['weight_decay'] for pg in self.param_groups)
         self._step += 1
         hip.agc_adamw(self._flat, self._grad, self._m, self._v, self._off, self._len, self._flags, g['lr'], g['betas'][0],
@@ -99,21 +108,61 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         self.gather_grads()
         self.apply_flat()
 
+    def _packed_ids(self):
+        ids, i = {}, 0
+        for g in self.param_groups:
+            for p in g['params']:
+                ids[id(p)] = i
+                i += 1
+        return ids
+
     def state_dict(self):
+        """torch.optim.AdamW's state_dict layout (per-parameter 'step' / 'exp_avg' / 'exp_avg_sq' under packed indices), so the
+        checkpoint's 'optimizer_state' (train_gpu.py:354-362) can be read back by torch.optim.AdamW / timm's AdamW and vice versa."""
         sd = super().state_dict()
-        sd['fused'] = dict(step=self._step, exp_avg=None if self._flat is None else self._m.cpu(),
-                           exp_avg_sq=None if self._flat is None else self._v.cpu())
+        if self._flat is not None and self._step > 0:
+            ids = self._packed_ids()
+            state, o = {}, 0
+            for p in self._params:
+                n = p.numel()
+                state[ids[id(p)]] = {'step': torch.tensor(float(self._step)),
+                                     'exp_avg': self._m[o:o + n].view(p.shape).detach().cpu().clone(),
+                                     'exp_avg_sq': self._v[o:o + n].view(p.shape).detach().cpu().clone()}
+                o += n
+            sd['state'] = state
         return sd
 
     def load_state_dict(self, sd):
-        fused = sd.pop('fused', None) if isinstance(sd, dict) else None
-        super().load_state_dict(sd)
+        """Accepts this class's own state_dict and a torch.optim.AdamW / timm AdamW one (the reference's checkpoints)."""
+        sd = dict(sd)
+        fused = sd.pop('fused', None)          # round-1 layout of this class
+        state = sd.get('state', {}) or {}
+        super().load_state_dict({'state': {}, 'param_groups': sd['param_groups']})
         if fused and fused.get('exp_avg') is not None:
-            if self._flat is None:
-                self._build()
-            self._step = fused['step']
+            self.ensure_built()
+            self._step = int(fused['step'])
             self._m.copy_(fused['exp_avg'])
             self._v.copy_(fused['exp_avg_sq'])
+            return
+        if not state:
+            return
+        self.ensure_built()
+        by_index = {}
+        for g in self.param_groups:
+            for p in g['params']:
+                by_index[len(by_index)] = p
+        offs, o = {}, 0
+        for p in self._params:
+            offs[id(p)] = o
+            o += p.numel()
+        for idx, st in state.items():
+            p = by_index[int(idx)]
+            if id(p) not in offs:
+                continue                        # frozen parameter: not part of the flat buffers
+            o, n = offs[id(p)], p.numel()
+            self._m[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self._v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            self._step = int(float(st['step']))
 
 
 class NativeScaler:

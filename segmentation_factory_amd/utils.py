@@ -201,8 +201,11 @@ def init_distributed_mode(args):
         args.distributed = False
         return
     args.distributed = True
-    backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    # SEGFAC_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices): used by the tests to drive the
+    # world_size > 1 code paths on a 1-GPU box; production runs use 'nccl' (= RCCL on ROCm), one rank per GPU
+    backend = os.environ.get('SEGFAC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if torch.cuda.is_available():
+        args.gpu = args.gpu % torch.cuda.device_count()
         torch.cuda.set_device(args.gpu)
     args.dist_backend = backend
     dist.init_process_group(backend=backend, init_method=getattr(args, 'dist_url', 'env://'),

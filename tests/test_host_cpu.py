@@ -190,3 +190,79 @@ def test_oracle_optimizer_restatement_properties():
         ref.step()
         OO.adamw_step_(pw, grad, m, v, step, 3e-3, weight_decay=0.05)
         assert torch.allclose(w.detach(), pw, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize('backbone,head,nc', [('MobileNetV2', 'FPNHead', 21), ('ConvNeXt', 'UPerHead', 150),
+                                              ('convnextv2_tiny', 'UPerHead', 19), ('convnextv2_large', 'UPerHead', 171)])
+def test_state_dict_keys_of_every_baseline_family(backbone, head, nc):
+    """BASELINE cfg1 / cfg3 / cfg5 models: key order, shapes, head width (quirk Q1) and __str__ equal the reference's inventory
+    (oracle/weights.py, itself asserted against the imported reference in oracle/make_goldens.py)."""
+    from oracle import weights as OW
+    from segmentation_factory_amd import SegmentationModel
+    m = SegmentationModel(backbone, num_classes=nc, seg_head=head)
+    inv = OW.model_inventory(backbone, head, nc)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(inv.keys())
+    for k, (shape, _) in inv.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert str(m) == f'{backbone}_{head}'
+    assert m.decode_head.embed_dim == OW.head_width(backbone)
+
+
+def test_load_model_and_pretrained_backbone_key_handling(tmp_path):
+    """util/utils.py:313-324 (load_model: unwrap 'state_dict'; for NVIDIA SegFormer files drop decode_head.conv_seg.*),
+    train_gpu.py:246-252 (drop linear_pred, load strict=False), build_models.py:56-60 (pretrained_backbone)."""
+    from oracle import weights as OW
+    from segmentation_factory_amd import SegmentationModel, utils
+    sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', 19, 5)
+    nvidia = dict(sd)
+    nvidia['decode_head.conv_seg.weight'] = torch.zeros(150, 768, 1, 1)      # the extra classifier of the released checkpoints
+    nvidia['decode_head.conv_seg.bias'] = torch.zeros(150)
+    f1 = tmp_path / 'segformer.b0.512x512.ade.160k.pth'
+    torch.save({'state_dict': nvidia, 'meta': {'note': 'NVIDIA-style file'}}, str(f1))
+    got = utils.load_model(str(f1))
+    assert 'decode_head.conv_seg.weight' not in got and 'decode_head.conv_seg.bias' not in got
+    assert set(got) == set(sd)
+    f2 = tmp_path / 'plain_checkpoint.pth'                                    # no 'state_dict' wrapper, no 'segformer' in the name
+    torch.save(dict(sd), str(f2))
+    assert set(utils.load_model(str(f2))) == set(sd)
+    # the finetune load of train_gpu.py: classifier dropped, everything else restored
+    m = SegmentationModel('MiT-B0', num_classes=7, seg_head='SegFormerHead')        # another class count than the checkpoint
+    ck = {k: v for k, v in got.items() if 'linear_pred' not in k}
+    msg = m.load_state_dict(ck, strict=False)
+    assert sorted(msg.missing_keys) == ['decode_head.linear_pred.bias', 'decode_head.linear_pred.weight'] and not msg.unexpected_keys
+    assert torch.equal(m.state_dict()['backbone.block1.0.attn.q.weight'], sd['backbone.block1.0.attn.q.weight'])
+    # pretrained_backbone: a file of backbone keys WITHOUT the 'backbone.' prefix, loaded strict=False
+    bb = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}
+    f3 = tmp_path / 'mit_b0.pth'
+    torch.save(bb, str(f3))
+    m2 = SegmentationModel('MiT-B0', pretrained_backbone=str(f3), num_classes=19, seg_head='SegFormerHead')
+    assert torch.equal(m2.backbone.state_dict()['patch_embed1.proj.weight'], bb['patch_embed1.proj.weight'])
+    m3 = SegmentationModel('MiT-B0', pretrained_backbone=str(tmp_path / 'missing.pth'), num_classes=19, seg_head='SegFormerHead')
+    assert not torch.equal(m3.backbone.state_dict()['patch_embed1.proj.weight'], bb['patch_embed1.proj.weight'])
+
+
+def test_fused_optimizer_state_dict_is_torch_adamw_layout():
+    """The checkpoint's 'optimizer_state' (train_gpu.py:354-362): FusedAGCAdamW reads a torch.optim.AdamW state_dict (what the
+    reference's finetune path saves) into its flat buffers and writes the same layout back (host-side plumbing only)."""
+    from segmentation_factory_amd.optim import FusedAGCAdamW
+    g = torch.Generator().manual_seed(9)
+    ps = [torch.nn.Parameter(torch.randn(4, 3, generator=g)), torch.nn.Parameter(torch.randn(5, generator=g)),
+          torch.nn.Parameter(torch.randn(2, 2, 3, generator=g))]
+    ps[1].requires_grad_(False)                                  # a frozen parameter keeps its packed index but has no state
+    ref = torch.optim.AdamW(ps, lr=2e-4, weight_decay=0.025)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g) if p.requires_grad else None
+        ref.step()
+    sd = ref.state_dict()
+    fused = FusedAGCAdamW([torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad) for p in ps], lr=1.0, weight_decay=0.5)
+    fused.load_state_dict(sd)
+    assert fused.param_groups[0]['lr'] == 2e-4 and fused.param_groups[0]['weight_decay'] == 0.025 and fused._step == 3
+    assert torch.equal(fused._m[:12].view(4, 3), sd['state'][0]['exp_avg'])
+    assert torch.equal(fused._v[12:].view(2, 2, 3), sd['state'][2]['exp_avg_sq'])
+    out = fused.state_dict()
+    assert set(out['state']) == {0, 2} and float(out['state'][2]['step']) == 3.0
+    back = torch.optim.AdamW(ps, lr=1.0)
+    back.load_state_dict(out)                                    # torch accepts what we wrote
+    assert torch.equal(back.state[ps[0]]['exp_avg'], sd['state'][0]['exp_avg'])

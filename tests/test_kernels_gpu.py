@@ -115,7 +115,7 @@ def test_gemm_epilogue_and_strides(hipmod, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('C', [32, 64, 160, 256, 768, 1536])
+@pytest.mark.parametrize('C', [32, 64, 160, 256, 768, 1536, 2816])     # 2816: convnextv2_huge's last stage (six chunks per lane)
 def test_layernorm(dtype, C):
     from segmentation_factory_amd import functional as Fh
     g = torch.Generator().manual_seed(3)
@@ -181,7 +181,8 @@ def _attn_ref(q, kv, B, N, Nkv, heads):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(2, 2, 100, 37, 32), (1, 1, 300, 256, 64), (2, 5, 64, 4, 32), (1, 8, 16, 16, 32), (1, 2, 700, 300, 64)])
+@pytest.mark.parametrize('shape', [(2, 2, 100, 37, 32), (1, 1, 300, 256, 64), (2, 5, 64, 4, 32), (1, 8, 16, 16, 32), (1, 2, 700, 300, 64),
+                                   (1, 2, 8192, 2048, 64), (1, 1, 8200, 2048, 64), (2, 1, 4096, 256, 32)])   # cfg4: 2048 keys x head_dim 64; cfg2 stage 2
 def test_attention(dtype, shape):
     from segmentation_factory_amd import functional as Fh
     B, heads, N, Nkv, hd = shape
@@ -374,24 +375,82 @@ def test_argmax_confmat_and_metrics_golden(golden_dir):
     assert str(cm) == str(g['confmat_str'])
 
 
-def test_argmax_confmat_fused_upsample():
-    from oracle import loss as OL
+def _fused_counts(lo, t, C, H, W):
     from segmentation_factory_amd.backbones import TokenMap
     from segmentation_factory_amd.metrics import Metrics
     from segmentation_factory_amd import utils
+    B, _, h, w = lo.shape
+    m, cm = Metrics(C, 255, 'cuda'), utils.ConfusionMatrix(C)
+    tm = TokenMap(lo.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous().cuda(), B, h, w)
+    m.update_lowres(tm, t.cuda(), (H, W), confmat=cm)
+    return cm.mat.cpu().numpy(), m.hist.cpu().numpy()
+
+
+@pytest.mark.parametrize('geom', [(2, 150, 8, 8, 32, 32), (2, 19, 16, 16, 64, 64), (1, 7, 4, 6, 16, 24), (2, 21, 16, 16, 32, 32),
+                                  (1, 5, 4, 4, 32, 32)])
+def test_argmax_confmat_fused_upsample(geom):
+    """evaluate()'s default path (fused upsample + arg max + counting, Metrics.update_lowres) against the reference's op
+    sequence F.interpolate -> argmax -> bincount on the CPU: EXACT (integer work).  The kernel interpolates in ATen's
+    operation order (common.h bilinear_aten), which is bit-identical to F.interpolate at these map sizes."""
+    from oracle import loss as OL
+    B, C, h, w, H, W = geom
     g = torch.Generator().manual_seed(10)
-    B, C, h, w, H, W = 2, 150, 8, 8, 32, 32
     lo = torch.randn(B, C, h, w, generator=g)
     t = torch.randint(0, C, (B, H, W), generator=g)
     t[:, :3] = 255
     up = F.interpolate(lo, size=(H, W), mode='bilinear', align_corners=False)
     mat, hist = OL.confusion_counts(up, t, C, 255)
-    m, cm = Metrics(C, 255, 'cuda'), utils.ConfusionMatrix(C)
-    tm = TokenMap(lo.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous().cuda(), B, h, w)
-    m.update_lowres(tm, t.cuda(), (H, W), confmat=cm)
-    # bilinear rounding can flip exact near-ties; allow a handful of pixels
-    assert np.abs(cm.mat.cpu().numpy() - mat).sum() <= 4
-    assert np.abs(m.hist.cpu().numpy() - hist).sum() <= 4
+    got_mat, got_hist = _fused_counts(lo, t, C, H, W)
+    assert np.array_equal(got_mat, mat)
+    assert np.array_equal(got_hist, hist)
+
+
+def test_argmax_tie_policy(hipmod):
+    """Tie rule of the evaluation kernels, on constructed ties and near-ties.
+    (1) exact ties (a class channel duplicated at a higher index) resolve to the LOWEST index, like torch.argmax;
+    (2) the materialised logits (segf_bilinear_to_nchw_f32 = SegmentationModel.forward's resize) are bit-identical to
+        F.interpolate where ATen uses its scalar loop (small maps, power-of-two ratio);
+    (3) at BASELINE size (128 -> 512, where ATen's vectorised loops associate the four products differently) every pixel whose
+        prediction differs from torch's is a NEAR-TIE: the reference's own top-2 margin there is below 4 ulp of the maximum."""
+    hip = hipmod
+    g = torch.Generator().manual_seed(12)
+    # (1) + (2)
+    B, C, h, w, H, W = 2, 12, 8, 8, 32, 32
+    lo = torch.randn(B, C, h, w, generator=g)
+    lo[:, 7] = lo[:, 2]                                   # exact tie between classes 2 and 7 wherever they are the maximum
+    lo[:, 2] += 3.0                                       # ... and make that pair the maximum almost everywhere
+    lo[:, 7] += 3.0
+    up = F.interpolate(lo, size=(H, W), mode='bilinear', align_corners=False)
+    tok = lo.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous().cuda()
+    mine = hip.bilinear_to_nchw_f32(tok, B, h, w, C, H, W).cpu()
+    assert torch.equal(mine, up)
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    pred = torch.empty((B, H, W), dtype=torch.int64, device='cuda')
+    z = torch.zeros((C, C), dtype=torch.int64, device='cuda')
+    hip.argmax_confmat(tok, B, C, h, w, H, W, t.cuda(), 255, z, z.clone(), torch.zeros(1, dtype=torch.int32, device='cuda'), pred)
+    ref = up.argmax(1)
+    assert torch.equal(pred.cpu(), ref)
+    assert (ref == 7).sum() == 0 and (ref == 2).sum() > 0.9 * ref.numel()
+    # (3)
+    B, C, h, w, H, W = 2, 150, 128, 128, 512, 512
+    lo = torch.randn(B, C, h, w, generator=g)
+    lo[:, 100] = lo[:, 3] + 1e-7 * torch.randn(B, h, w, generator=g)      # a near-tie pair on top of the random field
+    up = F.interpolate(lo, size=(H, W), mode='bilinear', align_corners=False)
+    tok = lo.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous().cuda()
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    pred = torch.empty((B, H, W), dtype=torch.int64, device='cuda')
+    z = torch.zeros((C, C), dtype=torch.int64, device='cuda')
+    hip.argmax_confmat(tok, B, C, h, w, H, W, t.cuda(), 255, z, z.clone(), torch.zeros(1, dtype=torch.int32, device='cuda'), pred)
+    ref = up.argmax(1)
+    diff = pred.cpu() != ref
+    top2 = up.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]) / top2[:, 0].abs().clamp_min(1e-30)
+    ulp = 2.0 ** -23
+    assert (margin[diff] <= 4 * ulp).all(), margin[diff].max()
+    # the predictions at those pixels are the runner-up of a near-tie, not something else
+    second = up.topk(2, dim=1).indices[:, 1]
+    assert torch.equal(pred.cpu()[diff], second[diff])
+    assert diff.float().mean().item() < 1e-3
 
 
 def test_agc_adamw_known_answers(hipmod):

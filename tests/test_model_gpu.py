@@ -30,9 +30,31 @@ def _build(backbone, head, nc, sd, dtype, B, deterministic=True):
     return m
 
 
-@pytest.mark.parametrize('tag', ['segformer_b0_64', 'segformer_b0_96x128', 'convnext_uper_64', 'convnextv2_tiny_uper_64'])
+E2E_TAGS = ['segformer_b0_64', 'segformer_b0_96x128', 'convnext_uper_64', 'convnextv2_tiny_uper_64', 'mbv2_fpn_64',
+            'convnext_uper_128', 'convnextv2_tiny_uper_128', 'mbv2_fpn_128']
+# Gradient tolerances (fraction `rt` of a parameter's gradient scale, see `tol` below), set from tools/grad_parity_report.py on
+# the MI355X with ~2x margin.  Measured worst sample error / scale: fp32 segformer 1e-4, convnext_64 3e-3, convnext*_128 2e-3,
+# mbv2_64 8e-3, mbv2_128 1.3e-2; bf16 segformer 0.064, convnext_uper_128 0.115, convnextv2_tiny_uper_128 0.133.
+GRAD_RT = {'segformer': (3e-3, 0.12), 'convnext_64': (2e-2, None), 'convnext_128': (5e-3, 0.25), 'mbv2': (3e-2, None)}
+
+
+def _kind(tag):
+    if tag.startswith('segformer'):
+        return 'segformer'
+    if tag.startswith('mbv2'):
+        return 'mbv2'
+    return 'convnext_128' if tag.endswith('_128') else 'convnext_64'
+
+
+@pytest.mark.parametrize('tag', E2E_TAGS)
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_e2e_against_reference_golden(golden_dir, tag, dtype):
+    """Every BASELINE model family against the REFERENCE's captured outputs: eval logits, train-mode logits, loss, sampled
+    parameter gradients + gradient norms, BatchNorm step counters.  The *_128 fixtures (128 x 128, batch 4 / 2) are the
+    BatchNorm-well-conditioned ones: there the bf16 production mode is held to SAMPLED-GRADIENT checks as well.  At the 64 x 64,
+    batch-2 fixtures ConvNeXt/UPer's and MobileNetV2/FPN's BatchNorms see 2..32 samples and bf16 rounding is amplified by
+    1/sigma of near-constant channels (fp32 stays within 1e-3 / 3e-2 there): bf16 is then held to logits, loss and
+    gradient norms only, and the same composition is pinned tightly by the *_128 fixture."""
     from segmentation_factory_amd import criterion_lowres
     g = np.load(os.path.join(golden_dir, f'e2e_{tag}.npz'))
     backbone, head, nc = str(g['backbone']), str(g['head']), int(g['nc'])
@@ -40,14 +62,26 @@ def test_e2e_against_reference_golden(golden_dir, tag, dtype):
     sd = OW.make_state_dict(backbone, head, nc, seed)
     x, y = OW.synthetic_batch(B, H, W, nc, seed)
     fp32 = dtype == torch.float32
+    kind = _kind(tag)
+    compact = 'lowres_eval' in g.files      # head output + strided sample of the full-size logits (oracle/make_goldens.py)
     rel = 1e-3 if fp32 else 5e-2          # north star: 1e-3 (fp32 path); bf16 storage: ~2^-8 per op, ~40 ops deep
+    # MobileNetV2 in bf16 TRAIN mode: 52 BatchNorms, several over (near-)dead ReLU6 channels of the random-weight fixture,
+    # whose 1/sigma amplifies the storage rounding (measured 0.22-0.31 of the logit scale; eval mode 7e-3..1e-2, fp32 3e-5).
+    # cfg1 is the reference's fp32 CPU configuration: fp32 is the pinned mode, bf16 is only sanity-checked here.
+    rel_train = rel if (fp32 or kind != 'mbv2') else 0.6
     model = _build(backbone, head, nc, sd, dtype, B)
-    # eval-mode full-resolution logits (SegmentationModel.forward, build_models.py:62-66)
+    # eval-mode logits (SegmentationModel.forward, build_models.py:62-66)
     model.eval()
     with torch.no_grad():
         ev = model(x.cuda()).cpu().numpy()
-    assert ev.shape == g['logits_eval'].shape
-    assert np.abs(ev - g['logits_eval']).max() <= rel * np.abs(g['logits_eval']).max()
+        if compact:
+            lo = model.forward_lowres(x.cuda()).nchw().float().cpu().numpy()
+            assert lo.shape == g['lowres_eval'].shape
+            assert np.abs(lo - g['lowres_eval']).max() <= rel * np.abs(g['lowres_eval']).max()
+            assert np.abs(ev[:, :, 1::4, 2::4] - g['logits_eval_sub']).max() <= rel * np.abs(g['logits_eval_sub']).max()
+        else:
+            assert ev.shape == g['logits_eval'].shape
+            assert np.abs(ev - g['logits_eval']).max() <= rel * np.abs(g['logits_eval']).max()
     # train-mode forward + fused loss + backward
     model.train()
     lo = model.forward_lowres(x.cuda())
@@ -55,33 +89,34 @@ def test_e2e_against_reference_golden(golden_dir, tag, dtype):
     loss.backward()
     assert abs(loss.item() - float(g['loss'])) <= (2e-4 if fp32 else 2e-2) * abs(float(g['loss']))
     with torch.no_grad():
-        tr = model(x.cuda()).cpu().numpy()        # second train-mode forward: same batch statistics
-    assert np.abs(tr - g['logits_train']).max() <= rel * np.abs(g['logits_train']).max()
+        if compact:
+            tr = model.forward_lowres(x.cuda()).nchw().float().cpu().numpy()        # second train-mode forward: same batch statistics
+            assert np.abs(tr - g['lowres_train']).max() <= rel_train * np.abs(g['lowres_train']).max()
+        else:
+            tr = model(x.cuda()).cpu().numpy()
+            assert np.abs(tr - g['logits_train']).max() <= rel_train * np.abs(g['logits_train']).max()
     gmax = float(g['grad_global_max'])
     params = dict(model.named_parameters())
-    rt = 3e-3 if fp32 else 0.12
-    if 'convnext' in tag:
-        # ConvNeXt + UPerHead at 64x64, batch 2: twelve BatchNorms over 2..512 samples (PPM's 1x1 map: two values) make the
-        # gradients ill-conditioned -- fp32 reorderings show up at ~5e-3, bf16 storage at ~30 % of a parameter's gradient
-        # norm (tests/debug_convnext.py measures 15 % median even at 160x160, batch 4).  The kernels themselves are pinned
-        # by tests/test_kernels_gpu.py; this case pins the composition in the exact-fp32 mode.
-        rt = 2e-2 if fp32 else 1.0
-    norms_only = ('convnext' in tag) and not fp32      # bf16 at this degenerate size: per-parameter gradient NORMS only
+    rt = GRAD_RT[kind][0 if fp32 else 1]
+    norms_only = rt is None                 # bf16 at the ill-conditioned fixtures: per-parameter gradient NORMS only
     bad = []
     for i, name in enumerate(g['grad_names']):
         name = str(name)
         gr = params[name].grad
-        assert gr is not None, name
-        gr = gr.detach().float().cpu()
         ref_norm = float(g['grad_norms'][i])
+        if gr is None:
+            assert ref_norm == 0.0, name      # FPNHead.output_convs[0] is never called (quirk Q3): no gradient in the reference either
+            continue
+        gr = gr.detach().float().cpu()
         got = gr.flatten()[sample_indices(name, gr.numel())].numpy()
-        tol = rt * (np.abs(g['grad_samples'][i]).max() + ref_norm / max(1.0, np.sqrt(gr.numel()))) + rt * 1e-2 * gmax
         if norms_only:
             if 'ppm.stages.0.' in name:      # PPM scale 1: BatchNorm over the 2 samples of a 1x1 map, a (near-)singular Jacobian
                 continue
             if abs(gr.double().norm().item() - ref_norm) > 0.6 * ref_norm + 1e-1 * gmax:
                 bad.append((name, gr.double().norm().item(), ref_norm))
-        elif np.abs(got - g['grad_samples'][i]).max() > tol or abs(gr.double().norm().item() - ref_norm) > rt * ref_norm + rt * 1e-1 * gmax:
+            continue
+        tol = rt * (np.abs(g['grad_samples'][i]).max() + ref_norm / max(1.0, np.sqrt(gr.numel()))) + rt * 1e-2 * gmax
+        if np.abs(got - g['grad_samples'][i]).max() > tol or abs(gr.double().norm().item() - ref_norm) > rt * ref_norm + rt * 1e-1 * gmax:
             bad.append((name, float(np.abs(got - g['grad_samples'][i]).max()), tol, gr.double().norm().item(), ref_norm))
     assert not bad, bad[:8]
     if fp32:
@@ -90,12 +125,16 @@ def test_e2e_against_reference_golden(golden_dir, tag, dtype):
             v = sdn[str(name)]
             got = v.float().double().norm().item() if v.ndim else float(v)
             # two train-mode forwards ran above -> compare only the first-forward quantity we can: num_batches_tracked
+            # (FPNHead's lateral BatchNorms count 3 / 2 / 2 per forward, quirk Q3)
             if str(name).endswith('num_batches_tracked'):
-                assert got == 2 * float(g['bn_norms'][i])
+                assert got == 2 * float(g['bn_norms'][i]), str(name)
 
 
-def test_bn_running_stats_after_one_forward(golden_dir):
-    g = np.load(os.path.join(golden_dir, 'e2e_segformer_b0_64.npz'))
+@pytest.mark.parametrize('tag', ['segformer_b0_64', 'mbv2_fpn_64', 'mbv2_fpn_128', 'convnext_uper_128'])
+def test_bn_running_stats_after_one_forward(golden_dir, tag):
+    """BatchNorm running_mean / running_var / num_batches_tracked after ONE train-mode forward vs the reference's buffers
+    (captures quirk Q3: FPNHead evaluates its lateral ConvModules 1 / 3 / 2 / 2 times per forward, fpn.py:29-36)."""
+    g = np.load(os.path.join(golden_dir, f'e2e_{tag}.npz'))
     backbone, head, nc = str(g['backbone']), str(g['head']), int(g['nc'])
     B, H, W, seed = int(g['B']), int(g['H']), int(g['W']), int(g['seed'])
     sd = OW.make_state_dict(backbone, head, nc, seed)
@@ -103,6 +142,7 @@ def test_bn_running_stats_after_one_forward(golden_dir):
     model = _build(backbone, head, nc, sd, torch.float32, B).train()
     model.forward_lowres(x.cuda())
     sdn = model.state_dict()
+    assert len(g['bn_names']) > 0
     for i, name in enumerate(g['bn_names']):
         v = sdn[str(name)]
         got = v.float().double().norm().item() if v.ndim else float(v)
@@ -160,8 +200,9 @@ def test_train_loop_golden(golden_dir):
     ref = g['losses']
     assert np.abs(np.array(losses) - ref).max() <= 2e-3 * np.abs(ref).max(), (losses, ref)
     confmat, metric = engine.evaluate(args, model, [(x, y)], 'cuda', 1, None)
-    # argmax near-ties may differ in a few pixels after 6 SGD steps in different arithmetic order
-    assert np.abs(confmat.mat.cpu().numpy() - g['mat']).sum() <= 0.01 * g['mat'].sum()
+    # the logits after 6 SGD steps differ from the reference's by ~1e-6 relative (other summation orders inside the network), so
+    # pixels whose top-2 margin is below that may flip: at most 0.1 % of the 8192 pixels
+    assert np.abs(confmat.mat.cpu().numpy() - g['mat']).sum() <= 0.002 * g['mat'].sum()
     assert abs(metric.compute_iou()[1] - float(g['miou'])) <= 0.1 + 1e-9      # north star: mIoU within +-0.1
 
 
@@ -210,32 +251,71 @@ def test_train_overfit_miou_parity(golden_dir, mode):
         assert confmat.mat.sum().item() == int(g[f'mat_{tag}'].sum())                        # same valid-pixel count
 
 
-def test_full_size_cfg2_fp32_and_bf16_vs_oracle():
-    """BASELINE cfg2 shape: SegFormer-B0, 150 classes, 512x512, batch 2 -- fp32 HIP vs the CPU oracle (1e-3),
-    bf16 HIP vs fp32 HIP (bf16 tolerance), loss both ways."""
+def _oracle_fwd_bwd(backbone, head, nc, x, y, sd, H, W):
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var')))
+           for k, v in sd.items()}
+    o, _ = ON.model_forward(sdg, x, backbone, head, training=True, lowres=True)
+    up = torch.nn.functional.interpolate(o, size=(H, W), mode='bilinear', align_corners=False)
+    ref_loss = OL.criterion_closed_form(up, y, None, num_classes=nc, dice=True, ignore_index=255)
+    ref_loss.backward()
+    return o.detach(), ref_loss.item(), {k: v.grad for k, v in sdg.items() if v.grad is not None}
+
+
+def _grad_report(model, ref_grads):
+    """worst over parameter tensors of max|g - r| / (max|r| + 0.05 * global max|r|); returns (worst, name, n_compared)."""
+    params = dict(model.named_parameters())
+    gmax = max(r.abs().max().item() for r in ref_grads.values())
+    worst, wname, n = 0.0, '', 0
+    for k, r in ref_grads.items():
+        g = params[k].grad
+        assert g is not None, k
+        e = (g.float().cpu() - r).abs().max().item() / (r.abs().max().item() + 0.05 * gmax)
+        n += 1
+        if e > worst:
+            worst, wname = e, k
+    return worst, wname, n
+
+
+FULL_SIZE = {   # BASELINE.json configs as the reference builds them, at their full spatial size (batch: what the CPU oracle finishes in ~1 min)
+    'cfg2': ('MiT-B0', 'SegFormerHead', 150, 2, 512, 512),
+    'cfg3': ('ConvNeXt', 'UPerHead', 150, 2, 512, 512),
+    'cfg4': ('MiT-B2', 'SegFormerHead', 19, 1, 1024, 2048),
+}
+
+
+@pytest.mark.parametrize('cfg', sorted(FULL_SIZE))
+def test_full_size_fp32_and_bf16_vs_oracle(cfg):
+    """BASELINE shapes at full size: exact-fp32 HIP path vs the (reference-pinned) CPU oracle -- low-res logits 1e-3, loss, and
+    EVERY parameter gradient; then the bf16 production mode vs the same oracle (bf16 tolerance).  cfg4 is where MiT's attention
+    sees 2048 keys x head_dim 64 (KV-tiled online softmax), cfg3 where the UPerHead 3x3 convs run at 3072 -> 768 channels."""
+    import time
     from segmentation_factory_amd import criterion_lowres
-    backbone, head, nc, B, H, W, seed = 'MiT-B0', 'SegFormerHead', 150, 2, 512, 512, 0
+    backbone, head, nc, B, H, W = FULL_SIZE[cfg]
+    seed = 0
     sd = OW.make_state_dict(backbone, head, nc, seed)
     x, y = OW.synthetic_batch(B, H, W, nc, seed)
-    with torch.no_grad():
-        o, _ = ON.model_forward(sd, x, backbone, head, training=True, lowres=True)
-        up = torch.nn.functional.interpolate(o, size=(H, W), mode='bilinear', align_corners=False)
-        ref_loss = OL.criterion_closed_form(up, y, None, num_classes=nc, dice=True, ignore_index=255).item()
-    outs, losses = {}, {}
+    t0 = time.time()
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    o, ref_loss, ref_grads = _oracle_fwd_bwd(backbone, head, nc, x, y, sd, H, W)
+    t_oracle = time.time() - t0
+    scale = o.abs().max()
     for dtype in (torch.float32, torch.bfloat16):
+        fp32 = dtype == torch.float32
         model = _build(backbone, head, nc, sd, dtype, B).train()
         lo = model.forward_lowres(x.cuda())
         loss = criterion_lowres(lo, y.cuda(), (H, W), None, num_classes=nc, dice=True, ignore_index=255)
         loss.backward()
-        outs[dtype] = lo.nchw().float().cpu()
-        losses[dtype] = loss.item()
-        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
-        del model
-    scale = o.abs().max()
-    assert (outs[torch.float32] - o).abs().max() <= 1e-3 * scale
-    assert abs(losses[torch.float32] - ref_loss) <= 1e-4 * abs(ref_loss)
-    assert (outs[torch.bfloat16] - o).abs().max() <= 6e-2 * scale
-    assert abs(losses[torch.bfloat16] - ref_loss) <= 2e-2 * abs(ref_loss)
+        got = lo.nchw().float().cpu()
+        e_log = ((got - o).abs().max() / scale).item()
+        e_loss = abs(loss.item() - ref_loss) / abs(ref_loss)
+        worst, wname, n = _grad_report(model, ref_grads)
+        print(f'[{cfg} {str(dtype)[6:]}] oracle {t_oracle:.0f} s; logits {e_log:.2e}, loss {e_loss:.2e}, worst gradient error {worst:.3e} ({wname}), {n} tensors')
+        assert n >= 50
+        assert e_log <= (1e-3 if fp32 else 6e-2)
+        assert e_loss <= (1e-4 if fp32 else 2e-2)
+        assert worst <= (1e-2 if fp32 else 0.25), (wname, worst)
+        del model, lo, loss
+        torch.cuda.empty_cache()
 
 
 def test_graphed_step_matches_eager_step():
@@ -387,3 +467,115 @@ def test_argmax_rows_kernel():
         x[5, :C] = 1.0                                                   # ties -> lowest index
         out = hip.argmax_rows(x, C)
         assert torch.equal(out, x[:, :C].float().argmax(dim=1))
+
+
+def test_fused_adamw_continues_a_torch_adamw_checkpoint():
+    """Resuming from the REFERENCE's checkpoint dict (train_gpu.py:286-298): its 'optimizer_state' is a torch.optim.AdamW
+    state_dict.  After loading it, the next fused step on the GPU must equal torch.optim.AdamW's own next step on the CPU."""
+    from segmentation_factory_amd.optim import FusedAGCAdamW
+    g = torch.Generator().manual_seed(21)
+    shapes = [(6, 5), (7,), (3, 2, 3, 3), (4,)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    ref = torch.optim.AdamW(ps, lr=2e-4, weight_decay=0.025)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g)
+        ref.step()
+    sd = ref.state_dict()
+    mine = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ps]
+    fused = FusedAGCAdamW(mine, lr=1.0, weight_decay=0.0)
+    fused.load_state_dict(sd)
+    grads = [torch.randn(p.shape, generator=g) for p in ps]
+    for p, q, gr in zip(ps, mine, grads):
+        p.grad = gr.clone()
+        q.grad = gr.clone().cuda()
+    ref.step()
+    fused.agc_clip = 0.0
+    fused.step()
+    for p, q in zip(ps, mine):
+        assert torch.allclose(q.detach().cpu(), p.detach(), rtol=2e-6, atol=1e-7)
+
+
+def _run_cli(args, cwd, env=None, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'train_gpu.py')] + args
+    e = dict(os.environ, PYTHONPATH=root)
+    e.update(env or {})
+    return subprocess.run(cmd, cwd=str(cwd), env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_train_gpu_cli_finetune_freeze_and_reference_checkpoint(tmp_path):
+    """(f3) drop-in files: --finetune from an NVIDIA-style {'state_dict': ...} file with decode_head.conv_seg.* + --freeze_layers
+    (train_gpu.py:238-260, util/utils.py:313-324): only linear_pred trains; then auto-resume from a checkpoint in the
+    REFERENCE's layout (train_gpu.py:281-307,354-362: torch.optim.AdamW 'optimizer_state', the scheduler's attribute dict,
+    best_mIoU / F1_Score / Acc, GradScaler 'scaler')."""
+    nc = 5
+    sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', nc, 31)
+    nvidia = dict(sd)
+    nvidia['decode_head.conv_seg.weight'] = torch.zeros(150, 768, 1, 1)
+    nvidia['decode_head.conv_seg.bias'] = torch.zeros(150)
+    ft = tmp_path / 'segformer.b0.fake.pth'
+    torch.save({'state_dict': nvidia}, str(ft))
+    out = tmp_path / 'out'
+    base = ['--dataset', 'synthetic', '--data_len', '8', '--image_size', '64', '--nb_classes', str(nc), '--backbone', 'MiT-B0',
+            '--heads', 'SegFormerHead', '--batch-size', '2', '--val_batch_size', '2', '--epochs', '1', '--save_weights_dir', str(out),
+            '--writer_output', str(tmp_path), '--train_print_freq', '1', '--val_print_freq', '1']
+    r = _run_cli(base + ['--finetune', str(ft), '--hip-graph'], tmp_path)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'Removing key decode_head.linear_pred.weight from pretrained checkpoint' in r.stdout
+    assert 'training decode_head.linear_pred.weight' in r.stdout and 'Number of parameters: %d' % (768 * nc + nc) in r.stdout
+    ck = torch.load(str(out / 'MiT-B0_SegFormerHead_best_model.pth'), map_location='cpu', weights_only=False)
+    ms = ck['model_state']
+    changed = [k for k in sd if sd[k].is_floating_point() and not torch.equal(ms[k], sd[k]) and 'running_' not in k]
+    assert changed and all('linear_pred' in k for k in changed), changed[:5]       # frozen everywhere else
+    assert len(ck['optimizer_state']['state']) == 2                                # AdamW moments exist for the two trained tensors only
+    # ---- a checkpoint in the reference's layout, written with torch's own AdamW on the CPU ----
+    from segmentation_factory_amd import SegmentationModel
+    from segmentation_factory_amd.optim import param_groups_weight_decay
+    cpu_model = SegmentationModel('MiT-B0', num_classes=nc, seg_head='SegFormerHead')       # parameter container (same keys)
+    cpu_model.load_state_dict(sd)
+    opt = torch.optim.AdamW(param_groups_weight_decay(cpu_model, 0.025), lr=1e-3)           # timm create_optimizer's grouping
+    g = torch.Generator().manual_seed(1)
+    for p in cpu_model.parameters():
+        p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    opt.step()
+    sched_state = {'param_group_field': 'lr', '_initial_param_group_field': 'initial_lr', 'base_values': [1e-3, 1e-3], 'metric': None,
+                   't_in_epochs': False, 'noise_range_t': None, 'noise_pct': 0.67, 'noise_type': 'normal', 'noise_std': 1.0,
+                   'noise_seed': 0, 't_initial': 20, 'lr_min': 1e-4, 'cycle_mul': 1.0, 'cycle_decay': 1.0, 'cycle_limit': 1,
+                   'warmup_t': 20, 'warmup_lr_init': 2e-4, 'warmup_prefix': False, 'k_decay': 1.0, 'warmup_steps': [4e-5, 4e-5]}
+    out2 = tmp_path / 'out2'
+    out2.mkdir()
+    torch.save({'model_state': cpu_model.state_dict(), 'optimizer_state': opt.state_dict(), 'scheduler_state': sched_state,
+                'best_mIoU': 12.34, 'F1_Score': 23.45, 'Acc': 34.56,
+                'scaler': {'scale': 65536.0, 'growth_factor': 2.0, 'backoff_factor': 0.5, 'growth_interval': 2000, '_growth_tracker': 0}},
+               str(out2 / 'reference_format.pth'))
+    base2 = [a if a != str(out) else str(out2) for a in base]
+    r2 = _run_cli(base2 + ['--hip-graph'], tmp_path)
+    assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
+    assert 'Loading local checkpoint' in r2.stdout and 'Now max mIOU is 12.34' in r2.stdout and '<All keys matched successfully>' in r2.stdout
+
+
+def test_two_rank_eager_ddp_finetune_freeze(tmp_path):
+    """DistributedDataParallel must be built AFTER the --finetune load / --freeze_layers and with
+    find_unused_parameters=True (train_gpu.py:233-260), or the second iteration raises 'Expected to have finished reduction'.
+    Two ranks (gloo, sharing this box's one GPU; fresh child processes), eager launches, two iterations per rank."""
+    import subprocess
+    import sys
+    nc = 5
+    sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', nc, 32)
+    ft = tmp_path / 'pretrained.pth'
+    torch.save(dict(sd), str(ft))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ['--dataset', 'synthetic', '--data_len', '8', '--image_size', '64', '--nb_classes', str(nc), '--backbone', 'MiT-B0',
+            '--heads', 'SegFormerHead', '--batch-size', '2', '--val_batch_size', '2', '--epochs', '1', '--save_weights_dir', '',
+            '--writer_output', str(tmp_path), '--train_print_freq', '1', '--val_print_freq', '1', '--finetune', str(ft)]
+    env = dict(os.environ, PYTHONPATH=root, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', WORLD_SIZE='2',
+               SEGFAC_DIST_BACKEND='gloo')
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'train_gpu.py')] + args, cwd=str(tmp_path),
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-2000:]
+    assert 'Epoch: [0]  [1/2]' in outs[0] and 'Val_mIOU' in outs[0]

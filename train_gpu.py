@@ -30,7 +30,7 @@ from torch.utils.data import DataLoader, Dataset, DistributedSampler, RandomSamp
 
 from segmentation_factory_amd import SegmentationModel, evaluate, train_one_epoch, utils
 from segmentation_factory_amd.build_models import backbone_registry, head_dict
-from segmentation_factory_amd.optim import NativeScaler, create_optimizer, FusedAGCAdamW, param_groups_weight_decay
+from segmentation_factory_amd.optim import NativeScaler, create_optimizer, FusedAGCAdamW
 from segmentation_factory_amd.scheduler import create_scheduler
 
 
@@ -189,31 +189,32 @@ def main(args):
     model = SegmentationModel(args.backbone, pretrained_backbone=args.pretrained_backbone, num_classes=args.nb_classes,
                               seg_head=args.heads, compute_dtype=dtype, args=args).to(device)
     model_without_ddp = model
-    if args.distributed and not args.hip_graph:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.gpu] if device == 'cuda' else None)
-        model_without_ddp = model.module
-
-    if args.finetune:
+    if args.finetune:       # train_gpu.py:238-260
         checkpoint_model = utils.load_model(args.finetune)
         for k in list(checkpoint_model.keys()):
             if 'linear_pred' in k:
                 print(f"Removing key {k} from pretrained checkpoint")
                 del checkpoint_model[k]
-        print(model_without_ddp.load_state_dict(checkpoint_model, strict=False))
+        print(model.load_state_dict(checkpoint_model, strict=False))
         if args.freeze_layers:
-            for name, para in model_without_ddp.named_parameters():
+            for name, para in model.named_parameters():
                 para.requires_grad_('linear_pred' in name)
                 if 'linear_pred' in name:
                     print('training {}'.format(name))
+    if args.distributed and not args.hip_graph:
+        # wrapped AFTER the finetune load / freeze (the reducer must see the final requires_grad flags), and with
+        # find_unused_parameters=True as the reference does (train_gpu.py:233-236: e.g. FPNHead.output_convs[0] is never used)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.gpu] if device == 'cuda' else None,
+                                                          find_unused_parameters=True)
+        model_without_ddp = model.module
 
     n_parameters = sum(p.numel() for p in model.parameters() if p.requires_grad)
     print('\n********ESTABLISH ARCHITECTURE********')
     print(f'Model: {model_without_ddp}\nNumber of parameters: {n_parameters}')
     print('**************************************\n')
 
-    if args.finetune:      # train_gpu.py:269: torch.optim.AdamW(lr=2e-4, weight_decay) on the finetune path
-        optimizer = FusedAGCAdamW(param_groups_weight_decay(model_without_ddp, args.weight_decay), lr=2e-4,
-                                  weight_decay=args.weight_decay)
+    if args.finetune:      # train_gpu.py:269: torch.optim.AdamW(model.parameters(), lr=2e-4, weight_decay): ONE group, biases decay too
+        optimizer = FusedAGCAdamW(model_without_ddp.parameters(), lr=2e-4, weight_decay=args.weight_decay)
     else:
         optimizer = create_optimizer(args, model_without_ddp)
     loss_scaler = NativeScaler()
@@ -227,8 +228,11 @@ def main(args):
             f.write(json.dumps({k: v for k, v in args.__dict__.items()}, indent=2, default=str) + "\n")
 
     checkpoint_name = utils.get_pth_file(args.save_weights_dir) if args.save_weights_dir else None
-    if checkpoint_name:                                  # auto-resume (train_gpu.py:281-307; quirk Q15 without the TypeError)
+    if checkpoint_name:                                  # auto-resume (train_gpu.py:281-307: any *.pth in the save dir wins)
         args.resume = os.path.join(f'{args.save_weights_dir}/', checkpoint_name)
+    elif args.resume and not os.path.isfile(args.resume):    # quirk Q15: the reference dies with a TypeError here
+        raise SystemExit(f'--resume {args.resume}: no such file (and no *.pth in --save_weights_dir to auto-resume from)')
+    if args.resume:                                      # an explicit --resume is honoured when the save dir holds no checkpoint
         print("Loading local checkpoint at {}".format(args.resume))
         checkpoint = torch.load(args.resume, map_location='cpu', weights_only=False)
         print(model_without_ddp.load_state_dict(checkpoint['model_state']))
