@@ -423,14 +423,21 @@ def test_argmax_tie_policy(hipmod):
     up = F.interpolate(lo, size=(H, W), mode='bilinear', align_corners=False)
     tok = lo.permute(0, 2, 3, 1).reshape(B * h * w, C).contiguous().cuda()
     mine = hip.bilinear_to_nchw_f32(tok, B, h, w, C, H, W).cpu()
-    assert torch.equal(mine, up)
+    # same operation order as ATen's scalar loop: bit-identical on the build container's CPU; ATen picks its loop by CPU
+    # capability and thread count, so on other hosts allow the last rounding (1 ulp of the largest tap) and report
+    nbits = int((mine != up).sum())
+    print(f'bilinear_to_nchw vs F.interpolate on this host: {nbits} of {up.numel()} values differ in the last bit')
+    assert (mine - up).abs().max() <= 2.0 ** -22 * up.abs().max()
     t = torch.randint(0, C, (B, H, W), generator=g)
     pred = torch.empty((B, H, W), dtype=torch.int64, device='cuda')
     z = torch.zeros((C, C), dtype=torch.int64, device='cuda')
     hip.argmax_confmat(tok, B, C, h, w, H, W, t.cuda(), 255, z, z.clone(), torch.zeros(1, dtype=torch.int32, device='cuda'), pred)
+    # the fused kernel and the materialised logits are the SAME numbers: identical predictions, ties included
+    assert torch.equal(pred.cpu(), mine.argmax(1))
     ref = up.argmax(1)
-    assert torch.equal(pred.cpu(), ref)
-    assert (ref == 7).sum() == 0 and (ref == 2).sum() > 0.9 * ref.numel()
+    assert (pred.cpu() == 7).sum() == 0 and (ref == 7).sum() == 0           # the duplicate at the higher index never wins
+    assert (pred.cpu() == 2).sum() > 0.9 * ref.numel()
+    assert torch.equal(pred.cpu(), ref)                                      # classes 2 / 7 tie exactly under any association
     # (3)
     B, C, h, w, H, W = 2, 150, 128, 128, 512, 512
     lo = torch.randn(B, C, h, w, generator=g)
@@ -448,8 +455,10 @@ def test_argmax_tie_policy(hipmod):
     ulp = 2.0 ** -23
     assert (margin[diff] <= 4 * ulp).all(), margin[diff].max()
     # the predictions at those pixels are the runner-up of a near-tie, not something else
-    second = up.topk(2, dim=1).indices[:, 1]
-    assert torch.equal(pred.cpu()[diff], second[diff])
+    idx2 = up.topk(2, dim=1).indices
+    pd = pred.cpu()[diff]
+    assert ((pd == idx2[:, 0][diff]) | (pd == idx2[:, 1][diff])).all()
+    print(f'128 -> 512: {int(diff.sum())} of {diff.numel()} predictions differ from torch (all near-ties, margin <= 4 ulp)')
     assert diff.float().mean().item() < 1e-3
 
 
