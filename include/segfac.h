@@ -52,6 +52,15 @@ int segf_add(int dt, const void* a, int64_t lda, const void* b, int64_t ldb, voi
 int64_t segf_colsum_ws(int64_t rows, int64_t cols);
 int segf_colsum(int dt, const void* x, int64_t ldx, int64_t rows, int64_t cols, float* out, float* ws, void* stream);
 
+/* ---- stream ordering for the data-parallel exchange (train_gpu.py:233-236: DistributedDataParallel overlaps the gradient
+ * all-reduce with backward through per-bucket hooks).  segf_event_record(.., external=1) during a stream capture adds an
+ * EVENT-RECORD NODE to the hipGraph (hipEventRecordExternal); at each replay a stream outside the graph can
+ * segf_stream_wait_event() on it: "this bucket of gradients is final".  `event` / `stream` are hipEvent_t / hipStream_t. */
+int segf_event_create(void** event);
+int segf_event_destroy(void* event);
+int segf_event_record(void* event, void* stream, int external);
+int segf_stream_wait_event(void* stream, void* event);
+
 /* ---- GEMM: nn.Linear / 1x1 conv / im2col'd conv, forward and both backward products -------------
  * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ), fp32 accumulate.
  *   layout 0: A stored [M][K] (lda), B stored [N][K] (ldb)   y  = x W^T      (F.linear forward)

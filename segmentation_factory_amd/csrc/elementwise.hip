@@ -230,3 +230,24 @@ extern "C" int segf_rowdot(const float* a, int64_t lda, const float* b, int64_t 
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- stream-ordering helpers for the graphed train step -------------------------------------------------------------------
+// An EXTERNAL event record inside a stream capture becomes an event-record node of the hipGraph: at every replay it fires when
+// the nodes captured before it have finished, and a stream outside the graph can wait on it (the per-bucket "gradients are
+// final" signal of the data-parallel exchange, segmentation_factory_amd/graph.py).  PyTorch's torch.cuda.Event(external=True)
+// refuses to do this on ROCm, HIP itself (7.x) provides it.
+extern "C" int segf_event_create(void** event) {
+    hipEvent_t e;
+    const hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (r != hipSuccess) return (int)r;
+    *event = (void*)e;
+    return 0;
+}
+extern "C" int segf_event_destroy(void* event) { return (int)hipEventDestroy((hipEvent_t)event); }
+extern "C" int segf_event_record(void* event, void* stream, int external) {
+    return (int)hipEventRecordWithFlags((hipEvent_t)event, (hipStream_t)stream, external ? hipEventRecordExternal : hipEventRecordDefault);
+}
+extern "C" int segf_stream_wait_event(void* stream, void* event) {
+    return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+}

@@ -26,6 +26,77 @@ def _splitk(n_out, k_in, tokens):
     return hip.pick_splitk(n_out, k_in, tokens)
 
 
+# ---- direct gradient placement ---------------------------------------------------------------------------------------------
+# When the fused optimizer has re-homed the parameters into one flat buffer and `enable_direct_grads()` was called (the
+# graphed train step does), every parameter carries `_segf_grad` = its fp32 view in the flat GRADIENT buffer.  The backward
+# formulas below then write (or copy with segf_cast2d) the parameter gradients straight into those views and hand autograd
+# `None`: no `.grad` tensors, no gather pass, no ATen accumulate / copy kernels inside the captured step, and the optimizer's
+# `_segf_grad_cb` learns the moment a gradient is final (bucketed all-reduce overlapped with the rest of backward, graph.py).
+def _slot(p):
+    return getattr(p, '_segf_grad', None) if isinstance(p, torch.Tensor) else None
+
+
+def _deliver(slot_info, value):
+    slot, cb = slot_info
+    if value is not None and value.data_ptr() != slot.data_ptr():
+        v = value.detach()
+        assert v.dtype == torch.float32 and v.numel() == slot.numel(), (v.dtype, v.shape, slot.shape)
+        if slot.ndim <= 1:                      # vectors (possibly a strided column of a wider buffer): copy as an [n, 1] matrix
+            v, d = v.reshape(-1).unsqueeze(1), slot.reshape(-1).unsqueeze(1)
+        else:
+            v, d = v.reshape(slot.shape[0], -1), slot.reshape(slot.shape[0], -1)
+            if v.stride(-1) != 1:
+                v = v.contiguous()
+        hip.cast2d(v, d)
+    if cb is not None:
+        cb(slot)
+
+
+def direct_grads(*param_idx):
+    """Class decorator for the autograd Functions: the gradients of the forward arguments at positions `param_idx` (parameters)
+    go to the optimizer's flat gradient buffer when the parameter carries a `_segf_grad` view; a backward that already wrote
+    into `ctx.gslot(i)` (e.g. as the `out=` of its GEMM) returns that view and no copy is made."""
+    def deco(cls):
+        fwd, bwd = cls.forward, cls.backward
+
+        def forward(ctx, *args):
+            slots = None
+            for i in param_idx:
+                if i < len(args):
+                    sl = _slot(args[i])
+                    if sl is not None:
+                        if slots is None:
+                            slots = {}
+                        slots[i] = (sl, getattr(args[i], '_segf_grad_cb', None))
+            ctx._gslots = slots
+            return fwd(ctx, *args)
+
+        def backward(ctx, *grads):
+            out = bwd(ctx, *grads)
+            slots = getattr(ctx, '_gslots', None)
+            if not slots:
+                return out
+            out = list(out) if isinstance(out, tuple) else [out]
+            for i, info in slots.items():
+                if out[i] is not None:
+                    _deliver(info, out[i])
+                    out[i] = None
+            return tuple(out)
+        cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+        return cls
+    return deco
+
+
+def gslot(ctx, i, shape=None):
+    """The flat-buffer view for forward argument i (or None): pass it as `out=` to write the gradient in place."""
+    slots = getattr(ctx, '_gslots', None)
+    if not slots or i not in slots:
+        return None
+    v = slots[i][0]
+    return v.view(shape) if shape is not None else v
+
+
+@direct_grads(1, 2)
 class LinearFn(Function):
     """y = [residual + rscale[b] *] (x W^T + bias)   (nn.Linear / 1x1 conv on tokens).
     reference: mit.py:45,52,58,98-99 (q/kv/proj/fc1/fc2), heads/segformer.py:13,24,39."""
@@ -81,14 +152,15 @@ class LinearFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = hip.gemm(1, dys, wv, M, K, N)
+        gw, gb = gslot(ctx, 1, (N, K)), gslot(ctx, 2)       # flat-gradient views (direct placement) or None
         if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
-            dw, db = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M))      # one pass over dy for both gradients
+            dw, db = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)   # one pass over dy for both
             dw = dw.view(wshape)
         else:
             if ctx.needs_input_grad[1]:
-                dw = hip.gemm(2, dys, x, N, K, M, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
+                dw = hip.gemm(2, dys, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
             if has_bias and ctx.needs_input_grad[2]:
-                db = hip.colsum(dys)
+                db = hip.colsum(dys, out=gb)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None
 
@@ -97,6 +169,7 @@ def linear(x, weight, bias=None, residual=None, rscale=None, rows_per_group=None
     return LinearFn.apply(x, weight, bias, residual, rscale, rows_per_group, pad_to)
 
 
+@direct_grads(1, 2)
 class LayerNormFn(Function):
     """nn.LayerNorm over the channel dim of token rows (mit.py:107,136-140; convnext.py:8-23 in NHWC)."""
 
@@ -112,7 +185,11 @@ class LayerNormFn(Function):
     def backward(ctx, dy):
         x, g, mean, rstd = ctx.saved_tensors
         dy = dy if dy.is_contiguous() else dy.contiguous()
-        dx, dg, db = hip.layernorm_bwd(x, dy, g, mean, rstd)
+        gg, gb = gslot(ctx, 1), gslot(ctx, 2)
+        dgb = None
+        if gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel():
+            dgb = (gg, gb)                                  # weight / bias views are adjacent in the flat buffer: one [2][C] target
+        dx, dg, db = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb)
         return dx, dg, db, None
 
 
@@ -120,6 +197,7 @@ def layer_norm(x, gamma, beta, eps):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+@direct_grads(1, 2)
 class ConvPatchFn(Function):
     """Strided conv as im2col + MFMA GEMM: PatchEmbed (mit.py:105,127: k7 s4 p3 / k3 s2 p1), the
     spatial-reduction conv (mit.py:21,48: k = s = sr) and ConvNeXt's stem / downsample convs.
@@ -199,6 +277,7 @@ def attention(q, kv, B, N, Nkv, heads):
     return AttentionFn.apply(q, kv, B, N, Nkv, heads)
 
 
+@direct_grads(1, 2)
 class DWConvGeluFn(Function):
     """gelu(depthwise3x3(x) + b) on NHWC tokens (mit.py:62-71 + F.gelu at :99)."""
 
@@ -226,6 +305,7 @@ def dwconv3x3_gelu(x, weight, bias, B, H, W, apply_gelu=True):
     return DWConvGeluFn.apply(x, weight, bias, B, H, W, apply_gelu)
 
 
+@direct_grads(1, 2)
 class BatchNormActFn(Function):
     """BatchNorm2d (+ReLU/ReLU6) (+Dropout2d channel scale) on NHWC rows.
     ConvModule of heads/segformer.py:21-29, layers/conv_module.py:4-9, mobilenetv2.py:5-11; Dropout2d of
@@ -263,6 +343,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
                                 rows_per_sample, pre_sums)
 
 
+@direct_grads(1, 2, 11, 12)
 class BnActLinearFn(Function):
     """ConvModule's BatchNorm2d + ReLU, the Dropout2d channel scale and the following 1x1 conv (heads/segformer.py:21-29,40,
     57-58: linear_fuse.bn/activate -> dropout -> linear_pred) as ONE product: the normalisation is folded into per-(sample,
@@ -329,6 +410,7 @@ def bn_act_linear(x, gamma, beta, running_mean, running_var, training, momentum,
     return linear(y, weight, bias, pad_to=pad_to)
 
 
+@direct_grads(5, 6, 7, 8, 9, 10, 11, 12)
 class SegformerProjectConcatFn(Function):
     """The front half of SegFormerHead.forward (heads/segformer.py:42-50): per-scale Linear(C_i -> E),
     bilinear resize to the stride-4 grid, channel concat in the order [c4, c3, c2, c1].  Every branch writes
@@ -382,6 +464,7 @@ def segformer_project_concat(feats, weights, biases, geoms):
     return SegformerProjectConcatFn.apply(tuple(geoms), *feats, *weights, *biases)
 
 
+@direct_grads(5, 6, 7, 8, 9, 10, 11, 12, 13)
 class SegformerFoldedFuseFn(Function):
     """linear_fuse.conv( cat_i( resize( linear_c{i}(x_i) ) ) ) of SegFormerHead.forward (heads/segformer.py:42-56) with
     the algebra folded: Linear -> bilinear resize -> concat -> 1x1 conv (no bias) is affine in x_i, and bilinear resizing
@@ -466,6 +549,7 @@ def segformer_folded_fuse(feats, weights, biases, fuse_weight, geoms):
     return y, (sums if sums.numel() else None)
 
 
+@direct_grads(1, 2)
 class DWConv7Fn(Function):
     """Depthwise 7x7 conv + bias on NHWC tokens (ConvNeXt Block.dwconv, convnext.py:29,39; convnextv2.py:88,101)."""
 
@@ -492,6 +576,7 @@ def dwconv7x7(x, weight, bias, B, H, W):
     return DWConv7Fn.apply(x, weight, bias, B, H, W)
 
 
+@direct_grads(1)
 class Conv3x3Fn(Function):
     """3x3 / stride 1 / pad 1 convolution without bias on NHWC tokens as an implicit MFMA GEMM (ConvModule(c1, c2, 3, 1, 1):
     heads/upernet.py:26,28, modules/ppm.py:19, heads/fpn.py:19).  x may be a column slice of a wider concat buffer."""
@@ -547,6 +632,7 @@ def gelu(u):
     return GeluFn.apply(u)
 
 
+@direct_grads(1, 2, 3)
 class LinearLayerScaleFn(Function):
     """x_in + drop_path( gamma * (x W^T + b) )  (convnext.py:44-49).  The layer scale is folded into the parameters
     (W' = diag(gamma) W, b' = gamma o b) so the activation is never touched; gradients for W, b and gamma follow by the
@@ -584,6 +670,7 @@ def linear_layer_scale(x, weight, bias, gamma, residual=None, rscale=None, rows_
     return LinearLayerScaleFn.apply(x, weight, bias, gamma, residual, rscale, rows_per_group)
 
 
+@direct_grads(1, 2)
 class GRNFn(Function):
     """Global Response Normalization of ConvNeXtV2 (convnextv2.py:68-80) on NHWC tokens; gamma / beta are [1,1,1,C]."""
 

@@ -1,26 +1,31 @@
-"""One training step as a replayed hipGraph.
+"""One training step as a replayed hipGraph, with the data-parallel gradient exchange overlapped with backward.
 
 The reference's step (engine.py:36-56) issues ~700 small kernels from Python; on MI355X the kernels of
 SegFormer-B0 finish faster than the host can enqueue them.  ``GraphedTrainStep`` captures
-zero_grad + forward + fused CE/Dice + backward + the gather of all parameter gradients into one flat fp32
-buffer as a single HIP graph (torch.cuda.CUDAGraph == hipGraph on ROCm) and replays it per step; the two
-things that stay outside the graph are the data-parallel exchange (ONE RCCL all-reduce of the flat gradient
-buffer, averaged) and the fused AGC + AdamW kernel, whose bias-correction scalars change every step.
+forward + fused CE/Dice + backward as a single HIP graph (torch.cuda.CUDAGraph == hipGraph on ROCm) and replays it per
+step.  Parameter gradients are written by the backward kernels straight into the optimizer's flat fp32 gradient buffer
+(functional.direct_grads): no ``.grad`` tensors, no gather pass, no zero-fill.  Outside the graph remain the data-parallel
+exchange and the fused AGC + AdamW kernel, whose bias-correction scalars change every step.
 
-Data parallelism (train_gpu.py:233-236 wraps the model in DistributedDataParallel): here each rank replays
-its own graph on its shard of the minibatch and the flat gradient buffer is all-reduced -- same arithmetic
-(mean of per-rank gradients), one collective per step instead of per-bucket hooks.  BatchNorm stays
-per-rank, as in the reference (plain nn.BatchNorm2d, no SyncBN).
+Data parallelism (train_gpu.py:233-236 wraps the model in DistributedDataParallel, whose bucket hooks all-reduce gradients
+while backward is still running): here the flat gradient buffer is laid out in parameter-registration order, i.e. the
+REVERSE of the order in which backward completes gradients, and cut into buckets of ~``bucket_mb``.  Inside the captured
+graph an EXTERNAL event (hipEventRecordExternal) is recorded the moment the last gradient of a bucket has been written; at
+replay the communication stream waits on that event and launches the bucket's all-reduce (RCCL over xGMI) while the graph
+keeps executing the rest of backward on the compute stream.  Same arithmetic as the reference (mean of per-rank gradients:
+the loss gradient is pre-scaled by 1/world and the collective sums), same bucket idea, no per-parameter Python hooks.
+BatchNorm stays per-rank, as in the reference (plain nn.BatchNorm2d, no SyncBN).
 """
 import torch
 import torch.distributed as dist
 
+from . import hip
 from .optim import FusedAGCAdamW
 
 
 def allreduce_mean_(flat: torch.Tensor, group=None):
-    """In-place mean over ranks of one flat buffer: the whole data-parallel exchange of a step (collective C1 of SURVEY.md
-    section 2.3).  RCCL ('nccl') averages inside the collective; gloo (CPU tests) sums and divides."""
+    """In-place mean over ranks of one flat buffer (collective C1 of SURVEY.md section 2.3).  RCCL ('nccl') averages inside
+    the collective; gloo (CPU tests) sums and divides."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return flat
     if dist.get_backend(group) == 'nccl':
@@ -38,9 +43,26 @@ def broadcast_flat_(flat: torch.Tensor, src: int = 0, group=None):
     return flat
 
 
+def plan_buckets(numels, bucket_elems):
+    """Cut the flat buffer (parameters in registration order, sizes `numels`) into contiguous buckets of >= bucket_elems
+    elements, walking from the END (the gradients that backward finishes first).  Returns [(lo, hi, first_param, last_param)]
+    in the order the buckets complete (last bucket of the buffer first)."""
+    buckets, hi_p = [], len(numels)
+    offs = [0]
+    for n in numels:
+        offs.append(offs[-1] + n)
+    acc = 0
+    for i in range(len(numels) - 1, -1, -1):
+        acc += numels[i]
+        if acc >= bucket_elems or i == 0:
+            buckets.append((offs[i], offs[hi_p], i, hi_p - 1))
+            hi_p, acc = i, 0
+    return buckets
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer: FusedAGCAdamW, loss_fn, example_inputs, clip_grad=None, clip_mode='agc',
-                 warmup: int = 2, process_group=None):
+                 warmup: int = 2, process_group=None, bucket_mb: float = 25.0, overlap: bool = True):
         """loss_fn(model, *inputs) -> scalar loss tensor.  ``example_inputs`` fix the shapes; their storage becomes
         the static input buffers (``step(*new_inputs)`` copies into them)."""
         assert isinstance(optimizer, FusedAGCAdamW), 'the graphed step drives the fused AGC/AdamW kernel'
@@ -51,8 +73,24 @@ class GraphedTrainStep:
         if clip_grad is not None and clip_mode != 'agc':
             raise NotImplementedError("clip_mode='agc' is the fused mode (engine.py:52-53 default)")
         self.opt.agc_clip = float(clip_grad) if clip_grad is not None else 0.0
-        self.opt.ensure_built()                 # parameters are re-homed into the flat buffer BEFORE capture
+        # parameters are re-homed into the flat buffer BEFORE capture, laid out in registration order (bucket = suffix)
+        self.opt.ensure_built(order=list(model.parameters()))
         broadcast_flat_(self.opt.flat_params, 0, self.group)     # DDP's initial parameter broadcast from rank 0
+        # ---- buckets of the flat gradient buffer, in completion order -------------------------------------------------
+        self.buckets, self.events, self._pending = [], [], {}
+        self._capturing = False
+        if self.world > 1:
+            numels = [p.numel() for p in self.opt._params]
+            plan = plan_buckets(numels, int(bucket_mb * (1 << 20) / 4)) if overlap else [(0, sum(numels), 0, len(numels) - 1)]
+            for k, (lo, hi, p0, p1) in enumerate(plan):
+                self.buckets.append((lo, hi))
+                self.events.append(hip.GraphEvent() if overlap else None)
+                for i in range(p0, p1 + 1):
+                    self._pending[self.opt._grad_views[i].data_ptr()] = k
+            self._left = [0] * len(self.buckets)
+            self.comm = torch.cuda.Stream()
+        self.opt.enable_direct_grads(self._on_grad_written if (self.world > 1 and overlap) else None)
+        self._seed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.static_inputs[0].device)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         # the warm-up passes run real train-mode forwards: snapshot every buffer (BatchNorm running_mean / running_var /
@@ -61,32 +99,80 @@ class GraphedTrainStep:
         with torch.cuda.stream(s):
             saved_buffers = [(b, b.detach().clone()) for b in self.model.buffers()]
             for _ in range(warmup):             # allocator / lazy-init warm-up on a side stream (no optimizer step)
-                self.opt.zero_grad(set_to_none=True)
-                self.loss_fn(self.model, *self.static_inputs).backward()
+                self._forward_backward_eager()
             with torch.no_grad():
                 for b, keep in saved_buffers:
                     b.copy_(keep)
             del saved_buffers
         torch.cuda.current_stream().wait_stream(s)
-        self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread polls events while we capture; in the default global mode that aborts the capture
+        self._capturing = True
+        self._reset_pending()
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.loss = self.loss_fn(self.model, *self.static_inputs)
-            self.loss.backward()
-            self.opt.gather_grads()
+            self.loss = self._forward_backward_eager()
+            self.opt.gather_grads()          # only gradients that arrived as .grad (foreign plugin modules); normally nothing
+        self._capturing = False
+        if self.world > 1 and overlap:
+            missing = [k for k, n in enumerate(self._left) if n > 0]
+            if missing:       # parameters without a gradient (frozen / unused): their buckets are complete when the graph ends
+                self.events = [None if k in missing else e for k, e in enumerate(self.events)]
+
+    # ---- pieces --------------------------------------------------------------------------------------------------------
+    def _forward_backward_eager(self):
+        loss = self.loss_fn(self.model, *self.static_inputs)
+        # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
+        loss.backward(gradient=self._seed if self.world > 1 else None)
+        return loss
+
+    def _reset_pending(self):
+        if self.world > 1:
+            counts = [0] * len(self.buckets)
+            have = {v.data_ptr() for p, v in zip(self.opt._params, self.opt._grad_views)}
+            for ptr, k in self._pending.items():
+                if ptr in have:
+                    counts[k] += 1
+            self._left = counts
+
+    def _on_grad_written(self, view):
+        """functional.direct_grads callback (runs while backward is being captured): when the last gradient of a bucket
+        has been enqueued, record the bucket's external event on the capture stream."""
+        if not self._capturing:
+            return
+        k = self._pending.get(view.data_ptr())
+        if k is None:
+            return
+        self._left[k] -= 1
+        if self._left[k] == 0 and self.events[k] is not None:
+            self.events[k].record_external()
+
+    def _exchange(self):
+        """All-reduce (sum; the gradients carry the 1/world factor) bucket by bucket on the communication stream, each one as
+        soon as its event inside the running graph has fired; the compute stream joins before the optimizer."""
+        works = []
+        with torch.cuda.stream(self.comm):
+            for (lo, hi), ev in zip(self.buckets, self.events):
+                if ev is not None:
+                    ev.wait()                                  # this replay's record node (the graph was launched above)
+                else:
+                    self.comm.wait_stream(self._main)          # bucket without an in-graph event: after the whole graph
+                works.append(dist.all_reduce(self.opt.flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()                                           # the compute stream waits for the collective's result
 
     def step(self, *inputs):
         """One optimisation step; returns the (device) loss tensor of this step."""
         for dst, src in zip(self.static_inputs, inputs):
             dst.copy_(src, non_blocking=True)
+        self._main = torch.cuda.current_stream()
         self.graph.replay()
-        allreduce_mean_(self.opt.flat_grads, self.group)
+        if self.world > 1:
+            self._exchange()
         self.opt.apply_flat()
         return self.loss
 
     def forward_backward(self, *inputs):
-        """Replay without the optimizer (forward + loss + backward only)."""
+        """Replay without the exchange / optimizer (forward + loss + backward only)."""
         for dst, src in zip(self.static_inputs, inputs):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()

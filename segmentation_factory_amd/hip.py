@@ -76,6 +76,10 @@ _PROTOS = {
     'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
     'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),
+    'segf_event_create': (_i, [C.POINTER(C.c_void_p)]),
+    'segf_event_destroy': (_i, [_p]),
+    'segf_event_record': (_i, [_p, _p, _i]),
+    'segf_stream_wait_event': (_i, [_p, _p]),
     'segf_version': (C.c_char_p, []),
 }
 
@@ -185,10 +189,12 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
+def colsum(x: torch.Tensor, out=None) -> torch.Tensor:
     _need_cuda(x)
     rows, cols = x.shape
-    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.numel() == cols and out.is_contiguous()
     ws = _f32(lib().segf_colsum_ws(rows, cols), x.device)
     _chk(lib().segf_colsum(dt_of(x), _ptr(x), x.stride(0), rows, cols, _ptr(out), _ptr(ws), _stream()), 'segf_colsum')
     return out
@@ -216,13 +222,14 @@ def gemm(layout: int, A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, 
     return out
 
 
-def gemm_dw_db(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, split_k=1, out=None):
+def gemm_dw_db(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, split_k=1, out=None, db_out=None):
     """(dW [M,N] fp32, db [M] fp32) = (dy^T x, column sums of dy) in one pass over dy [K,M]; x is [K,N]."""
     _need_cuda(dy, x)
     assert dy.stride(-1) == 1 and x.stride(-1) == 1 and dt_of(dy) == dt_of(x)
     dw = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dy.device)
     assert dw.stride(-1) == 1
-    db = torch.empty(M, dtype=torch.float32, device=dy.device)
+    db = db_out if db_out is not None else torch.empty(M, dtype=torch.float32, device=dy.device)
+    assert db.dtype == torch.float32 and db.numel() == M and db.is_contiguous()
     ws = _f32(lib().segf_gemm_dw_db_ws(M, N, K, split_k), dy.device)
     _chk(_timed(('gemm', 2, M, N, K), lambda: lib().segf_gemm_dw_db(
         dt_of(dy), M, N, K, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dt_of(dw), dw.stride(0), split_k, _ptr(ws),
@@ -255,6 +262,35 @@ def gemm_pro(layout, A, B, M, N, K, scale, shift, rows_per_group, act, bias=None
         dt_of(A), layout, M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), dt_of(out), out.stride(0), _ptr(bias),
         split_k, _ptr(ws), _ptr(scale), _ptr(shift), rows_per_group, act, _stream())), 'segf_gemm_pro')
     return out
+
+
+class GraphEvent:
+    """A HIP event that may be recorded INSIDE a stream capture as an external event-record node (hipEventRecordExternal) and
+    waited on by a stream outside the graph at replay (graph.py).  torch.cuda.Event(external=True) raises on ROCm."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _chk(lib().segf_event_create(C.byref(h)), 'segf_event_create')
+        self.handle = h
+
+    def record_external(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream()
+        _chk(lib().segf_event_record(self.handle, s.cuda_stream, 1), 'segf_event_record')
+
+    def record(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream()
+        _chk(lib().segf_event_record(self.handle, s.cuda_stream, 0), 'segf_event_record')
+
+    def wait(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream()
+        _chk(lib().segf_stream_wait_event(s.cuda_stream, self.handle), 'segf_stream_wait_event')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().segf_event_destroy(self.handle)
+        except Exception:
+            pass
 
 
 class KernelTimer:
@@ -305,14 +341,20 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(x, dy, gamma, mean, rstd):
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None):
+    """dgb_out: optional (dgamma, dbeta) fp32 [C] views that are ADJACENT in memory (dbeta == dgamma + C): written in place."""
     rows, Cc = x.shape
     dx = torch.empty_like(x)
-    dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    if dgb_out is not None:
+        dg, db = dgb_out
+        assert db.data_ptr() == dg.data_ptr() + 4 * Cc and dg.numel() == Cc and db.numel() == Cc
+    else:
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        dg, db = dgb[0], dgb[1]
     ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
     _chk(lib().segf_layernorm_bwd(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                  dgb.data_ptr(), dgb[1].data_ptr(), _ptr(ws), _stream()), 'segf_layernorm_bwd')
-    return dx, dgb[0], dgb[1]
+                                  dg.data_ptr(), db.data_ptr(), _ptr(ws), _stream()), 'segf_layernorm_bwd')
+    return dx, dg, db
 
 
 def bn_stats(x, running_mean, running_var, momentum, eps):

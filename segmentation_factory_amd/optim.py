@@ -18,22 +18,30 @@ class FusedAGCAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat = None
+        self.direct = False
         self._step = 0
         self.agc_clip = 0.0          # set per step by NativeScaler when clip_mode == 'agc'
 
-    def _build(self):
-        ps, decay = [], []
+    def _build(self, order=None):
+        """order: optional sequence of parameters (e.g. ``list(model.parameters())``) that fixes the LAYOUT of the flat buffers
+        (registration order = reverse of the order in which backward finishes the gradients, so a suffix of the buffer is a
+        bucket that completes early); default: parameter-group order.  The layout does not affect the arithmetic."""
+        ps, decay = [], {}
         for g in self.param_groups:
             for p in g['params']:
                 if p.requires_grad:
                     ps.append(p)
-                    decay.append(g['weight_decay'] > 0)
+                    decay[id(p)] = g['weight_decay'] > 0
+        if order is not None:
+            rank = {id(p): i for i, p in enumerate(order)}
+            ps.sort(key=lambda p: rank.get(id(p), len(rank)))
         dev = ps[0].device
         total = sum(p.numel() for p in ps)
         flat = torch.empty(total, dtype=torch.float32, device=dev)
         offs, lens, flags = [], [], []
         o = 0
-        for p, d in zip(ps, decay):
+        for p in ps:
+            d = decay[id(p)]
             n = p.numel()
             flat[o:o + n].copy_(p.data.reshape(-1))
             p.data = flat[o:o + n].view(p.shape)
@@ -47,19 +55,21 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         self._params = ps
         self._flat = flat
         self._grad = torch.zeros_like(flat)
-        self._grad_views, o = [], 0
+        self._grad_views, self._offsets, o = [], [], 0
         for p in ps:
             self._grad_views.append(self._grad[o:o + p.numel()].view(p.shape))
+            self._offsets.append(o)
             o += p.numel()
         self._m = torch.zeros_like(flat)
         self._v = torch.zeros_like(flat)
         self._off = torch.tensor(offs, dtype=torch.int64, device=dev)
         self._len = torch.tensor(lens, dtype=torch.int32, device=dev)
         self._flags = torch.tensor(flags, dtype=torch.uint8, device=dev)
+        self.direct = False
 
-    def ensure_built(self):
+    def ensure_built(self, order=None):
         if self._flat is None:
-            self._build()
+            self._build(order)
 
     @property
     def flat_params(self):
@@ -71,16 +81,36 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         self.ensure_built()
         return self._grad
 
+    def enable_direct_grads(self, callback=None):
+        """Hand every parameter its view of the flat gradient buffer (``p._segf_grad``): the backward formulas of
+        segmentation_factory_amd.functional then write parameter gradients in place and ``.grad`` stays None
+        (functional.direct_grads).  callback(view) is invoked, in backward order, whenever one gradient is final."""
+        self.ensure_built()
+        self._grad.zero_()
+        for p, view in zip(self._params, self._grad_views):
+            p._segf_grad = view
+            p._segf_grad_cb = callback
+            p.grad = None
+        self.direct = True
+
+    def disable_direct_grads(self):
+        for p in getattr(self, '_params', []):
+            for a in ('_segf_grad', '_segf_grad_cb'):
+                if hasattr(p, a):
+                    delattr(p, a)
+        self.direct = False
+
     @torch.no_grad()
     def gather_grads(self):
-        """Copy every parameter's .grad into the flat gradient buffer (multi-tensor copy; graph-capturable)."""
+        """Copy every parameter's .grad into the flat gradient buffer (multi-tensor copy; graph-capturable).  With direct
+        placement only gradients that still arrived as ``.grad`` (foreign plugin modules on plain autograd) are copied."""
         self.ensure_built()
         dst, src = [], []
         for p, view in zip(self._params, self._grad_views):
             if p.grad is not None:
                 dst.append(view)
                 src.append(p.grad)
-            else:
+            elif not self.direct:
                 view.zero_()
         if dst:
             torch._foreach_copy_(dst, src)

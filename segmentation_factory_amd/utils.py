@@ -167,6 +167,8 @@ class ConfusionMatrix:
     def reduce_from_all_processes(self):
         if not is_dist_avail_and_initialized():
             return
+        if self.mat is None:          # a rank whose shard held no complete batch still takes part in the collective
+            self._ensure(torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu'))
         dist.barrier()
         dist.all_reduce(self.mat)
 

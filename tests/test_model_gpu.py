@@ -587,3 +587,64 @@ def test_two_rank_eager_ddp_finetune_freeze(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-2000:]
     assert 'Epoch: [0]  [1/2]' in outs[0] and 'Val_mIOU' in outs[0]
+
+
+@pytest.mark.parametrize('bucket_mb', [4.0, 1000.0])
+def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb):
+    """D1 / collective C1 on the PRODUCT step: two ranks (fresh child processes, gloo, sharing this box's GPU) each drive
+    GraphedTrainStep on their shard -- hipGraph replay, per-bucket external events, all-reduce on the communication stream,
+    fused AGC/AdamW -- for three steps.  Expected values: data parallelism by hand in this process = per-shard forward /
+    backward on the SAME weights (BatchNorm statistics per shard, as per rank: the reference uses plain BatchNorm2d), mean of
+    the two gradients, one optimizer step (train_gpu.py:233-236 DistributedDataParallel semantics).  bucket_mb=4: six buckets
+    with in-graph events; 1000: a single bucket."""
+    import subprocess
+    import sys
+    from segmentation_factory_amd import criterion_lowres
+    from segmentation_factory_amd.optim import FusedAGCAdamW, param_groups_weight_decay
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    steps, world, per_rank = 3, 2, 2
+    out = tmp_path / 'rank0.pt'
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29583', WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(out), str(steps), str(bucket_mb)],
+                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-3000:]
+    got = torch.load(str(out), map_location='cpu', weights_only=False)
+    if bucket_mb < 100:
+        assert got['n_buckets'] >= 4 and got['events'] == got['n_buckets']
+    else:
+        assert got['n_buckets'] == 1
+    # ---- the same three steps by hand -------------------------------------------------------------------------------
+    backbone, head, nc, H, W, seed = 'MiT-B0', 'SegFormerHead', 19, 64, 64, 17
+    sd = OW.make_state_dict(backbone, head, nc, seed)                       # rank 0's initial weights
+    x, y = OW.synthetic_batch(per_rank * world, H, W, nc, seed)
+    models = [_build(backbone, head, nc, sd, torch.float32, per_rank).train() for _ in range(world)]
+    opt = FusedAGCAdamW(param_groups_weight_decay(models[0], 0.025), lr=1e-3)
+    opt.agc_clip = 0.02
+    losses = []
+    for _ in range(steps):
+        grads = []
+        for r, m in enumerate(models):
+            m.load_state_dict({k: v for k, v in models[0].state_dict().items() if 'running_' not in k and 'num_batches' not in k},
+                              strict=False)                                  # same weights, own BatchNorm buffers
+            for p in m.parameters():
+                p.grad = None
+            xs, ys = x[r * per_rank:(r + 1) * per_rank].cuda(), y[r * per_rank:(r + 1) * per_rank].cuda()
+            loss = criterion_lowres(m.forward_lowres(xs), ys, (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+            loss.backward()
+            grads.append([p.grad.clone() for p in m.parameters()])
+            if r == 0:
+                losses.append(loss.item())
+        for p, g0, g1 in zip(models[0].parameters(), grads[0], grads[1]):
+            p.grad = (g0 + g1) / world
+        opt.step()
+    np.testing.assert_allclose(got['losses'], losses, rtol=2e-5)
+    ref = models[0].state_dict()
+    worst = 0.0
+    for k, v in got['state'].items():
+        r = ref[k].detach().cpu()
+        if v.is_floating_point():
+            worst = max(worst, ((v - r).abs().max() / (r.abs().max() + 1e-6)).item())
+        else:
+            assert torch.equal(v, r), k
+    assert worst <= 2e-5, worst
