@@ -246,7 +246,26 @@ extern "C" int segf_event_create(void** event) {
 }
 extern "C" int segf_event_destroy(void* event) { return (int)hipEventDestroy((hipEvent_t)event); }
 extern "C" int segf_event_record(void* event, void* stream, int external) {
-    return (int)hipEventRecordWithFlags((hipEvent_t)event, (hipStream_t)stream, external ? hipEventRecordExternal : hipEventRecordDefault);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev = (hipEvent_t)event;
+    if (!external) return (int)hipEventRecord(ev, st);
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    hipError_t r = hipStreamGetCaptureInfo_v2(st, &status, nullptr, &graph, &deps, &ndeps);
+    if (r != hipSuccess) return (int)r;
+    if (status != hipStreamCaptureStatusActive) return SEGF_ERR_SHAPE;       // an external record only exists inside a capture
+    r = hipEventRecordWithFlags(ev, st, hipEventRecordExternal);
+    if (r == hipSuccess) return 0;
+    (void)hipGetLastError();
+    // the runtime refused the flag form: add the event-record node by hand behind the capture's current frontier and make it
+    // the new frontier (same graph, same semantics)
+    hipGraphNode_t node = nullptr;
+    r = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev);
+    if (r != hipSuccess) return (int)r;
+    r = hipStreamUpdateCaptureDependencies(st, &node, 1, hipStreamSetCaptureDependencies);
+    return (int)r;
 }
 extern "C" int segf_stream_wait_event(void* stream, void* event) {
     return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);

@@ -17,9 +17,10 @@ ev = hip.GraphEvent()
 side = torch.cuda.Stream()
 
 
-def body():
+def body(capturing=True):
     a.copy_(x * 2 + 1)            # "bucket" a is final here
-    ev.record_external()          # external event node
+    if capturing:
+        ev.record_external()      # external event node
     t = a
     for _ in range(200):          # long tail that the side stream may overlap with
         t = t * 1.0001 + 0.5
@@ -29,7 +30,7 @@ def body():
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
-    body()
+    body(False)
 torch.cuda.current_stream().wait_stream(s)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
