@@ -43,24 +43,59 @@ def synthetic_batch(batch, seed):
     return torch.from_numpy(img), torch.from_numpy(lbl)
 
 
-def cpu_baseline(sample_batch=2):
-    """The oracle (CPU restatement of the reference path, validated bit-exact against the imported reference in
-    the build container) timed on this host: forward + CE/Dice with the reference's B x C Python loop + backward."""
+def kernel_source_hash():
+    """Hash of the HIP sources the in-tree library is built from: stamps profiles/pmc_traffic_*.json so that a counter file
+    measured on other kernels is never reported as this run's traffic."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'segmentation_factory_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')) + [os.path.join(csrc, 'Makefile')]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(sample_batch=2, timed_steps=3):
+    """The oracle (CPU restatement of the reference path, validated bit-exact against the imported reference in the build
+    container) timed on this host, SURVEY section 8(d): same synthetic batch, 1 warm-up + 3 timed steps of forward + CE/Dice +
+    backward with the reference's B x C Python Dice loop (util/losses.py:141-170: its cost structure), and next to it the
+    same with the vectorised closed-form Dice."""
     from oracle import loss as OL, nets as ON, weights as OW
     # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share: oversubscribing stalls for minutes
     ncores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(ncores)
-    sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', NC, 0, lively=False)
+    sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', 150, 0, lively=False)
     sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var')))
           for k, v in sd.items()}
-    x, y = OW.synthetic_batch(sample_batch, H, W, NC, 0)
-    t0 = time.time()
-    o, _ = ON.model_forward(sd, x, 'MiT-B0', 'SegFormerHead', training=True)
-    loss = OL.criterion_loops(o, y, None, num_classes=NC, dice=True, ignore_index=255)
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 step fwd+CE/Dice(loop)+bwd, batch {sample_batch}, 512x512, 150 classes, fp32, {dt:.1f} s"}
+    x, y = OW.synthetic_batch(sample_batch, 512, 512, 150, 0)
+
+    def step(crit):
+        for v in sd.values():
+            v.grad = None
+        o, _ = ON.model_forward(sd, x, 'MiT-B0', 'SegFormerHead', training=True)
+        crit(o, y, None, num_classes=150, dice=True, ignore_index=255).backward()
+
+    def timed(crit, n):
+        step(crit)                                   # warm-up (allocator, thread pool, first-touch)
+        t0 = time.time()
+        for _ in range(n):
+            step(crit)
+        return (time.time() - t0) / n
+    t_loop = timed(OL.criterion_loops, timed_steps)
+    t_vec = timed(OL.criterion_closed_form, timed_steps)
+    cpu_model = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            cpu_model = next((l.split(':', 1)[1].strip() for l in fh if l.startswith('model name')), '')
+    except OSError:
+        pass
+    return {"value": round(sample_batch / t_loop, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 warm-up + {timed_steps} timed steps of fwd + CE/Dice (reference's B x C Python loop) + bwd, batch {sample_batch}, "
+                      f"512x512, 150 classes, fp32: {t_loop:.2f} s/step",
+            "vectorised_dice_value": round(sample_batch / t_vec, 4),
+            "vectorised_dice_sample": f"same with the closed-form Dice: {t_vec:.2f} s/step",
+            "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(), "cpu_model": cpu_model}
 
 
 def main():
@@ -183,10 +218,19 @@ def main():
     A_ = torch.randn(M, K, device=dev).to(dtype)
     W_ = torch.zeros(ld, K, device=dev, dtype=dtype)
     b_ = torch.zeros(ld, device=dev)
+    # the classifier product as it runs INSIDE the step: segf_gemm_pro, BatchNorm + ReLU + Dropout2d applied to the operand on
+    # its way into LDS (gemm_bf16_big_kernel<0, bf16, false, PRO=true>), not the plain segf_gemm of the same shape
+    rps_ = hq * wq
+    use_pro = dtype == torch.bfloat16 and hip.gemm_pro_supported(dtype, 0, M, ld, K, rps_)
+    sc_ = torch.ones(args.batch, K, device=dev)
+    sh_ = torch.zeros(args.batch, K, device=dev)
     with hip.KernelTimer(lambda k: k in (loss_key, gemm_key)) as kt:
         for _ in range(max(args.steps, 5)):
             hip.ce_dice_bwd(lo_, args.batch, NC, hq, wq, H, W, y, 255, None, True, stats_, go_)
-            hip.gemm(0, A_, W_, M, ld, K, bias=b_)
+            if use_pro:
+                hip.gemm_pro(0, A_, W_, M, ld, K, sc_, sh_, rps_, 1, bias=b_)
+            else:
+                hip.gemm(0, A_, W_, M, ld, K, bias=b_)
     esz = A_.element_size()
     loss_bytes = args.batch * (2 * hq * wq * ld * esz + H * W * 8)           # logits read + gradient written + labels
     loss_exps = float(args.batch) * H * W * (16 * ((NC + 15) // 16)) * (81.0 / 64.0)   # per pixel and padded class; 9x9 cells per 8x8-tap tile
@@ -195,14 +239,20 @@ def main():
 
     # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command,
     # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/): reported only for the batch it was measured at
-    traffic = {}
+    traffic, traffic_note = {}, 'no counter file for this batch / configuration'
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_b128.json')) as fh:
+        with open(os.path.join(ROOT, 'profiles', f'pmc_traffic_b{args.batch}.json')) as fh:
             pmc = json.load(fh)
-        if pmc.get('batch') == args.batch and args.config == 'cfg2' and args.dtype == 'bf16':
+        if pmc.get('source_hash') != kernel_source_hash():
+            traffic_note = f"profiles/pmc_traffic_b{args.batch}.json was measured on other kernel sources (hash {pmc.get('source_hash')}): not reported"
+        elif pmc.get('batch') == args.batch and args.config == 'cfg2' and args.dtype == 'bf16':
+            traffic_note = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, kernel sources {pmc['source_hash']}"
             for kname, v in pmc['kernels'].items():
-                traffic[kname.split('<')[0] + ('<0' if kname.startswith('gemm_bf16_big_kernel<0') else '')] = v['total_bytes']
-    except (OSError, ValueError):
+                if kname.startswith('ce_dice_bwd'):
+                    traffic['loss_bwd'] = v['total_bytes']
+                if kname.startswith('gemm_bf16_big_kernel<0') and kname.rstrip('>').endswith('true'):
+                    traffic['gemm_pro'] = v['total_bytes']
+    except (OSError, ValueError, KeyError):
         pass
     if rank == 0:
         summ = kt.summary()
@@ -233,15 +283,17 @@ def main():
             "roofline": {"kernel": "ce_dice_bwd_mfma4_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
                                    "backward, low-res logits [B,128,128,152] -> d logits, labels int64 [B,512,512]",
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('ce_dice_bwd_mfma4_kernel'),
+                         "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note,
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
                          "note": "transcendental-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~6 VALU "
                                  "ops; interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
-            "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0> heaviest GEMM launch: classifier 1x1 conv [B*128*128,768]x[768,152]",
+            "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true> (segf_gemm_pro, the in-graph variant): classifier 1x1 conv "
+                                        "[B*128*128,768]x[768,152] with BatchNorm + ReLU + Dropout2d applied on the operand load" if use_pro else
+                                        "gemm_bf16_big_kernel<0>: classifier 1x1 conv [B*128*128,768]x[768,152]",
                               "bound": "hbm", "achieved": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": round(gemm_bytes / (gemm_ms * 1e-3) / HBM_PEAK, 4),
-                              "traffic": traffic.get('gemm_bf16_big_kernel<0'), "launches_timed": ng,
+                              "traffic": traffic.get('gemm_pro'), "launches_timed": ng,
                               "avg_launch_ms": round(gemm_ms, 4), "algorithmic_bytes_per_launch": gemm_bytes,
                               "flops_per_launch": 2.0 * M * ld * K},
         }

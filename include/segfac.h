@@ -52,6 +52,14 @@ int segf_add(int dt, const void* a, int64_t lda, const void* b, int64_t ldb, voi
 int64_t segf_colsum_ws(int64_t rows, int64_t cols);
 int segf_colsum(int dt, const void* x, int64_t ldx, int64_t rows, int64_t cols, float* out, float* ws, void* stream);
 
+/* zero-fill / counter increment / stochastic-layer scales as library kernels (no framework kernels inside the captured step).
+ * segf_bernoulli_scale: out[i] = U_i < keep_prob[i / row_len] ? 1 / keep_prob[i / row_len] : 0 -- DropPath
+ * (models/layers/drop_path.py:18-25) with rows = draws and row_len = batch, Dropout2d (heads/segformer.py:40) with one row of
+ * B * C entries; state = {seed, launch counter} (uint64[2], advanced by the kernel: graph replays draw fresh numbers). */
+int segf_zero(void* p, int64_t nbytes, void* stream);
+int segf_add_i64(int64_t* p, int64_t v, void* stream);
+int segf_bernoulli_scale(uint64_t* state, const float* keep_prob, int64_t n, int64_t row_len, float* out, void* stream);
+
 /* ---- stream ordering for the data-parallel exchange (train_gpu.py:233-236: DistributedDataParallel overlaps the gradient
  * all-reduce with backward through per-bucket hooks).  segf_event_record(.., external=1) during a stream capture adds an
  * EVENT-RECORD NODE to the hipGraph (hipEventRecordExternal); at each replay a stream outside the graph can
@@ -107,6 +115,13 @@ int64_t segf_layernorm_bwd_ws(int64_t rows, int C);
 int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* gamma,
                        const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                        float* ws, void* stream);
+/* the same with two optional fan-in operands, so that a pre-norm residual block needs no separate gradient additions
+ * (mit.py:143-146 `x + drop_path(f(norm(x)))`: dx = dres + LN_bwd(dy)) and a normalised map with two consumers (the stage
+ * output feeding the head and the next patch embedding, mit.py:196-216) sums their gradients on load:
+ *   dx = LN_bwd(dy + dy2) + dres;   dy2, dres nullable, [rows][C] of dtype dt. */
+int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                             const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                             float* ws, void* stream);
 
 /* ---- BatchNorm2d (train: batch statistics) + ReLU/ReLU6 + Dropout2d, NHWC rows -------------------
  * ConvModule of heads/segformer.py:21-29, layers/conv_module.py:4-9, mobilenetv2.py:5-11.

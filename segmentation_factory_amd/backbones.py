@@ -62,7 +62,9 @@ class Attention(nn.Module):
 
     def tokens(self, h, B, H, W, residual, rscale):
         N = H * W
+        h, h2 = Fh.fork(h, 2)                        # two consumers (q and the key / value path): gradients joined by segf_add
         q = Fh.linear(h, self.q.weight, self.q.bias)
+        h = h2
         if self.sr_ratio > 1:
             sr = self.sr_ratio
             xr = Fh.conv_patch(h, self.sr.weight, self.sr.bias, (B, H, W, self.dim, sr, sr, 0))
@@ -128,9 +130,9 @@ class Block(nn.Module):
 
     def tokens(self, x, B, H, W, scales):
         s1, s2 = scales
-        h = Fh.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, h = Fh.layer_norm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)     # x passes through for the residual
         x = self.attn.tokens(h, B, H, W, x, s1)
-        h = Fh.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, h = Fh.layer_norm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp.tokens(h, B, H, W, x, s2)
 
 
@@ -168,15 +170,11 @@ class MiT(nn.Module):
         if not self.training or all(r == 0 for r in rates):
             return [(None, None)] * len(rates)
         draws = [r for r in rates if r > 0 for _ in range(2)]
-        key = (str(device), tuple(draws))
-        if getattr(self, '_kp_cache', (None, None))[0] != key:      # cached: a host->device copy cannot be graph-captured
-            self._kp_cache = (key, 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None])
-        kp = self._kp_cache[1]
         if self.stochastic_override is not None and 'drop_path' in self.stochastic_override:
-            keep = self.stochastic_override['drop_path'].to(device=device, dtype=torch.float32)
+            kp = 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None]
+            scale = (self.stochastic_override['drop_path'].to(device=device, dtype=torch.float32) / kp).contiguous()
         else:
-            keep = torch.floor(kp + torch.rand(len(draws), B, device=device))
-        scale = (keep / kp).contiguous()
+            scale = Fh.stochastic_scales(self, tuple(1.0 - r for r in draws), B, device)       # keep / kp, one row per draw
         out, i = [], 0
         for r in rates:
             if r > 0:
@@ -200,8 +198,11 @@ class MiT(nn.Module):
                 t = blk.tokens(t, B, H, W, scales[bi])
                 bi += 1
             nrm = getattr(self, f'norm{s + 1}')
-            t = Fh.layer_norm(t, nrm.weight, nrm.bias, nrm.eps)
-            outs.append(TokenMap(t, B, H, W))
+            if s < 3:       # the stage output feeds the decode head AND the next patch embedding: one LayerNorm, two consumers
+                t_head, t = Fh.layer_norm_fork(t, nrm.weight, nrm.bias, nrm.eps)
+            else:
+                t_head = t = Fh.layer_norm(t, nrm.weight, nrm.bias, nrm.eps)
+            outs.append(TokenMap(t_head, B, H, W))
             cur, image = t, False
         return outs
 
@@ -258,7 +259,8 @@ class ConvNeXtBlock(nn.Module):
         self.drop_prob = float(dpr)
 
     def tokens(self, x, B, H, W, scale):
-        h = Fh.dwconv7x7(x, self.dwconv.weight, self.dwconv.bias, B, H, W)
+        x, xc = Fh.fork(x, 2)                        # residual + depthwise conv both read x
+        h = Fh.dwconv7x7(xc, self.dwconv.weight, self.dwconv.bias, B, H, W)
         h = Fh.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps)
         h = Fh.gelu(Fh.linear(h, self.pwconv1.weight, self.pwconv1.bias))
         if self.v2:
@@ -300,15 +302,11 @@ class _ConvNeXtBase(nn.Module):
         if not self.training or all(r == 0 for r in rates):
             return [None] * len(rates)
         draws = [r for r in rates if r > 0]
-        key = (str(device), tuple(draws))
-        if getattr(self, '_kp_cache', (None, None))[0] != key:
-            self._kp_cache = (key, 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None])
-        kp = self._kp_cache[1]
         if self.stochastic_override is not None and 'drop_path' in self.stochastic_override:
-            keep = self.stochastic_override['drop_path'].to(device=device, dtype=torch.float32)
+            kp = 1.0 - torch.tensor(draws, dtype=torch.float32, device=device)[:, None]
+            scale = (self.stochastic_override['drop_path'].to(device=device, dtype=torch.float32) / kp).contiguous()
         else:
-            keep = torch.floor(kp + torch.rand(len(draws), B, device=device))
-        scale = (keep / kp).contiguous()
+            scale = Fh.stochastic_scales(self, tuple(1.0 - r for r in draws), B, device)
         out, i = [], 0
         for r in rates:
             out.append(scale[i] if r > 0 else None)
@@ -337,7 +335,11 @@ class _ConvNeXtBase(nn.Module):
                 t = blk.tokens(t, B, H, W, scales[bi])
                 bi += 1
             nrm = getattr(self, f'norm{i}')
-            outs.append(TokenMap(Fh.layer_norm(t, nrm.weight, nrm.bias, nrm.eps), B, H, W))
+            if i < 3:
+                t, th = Fh.fork(t, 2)                # the stage output feeds its output norm and the next downsampler's norm
+            else:
+                th = t
+            outs.append(TokenMap(Fh.layer_norm(th, nrm.weight, nrm.bias, nrm.eps), B, H, W))
         return outs
 
     def forward(self, x):
@@ -402,7 +404,7 @@ def _bn_act(x, bn, training, act):
     """BatchNorm2d (+ReLU6) of mobilenetv2.ConvModule (mobilenetv2.py:5-11) / the bare BatchNorm2d of :29."""
     y = Fh.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, act=act)
     if training:
-        bn.num_batches_tracked += 1
+        Fh.hip.add_i64_(bn.num_batches_tracked, 1)
     return y
 
 
@@ -431,7 +433,11 @@ class InvertedResidual(nn.Module):
         self.conv = nn.Sequential(*layers)
 
     def tokens(self, x, B, H, W, training):
-        h, li = x, 0
+        if self.use_res_connect:
+            x, h = Fh.fork(x, 2)
+        else:
+            h = x
+        li = 0
         if self.expand:
             m = self.conv[li]
             h = _bn_act(Fh.linear(h, m[0].weight), m[1], training, 2)
@@ -480,7 +486,11 @@ class MobileNetV2(nn.Module):
         for i in range(1, len(self.features)):
             t, H, W = self.features[i].tokens(t, B, H, W, tr)
             if i in self.out_indices:
-                outs.append(TokenMap(t, B, H, W))
+                if i != len(self.features) - 1:
+                    t, th = Fh.fork(t, 2)            # feature tap: decode head + the next inverted residual
+                else:
+                    th = t
+                outs.append(TokenMap(th, B, H, W))
         return outs
 
     def forward(self, x):

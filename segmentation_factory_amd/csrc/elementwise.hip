@@ -270,3 +270,58 @@ extern "C" int segf_event_record(void* event, void* stream, int external) {
 extern "C" int segf_stream_wait_event(void* stream, void* event) {
     return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
 }
+
+
+// ---- small device-side plumbing that keeps the captured train step free of framework kernels --------------------------------
+__global__ void zero_fill_kernel(uint32_t* __restrict__ p, int64_t nwords, uint8_t* __restrict__ tail, int ntail) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+extern "C" int segf_zero(void* p, int64_t nbytes, void* stream) {
+    if (nbytes <= 0) return 0;
+    if ((uintptr_t)p % 4) return SEGF_ERR_SHAPE;
+    const int64_t nwords = nbytes / 4;
+    const int blocks = (int)imin64(cdiv64(nwords > 0 ? nwords : 1, 256), 4096);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t*)p, nwords,
+                       (uint8_t*)p + nwords * 4, (int)(nbytes - nwords * 4));
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+__global__ void add_i64_kernel(int64_t* p, int64_t v) { if (threadIdx.x == 0) *p += v; }
+extern "C" int segf_add_i64(int64_t* p, int64_t v, void* stream) {
+    hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Keep / drop scales of the stochastic layers (DropPath, models/layers/drop_path.py:18-25: x / kp * floor(kp + U); Dropout2d,
+// heads/segformer.py:40: whole channels zeroed with p = 0.1, survivors scaled by 1 / 0.9):
+//   out[i] = U_i < kp[i / row_len] ? 1 / kp[i / row_len] : 0,   U_i = uniform [0, 1) from a counter-based generator.
+// state[0] = seed, state[1] = launch counter (advanced by the kernel itself, so a replayed hipGraph draws fresh numbers every
+// step without any host involvement).
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void bernoulli_scale_kernel(uint64_t* __restrict__ state, const float* __restrict__ kp, int64_t n, int64_t row_len,
+                                       float* __restrict__ out) {
+    const uint64_t seed = state[0], ctr = state[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = splitmix64(splitmix64(seed ^ (ctr * 0xD1B54A32D192ED03ull)) + (uint64_t)i);
+        const float u = (float)(r >> 40) * (1.f / 16777216.f);
+        const float k = kp[i / row_len];
+        out[i] = u < k ? 1.f / k : 0.f;
+    }
+    __syncthreads();
+    // the LAST workgroup to finish advances the counter (every workgroup has read it above): single-block launches in practice
+    if (gridDim.x == 1 && threadIdx.x == 0) state[1] = ctr + 1;
+}
+extern "C" int segf_bernoulli_scale(uint64_t* state, const float* keep_prob, int64_t n, int64_t row_len, float* out, void* stream) {
+    if (n <= 0) return 0;
+    if (row_len <= 0 || n > (1 << 20)) return SEGF_ERR_SHAPE;       // one workgroup walks the whole (small) table
+    hipLaunchKernelGGL(bernoulli_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, state, keep_prob, n, row_len, out);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -75,6 +75,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
 #define LN_BWD_MAX_BLOCKS 1024      // 4 workgroups per CU (one per CU left the HBM pipe half empty: 2.7 TB/s at 2M x 32)
 template <typename T, int VPT>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                      const T* __restrict__ dy2 /*nullable: second consumer's gradient, added to dy*/,
+                                                      const T* __restrict__ dres /*nullable: residual-path gradient, added to dx*/,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, T* __restrict__ dx,
                                                       float* __restrict__ partial /*[grid][2][C]*/, int64_t rows, int C,
@@ -102,12 +104,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
         const float mu = mean[rc], rs = rv ? rstd[rc] : 0.f;
         float xh[VPT][8], gy[VPT][8];
         float s1 = 0.f, s2 = 0.f;
-        Raw8<T> rx[VPT], rd[VPT];
+        Raw8<T> rx[VPT], rd[VPT], rd2[VPT], rr[VPT];
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int c0 = (sub + i * lpr) * 8, cc = c0 < C ? c0 : 0;
             rx[i] = load8_raw<T>(x + rc * C + cc);
             rd[i] = load8_raw<T>(dy + rc * C + cc);
+            if (dy2) rd2[i] = load8_raw<T>(dy2 + rc * C + cc);          // workgroup-uniform branches: the loads stay batched
+            if (dres) rr[i] = load8_raw<T>(dres + rc * C + cc);
         }
         SEGF_LOADS_ISSUED();
 #pragma unroll
@@ -117,6 +121,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
                 float xv[8], dv[8];
                 unpack8(rx[i], xv);
                 unpack8(rd[i], dv);
+                if (dy2) {
+                    float d2[8];
+                    unpack8(rd2[i], d2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dv[j] += d2[j];
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[i][j] = (xv[j] - mu) * rs;
@@ -141,6 +151,12 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
                     float o[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = rs * (gy[i][j] - s1 - xh[i][j] * s2);
+                    if (dres) {
+                        float rv8[8];
+                        unpack8(rr[i], rv8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] += rv8[j];
+                    }
                     store8<T>(dx + r * C + c0, o);
                 }
             }
@@ -185,9 +201,9 @@ static void ln_fwd_launch(int vpt, int blocks, hipStream_t st, const T* x, const
 #undef LN_F
 }
 template <typename T>
-static void ln_bwd_launch(int vpt, int blocks, size_t shm, hipStream_t st, const T* x, const T* dy, const float* gamma,
+static void ln_bwd_launch(int vpt, int blocks, size_t shm, hipStream_t st, const T* x, const T* dy, const T* dy2, const T* dres, const float* gamma,
                           const float* mean, const float* rstd, T* dx, float* ws, int64_t rows, int C, int lpr_log2) {
-#define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, gamma, mean, rstd, dx, ws, rows, C, lpr_log2)
+#define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, dy2, dres, gamma, mean, rstd, dx, ws, rows, C, lpr_log2)
     // C in (2048, 3072] (convnextv2_huge's 2816-wide last stage): six chunks per lane and 96 KB of dynamic LDS -- above the 64 KB
     // a kernel gets by default, so the limit is raised on the function first (160 KB per CU on gfx950)
 #define LN_B_BIG(V) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); LN_B(V); } while (0)
@@ -226,10 +242,19 @@ static inline int ln_bwd_blocks(int64_t rows, int C) {
 }
 extern "C" int64_t segf_layernorm_bwd_ws(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(rows, C) * 2 * C; }
 
+extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                                        const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                                        float* dbeta, float* ws, void* stream);
 extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* gamma,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                   float* ws, void* stream) {
+    return segf_layernorm_bwd_fused(dt, rows, C, x, dy, nullptr, nullptr, gamma, mean, rstd, dx, dgamma, dbeta, ws, stream);
+}
+extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                                        const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                                        float* dbeta, float* ws, void* stream) {
     if (rows <= 0) return 0;
+    if (((uintptr_t)dy2 % 16) || ((uintptr_t)dres % 16)) return SEGF_ERR_SHAPE;
     if (C <= 0 || C % 8 != 0 || C > 3072) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
     if (dbeta != dgamma + C) return SEGF_ERR_SHAPE;   // dgamma and dbeta are one [2][C] fp32 buffer
@@ -238,7 +263,7 @@ extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, co
     const int vpt = ln_plan(C, lpr_log2);
     const int blocks = ln_bwd_blocks(rows, C);
     const size_t shm = (size_t)4 * 2 * C * sizeof(float);
-    SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2); })
+    SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, (const T*)dy2, (const T*)dres, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2); })
     SEGF_CHECK_LAUNCH();
     const int64_t n = 2 * (int64_t)C;
     colreduce_finalize_launch(ws, blocks, n, dgamma, st);

@@ -112,11 +112,11 @@ class LinearFn(Function):
             # and biases are zero, so the pad columns of y are exact zeros, every 16-byte chunk of a row is either fully
             # valid or fully padding, and the backward products take the padded gradient as it stands
             assert residual is None
-            w = torch.zeros((Np, K), dtype=x.dtype, device=x.device)
+            w = hip.zeros((Np, K), x.dtype, x.device)
             hip.cast2d(weight.detach().reshape(N, -1), w[:N])
             b = None
             if bias is not None:
-                b = torch.zeros(Np, dtype=torch.float32, device=x.device)
+                b = hip.zeros((Np,), torch.float32, x.device)
                 hip.cast2d(bias.detach().unsqueeze(1), b[:N].unsqueeze(1))
             y = hip.gemm(0, x, w, M, Np, K, bias=b)[:, :N]
         else:
@@ -195,6 +195,112 @@ class LayerNormFn(Function):
 
 def layer_norm(x, gamma, beta, eps):
     return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+@direct_grads(1, 2)
+class LayerNormResFn(Function):
+    """The pre-norm residual pattern `x + f(norm(x))` (mit.py:143-146, convnext.py:36-50): returns (x, norm(x)) -- x passes
+    through for the residual add -- so that the backward sees BOTH gradients of x at once and the LayerNorm backward kernel adds
+    the residual-path gradient while it stores dx (no separate gradient-accumulation kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x if x.is_contiguous() else x.contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y, mean, rstd = hip.layernorm_fwd(x, g, b, eps)
+        ctx.save_for_backward(x, g, mean, rstd)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        if dres is not None and not dres.is_contiguous():
+            dres = dres.contiguous()
+        gg, gb = gslot(ctx, 1), gslot(ctx, 2)
+        dgb = (gg, gb) if (gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel()) else None
+        dx, dg, db = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dres=dres)
+        return dx, dg, db, None
+
+
+def layer_norm_res(x, gamma, beta, eps):
+    """-> (x, LayerNorm(x)): use the returned x for the residual connection."""
+    return LayerNormResFn.apply(x, gamma, beta, eps)
+
+
+@direct_grads(1, 2)
+class LayerNormForkFn(Function):
+    """LayerNorm whose output has TWO consumers (a MiT / ConvNeXt stage output feeds the decode head and the next stage,
+    mit.py:196-216): returns the normalised map twice; the backward kernel sums the two incoming gradients on load."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x if x.is_contiguous() else x.contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y, mean, rstd = hip.layernorm_fwd(x, g, b, eps)
+        ctx.save_for_backward(x, g, mean, rstd)
+        return y, y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x, g, mean, rstd = ctx.saved_tensors
+        if dy1 is None:
+            dy1, dy2 = dy2, None
+        dy1 = dy1 if dy1.is_contiguous() else dy1.contiguous()
+        if dy2 is not None and not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        gg, gb = gslot(ctx, 1), gslot(ctx, 2)
+        dgb = (gg, gb) if (gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel()) else None
+        dx, dg, db = hip.layernorm_bwd(x, dy1, g, mean, rstd, dgb_out=dgb, dy2=dy2)
+        return dx, dg, db, None
+
+
+def layer_norm_fork(x, gamma, beta, eps):
+    return LayerNormForkFn.apply(x, gamma, beta, eps)
+
+
+class ForkFn(Function):
+    """x -> n aliases of x for n consumers; the backward adds the n gradients with the library's own add kernel (autograd's
+    implicit accumulation would run a framework kernel inside the captured step)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for g in gs[1:]:
+            acc = hip.add(_rowmajor(acc), _rowmajor(g))
+        return acc, None
+
+
+def fork(x, n=2):
+    return ForkFn.apply(x, n)
+
+
+_RNG_SALT = [0]
+
+
+def stochastic_scales(owner, keep_probs, row_len, device):
+    """fp32 [len(keep_probs), row_len]: per entry 1 / kp with probability kp else 0 (DropPath: one row per draw, row_len = batch;
+    Dropout2d: one row of B * C entries).  The generator state {seed, launch counter} lives on the device and is advanced by
+    the kernel (segf_bernoulli_scale), so a replayed hipGraph draws fresh numbers; seeded from torch.initial_seed() and the
+    order in which the layers first draw.  First call per layer = outside graph capture (the warm-up pass)."""
+    key = (str(device), tuple(keep_probs), int(row_len))
+    st = getattr(owner, '_segf_rng', None)
+    if st is None or st[0] != key:
+        _RNG_SALT[0] += 1
+        seed = (torch.initial_seed() * 6364136223846793005 + _RNG_SALT[0] * 1442695040888963407) & 0x7FFFFFFFFFFFFFFF
+        st = (key, torch.tensor([seed, 0], dtype=torch.int64, device=device),
+              torch.tensor(list(keep_probs), dtype=torch.float32, device=device))
+        owner._segf_rng = st
+    return hip.bernoulli_scale(st[1], st[2], len(keep_probs) * int(row_len), int(row_len)).view(len(keep_probs), int(row_len))
 
 
 @direct_grads(1, 2)
@@ -366,11 +472,11 @@ class BnActLinearFn(Function):
             mean = running_mean.detach().clone()
             rstd = torch.rsqrt(running_var.detach() + eps)
         scale, shift = hip.bn_affine_table(mean, rstd, g, b, chan_scale, M // rps, K)
-        w = torch.zeros((Np, K), dtype=x.dtype, device=x.device)
+        w = hip.zeros((Np, K), x.dtype, x.device)
         hip.cast2d(weight.detach().reshape(N, -1), w[:N])
         bp = None
         if bias is not None:
-            bp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+            bp = hip.zeros((Np,), torch.float32, x.device)
             hip.cast2d(bias.detach().unsqueeze(1), bp[:N].unsqueeze(1))
         y = hip.gemm_pro(0, x, w, M, Np, K, scale, shift, rps, act, bias=bp)[:, :N]
         ctx.save_for_backward(x, mean, rstd, g, b, chan_scale, scale, shift, w)
@@ -384,8 +490,8 @@ class BnActLinearFn(Function):
         if dy.stride(-1) == 1 and dy.stride(0) == Np:
             dyp = dy.as_strided((M, Np), (Np, 1))           # the producer zero-fills the pad columns (segfac.h)
         else:
-            dyp = torch.zeros((M, Np), dtype=x.dtype, device=x.device)
-            dyp[:, :N] = dy
+            dyp = hip.zeros((M, Np), x.dtype, x.device)
+            hip.cast2d(_rowmajor(dy), dyp[:, :N])
         da = hip.gemm(1, dyp, w, M, K, Np)                   # gradient w.r.t. the (never materialised) normalised tensor
         dw = hip.gemm_pro(2, dyp, x, Np, K, M, scale, shift, rps, act, split_k=_splitk(Np, K, M))[:N].view(wshape)
         db = hip.colsum(dyp)[:N] if has_bias else None
@@ -489,7 +595,7 @@ class SegformerFoldedFuseFn(Function):
             x = _rowmajor(feats[i])
             Ci = x.shape[1]
             # W'_i = [W_i | b_i | 0] (bias as one extra input column): one GEMM yields G_i = F_i W_i and beta_i = F_i b_i
-            Wp = torch.zeros((E, Ci + 8), dtype=dtype, device=dev)
+            Wp = hip.zeros((E, Ci + 8), dtype, dev)
             hip.cast2d(weights[i].detach(), Wp[:, :Ci])
             hip.cast2d(biases[i].detach().unsqueeze(1), Wp[:, Ci:Ci + 1])
             Fi = wfc[:, (3 - i) * E:(4 - i) * E]
@@ -527,7 +633,7 @@ class SegformerFoldedFuseFn(Function):
             M, Ci = x.shape
             dt = dy if i == 0 else hip.bilinear_bwd(dy, B, h, w, E, H1, W1, align_corners=False)
             dxs.append(hip.gemm(1, dt, G, M, Ci, E) if ctx.needs_input_grad[1 + i] else None)
-            dGp = torch.zeros((E, Ci + 8), dtype=torch.float32, device=dev)                 # d [G_i | beta_i | 0]
+            dGp = hip.zeros((E, Ci + 8), torch.float32, dev)                                # d [G_i | beta_i | 0]
             if i == 0:
                 _, dbeta = hip.gemm_dw_db(dt, x, E, Ci, M, split_k=_splitk(E, Ci, M), out=dGp[:, :Ci])
             else:

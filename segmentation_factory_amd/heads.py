@@ -30,15 +30,14 @@ class ConvModule(nn.Module):
         self.bn = BatchNormWeights(c2)
 
 
-def dropout2d_scale(training, B, C, device, override):
+def dropout2d_scale(training, B, C, device, override, owner=None):
     """nn.Dropout2d(0.1): whole channels of a sample are zeroed, survivors scaled by 1/0.9."""
     if not training:
         return None
     if override is not None and 'dropout2d' in override:
         keep = override['dropout2d'].to(device=device, dtype=torch.float32)
-    else:
-        keep = (torch.rand(B, C, device=device) >= DROPOUT2D_P).to(torch.float32)
-    return (keep / (1.0 - DROPOUT2D_P)).contiguous()
+        return (keep / (1.0 - DROPOUT2D_P)).contiguous()
+    return Fh.stochastic_scales(owner, (1.0 - DROPOUT2D_P,), B * C, device).view(B, C)
 
 
 class SegFormerHead(nn.Module):
@@ -73,12 +72,12 @@ class SegFormerHead(nn.Module):
             x = Fh.linear(cat, self.linear_fuse.conv.weight)                   # 1x1 conv 4E -> E, no bias
             pre = None
         bn = self.linear_fuse.bn
-        drop = dropout2d_scale(self.training and self.dropout.p > 0, B, E, x.device, self.stochastic_override)
+        drop = dropout2d_scale(self.training and self.dropout.p > 0, B, E, x.device, self.stochastic_override, self.dropout)
         logits = Fh.bn_act_linear(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, 1,
                                   drop, H1 * W1, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 7) // 8 * 8,
                                   pre_sums=pre if self.training else None)
         if self.training:
-            bn.num_batches_tracked += 1
+            Fh.hip.add_i64_(bn.num_batches_tracked, 1)
         return TokenMap(logits, B, H1, W1)
 
     def forward(self, features):
@@ -97,7 +96,7 @@ def _bn_relu(x, bn, training, chan_scale=None, rows_per_sample=None):
     y = Fh.batch_norm_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, act=1,
                           chan_scale=chan_scale, rows_per_sample=rows_per_sample)
     if training:
-        bn.num_batches_tracked += 1
+        Fh.hip.add_i64_(bn.num_batches_tracked, 1)
     return y
 
 
@@ -114,13 +113,14 @@ class PPM(nn.Module):
         B, H, W = x.B, x.H, x.W
         C1 = x.data.shape[1]
         outs, geoms = [], []
-        for S, stage in zip(self.scales, self.stages):
+        xs = Fh.fork(x.data, len(self.scales) + 1)                         # the pools and the concat all read x
+        for k, (S, stage) in enumerate(zip(self.scales, self.stages)):
             conv, bn = stage[1][0], stage[1][1]
-            p = Fh.adaptive_avgpool(x.data, B, H, W, S)                    # [B*S*S, C1]
+            p = Fh.adaptive_avgpool(xs[k + 1], B, H, W, S)                 # [B*S*S, C1]
             p = _bn_relu(Fh.linear(p, conv.weight), bn, training)         # 1x1 conv (no bias) + BN + ReLU
             outs.append(p)
             geoms.append((S, S))
-        feats = [x.data] + outs[::-1]                                      # ppm.py:25: [x] + outs[::-1]
+        feats = [xs[0]] + outs[::-1]                                       # ppm.py:25: [x] + outs[::-1]
         gs = [(H, W)] + geoms[::-1]
         cat = Fh.resize_concat(feats, gs, [False] + [True] * len(outs), (B, H, W))     # align_corners=True (ppm.py:23)
         conv, bn = self.bottleneck[0], self.bottleneck[1]
@@ -150,20 +150,24 @@ class UPerHead(nn.Module):
         tr = self.training
         B = feats[0].B
         ch, nc = self.embed_dim, self.num_classes
-        f = TokenMap(self.ppm.tokens(feats[-1], tr), B, feats[-1].H, feats[-1].W)
-        fpn = [f]
+        fa, fb = Fh.fork(self.ppm.tokens(feats[-1], tr), 2)               # PPM output: a pyramid level AND the top-down input
+        f = TokenMap(fb, B, feats[-1].H, feats[-1].W)
+        fpn = [TokenMap(fa, B, feats[-1].H, feats[-1].W)]
         for i in reversed(range(len(feats) - 1)):
             lat_conv, lat_bn = self.fpn_in[i][0], self.fpn_in[i][1]
             fi = feats[i]
             lat = _bn_relu(Fh.linear(fi.data, lat_conv.weight), lat_bn, tr)
-            f = TokenMap(Fh.upsample_add(lat, f.data, (B, fi.H, fi.W, f.H, f.W)), B, fi.H, fi.W)     # upernet.py:41
+            fsum = Fh.upsample_add(lat, f.data, (B, fi.H, fi.W, f.H, f.W))                          # upernet.py:41
+            if i > 0:
+                fsum, fnext = Fh.fork(fsum, 2)                              # feeds its 3x3 output conv and the next finer level
+                f = TokenMap(fnext, B, fi.H, fi.W)
             oc, obn = self.fpn_out[i][0], self.fpn_out[i][1]
-            fpn.append(TokenMap(_bn_relu(Fh.conv3x3(f.data, oc.weight, B, fi.H, fi.W), obn, tr), B, fi.H, fi.W))
+            fpn.append(TokenMap(_bn_relu(Fh.conv3x3(fsum, oc.weight, B, fi.H, fi.W), obn, tr), B, fi.H, fi.W))
         fpn.reverse()
         H1, W1 = fpn[0].H, fpn[0].W
         cat = Fh.resize_concat([t.data for t in fpn], [(t.H, t.W) for t in fpn], [False] * len(fpn), (B, H1, W1))
         conv, bn = self.bottleneck[0], self.bottleneck[1]
-        drop = dropout2d_scale(tr and self.dropout.p > 0, B, ch, cat.device, self.stochastic_override)
+        drop = dropout2d_scale(tr and self.dropout.p > 0, B, ch, cat.device, self.stochastic_override, self.dropout)
         x = _bn_relu(Fh.conv3x3(cat, conv.weight, B, H1, W1), bn, tr, chan_scale=drop, rows_per_sample=H1 * W1)
         logits = Fh.linear(x, self.conv_seg.weight, self.conv_seg.bias, pad_to=(nc + 7) // 8 * 8)
         return TokenMap(logits, B, H1, W1)
@@ -202,7 +206,7 @@ class FPNHead(nn.Module):
             with torch.no_grad():                      # the discarded evaluations: same batch statistics, extra momentum steps
                 for _ in range(evaluations - 1):
                     Fh.hip.bn_stats(z.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps)
-                    bn.num_batches_tracked += 1
+                    Fh.hip.add_i64_(bn.num_batches_tracked, 1)
         return _bn_relu(z, bn, self.training)
 
     def forward_tokens(self, feats):
@@ -227,7 +231,7 @@ class FPNHead(nn.Module):
             conv, bn = self.output_convs[i][0], self.output_convs[i][1]
             y = Fh.conv3x3(out, conv.weight, B, H, W)
             if i == n - 1:                                                      # fpn.py:37: Dropout2d in front of the classifier
-                drop = dropout2d_scale(self.training and self.dropout.p > 0, B, ch, y.device, self.stochastic_override)
+                drop = dropout2d_scale(self.training and self.dropout.p > 0, B, ch, y.device, self.stochastic_override, self.dropout)
                 out = _bn_relu(y, bn, self.training, chan_scale=drop, rows_per_sample=H * W)
             else:
                 out = _bn_relu(y, bn, self.training)

@@ -76,6 +76,10 @@ _PROTOS = {
     'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
     'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),
+    'segf_zero': (_i, [_p, _l, _p]),
+    'segf_add_i64': (_i, [_p, _l, _p]),
+    'segf_bernoulli_scale': (_i, [_p, _p, _l, _l, _p, _p]),
+    'segf_layernorm_bwd_fused': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'segf_event_destroy': (_i, [_p]),
     'segf_event_record': (_i, [_p, _p, _i]),
@@ -341,8 +345,30 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None):
-    """dgb_out: optional (dgamma, dbeta) fp32 [C] views that are ADJACENT in memory (dbeta == dgamma + C): written in place."""
+def zeros(shape, dtype, device):
+    """torch.zeros through the library's own fill kernel (keeps framework kernels out of the captured step)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    _chk(lib().segf_zero(_ptr(t), t.numel() * t.element_size(), _stream()), 'segf_zero')
+    return t
+
+
+def add_i64_(t, v=1):
+    """t += v for an int64 scalar on the device (BatchNorm's num_batches_tracked)."""
+    assert t.dtype == torch.int64 and t.numel() == 1 and t.is_cuda
+    _chk(lib().segf_add_i64(_ptr(t), int(v), _stream()), 'segf_add_i64')
+    return t
+
+
+def bernoulli_scale(state, keep_prob, n, row_len):
+    """fp32 [n]: 1 / kp with probability kp, else 0, kp = keep_prob[i // row_len]; state = uint64-as-int64 [2] {seed, counter}."""
+    out = torch.empty(n, dtype=torch.float32, device=state.device)
+    _chk(lib().segf_bernoulli_scale(_ptr(state), _ptr(keep_prob), n, row_len, _ptr(out), _stream()), 'segf_bernoulli_scale')
+    return out
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None):
+    """dgb_out: optional (dgamma, dbeta) fp32 [C] views that are ADJACENT in memory (dbeta == dgamma + C): written in place.
+    dy2 / dres: optional fan-in operands, dx = LN_bwd(dy + dy2) + dres (segf_layernorm_bwd_fused)."""
     rows, Cc = x.shape
     dx = torch.empty_like(x)
     if dgb_out is not None:
@@ -352,8 +378,11 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None):
         dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
         dg, db = dgb[0], dgb[1]
     ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
-    _chk(lib().segf_layernorm_bwd(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                  dg.data_ptr(), db.data_ptr(), _ptr(ws), _stream()), 'segf_layernorm_bwd')
+    for t in (dy2, dres):
+        assert t is None or (t.shape == x.shape and t.dtype == x.dtype and t.is_contiguous())
+    _chk(lib().segf_layernorm_bwd_fused(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(dy2), _ptr(dres), _ptr(gamma), _ptr(mean),
+                                        _ptr(rstd), _ptr(dx), dg.data_ptr(), db.data_ptr(), _ptr(ws), _stream()),
+         'segf_layernorm_bwd_fused')
     return dx, dg, db
 
 
@@ -544,9 +573,7 @@ def argmax_rows(x, Cc):
 
 def bilinear_bwd(dout, B, h, w, Cc, H, W, align_corners=False, ld_in=None):
     ld_in = Cc if ld_in is None else ld_in
-    din = torch.empty((B * h * w, ld_in), dtype=dout.dtype, device=dout.device)
-    if ld_in != Cc:
-        din.zero_()
+    din = torch.empty((B * h * w, ld_in), dtype=dout.dtype, device=dout.device) if ld_in == Cc else zeros((B * h * w, ld_in), dout.dtype, dout.device)
     _chk(lib().segf_bilinear_bwd(dt_of(dout), B, h, w, Cc, _ptr(din), ld_in, H, W, _ptr(dout), dout.stride(0),
                                  int(align_corners), _stream()), 'segf_bilinear_bwd')
     return din
