@@ -206,6 +206,12 @@ int segf_bilinear_fwd(int dt, int B, int h, int w, int C, const void* in, int64_
                       int H, int W, void* out, int64_t ldo, int align_corners, void* stream);
 int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, int64_t ldi,
                       int H, int W, const void* dout, int64_t ldo, int align_corners, void* stream);
+/* The transposes of the x2 / x4 / x8 bilinear upsamplings (align_corners = 0) of ONE gradient map in one pass over it: the
+ * backward of the folded SegFormerHead's accumulation step (segf_upsample_add with sources at 1/2, 1/4, 1/8 of the grid,
+ * heads/segformer.py:44-56).  dout [B][H][W][ldo >= C] -> d2 [B][H/2][W/2][C], d4 [B][H/4][W/4][C], d8 [B][H/8][W/8][C];
+ * H % 8 == 0, W % 8 == 0, C % 8 == 0.  Same values as three segf_bilinear_bwd calls. */
+int segf_bilinear_bwd_248(int dt, int B, int H, int W, int C, const void* dout, int64_t ldo, void* d2, void* d4, void* d8,
+                          void* stream);
 /* out = base + sum_{k<nsrc} bilinear_up(src_k), all NHWC of dtype dt, C % 8 == 0: the accumulation step of the folded
  * SegFormerHead (heads/segformer.py:44-56: Linear -> resize -> concat -> 1x1 conv is affine, and bilinear resizing
  * commutes with affine maps, so the per-scale products are formed at native resolution and added here).  nsrc <= 3.  */

@@ -106,11 +106,15 @@ __global__ void __launch_bounds__(256) upsample_add_248_kernel(const T* __restri
                                                                 T* __restrict__ out, int64_t ldo, int B, int H, int W, int C,
                                                                 float* __restrict__ partial) {
     __shared__ float red[STATS ? 256 * 16 : 1];
-    const int nch = C / 8, nst = W / 4;
+    // Channel groups: blockIdx.y owns `nch` = C / 8 / gridDim.y consecutive 16-byte chunks (128 bytes per pixel when there are 8
+    // of them) and walks the whole (image, row, strip) plane for them before the next group is dispatched.  The rows of the three
+    // sources that neighbouring output rows share are then 128 bytes per pixel wide and stay in one XCD's L2 between their uses;
+    // with all C channels per unit the sources were re-fetched 2.5x (PMC FETCH_SIZE: 10.1 GB per launch against 7.5 GB algorithmic).
+    const int nch = C / 8 / (int)gridDim.y, nst = W / 4;
     const int64_t units = (int64_t)B * H * nst;
     const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
     const int64_t ustep = ((int64_t)gridDim.x * 256) / nch;
-    const int ch = (int)(g % nch);
+    const int ch = (int)blockIdx.y * nch + (int)(g % nch);
     float sm1[8], sm2[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { sm1[c] = 0.f; sm2[c] = 0.f; }
@@ -177,7 +181,7 @@ __global__ void __launch_bounds__(256) upsample_add_248_kernel(const T* __restri
 #pragma unroll
         for (int c = 0; c < 8; ++c) { red[threadIdx.x * 16 + c] = sm1[c]; red[threadIdx.x * 16 + 8 + c] = sm2[c]; }
         __syncthreads();
-        if ((int)threadIdx.x < nch) {          // first thread of each chunk in this workgroup adds the later ones in order
+        if ((int)threadIdx.x < nch && (int)threadIdx.x < 256) {   // first thread of each chunk in this workgroup adds the later ones in order
             float a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = red[threadIdx.x * 16 + c];
@@ -195,8 +199,15 @@ static bool upsample_add_is_248(int H, int W, int C, int nsrc, int h0, int w0, i
     return nsrc == 3 && !align_corners && W % 8 == 0 && H % 8 == 0 && h0 * 2 == H && w0 * 2 == W && h1 * 4 == H && w1 * 4 == W &&
            h2 * 8 == H && w2 * 8 == W && C % 8 == 0 && !getenv("SEGFAC_UPADD_GENERIC");
 }
+static int upsample_add_248_groups(int C) {        // channel groups of 8 chunks (128 bytes per pixel) when C allows it
+    const int nch = C / 8;
+    // measured on MI355X (cfg2, batch 128): 128-byte channel groups leave the launch at 1.77 ms (4.2 TB/s) with or without them and
+    // slow the fused-statistics variant (1.99 -> 2.26 ms: 8 instead of 96 reducing threads per workgroup), i.e. the 2.5x source
+    // re-fetches that FETCH_SIZE reports are served by the Infinity Cache and are not what bounds the kernel: opt-in only
+    return (nch % 8 == 0 && getenv("SEGFAC_UPADD_GROUP")) ? nch / 8 : 1;
+}
 static int upsample_add_248_blocks(int B, int H, int W, int C) {
-    return colfixed_blocks((int64_t)B * H * (W / 4), C / 8, 2, 16384);
+    return colfixed_blocks((int64_t)B * H * (W / 4), C / 8 / upsample_add_248_groups(C), 2, 16384);
 }
 static int upsample_add_impl(int dt, int B, int H, int W, int C, const void* base, int64_t ldb, int nsrc,
                              const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
@@ -245,11 +256,11 @@ static int upsample_add_impl(int dt, int B, int H, int W, int C, const void* bas
     hipStream_t st = (hipStream_t)stream;
     UpSrc s0{src0, h0, w0, ld0}, s1{src1, h1, w1, ld1}, s2{src2, h2, w2, ld2};
     if (upsample_add_is_248(H, W, C, nsrc, h0, w0, h1, w1, h2, w2, align_corners)) {
-        const int blocks4 = upsample_add_248_blocks(B, H, W, C);
+        const dim3 grid4((unsigned)upsample_add_248_blocks(B, H, W, C), (unsigned)upsample_add_248_groups(C));
         SEGF_DISPATCH_DT(dt, T, {
-            if (partial) hipLaunchKernelGGL((upsample_add_248_kernel<T, true>), dim3(blocks4), dim3(256), 0, st, (const T*)base, ldb,
+            if (partial) hipLaunchKernelGGL((upsample_add_248_kernel<T, true>), grid4, dim3(256), 0, st, (const T*)base, ldb,
                                             s0, s1, s2, (T*)out, ldo, B, H, W, C, partial);
-            else hipLaunchKernelGGL((upsample_add_248_kernel<T, false>), dim3(blocks4), dim3(256), 0, st, (const T*)base, ldb, s0,
+            else hipLaunchKernelGGL((upsample_add_248_kernel<T, false>), grid4, dim3(256), 0, st, (const T*)base, ldb, s0,
                                     s1, s2, (T*)out, ldo, B, H, W, C, partial);
         })
         SEGF_CHECK_LAUNCH();
@@ -564,6 +575,202 @@ extern "C" int segf_nearest_up(int dt, int bwd, int B, int h, int w, int C, int 
     SEGF_DISPATCH_DT(dt, T, {
         if (bwd) hipLaunchKernelGGL((nearest_up_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)nullptr, (T*)out, B, h, w, C, H, W);
         else hipLaunchKernelGGL((nearest_up_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, C, H, W);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- the three transposed resizes of the folded SegFormerHead in ONE pass over the gradient ---------------------------------
+// dy [B][H][W][C] -> d2 [B][H/2][W/2][C], d4 [B][H/4][W/4][C], d8 [B][H/8][W/8][C]: the transposes of the bilinear
+// (align_corners=False) x2 / x4 / x8 upsamplings that segf_upsample_add sums in the forward (heads/segformer.py:44-56 folded).
+// Three segf_bilinear_bwd launches each stream the full [B*H*W, C] gradient (3 x 3.2 GB at cfg2, batch 128); here a thread owns
+// ONE x8 output pixel and reads its 16 x 16 window of dy once; that window contains the complete windows of the 2 x 2 x4-outputs
+// and the 4 x 4 x2-outputs nested in it (x4 output 2y+a: window rows [8y+4a-2, 8y+4a+6); x2 output 4y+a: rows [8y+2a-1, 8y+2a+3)),
+// so every (gradient pixel, output) pair is accumulated exactly once.  The static supports are those of interior pixels; the
+// weights are evaluated at run time with the forward's source-index arithmetic (bilinear_src), so that the clamped image borders
+// -- where the true support is a subset of the static one -- come out exact.  Rows are reduced separably: 16 loads in flight,
+// x-weighted row sums per nested output, then one y-weighted update per output row.
+__device__ __forceinline__ float tap_w(int P, int inR, int out, int po) {     // weight of gradient row / column P for output po
+    if (P < 0 || P >= out) return 0.f;
+    int p0, p1; float l;
+    bilinear_src(P, inR, out, 0, p0, p1, l);
+    return (p0 == po ? 1.f - l : 0.f) + (p1 == po ? l : 0.f);
+}
+// four channels per thread (8-byte accesses for bf16): with eight the nested accumulators (1 + 4 + 16 outputs) plus a row of loads
+// need ~300 VGPRs and spill; with four the kernel fits 256 without scratch and the loads of a whole window row stay in flight
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { float4 a; };
+template <> struct Raw4<bf16_t> { uint2 u; };
+__device__ __forceinline__ Raw4<float> load4_raw(const float* p) { Raw4<float> r; r.a = *reinterpret_cast<const float4*>(p); return r; }
+__device__ __forceinline__ Raw4<bf16_t> load4_raw(const bf16_t* p) { Raw4<bf16_t> r; r.u = *reinterpret_cast<const uint2*>(p); return r; }
+__device__ __forceinline__ void unpack4(const Raw4<float>& r, float (&v)[4]) { v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; }
+__device__ __forceinline__ void unpack4(const Raw4<bf16_t>& r, float (&v)[4]) {
+    v[0] = __uint_as_float(r.u.x << 16); v[1] = __uint_as_float(r.u.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.u.y << 16); v[3] = __uint_as_float(r.u.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    uint2 u; u.x = pack2bf(v[0], v[1]); u.y = pack2bf(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void unpack4v(const Raw4<float>& r, f32x2_t (&v)[2]) { v[0] = f32x2_t{r.a.x, r.a.y}; v[1] = f32x2_t{r.a.z, r.a.w}; }
+__device__ __forceinline__ void unpack4v(const Raw4<bf16_t>& r, f32x2_t (&v)[2]) {
+    v[0] = f32x2_t{__uint_as_float(r.u.x << 16), __uint_as_float(r.u.x & 0xffff0000u)};
+    v[1] = f32x2_t{__uint_as_float(r.u.y << 16), __uint_as_float(r.u.y & 0xffff0000u)};
+}
+template <typename T> __device__ __forceinline__ void store4v(T* p, const f32x2_t (&v)[2]) {
+    const float f[4] = {v[0].x, v[0].y, v[1].x, v[1].y};
+    store4(p, f);
+}
+template <typename T>
+__global__ void __launch_bounds__(256, 2) bilinear_bwd_248_kernel(const T* __restrict__ dy, int64_t ldo, T* __restrict__ d2, T* __restrict__ d4,
+                                                                T* __restrict__ d8, int B, int H, int W, int C) {
+    constexpr int CW = 4;
+    const int h8 = H / 8, w8 = W / 8, h4 = H / 4, w4 = W / 4, h2 = H / 2, w2 = W / 2;
+    const int nch = C / CW;
+    const int G = nch % 16 == 0 ? 16 : (nch % 8 == 0 ? 8 : 2), ngrp = nch / G;    // 128-byte channel groups (see bilinear_bwd_int_kernel)
+    const int64_t total = (int64_t)B * h8 * w8 * nch;
+    // Weight tables for the four border variants of an x8 pixel along one axis (first, interior, last, the only one): the weights
+    // of all interior pixels coincide (translation invariance), so 4 small tables per axis cover every thread of the launch and
+    // the 48 column weights need no registers.
+    // Columns, per variant: [0,16) x8 weights of the 16 window columns, [16,32) x4 outputs a = 0, 1 (8 columns each, from window
+    // column 2 + 4a), [32,48) x2 outputs a = 0..3 (4 columns each, from window column 3 + 2a).
+    // Rows, per variant and window row i: {x8, x4 a = 0, 1, x2 a = 0..3, pad}: 0 where row i is outside the output's support.
+    __shared__ float wxt[4][48];
+    __shared__ float wyt[4][16][8];
+    for (int e = threadIdx.x; e < 4 * 48 + 4 * 16 * 8; e += blockDim.x) {
+        if (e < 192) {
+            const int var = e / 48, k = e % 48;
+            const int xr = var == 0 ? 0 : (var == 1 ? (w8 > 2 ? 1 : 0) : (var == 2 ? w8 - 1 : 0));     // a representative pixel
+            const int X0r = 8 * xr - 4;
+            float wv;
+            if (k < 16) wv = tap_w(X0r + k, w8, W, xr);
+            else if (k < 32) { const int a = (k - 16) >> 3, j = (k - 16) & 7; wv = tap_w(X0r + 2 + 4 * a + j, w4, W, 2 * xr + a); }
+            else { const int a = (k - 32) >> 2, j = (k - 32) & 3; wv = tap_w(X0r + 3 + 2 * a + j, w2, W, 4 * xr + a); }
+            wxt[var][k] = wv;
+        } else {
+            const int f = e - 192, var = f / 128, i = (f % 128) / 8, k = f % 8;
+            const int yr = var == 0 ? 0 : (var == 1 ? (h8 > 2 ? 1 : 0) : (var == 2 ? h8 - 1 : 0));
+            const int Y = 8 * yr - 4 + i;
+            float wv = 0.f;
+            if (k == 0) wv = tap_w(Y, h8, H, yr);
+            else if (k < 3) { const int a = k - 1; if (i >= 2 + 4 * a && i < 10 + 4 * a) wv = tap_w(Y, h4, H, 2 * yr + a); }
+            else if (k < 7) { const int a = k - 3; if (i >= 3 + 2 * a && i < 7 + 2 * a) wv = tap_w(Y, h2, H, 4 * yr + a); }
+            wyt[var][i][k] = wv;
+        }
+    }
+    __syncthreads();
+    for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int chl = (int)(idx % G);
+        int64_t t = idx / G;
+        const int x8 = (int)(t % w8); t /= w8;
+        const int y8 = (int)(t % h8); t /= h8;
+        const int grp = (int)(t % ngrp);
+        const int64_t b = t / ngrp;
+        const int c0 = (grp * G + chl) * CW;
+        const int Y0 = 8 * y8 - 4, X0 = 8 * x8 - 4;
+        const float* wtab = wxt[w8 == 1 ? 3 : (x8 == 0 ? 0 : (x8 == w8 - 1 ? 2 : 1))];
+        const float* wytab = &wyt[h8 == 1 ? 3 : (y8 == 0 ? 0 : (y8 == h8 - 1 ? 2 : 1))][0][0];
+        // 32-bit element offsets of the 16 (clamped) window columns relative to a gradient row
+        int xoff[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int X = X0 + j;
+            xoff[j] = (X < 0 ? 0 : (X >= W ? W - 1 : X)) * (int)ldo;
+        }
+        // accumulators on channel PAIRS (v_pk_fma_f32: two channels per issue slot)
+        f32x2_t a8[2], a4[2][2][2], a2[4][4][2];
+        const f32x2_t zero2 = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a8[q] = zero2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a4[k >> 1][k & 1][q] = zero2;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a2[k >> 2][k & 3][q] = zero2;
+        }
+        const T* src = dy + (b * H * W) * ldo + c0;
+        // the row loop is NOT unrolled (16 x 16 hoisted addresses would not fit the register file): rows outside an output's
+        // support simply carry weight 0 in its y-update
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const int Y = Y0 + i, Yc = Y < 0 ? 0 : (Y >= H ? H - 1 : Y);
+            const T* row = src + (int64_t)Yc * W * ldo;
+            Raw4<T> raw[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) raw[j] = load4_raw(row + xoff[j]);
+            SEGF_LOADS_ISSUED();
+            const float* wt = wtab;
+            const float* wy = wytab + 8 * i;
+            asm volatile("" : "+v"(wt));          // keep the table reads inside the row loop (hoisted they cost 48 VGPRs)
+            // x-weighted row sums: one for the x8 output, two for the x4 outputs, four for the x2 outputs (static column supports)
+            f32x2_t r8[2], r4[2][2], r2[4][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                r8[q] = zero2; r4[0][q] = zero2; r4[1][q] = zero2; r2[0][q] = zero2; r2[1][q] = zero2; r2[2][q] = zero2; r2[3][q] = zero2;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                f32x2_t v[2];
+                unpack4v(raw[j], v);
+                const float w8j = wt[j];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) r8[q] = v[q] * w8j + r8[q];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    if (j >= 2 + 4 * a && j < 10 + 4 * a) {
+                        const float ww = wt[16 + 8 * a + j - 2 - 4 * a];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) r4[a][q] = v[q] * ww + r4[a][q];
+                    }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    if (j >= 3 + 2 * a && j < 7 + 2 * a) {
+                        const float ww = wt[32 + 4 * a + j - 3 - 2 * a];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) r2[a][q] = v[q] * ww + r2[a][q];
+                    }
+            }
+            // y-weighted updates (the table holds 0 for rows outside an output's support and outside the image)
+            const float4 wya = *reinterpret_cast<const float4*>(wy), wyb = *reinterpret_cast<const float4*>(wy + 4);
+            const float wy4[2] = {wya.y, wya.z}, wy2[4] = {wya.w, wyb.x, wyb.y, wyb.z};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a8[q] = r8[q] * wya.x + a8[q];
+#pragma unroll
+            for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+                for (int ax = 0; ax < 2; ++ax)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) a4[ay][ax][q] = r4[ax][q] * wy4[ay] + a4[ay][ax][q];
+#pragma unroll
+            for (int ay = 0; ay < 4; ++ay)
+#pragma unroll
+                for (int ax = 0; ax < 4; ++ax)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) a2[ay][ax][q] = r2[ax][q] * wy2[ay] + a2[ay][ax][q];
+        }
+#pragma unroll
+        for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) store4v<T>(d4 + ((b * h4 + 2 * y8 + ay) * w4 + 2 * x8 + ax) * C + c0, a4[ay][ax]);
+#pragma unroll
+        for (int ay = 0; ay < 4; ++ay)
+#pragma unroll
+            for (int ax = 0; ax < 4; ++ax) store4v<T>(d2 + ((b * h2 + 4 * y8 + ay) * w2 + 4 * x8 + ax) * C + c0, a2[ay][ax]);
+        store4v<T>(d8 + ((b * h8 + y8) * w8 + x8) * C + c0, a8);
+    }
+}
+
+extern "C" int segf_bilinear_bwd_248(int dt, int B, int H, int W, int C, const void* dout, int64_t ldo, void* d2, void* d4, void* d8,
+                                     void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    if (H % 8 || W % 8 || C % 8 || ldo < C || (ldo % 8)) return SEGF_ERR_SHAPE;
+    if (((uintptr_t)dout | (uintptr_t)d2 | (uintptr_t)d4 | (uintptr_t)d8) % 16) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * (H / 8) * (W / 8) * (C / 4);
+    const int blocks = (int)imin64(cdiv64(total, 256), 32768);
+    SEGF_DISPATCH_DT(dt, T, {
+        hipLaunchKernelGGL((bilinear_bwd_248_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)dout, ldo, (T*)d2, (T*)d4, (T*)d8, B, H, W, C);
     })
     SEGF_CHECK_LAUNCH();
     return 0;

@@ -5,6 +5,8 @@ Activations are token-major 2-D tensors ``[B*H*W, C]`` (NHWC flattened) in the c
 Every forward/backward below is a hand-written formula over C-ABI kernel calls -- torch autograd
 only sequences them.  Nothing here falls back to eager PyTorch math.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -627,11 +629,15 @@ class SegformerFoldedFuseFn(Function):
                                              # to one); it rides along with the stage-1 weight-gradient product below
         dwf = torch.empty((E, 4 * E), dtype=torch.float32, device=dev)
         dxs, dws, dbs = [], [], []
+        dts = None
+        if (H1 % 8 == 0 and W1 % 8 == 0 and E % 8 == 0 and not os.environ.get('SEGFAC_NO_BWD248')
+                and all(geoms[i][1:] == (H1 >> i, W1 >> i) for i in (1, 2, 3))):
+            dts = hip.bilinear_bwd_248(dy, B, H1, W1, E)          # the three transposed resizes in ONE pass over dy
         for i in range(4):
             x, G, Wp = sv[1 + 3 * i], sv[2 + 3 * i], sv[3 + 3 * i]
             _, h, w = geoms[i]
             M, Ci = x.shape
-            dt = dy if i == 0 else hip.bilinear_bwd(dy, B, h, w, E, H1, W1, align_corners=False)
+            dt = dy if i == 0 else (dts[i - 1] if dts is not None else hip.bilinear_bwd(dy, B, h, w, E, H1, W1, align_corners=False))
             dxs.append(hip.gemm(1, dt, G, M, Ci, E) if ctx.needs_input_grad[1 + i] else None)
             dGp = hip.zeros((E, Ci + 8), torch.float32, dev)                                # d [G_i | beta_i | 0]
             if i == 0:

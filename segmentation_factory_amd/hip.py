@@ -62,6 +62,7 @@ _PROTOS = {
     'segf_col2im': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _p]),
     'segf_bilinear_fwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
     'segf_bilinear_bwd': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _l, _i, _p]),
+    'segf_bilinear_bwd_248': (_i, [_i, _i, _i, _i, _i, _p, _l, _p, _p, _p, _p]),
     'segf_nearest_up': (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     'segf_upsample_add': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p]),
     'segf_upsample_add_stats_ws': (_l, [_i, _i, _i, _i]),
@@ -587,6 +588,15 @@ def nearest_up(x, B, h, w, Cc, H, W, base=None, bwd=False):
     out = torch.empty(((B * h * w) if bwd else (B * H * W), Cc), dtype=x.dtype, device=x.device)
     _chk(lib().segf_nearest_up(dt_of(x), int(bwd), B, h, w, Cc, H, W, _ptr(x), _ptr(base), _ptr(out), _stream()), 'segf_nearest_up')
     return out
+
+
+def bilinear_bwd_248(dout, B, H, W, Cc):
+    """(d2, d4, d8): transposed x2 / x4 / x8 bilinear resizes of dout [B*H*W, >= C] in one pass (segf_bilinear_bwd_248)."""
+    _need_cuda(dout)
+    outs = [torch.empty((B * (H // r) * (W // r), Cc), dtype=dout.dtype, device=dout.device) for r in (2, 4, 8)]
+    _chk(lib().segf_bilinear_bwd_248(dt_of(dout), B, H, W, Cc, _ptr(dout), dout.stride(0), _ptr(outs[0]), _ptr(outs[1]),
+                                     _ptr(outs[2]), _stream()), 'segf_bilinear_bwd_248')
+    return outs
 
 
 def upsample_add(base, srcs, B, H, W, Cc, align_corners=False):

@@ -802,3 +802,24 @@ def test_upsample_add_with_batchnorm_statistics(hipmod, dtype):
     # a geometry outside the fused case reports "no sums"
     out2, sums2 = hipmod.upsample_add_stats(_dev(base, dtype), [(_dev(srcs[0], dtype), *sizes[0])], B, H, W, C)
     assert sums2 is None and out2.shape == out.shape
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('geom', [(2, 16, 24, 16), (1, 8, 8, 40), (1, 32, 16, 8), (2, 128, 128, 64)])
+def test_bilinear_bwd_248_equals_three_transposed_resizes(hipmod, dtype, geom):
+    """segf_bilinear_bwd_248 (one pass over the gradient, nested windows) against the three segf_bilinear_bwd launches it
+    replaces and against autograd through F.interpolate on the CPU; includes the clamped borders (8-wide maps: every output
+    pixel is a border pixel)."""
+    B, H, W, C = geom
+    g = torch.Generator().manual_seed(33)
+    dy = torch.randn(B * H * W, C, generator=g)
+    d = _dev(dy, dtype)
+    outs = hipmod.bilinear_bwd_248(d, B, H, W, C)
+    for r, got in zip((2, 4, 8), outs):
+        sep = hipmod.bilinear_bwd(d, B, H // r, W // r, C, H, W, align_corners=False)
+        _close(got, sep, dtype, fac=2)
+        x = torch.zeros(B, C, H // r, W // r, requires_grad=True)
+        up = F.interpolate(x, size=(H, W), mode='bilinear', align_corners=False)
+        up.backward(_q(dy, dtype).reshape(B, H, W, C).permute(0, 3, 1, 2))
+        ref = x.grad.permute(0, 2, 3, 1).reshape(-1, C)
+        _close(got, ref, dtype, fac=4)

@@ -127,6 +127,26 @@ def main():
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ms = timeit(lambda: hip.argmax_confmat(lo, B, nc, h, h, H, H, tgt, 255, mat, hist, flag))
         report('argmax_confmat (fused upsample)', ms, nbytes=B * (h * h * ld * 2 + H * H * 8))
+    if want('upadd'):
+        E, Hh = 768, 128
+        base = rnd(B * Hh * Hh, E)
+        srcs = [(rnd(B * (Hh // r) * (Hh // r), E), Hh // r, Hh // r) for r in (2, 4, 8)]
+        nb = int(2 * B * Hh * Hh * E * (2 + 1 / 4 + 1 / 16 + 1 / 64))
+        ms = timeit(lambda: hip.upsample_add_stats(base, srcs, B, Hh, Hh, E))
+        report('upsample_add_248 + BN statistics', ms, nbytes=nb)
+        ms = timeit(lambda: hip.upsample_add(base, srcs, B, Hh, Hh, E))
+        report('upsample_add_248', ms, nbytes=nb)
+    if want('bwd248'):
+        E, Hh = 768, 128
+        dy = rnd(B * Hh * Hh, E)
+        ms = timeit(lambda: hip.bilinear_bwd_248(dy, B, Hh, Hh, E))
+        report('bilinear_bwd_248 (x2, x4, x8 in one pass)', ms, nbytes=int(2 * B * Hh * Hh * E * (1 + 1 / 4 + 1 / 16 + 1 / 64)))
+        tot = 0.0
+        for r in (2, 4, 8):
+            ms1 = timeit(lambda: hip.bilinear_bwd(dy, B, Hh // r, Hh // r, E, Hh, Hh))
+            report(f'  separate bilinear_bwd x{r}', ms1, nbytes=int(2 * B * Hh * Hh * E * (1 + 1 / r / r)))
+            tot += ms1
+        print(f'  three separate launches: {tot * 1e3:.1f} us')
     if want('resize'):
         E = 768
         for h in (64, 32, 16):
