@@ -138,6 +138,19 @@ int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, cons
                 const float* gamma, const float* beta, int act, const float* chan_scale, int64_t rows_per_sample,
                 int eval_mode, void* dx, float* dgamma, float* dbeta, float* ws, void* stream);
 
+/* BatchNorm backward of SegFormerHead's fuse ConvModule WITH the classifier's data gradient folded in (heads/segformer.py:21-29,
+ * 40,57-58: linear_fuse.bn / activate -> Dropout2d -> linear_pred): instead of materialising da = dy W ([tokens, C]) and
+ * streaming it twice through segf_bn_bwd, both BatchNorm passes recompute their da tile on the matrix pipe from the class
+ * gradients dy [M][ldy >= K] (K = padded class count, a multiple of 32, pad columns zero) and w [K][ldw >= C] (classifier weight,
+ * rows = classes, pad rows zero).  Same results as segf_gemm(layout 1) + segf_bn_bwd with da kept in fp32.
+ * bf16 only; C % 128 == 0; rows_per_sample % 16 == 0: ask segf_bn_cls_bwd_supported.  ws >= segf_bn_cls_bwd_ws floats. */
+int segf_bn_cls_bwd_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample);
+int64_t segf_bn_cls_bwd_ws(int64_t M, int C, int64_t rows_per_sample);
+int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
+                    const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                    const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma, float* dbeta,
+                    float* ws, void* stream);
+
 /* ---- Global Response Normalization (ConvNeXtV2 GRN, convnextv2.py:68-80) on NHWC rows, B images of rows_per_sample rows:
  * y = gamma * (x * Nx) + beta + x, Nx = ||x||_2(H,W) / (mean_c ||x||_2 + 1e-6).  sumsq_out [B][C] is saved for the backward. */
 int64_t segf_grn_ws(int B, int64_t rows_per_sample, int C, int bwd);

@@ -1,0 +1,205 @@
+// BatchNorm backward of SegFormerHead's fuse ConvModule with the classifier's data gradient folded in
+//   reference: heads/segformer.py:21-29,40,57-58  (linear_fuse.bn / activate -> Dropout2d -> linear_pred), backward of
+//              a = relu(bn(x)) * drop;  y = a W^T + b
+// The tiled path runs three launches over [B*h*w, 768] tensors: da = dy W (writes 3.2 GB at cfg2, batch 128), the column sums
+// of BatchNorm's backward (reads x and da), and its apply pass (reads x and da again, writes dx): 19.8 GB of traffic.
+// da[token][feature] = sum_class dy[token][class] W[class][feature] has only K = #classes (<= 192) terms, so it is cheaper to
+// RECOMPUTE than to store: both BatchNorm passes below rebuild their da tile on the matrix pipe from the dy rows (0.64 GB) and
+// a register-resident slice of W, and da is never written or read (10.9 GB).
+// Structure = the streaming skinny GEMM of gemm.hip: a wave owns 32 output features, keeps their K x 32 weight fragments in
+// registers, walks 16-token groups, computes the product transposed (C^T = W^T dy^T: the dy rows ARE the MFMA B operand as
+// they lie in memory) with the feature rows permuted so that each lane ends up with 8 consecutive features of one token =
+// one 16-byte access into x / dx.  The four waves of a workgroup take four neighbouring feature slices of the SAME tokens
+// (their dy loads hit the same lines).  Per-feature BatchNorm constants sit in registers (column-fixed lanes).
+//   pass 1: partial[blk][2][C] = per-workgroup sums of g and g * xhat  (g = da * drop * relu'(bn(x)));  finalize -> dbeta, dgamma
+//   pass 2: dx = gamma rstd (g - mean(g) - xhat mean(g xhat))          (eval mode: dx = gamma rstd g)
+// Deterministic: fixed token order per lane, DPP row sums, fixed-order finalize.
+#include "colreduce.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 hf_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float hf_f32x4;
+typedef __attribute__((ext_vector_type(8))) short hf_s16x8;
+
+struct HeadFusedArgs {
+    const bf16_t* dy; int64_t ldy;        // [M][>= 32 KS] class gradients (pad columns zero)
+    const bf16_t* w; int64_t ldw;         // [32 KS][C] classifier weight, rows = classes (pad rows zero)
+    const bf16_t* x;                      // [M][C] input of the BatchNorm
+    const float *mean, *rstd, *gamma, *beta;
+    const float* cscale;                  // [B][C] Dropout2d scale or nullptr
+    const float* sums;                    // pass 2: [2][C] = {dbeta, dgamma} from pass 1
+    bf16_t* dx;                           // pass 2
+    float* partial;                       // pass 1: [gridDim.x][2][C]
+    int64_t M; int C; int64_t rps; int groups_per_sample, chunks_per_sample; int act, eval_mode;
+};
+
+__device__ __forceinline__ float hf_row_sum16(float v) {
+    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
+    return v;
+}
+
+template <int PASS, int KS>
+__global__ void __launch_bounds__(256) bn_cls_bwd_kernel(HeadFusedArgs a) {
+    constexpr int NT = 2;                                   // 32 features per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mi = lane & 15, g = lane >> 4;
+    const int n0 = ((int)blockIdx.y * 4 + wave) * (16 * NT);
+    // weight fragments (skinny-GEMM order): MFMA row i of tile nt carries feature n0 + 8 (i >> 2) + 4 nt + (i & 3), so the tile
+    // pair gives lane group g the 8 consecutive features n0 + 8 g .. + 7
+    hf_bf16x8 Wf[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + 8 * (mi >> 2) + 4 * nt + (mi & 3);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            hf_s16x8 wv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = (short)a.w[(int64_t)(32 * s + 8 * g + j) * a.ldw + n];
+            Wf[nt][s] = __builtin_bit_cast(hf_bf16x8, wv);
+        }
+    }
+    // per-feature constants of this lane's 8 features f = n0 + 8 g + j:
+    //   z = x zA + zB (pre-activation), xhat = x hC + hD;  pass 2: dx = E gg - P - x Q
+    const int f0 = n0 + 8 * g;
+    float zA[8], zB[8], hC[8], hD[8], E[8], P[8], Q[8];
+    const float invn = 1.f / (float)a.M;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float mu = a.mean[f0 + j], rs = a.rstd[f0 + j], ga = a.gamma[f0 + j], be = a.beta[f0 + j];
+        zA[j] = ga * rs; zB[j] = be - mu * ga * rs;
+        hC[j] = rs; hD[j] = -mu * rs;
+        if (PASS == 2) {
+            const float mg = a.eval_mode ? 0.f : a.sums[f0 + j] * invn, mgx = a.eval_mode ? 0.f : a.sums[a.C + f0 + j] * invn;
+            E[j] = ga * rs;
+            P[j] = ga * rs * (mg + hD[j] * mgx);
+            Q[j] = ga * rs * hC[j] * mgx;
+        }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    // this workgroup's token groups: sample b, chunk c of its groups_per_sample 16-token groups
+    const int b = (int)blockIdx.x / a.chunks_per_sample, chunk = (int)blockIdx.x % a.chunks_per_sample;
+    const int gbeg = (int)((int64_t)a.groups_per_sample * chunk / a.chunks_per_sample);
+    const int gend = (int)((int64_t)a.groups_per_sample * (chunk + 1) / a.chunks_per_sample);
+    float cs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = a.cscale ? a.cscale[(int64_t)b * a.C + f0 + j] : 1.f;
+    const int64_t row0 = (int64_t)b * a.rps;
+    uint4 ya[KS], yb[KS], xa, xb;
+    auto load_rows = [&](int gp, uint4 (&y)[KS], uint4& xv) {
+        const int64_t m = row0 + (int64_t)gp * 16 + mi;
+        const bf16_t* p = a.dy + m * a.ldy + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) y[s] = *reinterpret_cast<const uint4*>(p + 32 * s);
+        xv = *reinterpret_cast<const uint4*>(a.x + m * a.C + f0);
+    };
+    if (gbeg < gend) load_rows(gbeg, ya, xa);
+    for (int gp = gbeg; gp < gend; ++gp) {
+        if (gp + 1 < gend) load_rows(gp + 1, yb, xb);
+        hf_f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[nt] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], __builtin_bit_cast(hf_bf16x8, ya[s]), acc[nt], 0, 0, 0);
+        }
+        const uint32_t xw[4] = {xa.x, xa.y, xa.z, xa.w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float da = j < 4 ? acc[0][j] : acc[1][j - 4];                   // d loss / d a[token][f0 + j]
+            const float xv = (j & 1) ? __uint_as_float(xw[j >> 1] & 0xffff0000u) : __uint_as_float(xw[j >> 1] << 16);
+            const float z = fmaf(xv, zA[j], zB[j]);
+            const bool on = a.act == 0 || (z > 0.f && (a.act == 1 || z < 6.f));
+            const float gg = on ? da * cs[j] : 0.f;
+            if (PASS == 1) {
+                s1[j] += gg;
+                s2[j] = fmaf(gg, fmaf(xv, hC[j], hD[j]), s2[j]);
+            } else {
+                o[j] = fmaf(E[j], gg, -fmaf(xv, Q[j], P[j]));
+            }
+        }
+        if (PASS == 2) {
+            uint4 ov;
+            ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]); ov.z = pack2bf(o[4], o[5]); ov.w = pack2bf(o[6], o[7]);
+            *reinterpret_cast<uint4*>(a.dx + (row0 + (int64_t)gp * 16 + mi) * a.C + f0) = ov;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ya[s] = yb[s];
+        xa = xb;
+    }
+    if (PASS == 1) {
+        // tokens of a group sit in the 16 lanes of a row group: DPP row sums, then lane mi == 0 of each (wave, g) writes its 8 features
+        float* dst = a.partial + (int64_t)blockIdx.x * 2 * a.C + f0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t1 = hf_row_sum16(s1[j]), t2 = hf_row_sum16(s2[j]);
+            if (mi == 0) { dst[j] = t1; dst[a.C + j] = t2; }
+        }
+    }
+}
+
+// out [2][C] = {dbeta, dgamma} -> separate arrays
+__global__ void hf_split_kernel(const float* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = sums[c];
+    dgamma[c] = sums[C + c];
+}
+
+static int hf_chunks(int B, int groups_per_sample, int ny) {
+    // ~3000 workgroups in flight, at least 8 token groups per workgroup
+    int s = (3072 / ny + B - 1) / B;
+    if (s > groups_per_sample / 8) s = groups_per_sample / 8;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int segf_bn_cls_bwd_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample) {
+    if (dt != SEGF_BF16 || getenv("SEGFAC_NO_HEAD_FUSED")) return 0;
+    if (K % 32 || K < 32 || K > 192 || C % 128 || rows_per_sample <= 0 || rows_per_sample % 16 || M % rows_per_sample) return 0;
+    if (M / rows_per_sample > 65535 || M < 16384) return 0;
+    return 1;
+}
+extern "C" int64_t segf_bn_cls_bwd_ws(int64_t M, int C, int64_t rows_per_sample) {
+    const int B = (int)(M / rows_per_sample);
+    return (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / 128) * 2 * C + 2 * C;
+}
+
+extern "C" int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                               const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
+                               float* dbeta, float* ws, void* stream) {
+    if (!segf_bn_cls_bwd_supported(dt, M, C, K, rows_per_sample) || ldy < K || ldw < C || act < 0 || act > 2) return SEGF_ERR_SHAPE;
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) % 16 || (ldy % 8)) return SEGF_ERR_SHAPE;
+    if (!ws) return SEGF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = (int)(M / rows_per_sample), gps = (int)(rows_per_sample / 16), ny = C / 128;
+    const int chunks = hf_chunks(B, gps, ny);
+    const int nblk = B * chunks;
+    float* sums = ws + (int64_t)nblk * 2 * C;
+    HeadFusedArgs a{(const bf16_t*)dy, ldy, (const bf16_t*)w, ldw, (const bf16_t*)x, mean, rstd, gamma, beta, chan_scale, sums,
+                    (bf16_t*)dx, ws, M, C, rows_per_sample, gps, chunks, act, eval_mode};
+    const dim3 grid((unsigned)nblk, (unsigned)ny);
+#define HF_LAUNCH(PASS)                                                                                                  \
+    do {                                                                                                                 \
+        switch (K / 32) {                                                                                                \
+        case 1: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 1>), grid, dim3(256), 0, st, a); break;                      \
+        case 2: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 2>), grid, dim3(256), 0, st, a); break;                      \
+        case 3: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 3>), grid, dim3(256), 0, st, a); break;                      \
+        case 4: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 4>), grid, dim3(256), 0, st, a); break;                      \
+        case 5: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 5>), grid, dim3(256), 0, st, a); break;                      \
+        default: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 6>), grid, dim3(256), 0, st, a); break;                     \
+        }                                                                                                                \
+    } while (0)
+    HF_LAUNCH(1);
+    SEGF_CHECK_LAUNCH();
+    colreduce_finalize_launch(ws, nblk, 2 * (int64_t)C, sums, st);
+    SEGF_CHECK_LAUNCH();
+    HF_LAUNCH(2);
+    SEGF_CHECK_LAUNCH();
+#undef HF_LAUNCH
+    hipLaunchKernelGGL(hf_split_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -56,7 +56,8 @@ class SegFormerHead(nn.Module):
         self.fold = True      # fold Linear -> resize -> concat -> 1x1 conv algebraically (functional.SegformerFoldedFuseFn)
 
     def forward_tokens(self, feats):
-        """feats: 4 TokenMaps.  Returns a TokenMap of logits at stride 4 (leading dim padded to 8)."""
+        """feats: 4 TokenMaps.  Returns a TokenMap of logits at stride 4 (class rows padded to a multiple of 32 columns: the
+        classifier's backward then runs inside the BatchNorm backward, functional.BnActLinearFn)."""
         if len(feats) != 4:
             raise ValueError('SegFormerHead expects 4 feature maps (the 5-feature adjust_channels path of '
                              'heads/segformer.py:52-54 builds fresh random weights per call and is not supported)')
@@ -74,7 +75,7 @@ class SegFormerHead(nn.Module):
         bn = self.linear_fuse.bn
         drop = dropout2d_scale(self.training and self.dropout.p > 0, B, E, x.device, self.stochastic_override, self.dropout)
         logits = Fh.bn_act_linear(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training, bn.momentum, bn.eps, 1,
-                                  drop, H1 * W1, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 7) // 8 * 8,
+                                  drop, H1 * W1, self.linear_pred.weight, self.linear_pred.bias, pad_to=(nc + 31) // 32 * 32,
                                   pre_sums=pre if self.training else None)
         if self.training:
             Fh.hip.add_i64_(bn.num_batches_tracked, 1)

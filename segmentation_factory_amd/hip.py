@@ -41,6 +41,9 @@ _PROTOS = {
     'segf_bn_stats': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p]),
     'segf_bn_apply': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _i, _p, _l, _p, _p]),
     'segf_bn_bwd': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p]),
+    'segf_bn_cls_bwd_supported': (_i, [_i, _l, _i, _i, _l]),
+    'segf_bn_cls_bwd_ws': (_l, [_l, _i, _l]),
+    'segf_bn_cls_bwd': (_i, [_i, _l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p]),
     'segf_grn_ws': (_l, [_i, _l, _i, _i]),
     'segf_grn_fwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_grn_bwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -414,6 +417,27 @@ def bn_bwd(x, dy, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eva
     _chk(lib().segf_bn_bwd(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), act,
                            _ptr(chan_scale), rows_per_sample, int(eval_mode), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
                            _ptr(ws), _stream()), 'segf_bn_bwd')
+    return dx, dgamma, dbeta
+
+
+def bn_cls_bwd_supported(dtype, M, Cc, K, rps):
+    return dtype == torch.bfloat16 and bool(lib().segf_bn_cls_bwd_supported(BF16, M, Cc, K, rps))
+
+
+def bn_cls_bwd(dy, w, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode):
+    """(dx, dgamma, dbeta) of BatchNorm(+act, +Dropout2d scale) whose output gradient is dy @ w (never materialised).
+    dy: [M, K] class gradients (K % 32 == 0, pad columns zero); w: [K, C] bf16 classifier weight; x: [M, C] BatchNorm input."""
+    _need_cuda(dy, w, x)
+    M, Cc = x.shape
+    K = w.shape[0]
+    assert dy.shape[0] == M and dy.stride(1) == 1 and dy.stride(0) >= K and w.shape[1] == Cc and w.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    ws = _f32(lib().segf_bn_cls_bwd_ws(M, Cc, rows_per_sample), x.device)
+    _chk(lib().segf_bn_cls_bwd(BF16, M, Cc, K, _ptr(dy), dy.stride(0), _ptr(w), w.stride(0), _ptr(x), _ptr(mean), _ptr(rstd),
+                               _ptr(gamma), _ptr(beta), act, _ptr(chan_scale), rows_per_sample, int(eval_mode), _ptr(dx),
+                               _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream()), 'segf_bn_cls_bwd')
     return dx, dgamma, dbeta
 
 

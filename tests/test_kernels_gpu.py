@@ -823,3 +823,51 @@ def test_bilinear_bwd_248_equals_three_transposed_resizes(hipmod, dtype, geom):
         up.backward(_q(dy, dtype).reshape(B, H, W, C).permute(0, 3, 1, 2))
         ref = x.grad.permute(0, 2, 3, 1).reshape(-1, C)
         _close(got, ref, dtype, fac=4)
+
+
+@pytest.mark.parametrize('cfg', [(2, 128, 128, 768, 150, 1, True, False), (2, 64, 128, 256, 19, 1, False, False),
+                                 (1, 128, 128, 128, 21, 0, True, True), (3, 96, 64, 768, 171, 2, False, False)])
+def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
+    """segf_bn_cls_bwd (head_fused.hip: both BatchNorm-backward passes recompute da = dy W on the matrix pipe, da is never
+    materialised) against fp32 autograd of  a = act(bn(x)) * drop;  y = a W^T  on the CPU, and against the two-launch path
+    segf_gemm(layout 1) + segf_bn_bwd it replaces."""
+    B, h, w, C, nc, act, with_drop, eval_mode = cfg
+    hip = hipmod
+    g = torch.Generator().manual_seed(41)
+    M, K = B * h * w, (nc + 31) // 32 * 32
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    dy = torch.zeros(M, K)
+    dy[:, :nc] = torch.randn(M, nc, generator=g) * 1e-3
+    W = torch.zeros(K, C)
+    W[:nc] = torch.randn(nc, C, generator=g) / C ** 0.5
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    drop = ((torch.rand(B, C, generator=g) > 0.1).float() / 0.9) if with_drop else None
+    xq, dyq, Wq = _q(x, torch.bfloat16), _q(dy, torch.bfloat16), _q(W, torch.bfloat16)
+    # reference: fp32 autograd on the CPU
+    xr = xq.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    if eval_mode:
+        mean, var = torch.randn(C, generator=g) * 0.1 + 0.3, 2.0 + torch.rand(C, generator=g)
+        xh = (xr - mean) / torch.sqrt(var + 1e-5)
+    else:
+        mean, var = xq.mean(0), xq.var(0, unbiased=False)
+        xh = (xr - xr.mean(0)) / torch.sqrt(xr.var(0, unbiased=False) + 1e-5)
+    z = xh * gr + br
+    a = z if act == 0 else (torch.relu(z) if act == 1 else torch.clamp(z, 0, 6))
+    if drop is not None:
+        a = a * drop.repeat_interleave(h * w, dim=0)
+    (a @ Wq.t()).backward(dyq)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    args = (_dev(dyq, torch.bfloat16), _dev(Wq, torch.bfloat16), _dev(xq, torch.bfloat16), _dev(mean), _dev(rstd), _dev(gam), _dev(bet),
+            act, _dev(drop) if drop is not None else None, h * w, eval_mode)
+    assert hip.bn_cls_bwd_supported(torch.bfloat16, M, C, K, h * w)
+    dx, dg, db = hip.bn_cls_bwd(*args)
+    scale = xr.grad.abs().max().item()
+    assert (dx.float().cpu() - xr.grad).abs().max().item() <= 2e-2 * scale                 # bf16 output rounding
+    assert (dg.cpu() - gr.grad).abs().max().item() <= 2e-3 * gr.grad.abs().max().item() + 1e-6
+    assert (db.cpu() - br.grad).abs().max().item() <= 2e-3 * br.grad.abs().max().item() + 1e-6
+    # the two-launch path it replaces (da rounded to bf16 in between)
+    da = hip.gemm(1, args[0], args[1], M, C, K)
+    dx2, dg2, db2 = hip.bn_bwd(args[2], da, args[3], args[4], args[5], args[6], act, args[8], h * w, eval_mode)
+    assert (dx.float() - dx2.float()).abs().max().item() <= 3e-2 * scale
+    assert (dg - dg2).abs().max().item() <= 2e-2 * dg2.abs().max().item() + 1e-6
