@@ -37,12 +37,32 @@ __device__ __forceinline__ float hf_row_sum16(float v) {
     return v;
 }
 
+#ifndef HF_WAVES
+#define HF_WAVES 8                 // waves per workgroup = 32-feature slices that share one staged dy tile (256 features)
+#endif
+#ifndef HF_OCC
+#define HF_OCC 1
+#endif
+#define HF_U 2                     // 16-token groups per iteration
 template <int PASS, int KS>
-__global__ void __launch_bounds__(256) bn_cls_bwd_kernel(HeadFusedArgs a) {
+__global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadFusedArgs a) {
     constexpr int NT = 2;                                   // 32 features per wave
+    constexpr int TOK = 16 * HF_U;                          // tokens per iteration
+    constexpr int RS = 32 * KS + 8;                         // LDS row stride in bf16 (+16 bytes: rows land on different banks)
+    constexpr int NCH = TOK * 4 * KS;                       // 16-byte chunks of one dy tile
+    constexpr int CPT = (NCH + 64 * HF_WAVES - 1) / (64 * HF_WAVES);
+    // Every wave of the workgroup needs the same dy rows (its B operand): they are fetched ONCE per workgroup into LDS (double
+    // buffered, one barrier per 32 tokens) instead of once per wave -- with per-wave global loads the dy rows crossed the
+    // L2 -> CU path 24 times per pass and cost 1.5 of the 4.0 ms (measured by removing them).
+    __shared__ __attribute__((aligned(16))) bf16_t tile[2][TOK][RS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mi = lane & 15, g = lane >> 4;
-    const int n0 = ((int)blockIdx.y * 4 + wave) * (16 * NT);
+    // 1-D grid, XCD-aware logical id L = (token chunk, feature slice) with the slice fastest: the workgroups that cover the whole
+    // row of the same tokens are dispatched together on one XCD (full 2C-byte runs of x / dx, dy rows shared in that L2)
+    const unsigned L = xcd_block();
+    const int ny = a.C / (32 * HF_WAVES);
+    const int slice = (int)(L % (unsigned)ny), blk = (int)(L / (unsigned)ny);
+    const int n0 = (slice * HF_WAVES + wave) * (16 * NT);
     // weight fragments (skinny-GEMM order): MFMA row i of tile nt carries feature n0 + 8 (i >> 2) + 4 nt + (i & 3), so the tile
     // pair gives lane group g the 8 consecutive features n0 + 8 g .. + 7
     hf_bf16x8 Wf[NT][KS];
@@ -74,64 +94,108 @@ __global__ void __launch_bounds__(256) bn_cls_bwd_kernel(HeadFusedArgs a) {
             Q[j] = ga * rs * hC[j] * mgx;
         }
     }
+    const float zlo = a.act == 0 ? -INFINITY : 0.f, zhi = a.act == 2 ? 6.f : INFINITY;     // act(z) passes gradient iff zlo < z < zhi
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
     // this workgroup's token groups: sample b, chunk c of its groups_per_sample 16-token groups
-    const int b = (int)blockIdx.x / a.chunks_per_sample, chunk = (int)blockIdx.x % a.chunks_per_sample;
+    const int b = blk / a.chunks_per_sample, chunk = blk % a.chunks_per_sample;
     const int gbeg = (int)((int64_t)a.groups_per_sample * chunk / a.chunks_per_sample);
     const int gend = (int)((int64_t)a.groups_per_sample * (chunk + 1) / a.chunks_per_sample);
     float cs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = a.cscale ? a.cscale[(int64_t)b * a.C + f0 + j] : 1.f;
     const int64_t row0 = (int64_t)b * a.rps;
-    uint4 ya[KS], yb[KS], xa, xb;
-    auto load_rows = [&](int gp, uint4 (&y)[KS], uint4& xv) {
-        const int64_t m = row0 + (int64_t)gp * 16 + mi;
-        const bf16_t* p = a.dy + m * a.ldy + 8 * g;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) y[s] = *reinterpret_cast<const uint4*>(p + 32 * s);
-        xv = *reinterpret_cast<const uint4*>(a.x + m * a.C + f0);
+    const int64_t last_row = row0 + (int64_t)gend * 16 - 1;
+    // cooperative dy tile fetch: chunk q of the tile = (token q / (4 KS), 16-byte column q % (4 KS)); at most two chunks per thread,
+    // held in two NAMED registers (an indexed private array was demoted to LDS by the compiler and waited for at once)
+    static_assert(CPT <= 2, "dy tile: at most two 16-byte chunks per thread");
+    uint4 stg0 = make_uint4(0, 0, 0, 0), stg1 = make_uint4(0, 0, 0, 0);
+    auto fetch_one = [&](int gp, int q) -> uint4 {
+        // unconditional load from clamped chunk / row indices: a load inside a divergent `if` is followed by a full
+        // s_waitcnt and the "prefetch" would wait out the HBM latency at the top of every iteration
+        q = q < NCH ? q : NCH - 1;
+        const int tk = q / (4 * KS), col = q % (4 * KS);
+        int64_t m = row0 + (int64_t)gp * 16 + tk;
+        m = m <= last_row ? m : last_row;                                       // odd tail: clamp (results of dead groups are dropped)
+        return *reinterpret_cast<const uint4*>(a.dy + m * a.ldy + 8 * col);
     };
-    if (gbeg < gend) load_rows(gbeg, ya, xa);
-    for (int gp = gbeg; gp < gend; ++gp) {
-        if (gp + 1 < gend) load_rows(gp + 1, yb, xb);
-        hf_f32x4 acc[NT];
+    auto fetch_tile = [&](int gp) {
+        stg0 = fetch_one(gp, (int)threadIdx.x);
+        if (CPT > 1) stg1 = fetch_one(gp, (int)threadIdx.x + 64 * HF_WAVES);
+    };
+    auto stash_one = [&](int bufi, int q, const uint4& v) {
+        const int tk = q / (4 * KS), col = q % (4 * KS);
+        if (q < NCH) *reinterpret_cast<uint4*>(&tile[bufi][tk][8 * col]) = v;
+    };
+    auto stash_tile = [&](int bufi) {
+        stash_one(bufi, (int)threadIdx.x, stg0);
+        if (CPT > 1) stash_one(bufi, (int)threadIdx.x + 64 * HF_WAVES, stg1);
+    };
+    uint4 xa[HF_U], xb[HF_U];
+    auto load_x = [&](int gp, uint4 (&xv)[HF_U]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[nt] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], __builtin_bit_cast(hf_bf16x8, ya[s]), acc[nt], 0, 0, 0);
+        for (int u = 0; u < HF_U; ++u) {
+            int64_t m = row0 + (int64_t)(gp + u) * 16 + mi;
+            m = m <= last_row ? m : last_row;
+            xv[u] = *reinterpret_cast<const uint4*>(a.x + m * a.C + f0);
         }
-        const uint32_t xw[4] = {xa.x, xa.y, xa.z, xa.w};
-        float o[8];
+    };
+    if (gbeg < gend) { fetch_tile(gbeg); load_x(gbeg, xa); stash_tile(0); }
+    __syncthreads();
+    int bufi = 0;
+    for (int gp = gbeg; gp < gend; gp += HF_U) {
+        const bool more = gp + HF_U < gend;
+        if (more) { fetch_tile(gp + HF_U); load_x(gp + HF_U, xb); }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float da = j < 4 ? acc[0][j] : acc[1][j - 4];                   // d loss / d a[token][f0 + j]
-            const float xv = (j & 1) ? __uint_as_float(xw[j >> 1] & 0xffff0000u) : __uint_as_float(xw[j >> 1] << 16);
-            const float z = fmaf(xv, zA[j], zB[j]);
-            const bool on = a.act == 0 || (z > 0.f && (a.act == 1 || z < 6.f));
-            const float gg = on ? da * cs[j] : 0.f;
-            if (PASS == 1) {
-                s1[j] += gg;
-                s2[j] = fmaf(gg, fmaf(xv, hC[j], hD[j]), s2[j]);
-            } else {
-                o[j] = fmaf(E[j], gg, -fmaf(xv, Q[j], P[j]));
+        for (int u = 0; u < HF_U; ++u) {
+            hf_f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const hf_bf16x8 yv = *reinterpret_cast<const hf_bf16x8*>(&tile[bufi][16 * u + mi][32 * s + 8 * g]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], yv, acc[nt], 0, 0, 0);
+            }
+            const bool live = gp + u < gend;
+            const uint32_t xw[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w};
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float da = j < 4 ? acc[0][j] : acc[1][j - 4];                   // d loss / d a[token][f0 + j]
+                const float xv = (j & 1) ? __uint_as_float(xw[j >> 1] & 0xffff0000u) : __uint_as_float(xw[j >> 1] << 16);
+                const float z = fmaf(xv, zA[j], zB[j]);
+                const bool on = live & (z > zlo) & (z < zhi);                          // branch-free: act as an open interval
+                const float gg = on ? da * cs[j] : 0.f;
+                if (PASS == 1) {
+                    s1[j] += gg;
+                    s2[j] = fmaf(gg, fmaf(xv, hC[j], hD[j]), s2[j]);
+                } else {
+                    o[j] = fmaf(E[j], gg, -fmaf(xv, Q[j], P[j]));
+                }
+            }
+            if (PASS == 2 && live) {
+                uint4 ov;
+                ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]); ov.z = pack2bf(o[4], o[5]); ov.w = pack2bf(o[6], o[7]);
+                *reinterpret_cast<uint4*>(a.dx + (row0 + (int64_t)(gp + u) * 16 + mi) * a.C + f0) = ov;
             }
         }
-        if (PASS == 2) {
-            uint4 ov;
-            ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]); ov.z = pack2bf(o[4], o[5]); ov.w = pack2bf(o[6], o[7]);
-            *reinterpret_cast<uint4*>(a.dx + (row0 + (int64_t)gp * 16 + mi) * a.C + f0) = ov;
-        }
+        // keep the LDS writes of the prefetched tile BELOW the arithmetic: hoisted above it (the compiler sees no dependence) they
+        // wait for the global loads at the top of the iteration and expose the whole HBM latency
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        if (more) {
+            stash_tile(bufi ^ 1);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) ya[s] = yb[s];
-        xa = xb;
+            for (int u = 0; u < HF_U; ++u) xa[u] = xb[u];
+        }
+        __syncthreads();                 // the next tile is complete, and nobody still reads the buffer that gets overwritten next
+        bufi ^= 1;
     }
     if (PASS == 1) {
         // tokens of a group sit in the 16 lanes of a row group: DPP row sums, then lane mi == 0 of each (wave, g) writes its 8 features
-        float* dst = a.partial + (int64_t)blockIdx.x * 2 * a.C + f0;
+        float* dst = a.partial + (int64_t)blk * 2 * a.C + f0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float t1 = hf_row_sum16(s1[j]), t2 = hf_row_sum16(s2[j]);
@@ -157,13 +221,13 @@ static int hf_chunks(int B, int groups_per_sample, int ny) {
 
 extern "C" int segf_bn_cls_bwd_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample) {
     if (dt != SEGF_BF16 || getenv("SEGFAC_NO_HEAD_FUSED")) return 0;
-    if (K % 32 || K < 32 || K > 192 || C % 128 || rows_per_sample <= 0 || rows_per_sample % 16 || M % rows_per_sample) return 0;
+    if (K % 32 || K < 32 || K > 192 || C % (32 * HF_WAVES) || rows_per_sample <= 0 || rows_per_sample % 16 || M % rows_per_sample) return 0;
     if (M / rows_per_sample > 65535 || M < 16384) return 0;
     return 1;
 }
 extern "C" int64_t segf_bn_cls_bwd_ws(int64_t M, int C, int64_t rows_per_sample) {
     const int B = (int)(M / rows_per_sample);
-    return (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / 128) * 2 * C + 2 * C;
+    return (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / (32 * HF_WAVES)) * 2 * C + 2 * C;
 }
 
 extern "C" int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
@@ -174,22 +238,22 @@ extern "C" int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, 
     if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) % 16 || (ldy % 8)) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int B = (int)(M / rows_per_sample), gps = (int)(rows_per_sample / 16), ny = C / 128;
+    const int B = (int)(M / rows_per_sample), gps = (int)(rows_per_sample / 16), ny = C / (32 * HF_WAVES);
     const int chunks = hf_chunks(B, gps, ny);
     const int nblk = B * chunks;
     float* sums = ws + (int64_t)nblk * 2 * C;
     HeadFusedArgs a{(const bf16_t*)dy, ldy, (const bf16_t*)w, ldw, (const bf16_t*)x, mean, rstd, gamma, beta, chan_scale, sums,
                     (bf16_t*)dx, ws, M, C, rows_per_sample, gps, chunks, act, eval_mode};
-    const dim3 grid((unsigned)nblk, (unsigned)ny);
+    const dim3 grid((unsigned)(nblk * ny));
 #define HF_LAUNCH(PASS)                                                                                                  \
     do {                                                                                                                 \
         switch (K / 32) {                                                                                                \
-        case 1: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 1>), grid, dim3(256), 0, st, a); break;                      \
-        case 2: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 2>), grid, dim3(256), 0, st, a); break;                      \
-        case 3: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 3>), grid, dim3(256), 0, st, a); break;                      \
-        case 4: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 4>), grid, dim3(256), 0, st, a); break;                      \
-        case 5: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 5>), grid, dim3(256), 0, st, a); break;                      \
-        default: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 6>), grid, dim3(256), 0, st, a); break;                     \
+        case 1: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 1>), grid, dim3(64 * HF_WAVES), 0, st, a); break;                      \
+        case 2: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 2>), grid, dim3(64 * HF_WAVES), 0, st, a); break;                      \
+        case 3: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 3>), grid, dim3(64 * HF_WAVES), 0, st, a); break;                      \
+        case 4: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 4>), grid, dim3(64 * HF_WAVES), 0, st, a); break;                      \
+        case 5: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 5>), grid, dim3(64 * HF_WAVES), 0, st, a); break;                      \
+        default: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 6>), grid, dim3(64 * HF_WAVES), 0, st, a); break;                     \
         }                                                                                                                \
     } while (0)
     HF_LAUNCH(1);

@@ -826,7 +826,7 @@ def test_bilinear_bwd_248_equals_three_transposed_resizes(hipmod, dtype, geom):
 
 
 @pytest.mark.parametrize('cfg', [(2, 128, 128, 768, 150, 1, True, False), (2, 64, 128, 256, 19, 1, False, False),
-                                 (1, 128, 128, 128, 21, 0, True, True), (3, 96, 64, 768, 171, 2, False, False)])
+                                 (1, 128, 128, 512, 21, 0, True, True), (3, 96, 64, 768, 171, 2, False, False)])
 def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
     """segf_bn_cls_bwd (head_fused.hip: both BatchNorm-backward passes recompute da = dy W on the matrix pipe, da is never
     materialised) against fp32 autograd of  a = act(bn(x)) * drop;  y = a W^T  on the CPU, and against the two-launch path

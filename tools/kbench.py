@@ -127,6 +127,17 @@ def main():
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         ms = timeit(lambda: hip.argmax_confmat(lo, B, nc, h, h, H, H, tgt, 255, mat, hist, flag))
         report('argmax_confmat (fused upsample)', ms, nbytes=B * (h * h * ld * 2 + H * H * 8))
+    if want('bncls'):
+        rows, C, K = B * 128 * 128, 768, 160
+        x = rnd(rows, C)
+        dyc = rnd(rows, K) * 1e-3
+        wc = rnd(K, C) * 0.03
+        g, b_ = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        mean, rstd = hip.bn_stats(x, rm, rv, 0.1, 1e-5)
+        cs = torch.ones(B, C, device=dev)
+        ms = timeit(lambda: hip.bn_cls_bwd(dyc, wc, x, mean, rstd, g, b_, 1, cs, 128 * 128, False))
+        report('bn_cls_bwd (both passes, da recomputed)', ms, nbytes=2 * rows * (3 * C + 2 * K))
     if want('upadd'):
         E, Hh = 768, 128
         base = rnd(B * Hh * Hh, E)
