@@ -273,6 +273,64 @@ def train_overfit_case():
     np.savez_compressed(os.path.join(OUT, 'train_overfit_segformer_b0.npz'), **out)
 
 
+def scheduler_cases():
+    """LR sequences of every --sched value, captured from the reference's create_scheduler (scheduler/scheduler_factory.py:12-110)
+    driven the way train_gpu.py drives it (step(epoch) per epoch; plus step_update per iteration to pin the live clock of the
+    default cosine, quirk Q9).  Stored as JSON: argument dict + the optimizer's lr after each call."""
+    import json
+    fac = ref_shim.load_schedulers()
+    base = dict(epochs=12, data_len=40, batch_size=4, world_size=1, warmup_epochs=3, cooldown_epochs=2, min_lr=1e-5, warmup_lr=1e-4,
+                lr=1e-2, lr_ep=False, lr_noise=None, lr_noise_pct=0.67, lr_noise_std=1.0, seed=3, lr_cycle_mul=1.0, lr_cycle_decay=0.5,
+                lr_cycle_limit=1, lr_k_decay=1.0, decay_epochs=4, decay_rate=0.1, decay_milestones=[4, 8], patience_epochs=2,
+                eval_metric='miou')
+    variants = [
+        ('cosine_default_inert', dict(sched='cosine')),
+        ('cosine_epochs', dict(sched='cosine', lr_ep=True)),
+        ('cosine_cycles_kdecay_noise', dict(sched='cosine', lr_ep=True, epochs=2, lr_cycle_mul=2.0, lr_cycle_limit=3, lr_k_decay=1.5,
+                                           lr_noise=[0.4, 0.9], warmup_epochs=1)),
+        ('tanh', dict(sched='tanh')),
+        ('tanh_cycles', dict(sched='tanh', epochs=5, lr_cycle_limit=2, lr_cycle_mul=1.5, warmup_epochs=2)),
+        ('step', dict(sched='step')),
+        ('step_noise', dict(sched='step', lr_noise=0.5)),
+        ('multistep', dict(sched='multistep')),
+        ('poly', dict(sched='poly', decay_rate=0.9)),
+        ('poly_kdecay', dict(sched='poly', decay_rate=2.0, lr_k_decay=0.5, warmup_epochs=0)),
+        # 'plateau': the reference's PlateauLRScheduler passes verbose= to torch's ReduceLROnPlateau, which torch >= 2.4 rejects
+        # (TypeError at construction, plateau_lr.py:44-53), so there is nothing to capture: tests/test_host_cpu.py checks our
+        # wrapper against torch's ReduceLROnPlateau directly
+    ]
+    out = []
+    for name, upd in variants:
+        a = dict(base)
+        a.update(upd)
+        args = types.SimpleNamespace(**a)
+        p = torch.nn.Parameter(torch.zeros(3))
+        q = torch.nn.Parameter(torch.zeros(2))
+        opt = torch.optim.SGD([{'params': [p]}, {'params': [q], 'lr': a['lr'] * 0.5}], lr=a['lr'])
+        sch, n_epochs = fac.create_scheduler(args, opt)
+        n_iter = a['data_len'] // (a['batch_size'] * a['world_size'])
+        seq = {'init': [g['lr'] for g in opt.param_groups], 'epoch': [], 'update': []}
+        metrics = [10, 20, 30, 30, 30, 30, 29, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31, 31]
+        upd_ctr = 0
+        for ep in range(n_epochs + 2):
+            for _ in range(n_iter):
+                upd_ctr += 1
+                sch.step_update(upd_ctr)
+                if upd_ctr % 5 == 0:
+                    seq['update'].append([g['lr'] for g in opt.param_groups])
+            if a['sched'] == 'plateau':
+                sch.step(ep, metrics[ep])
+            else:
+                sch.step(ep)
+            seq['epoch'].append([g['lr'] for g in opt.param_groups])
+        sd = sch.state_dict()
+        out.append({'name': name, 'args': a, 'num_epochs': n_epochs, 'seq': seq,
+                    'state_keys': sorted(k for k in sd.keys())})
+        print(f'[scheduler {name}] epochs {n_epochs} lr after epochs', [round(v[0], 8) for v in seq['epoch'][:8]])
+    with open(os.path.join(OUT, 'scheduler_cases.json'), 'w') as fh:
+        json.dump(out, fh, indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -290,6 +348,7 @@ def main():
     e2e_case('mbv2_fpn_128', 'MobileNetV2', 'FPNHead', 21, 2, 128, 128, seed=79, compact=True)
     train_loop_case()
     train_overfit_case()
+    scheduler_cases()
     print('goldens written to', OUT)
 
 

@@ -98,3 +98,24 @@ def build_reference_model(backbone, head, nc, state_dict, zero_stochastic=True):
             if isinstance(m, torch.nn.Dropout2d):
                 m.p = 0.
     return model
+
+
+def load_schedulers():
+    """The reference's scheduler package (scheduler/*.py, vendored timm schedulers).  multistep_lr.py:7 imports the base class
+    from timm (not installed here): it is given the reference's OWN vendored copy of that class (scheduler/scheduler_main.py,
+    which every other file of the package already uses), so the arithmetic executed is the reference's throughout."""
+    if not available():
+        raise RuntimeError(f'reference not present at {REF_ROOT}')
+    sys.dont_write_bytecode = True
+    pkg = _pkg('scheduler')
+    main = _load('scheduler.scheduler_main', 'scheduler/scheduler_main.py')
+    timm = sys.modules.get('timm') or _pkg('timm')
+    ts = _pkg('timm.scheduler')
+    tss = _pkg('timm.scheduler.scheduler')
+    tss.Scheduler = main.Scheduler
+    ts.scheduler = tss
+    timm.scheduler = ts
+    for f in ('cosine_lr', 'tanh_lr', 'step_lr', 'multistep_lr', 'plateau_lr', 'poly_lr'):
+        setattr(pkg, f, _load(f'scheduler.{f}', f'scheduler/{f}.py'))
+    fac = _load('scheduler.scheduler_factory', 'scheduler/scheduler_factory.py')
+    return fac

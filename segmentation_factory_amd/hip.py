@@ -352,6 +352,7 @@ def layernorm_fwd(x, gamma, beta, eps):
 def zeros(shape, dtype, device):
     """torch.zeros through the library's own fill kernel (keeps framework kernels out of the captured step)."""
     t = torch.empty(shape, dtype=dtype, device=device)
+    _need_cuda(t)
     _chk(lib().segf_zero(_ptr(t), t.numel() * t.element_size(), _stream()), 'segf_zero')
     return t
 
@@ -365,6 +366,7 @@ def add_i64_(t, v=1):
 
 def bernoulli_scale(state, keep_prob, n, row_len):
     """fp32 [n]: 1 / kp with probability kp, else 0, kp = keep_prob[i // row_len]; state = uint64-as-int64 [2] {seed, counter}."""
+    _need_cuda(state, keep_prob)
     out = torch.empty(n, dtype=torch.float32, device=state.device)
     _chk(lib().segf_bernoulli_scale(_ptr(state), _ptr(keep_prob), n, row_len, _ptr(out), _stream()), 'segf_bernoulli_scale')
     return out

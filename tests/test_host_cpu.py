@@ -266,3 +266,62 @@ def test_fused_optimizer_state_dict_is_torch_adamw_layout():
     back = torch.optim.AdamW(ps, lr=1.0)
     back.load_state_dict(out)                                    # torch accepts what we wrote
     assert torch.equal(back.state[ps[0]]['exp_avg'], sd['state'][0]['exp_avg'])
+
+
+def test_schedulers_match_reference_lr_sequences(golden_dir):
+    """(f4) every --sched value: create_scheduler driven like train_gpu.py (step_update per iteration, step(epoch) per epoch)
+    reproduces the LR sequences captured from the reference's scheduler package (tests/golden/scheduler_cases.json,
+    oracle/make_goldens.py::scheduler_cases), both parameter groups, including restart cycles, k-decay and seeded LR noise."""
+    import json
+    import types
+    from segmentation_factory_amd.scheduler import create_scheduler
+    cases = json.load(open(os.path.join(golden_dir, 'scheduler_cases.json')))
+    assert {c['name'] for c in cases} >= {'cosine_default_inert', 'cosine_epochs', 'tanh', 'step', 'multistep', 'poly'}
+    for c in cases:
+        a = c['args']
+        args = types.SimpleNamespace(**a)
+        p, q = torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2))
+        opt = torch.optim.SGD([{'params': [p]}, {'params': [q], 'lr': a['lr'] * 0.5}], lr=a['lr'])
+        sch, n_epochs = create_scheduler(args, opt)
+        assert n_epochs == c['num_epochs'], c['name']
+        assert [g['lr'] for g in opt.param_groups] == pytest.approx(c['seq']['init'], rel=1e-12), c['name']
+        n_iter = a['data_len'] // (a['batch_size'] * a['world_size'])
+        ep_seq, up_seq, upd = [], [], 0
+        for ep in range(n_epochs + 2):
+            for _ in range(n_iter):
+                upd += 1
+                sch.step_update(upd)
+                if upd % 5 == 0:
+                    up_seq.append([g['lr'] for g in opt.param_groups])
+            sch.step(ep)
+            ep_seq.append([g['lr'] for g in opt.param_groups])
+        assert np.allclose(ep_seq, c['seq']['epoch'], rtol=1e-10, atol=0), c['name']
+        assert np.allclose(up_seq, c['seq']['update'], rtol=1e-10, atol=0), c['name']
+        assert sorted(sch.state_dict().keys()) == c['state_keys'], c['name']      # same 'scheduler_state' keys in the checkpoint
+    inert = next(c for c in cases if c['name'] == 'cosine_default_inert')
+    assert len({tuple(v) for v in inert['seq']['epoch']}) == 1                   # quirk Q9: without --lr-ep step(epoch) never moves it
+
+
+def test_plateau_scheduler_wraps_torch_reduce_on_plateau():
+    """--sched plateau (scheduler/plateau_lr.py:10-102; the reference class itself does not construct on torch >= 2.4): warm-up,
+    then torch.optim.lr_scheduler.ReduceLROnPlateau on the epoch metric; state_dict = {'best', 'last_epoch'}."""
+    import types
+    from segmentation_factory_amd.scheduler import create_scheduler
+    args = types.SimpleNamespace(epochs=12, data_len=40, batch_size=4, world_size=1, warmup_epochs=2, cooldown_epochs=0, min_lr=1e-5,
+                                 warmup_lr=1e-4, lr=1e-2, lr_ep=False, sched='plateau', decay_rate=0.5, patience_epochs=2, seed=0)
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([p], lr=args.lr)
+    sch, _ = create_scheduler(args, opt)
+    assert opt.param_groups[0]['lr'] == 1e-4
+    ref_p = torch.nn.Parameter(torch.zeros(3))
+    ref_opt = torch.optim.SGD([ref_p], lr=args.lr)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref_opt, patience=2, factor=0.5, threshold=1e-4, cooldown=0, mode='max', min_lr=1e-5)
+    metrics = [10, 20, 30, 30, 30, 30, 30, 31, 31, 31, 31, 31]
+    for ep, m in enumerate(metrics):
+        sch.step(ep, m)
+        if ep <= 2:
+            assert opt.param_groups[0]['lr'] == pytest.approx(1e-4 + ep * (1e-2 - 1e-4) / 2)
+        else:
+            ref.step(m, ep)
+            assert opt.param_groups[0]['lr'] == ref_opt.param_groups[0]['lr']
+    assert opt.param_groups[0]['lr'] < 1e-2 and set(sch.state_dict()) == {'best', 'last_epoch'}
