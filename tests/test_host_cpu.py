@@ -298,8 +298,16 @@ def test_schedulers_match_reference_lr_sequences(golden_dir):
         assert np.allclose(ep_seq, c['seq']['epoch'], rtol=1e-10, atol=0), c['name']
         assert np.allclose(up_seq, c['seq']['update'], rtol=1e-10, atol=0), c['name']
         assert sorted(sch.state_dict().keys()) == c['state_keys'], c['name']      # same 'scheduler_state' keys in the checkpoint
+    # quirk Q9: the reference's loop only ever calls step(epoch) (train_gpu.py:336), and without --lr-ep that never moves the rate;
+    # the step_update calls above are what WOULD drive the default cosine
     inert = next(c for c in cases if c['name'] == 'cosine_default_inert')
-    assert len({tuple(v) for v in inert['seq']['epoch']}) == 1                   # quirk Q9: without --lr-ep step(epoch) never moves it
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([p], lr=inert['args']['lr'])
+    sch, n_epochs = create_scheduler(types.SimpleNamespace(**inert['args']), opt)
+    for ep in range(n_epochs):
+        sch.step(ep)
+        assert opt.param_groups[0]['lr'] == inert['args']['warmup_lr']
+    assert len({tuple(v) for v in inert['seq']['update']}) > 1
 
 
 def test_plateau_scheduler_wraps_torch_reduce_on_plateau():
