@@ -282,6 +282,7 @@ FULL_SIZE = {   # BASELINE.json configs as the reference builds them, at their f
     'cfg2': ('MiT-B0', 'SegFormerHead', 150, 2, 512, 512),
     'cfg3': ('ConvNeXt', 'UPerHead', 150, 4, 512, 512),      # batch 4: PPM's scale-1 BatchNorm sees 4 values per channel (2 is degenerate)
     'cfg4': ('MiT-B2', 'SegFormerHead', 19, 1, 1024, 2048),
+    'cfg5': ('convnextv2_large', 'UPerHead', 171, 4, 640, 640),    # BASELINE cfg5's model / classes / size (its fp8 option: test_fp8_*)
 }
 
 
@@ -312,7 +313,7 @@ def test_full_size_fp32_and_bf16_vs_oracle(cfg):
         e_loss = abs(loss.item() - ref_loss) / abs(ref_loss)
         # bf16, cfg3: PPM's scale-1 branch is a BatchNorm over B values per channel (quirk Q16): its own parameters' gradients are
         # differences of nearly equal numbers divided by a small sigma -- checked in fp32 only
-        skip = ('ppm.stages.0.',) if (cfg == 'cfg3' and not fp32) else ()
+        skip = ('ppm.stages.0.',) if (cfg in ('cfg3', 'cfg5') and not fp32) else ()
         worst, wname, n = _grad_report(model, ref_grads, skip)
         print(f'[{cfg} {str(dtype)[6:]}] oracle {t_oracle:.0f} s; logits {e_log:.2e}, loss {e_loss:.2e}, worst gradient error {worst:.3e} ({wname}), {n} tensors')
         assert n >= 50
@@ -320,8 +321,8 @@ def test_full_size_fp32_and_bf16_vs_oracle(cfg):
         assert e_loss <= (1e-4 if fp32 else 2e-2)
         # cfg3: PPM's scale-1 branch feeds a BatchNorm with B samples per channel (quirk Q16), whose Jacobian is
         # ill-conditioned; its neighbours' fp32 gradients move at the 1e-2 level with the summation order
-        # measured on the MI355X (fp32 / bf16): cfg2 2.0e-3 / 3.1e-2, cfg3 1.4e-2 / 1.4e-1, cfg4 4.4e-4 / 7.5e-3; ~2x margin
-        assert worst <= {'cfg2': (5e-3, 8e-2), 'cfg3': (3e-2, 0.3), 'cfg4': (2e-3, 3e-2)}[cfg][0 if fp32 else 1], (wname, worst)
+        # measured on the MI355X (fp32 / bf16): cfg2 2.0e-3 / 3.1e-2, cfg3 1.4e-2 / 1.4e-1, cfg4 4.4e-4 / 7.5e-3, cfg5 6.8e-3 / 2.6e-1; ~2x margin
+        assert worst <= {'cfg2': (5e-3, 8e-2), 'cfg3': (3e-2, 0.3), 'cfg4': (2e-3, 3e-2), 'cfg5': (1.5e-2, 0.5)}[cfg][0 if fp32 else 1], (wname, worst)
         del model, lo, loss
         torch.cuda.empty_cache()
 
