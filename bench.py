@@ -44,19 +44,19 @@ def synthetic_batch(batch, seed):
 
 
 def kernel_source_hash():
-    """Hash of the HIP sources the in-tree library is built from: stamps profiles/pmc_traffic_*.json so that a counter file
-    measured on other kernels is never reported as this run's traffic."""
-    import glob
+    """Hash of the HIP sources of the kernels in the roofline objects: stamps profiles/pmc_traffic_*.json so that a counter file
+    measured on other kernel code is never reported as this run's traffic."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'segmentation_factory_amd', 'csrc')
-    for f in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')) + [os.path.join(csrc, 'Makefile')]):
+    # the sources of the two kernels whose traffic is reported (+ the shared headers and the build flags)
+    for f in sorted(os.path.join(csrc, n) for n in ('loss.hip', 'gemm.hip', 'common.h', 'colreduce.h', 'Makefile')):
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(sample_batch=2, timed_steps=3):
+def cpu_baseline(sample_batch=2, timed_steps=3, loop_timed_steps=2):
     """The oracle (CPU restatement of the reference path, validated bit-exact against the imported reference in the build
     container) timed on this host, SURVEY section 8(d): same synthetic batch, 1 warm-up + 3 timed steps of forward + CE/Dice +
     backward with the reference's B x C Python Dice loop (util/losses.py:141-170: its cost structure), and next to it the
@@ -82,7 +82,7 @@ def cpu_baseline(sample_batch=2, timed_steps=3):
         for _ in range(n):
             step(crit)
         return (time.time() - t0) / n
-    t_loop = timed(OL.criterion_loops, timed_steps)
+    t_loop = timed(OL.criterion_loops, loop_timed_steps)     # ~28 s per step on the GPU box's 16-thread share: two timed steps
     t_vec = timed(OL.criterion_closed_form, timed_steps)
     cpu_model = ''
     try:
@@ -91,10 +91,10 @@ def cpu_baseline(sample_batch=2, timed_steps=3):
     except OSError:
         pass
     return {"value": round(sample_batch / t_loop, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 warm-up + {timed_steps} timed steps of fwd + CE/Dice (reference's B x C Python loop) + bwd, batch {sample_batch}, "
+            "sample": f"1 warm-up + {loop_timed_steps} timed steps of fwd + CE/Dice (reference's B x C Python loop) + bwd, batch {sample_batch}, "
                       f"512x512, 150 classes, fp32: {t_loop:.2f} s/step",
             "vectorised_dice_value": round(sample_batch / t_vec, 4),
-            "vectorised_dice_sample": f"same with the closed-form Dice: {t_vec:.2f} s/step",
+            "vectorised_dice_sample": f"1 warm-up + {timed_steps} timed steps with the closed-form (vectorised) Dice: {t_vec:.2f} s/step",
             "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(), "cpu_model": cpu_model}
 
 
@@ -158,7 +158,8 @@ def main():
     hq, wq = H // 4, W // 4
     M, N, K = args.batch * hq * wq, NC, 768
     loss_key = ('ce_dice_bwd', args.batch, NC, hq, wq, H, W)
-    gemm_key = ('gemm', 0, M, (NC + 7) // 8 * 8, K)
+    ld = (NC + 31) // 32 * 32 if head_name == 'SegFormerHead' else (NC + 7) // 8 * 8      # class rows as the head pads them
+    gemm_key = ('gemm', 0, M, ld, K)
     if args.eager:
         scaler = NativeScaler()
         model = core
@@ -211,7 +212,6 @@ def main():
     # roofline leg: the same C-ABI calls on the same shapes, HIP-event timed on the launch stream right after the timed
     # region (launches inside a graph replay cannot be bracketed by events; the rocprofv3 summary of this command under
     # profiles/ gives the in-graph durations of the same launches)
-    ld = (NC + 7) // 8 * 8
     lo_ = torch.randn(M, ld, device=dev).to(dtype)[:, :NC]
     loss_, stats_ = hip.ce_dice_fwd(lo_, args.batch, NC, hq, wq, H, W, y, 255, None, True)
     go_ = torch.ones(1, device=dev)
@@ -281,7 +281,7 @@ def main():
             "step_algorithmic_hbm": ({"bytes_per_image": 580e6, "achieved_GBps": round(580e6 * ips / world / 1e9, 1),
                                       "frac_of_peak": round(580e6 * ips / world / HBM_PEAK, 4)} if args.config == 'cfg2' else None),
             "roofline": {"kernel": "ce_dice_bwd_mfma4_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
-                                   "backward, low-res logits [B,128,128,152] -> d logits, labels int64 [B,512,512]",
+                                   f"backward, low-res logits [B,{hq},{wq},{ld}] -> d logits, labels int64 [B,{H},{W}]",
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note,
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
@@ -289,8 +289,8 @@ def main():
                                  "ops; interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
             "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true> (segf_gemm_pro, the in-graph variant): classifier 1x1 conv "
-                                        "[B*128*128,768]x[768,152] with BatchNorm + ReLU + Dropout2d applied on the operand load" if use_pro else
-                                        "gemm_bf16_big_kernel<0>: classifier 1x1 conv [B*128*128,768]x[768,152]",
+                                        f"[B*{hq}*{wq},768]x[768,{ld}] with BatchNorm + ReLU + Dropout2d applied on the operand load" if use_pro else
+                                        f"gemm_bf16_big_kernel<0>: classifier 1x1 conv [B*{hq}*{wq},768]x[768,{ld}]",
                               "bound": "hbm", "achieved": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": round(gemm_bytes / (gemm_ms * 1e-3) / HBM_PEAK, 4),
                               "traffic": traffic.get('gemm_pro'), "launches_timed": ng,
