@@ -110,6 +110,7 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=sorted(CONFIGS),
                     help='BASELINE.json configs as the reference builds them; cfg2 = SegFormer-B0 (headline)')
     ap.add_argument('--eager', action='store_true', help='per-kernel launches + torch DDP instead of the hipGraph step')
+    ap.add_argument('--fp8', action='store_true', help='cfg3 / cfg5: forward products of the ConvNeXt pointwise linears in OCP e4m3 (set_fp8)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -135,6 +136,8 @@ def main():
     global NC, H, W
     bb_name, head_name, NC, H, W = CONFIGS[args.config]
     core = SegmentationModel(bb_name, num_classes=NC, seg_head=head_name, compute_dtype=dtype).to(dev).train()
+    if args.fp8:
+        core.set_fp8(True)
     opt = FusedAGCAdamW(param_groups_weight_decay(core, 0.025), lr=2e-4)
     x, y = synthetic_batch(args.batch, seed=rank)
     x, y = x.to(dev), y.to(dev)
@@ -271,6 +274,7 @@ def main():
                                    ("full train step (zero_grad+fwd+CE/Dice+bwd+AGC/AdamW)" if with_opt else "forward+loss+backward only"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "init": "random (reference initialisers)", "loss_after": round(final_loss, 4),
+                       "fp8": bool(args.fp8),
                        "launch": "eager" if args.eager else "hipGraph(zero_grad+fwd+loss+bwd+grad gather) + RCCL all-reduce + fused AGC/AdamW"},
             "images_per_sec_per_gpu": round(ips / world, 2),
             "peak_hbm_allocated_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),

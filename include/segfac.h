@@ -60,6 +60,19 @@ int segf_zero(void* p, int64_t nbytes, void* stream);
 int segf_add_i64(int64_t* p, int64_t v, void* stream);
 int segf_bernoulli_scale(uint64_t* state, const float* keep_prob, int64_t n, int64_t row_len, float* out, void* stream);
 
+/* ---- FP8 (OCP e4m3fn) forward GEMM: BASELINE cfg5 "ConvNeXtV2-L + UPerNet, fp8 MFMA weights" (the pointwise linears of
+ * convnextv2.py:90-95; no fp8 exists in the reference -- an option of this build, tolerance stated in the tests) ------------
+ * segf_quant_rows_fp8: q[r][k] = e4m3(x[r][k] / scale[r]), scale[r] = amax_k |x[r][k]| / 448 (token rows of the activations,
+ * output-channel rows of the weights); x of dtype dt, K % 8 == 0.
+ * segf_gemm_fp8: C[M][N] (bf16) = (A[M][K] . B[N][K]^T) * scale_a[m] * scale_b[n] + bias[n], optionally
+ * residual[m][n] + rscale[m / rows_per_group] * (...); A, B e4m3 bytes; v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulate;
+ * K % 128 == 0 (segf_gemm_fp8_supported). */
+int segf_quant_rows_fp8(int dt, int64_t rows, int K, const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, void* stream);
+int segf_gemm_fp8_supported(int64_t M, int64_t N, int64_t K);
+int segf_gemm_fp8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const float* scale_a, const void* B, int64_t ldb,
+                  const float* scale_b, const float* bias, const void* residual, int64_t ldr, const float* rscale,
+                  int64_t rows_per_group, void* C, int64_t ldc, void* stream);
+
 /* ---- stream ordering for the data-parallel exchange (train_gpu.py:233-236: DistributedDataParallel overlaps the gradient
  * all-reduce with backward through per-bucket hooks).  segf_event_record(.., external=1) during a stream capture adds an
  * EVENT-RECORD NODE to the hipGraph (hipEventRecordExternal); at each replay a stream outside the graph can

@@ -257,15 +257,16 @@ class ConvNeXtBlock(nn.Module):
         elif init_value > 0:
             self.gamma = nn.Parameter(init_value * torch.ones((dim)), requires_grad=True)
         self.drop_prob = float(dpr)
+        self.fp8 = False          # forward products of pwconv1 / pwconv2 on the fp8 matrix pipe (SegmentationModel.set_fp8)
 
     def tokens(self, x, B, H, W, scale):
         x, xc = Fh.fork(x, 2)                        # residual + depthwise conv both read x
         h = Fh.dwconv7x7(xc, self.dwconv.weight, self.dwconv.bias, B, H, W)
         h = Fh.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps)
-        h = Fh.gelu(Fh.linear(h, self.pwconv1.weight, self.pwconv1.bias))
+        h = Fh.gelu(Fh.linear(h, self.pwconv1.weight, self.pwconv1.bias, fp8=self.fp8))
         if self.v2:
             h = Fh.grn(h, self.grn.gamma, self.grn.beta, B, H * W)
-            return Fh.linear(h, self.pwconv2.weight, self.pwconv2.bias, residual=x, rscale=scale, rows_per_group=H * W)
+            return Fh.linear(h, self.pwconv2.weight, self.pwconv2.bias, residual=x, rscale=scale, rows_per_group=H * W, fp8=self.fp8)
         if hasattr(self, 'gamma'):
             return Fh.linear_layer_scale(h, self.pwconv2.weight, self.pwconv2.bias, self.gamma, residual=x, rscale=scale,
                                          rows_per_group=H * W)

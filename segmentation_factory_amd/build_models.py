@@ -79,6 +79,19 @@ class SegmentationModel(BaseSegModel):
                 m.compute_dtype = dtype
         return self
 
+    def set_fp8(self, enabled: bool = True):
+        """BASELINE cfg5 ("fp8 MFMA weights"): run the forward products of the ConvNeXt / ConvNeXtV2 pointwise linears
+        (convnextv2.py:90-95) in OCP e4m3 on the block-scaled fp8 matrix instruction (csrc/fp8.hip): weights quantised per output
+        channel, activations per token, fp32 accumulate; backward stays bf16.  Not a reference feature: tolerance in the tests."""
+        n = 0
+        for m in self.backbone.modules():
+            if hasattr(m, 'fp8') and hasattr(m, 'pwconv1'):
+                m.fp8 = bool(enabled)
+                n += 1
+        if enabled and n == 0:
+            raise ValueError(f'set_fp8: backbone {self.backbone_name!r} has no fp8-capable layers (ConvNeXt / ConvNeXtV2 blocks)')
+        return self
+
     def _features(self, x):
         if hasattr(self.backbone, 'forward_tokens'):
             return self.backbone.forward_tokens(x)

@@ -104,11 +104,22 @@ class LinearFn(Function):
     reference: mit.py:45,52,58,98-99 (q/kv/proj/fc1/fc2), heads/segformer.py:13,24,39."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, rscale, rows_per_group, pad_to):
+    def forward(ctx, x, weight, bias, residual, rscale, rows_per_group, pad_to, fp8=False):
         x = _rowmajor(x)
         M, K = x.shape
         N = weight.shape[0]
         Np = pad_to if (pad_to and pad_to > N) else N
+        if fp8 and Np == N and x.dtype == torch.bfloat16 and hip.gemm_fp8_supported(M, N, K):
+            # FP8 forward (BASELINE cfg5): token rows and output-channel rows quantised to e4m3 with dynamic amax scales, product
+            # on the block-scaled fp8 matrix instruction; the backward products below stay bf16 on the saved operands
+            w = _w(weight.reshape(N, -1), x.dtype)
+            xq, sx = hip.quant_rows_fp8(x)
+            wq, sw = hip.quant_rows_fp8(weight.detach().reshape(N, -1))
+            y = hip.gemm_fp8(xq, sx, wq, sw, bias=bias.detach() if bias is not None else None, residual=residual, rscale=rscale,
+                             rows_per_group=rows_per_group or 1)
+            ctx.save_for_backward(x, w, rscale)
+            ctx.meta = (M, N, K, bias is not None, residual is not None, rows_per_group or 1, weight.shape, Np)
+            return y
         if Np > N:
             # column-padded output (e.g. 150 classes -> 152): the layer is run as an Np-wide linear whose extra weight rows
             # and biases are zero, so the pad columns of y are exact zeros, every 16-byte chunk of a row is either fully
@@ -148,7 +159,7 @@ class LinearFn(Function):
                     dw = hip.gemm(2, dyp, x, Np, K, M, out_dtype=torch.float32, split_k=_splitk(Np, K, M))[:N].view(wshape)
                 if has_bias and ctx.needs_input_grad[2]:
                     db = hip.colsum(dyp)[:N]
-            return dx, dw, db, None, None, None, None
+            return dx, dw, db, None, None, None, None, None
         wv = w[:N] if Np > N else w
         dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
         dx = dw = db = None
@@ -164,11 +175,11 @@ class LinearFn(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 db = hip.colsum(dys, out=gb)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
-def linear(x, weight, bias=None, residual=None, rscale=None, rows_per_group=None, pad_to=None):
-    return LinearFn.apply(x, weight, bias, residual, rscale, rows_per_group, pad_to)
+def linear(x, weight, bias=None, residual=None, rscale=None, rows_per_group=None, pad_to=None, fp8=False):
+    return LinearFn.apply(x, weight, bias, residual, rscale, rows_per_group, pad_to, fp8)
 
 
 @direct_grads(1, 2)

@@ -84,6 +84,9 @@ _PROTOS = {
     'segf_add_i64': (_i, [_p, _l, _p]),
     'segf_bernoulli_scale': (_i, [_p, _p, _l, _l, _p, _p]),
     'segf_layernorm_bwd_fused': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_quant_rows_fp8': (_i, [_i, _l, _i, _p, _l, _p, _l, _p, _p]),
+    'segf_gemm_fp8_supported': (_i, [_l, _l, _l]),
+    'segf_gemm_fp8': (_i, [_l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p, _l, _p]),
     'segf_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'segf_event_destroy': (_i, [_p]),
     'segf_event_record': (_i, [_p, _p, _i]),
@@ -269,6 +272,33 @@ def gemm_pro(layout, A, B, M, N, K, scale, shift, rows_per_group, act, bias=None
     _chk(_timed(('gemm', layout, M, N, K), lambda: lib().segf_gemm_pro(
         dt_of(A), layout, M, N, K, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), dt_of(out), out.stride(0), _ptr(bias),
         split_k, _ptr(ws), _ptr(scale), _ptr(shift), rows_per_group, act, _stream())), 'segf_gemm_pro')
+    return out
+
+
+def quant_rows_fp8(x):
+    """(q uint8 [rows, K] of e4m3fn bytes, scale fp32 [rows]): row-wise dynamic quantisation, x = q * scale."""
+    _need_cuda(x)
+    assert x.ndim == 2 and x.stride(1) == 1
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _chk(lib().segf_quant_rows_fp8(dt_of(x), rows, K, _ptr(x), x.stride(0), _ptr(q), K, _ptr(scale), _stream()), 'segf_quant_rows_fp8')
+    return q, scale
+
+
+def gemm_fp8_supported(M, N, K):
+    return bool(lib().segf_gemm_fp8_supported(M, N, K))
+
+
+def gemm_fp8(xq, sx, wq, sw, bias=None, residual=None, rscale=None, rows_per_group=1):
+    """bf16 [M, N] = (xq . wq^T) * sx[:, None] * sw[None, :] (+ bias) (residual + rscale * .) on the fp8 matrix pipe."""
+    _need_cuda(xq, wq)
+    M, K = xq.shape
+    N = wq.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
+    _chk(_timed(('gemm_fp8', M, N, K), lambda: lib().segf_gemm_fp8(
+        M, N, K, _ptr(xq), xq.stride(0), _ptr(sx), _ptr(wq), wq.stride(0), _ptr(sw), _ptr(bias), _ptr(residual),
+        residual.stride(0) if residual is not None else 0, _ptr(rscale), rows_per_group, _ptr(out), N, _stream())), 'segf_gemm_fp8')
     return out
 
 

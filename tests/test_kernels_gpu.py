@@ -871,3 +871,35 @@ def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
     dx2, dg2, db2 = hip.bn_bwd(args[2], da, args[3], args[4], args[5], args[6], act, args[8], h * w, eval_mode)
     assert (dx.float() - dx2.float()).abs().max().item() <= 3e-2 * scale
     assert (dg - dg2).abs().max().item() <= 2e-2 * dg2.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize('shape', [(300, 256, 128), (1000, 768, 3072), (4096, 1536, 384), (129, 40, 256)])
+def test_fp8_quantise_and_gemm(hipmod, shape):
+    """csrc/fp8.hip: row-wise e4m3fn quantisation (decode with torch.float8_e4m3fn) and the block-scaled fp8 MFMA product against
+    an fp32 matmul of the DEQUANTISED operands (the fp8 products are exact in fp32, so only the bf16 output rounding remains)."""
+    hip = hipmod
+    M, N, K = shape
+    g = torch.Generator().manual_seed(61)
+    x = (torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    xq, sx = hip.quant_rows_fp8(x.cuda())
+    wq, sw = hip.quant_rows_fp8(w.cuda())
+    xd = xq.view(torch.float8_e4m3fn).float() * sx[:, None]
+    wd = wq.view(torch.float8_e4m3fn).float() * sw[:, None]
+    assert torch.isfinite(xd).all() and torch.isfinite(wd).all()
+    assert torch.allclose(sx.cpu(), x.float().abs().amax(1) / 448, rtol=1e-6)
+    assert (xd.cpu() - x.float()).abs().max() <= 0.0625 * x.float().abs().amax() + 1e-6     # e4m3: 3 mantissa bits, RNE
+    assert ((xd.cpu() - x.float()).abs() <= 0.0626 * x.float().abs().clamp_min(sx.cpu()[:, None] * 2 ** -6) + 1e-12).all()
+    ref = xd @ wd.t() + bias.cuda()
+    out = hip.gemm_fp8(xq, sx, wq, sw, bias=bias.cuda())
+    assert (out.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    rs = torch.rand(4, generator=g).cuda()
+    rpg = (M + 3) // 4
+    out2 = hip.gemm_fp8(xq, sx, wq, sw, bias=bias.cuda(), residual=res, rscale=rs, rows_per_group=rpg)
+    ref2 = res.float() + rs.repeat_interleave(rpg)[:M, None] * ref
+    assert (out2.float() - ref2).abs().max().item() <= 2e-2 * ref2.abs().max().item()
+    # against the unquantised product: the fp8 error itself (about 2^-4 per operand element, averaged over K)
+    full = x.float().cuda() @ w.cuda().t() + bias.cuda()
+    assert (out.float() - full).abs().max().item() <= 8e-2 * full.abs().max().item()
