@@ -50,7 +50,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'segmentation_factory_amd', 'csrc')
     # the sources of the two kernels whose traffic is reported (+ the shared headers and the build flags)
-    for f in sorted(os.path.join(csrc, n) for n in ('loss.hip', 'gemm.hip', 'common.h', 'colreduce.h', 'Makefile')):
+    for f in sorted(os.path.join(csrc, n) for n in ('loss.hip', 'loss_band.hip', 'loss_geom.h', 'gemm.hip', 'common.h', 'colreduce.h', 'Makefile')):
         h.update(os.path.basename(f).encode())
         h.update(open(f, 'rb').read())
     return h.hexdigest()[:16]
@@ -152,7 +152,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Dominant kernel of the step by GPU time (profiles/r01*_kernel_stats.csv): ce_dice_bwd_mfma4_kernel, the fused
+    # Dominant kernel of the step by GPU time (profiles/r02*_kernel_stats.csv): ce_dice_bwd_band_kernel (loss_band.hip), the fused
     # transposed-upsample + softmax + CE/Dice backward (one launch per step).  Its algorithmic HBM traffic is tiny -- it is
     # bound by the exponentials per (full-resolution pixel, class) on the VALU (the interpolation and the tap scatter run on
     # the matrix pipe), not by HBM or MFMA; the roofline leg prices it in bytes against HBM as the contract asks and states the
@@ -251,8 +251,8 @@ def main():
         elif pmc.get('batch') == args.batch and args.config == 'cfg2' and args.dtype == 'bf16':
             traffic_note = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, kernel sources {pmc['source_hash']}"
             for kname, v in pmc['kernels'].items():
-                if kname.startswith('ce_dice_bwd'):
-                    traffic['loss_bwd'] = v['total_bytes']
+                if kname.startswith('ce_dice_bwd'):        # the retry kernel shares the prefix and moves no data: keep the larger
+                    traffic['loss_bwd'] = max(traffic.get('loss_bwd', 0), v['total_bytes'])
                 if kname.startswith('gemm_bf16_big_kernel<0') and kname.rstrip('>').endswith('true'):
                     traffic['gemm_pro'] = v['total_bytes']
     except (OSError, ValueError, KeyError):
@@ -284,12 +284,12 @@ def main():
             # output written once / read once per pass, bf16) -- the per-kernel rooflines below are the graded ones
             "step_algorithmic_hbm": ({"bytes_per_image": 580e6, "achieved_GBps": round(580e6 * ips / world / 1e9, 1),
                                       "frac_of_peak": round(580e6 * ips / world / HBM_PEAK, 4)} if args.config == 'cfg2' else None),
-            "roofline": {"kernel": "ce_dice_bwd_mfma4_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
+            "roofline": {"kernel": "ce_dice_bwd_band_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
                                    f"backward, low-res logits [B,{hq},{wq},{ld}] -> d logits, labels int64 [B,{H},{W}]",
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note,
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
-                         "note": "transcendental-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~6 VALU "
+                         "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~3 VALU "
                                  "ops; interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
             "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true> (segf_gemm_pro, the in-graph variant): classifier 1x1 conv "

@@ -19,12 +19,7 @@
 #include <stdlib.h>
 #include "colreduce.h"
 
-#define LS_NBLK 128         // workgroups per image in the forward / eval kernels
-#define LS_THREADS 256
-#define LS_EPS 1e-6f
-#define LS_TILE 8           // backward: low-res taps per workgroup tile edge
-
-struct LossGeom { int B, C, h, w, H, W; int64_t ldl; };
+#include "loss_geom.h"
 
 static inline int pow2_scale(int h, int w, int H, int W) {
     // sc >= 1 when H == sc*h, W == sc*w and sc is a power of two (exact source-index arithmetic); else 0
@@ -243,8 +238,6 @@ __device__ __forceinline__ void wave_reduce8(const float (&v)[8], float (&out)[8
 // so that a pixel's exponent argument is a plain bilinear combination of the four u's (weights sum to one), evaluated
 // separably: one fma per row for the left / right columns and ONE fma per (pixel, class) for the column weight, with
 // the weights (k + 0.5) / SC folded into the instructions as literals.  exp2(-1e30) == 0 removes the class mask.
-#define LS_LOG2E 1.4426950408889634f
-#define LS_LN2 0.6931471805599453f
 template <int NS>
 __device__ __forceinline__ void cell_scaled_taps(float (&t00)[NS], float (&t01)[NS], float (&t10)[NS], float (&t11)[NS], float mb,
                                                  int lane, int C, float (&d0)[NS], float (&d1)[NS]) {
@@ -787,19 +780,6 @@ __global__ void __launch_bounds__(LS_THREADS, 4) ce_dice_bwd_cells8_kernel(const
 // pixel = 4 gq + (c >> 2)): one gathered tap value per lane and a quad reduction give the label logit; I / T (forward) and
 // the [c == t] terms of the gradient (backward) go through shared-memory float adds, where only lanes of ONE instruction
 // ever collide (a wave owns its histogram / its colour's taps), so the summation order is fixed.
-typedef float lossf4 __attribute__((ext_vector_type(4)));
-typedef __bf16 lossbf8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ float tap_weight(int k, float ly, float lx) {      // k = 2 * (row tap) + (column tap)
-    return ((k >> 1) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
-}
-__device__ __forceinline__ float row_sum16(float v) {
-    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
-    return v;
-}
-__device__ __forceinline__ float sel4(const float (&v)[4], int r) {
-    return r == 0 ? v[0] : (r == 1 ? v[1] : (r == 2 ? v[2] : v[3]));
-}
 
 // Front end shared by forward and backward, split in two so that the loads of the NEXT cell are in flight while the current
 // one is evaluated: issue() = this lane's tap row (MFMA operand) + its label; finish() = label-class gather (issued before
@@ -938,20 +918,6 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_mfma4_kernel(const T* 
         }
     }
     if (threadIdx.x < 4) dst[3 * g.C + threadIdx.x] = (redS[0][threadIdx.x] + redS[1][threadIdx.x]) + (redS[2][threadIdx.x] + redS[3][threadIdx.x]);
-}
-
-__device__ __forceinline__ void dice_coef_one(const float* __restrict__ stats, int b, int B, int C, int dice, int cls, float& gI, float& gP) {
-    gI = 0.f; gP = 0.f;
-    if (cls < C && dice) {
-        const float* st = stats + (int64_t)b * (3 * C + 4);
-        const float I = st[cls], P = st[C + cls], Tt = st[2 * C + cls];
-        const float sets = P + Tt;
-        if (sets != 0.f) {
-            const float nbc = 1.f / (float)(B * C);
-            gI = -nbc * 2.f / (sets + LS_EPS);
-            gP = nbc * (2.f * I + LS_EPS) / ((sets + LS_EPS) * (sets + LS_EPS));
-        }
-    }
 }
 
 // Backward: workgroup = LS_TILE x LS_TILE low-res taps (+ the halo cells), four parity colours as in the VALU kernels.  A wave
@@ -1224,7 +1190,13 @@ static void bwd_cells_launch(int ns, int sc, dim3 grid, hipStream_t st, const T*
                              int64_t ignore_index, const float* cw, int dice, const float* stats, const float* grad_out,
                              T* dlow, int64_t ldd, int* retry) {
     if (sc >= 2) hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, 4);
-    if (loss_use_mfma(sc)) {
+    bool band = false;
+    if constexpr (sizeof(T) == 2) {
+        if (loss_use_mfma(sc))
+            band = loss_band_bwd_launch((const bf16_t*)logits, g, target, ignore_index, cw, dice, stats, grad_out, (bf16_t*)dlow, ldd, retry, st);
+    }
+    if (band) {}
+    else if (loss_use_mfma(sc)) {
 #define CALLM(NT) hipLaunchKernelGGL((ce_dice_bwd_mfma4_kernel<T, NT>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry)
         LS_NT_DISPATCH(g.C, CALLM);
 #undef CALLM

@@ -355,6 +355,73 @@ def test_upsample_ce_dice_retry_and_reproducible():
         _close(outs[0][1], lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C), torch.float32, fac=2)
 
 
+@pytest.mark.parametrize('cfg', [(2, 150, 16, 23, 160, False), (2, 19, 32, 64, 32, True), (1, 171, 9, 7, 176, False), (2, 40, 9, 30, 40, True),
+                                 (1, 2, 5, 5, 8, False), (2, 150, 40, 40, 152, True)])
+def test_loss_backward_band_kernel_vs_tile_kernel_and_oracle(cfg, monkeypatch):
+    """bf16, ratio 4: the band-sweep backward (loss_band.hip) against the tile kernel it replaces (same library, env switch) and
+    against the fp32 oracle on the same bf16-rounded logits; two runs bitwise equal; pad columns exactly zero.  Shapes cover
+    bands that end inside the image, one-band images, several segments, class counts in every tile bucket and padded rows."""
+    from oracle import loss as OL
+    from segmentation_factory_amd import hip
+    B, C, h, w, ld, weighted = cfg
+    H, W = 4 * h, 4 * w
+    g = torch.Generator().manual_seed(21)
+    lo = (torch.randn(B, C, h, w, generator=g) * 2).to(torch.bfloat16)
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    t[:, :3] = 255
+    t[:, :, -5:] = 255
+    cw = (torch.rand(C, generator=g) + 0.5) if weighted else None
+    lr = lo.float().requires_grad_(True)
+    up = F.interpolate(lr, size=(H, W), mode='bilinear', align_corners=False)
+    ref = OL.criterion_closed_form(up, t, cw, num_classes=C, dice=True, ignore_index=255)
+    (1.7 * ref).backward()
+    buf = torch.zeros(B * h * w, ld, dtype=torch.bfloat16, device='cuda')
+    buf[:, :C] = lo.permute(0, 2, 3, 1).reshape(B * h * w, C).cuda()
+    tok, tg = buf[:, :C], t.cuda()
+    cwd = cw.cuda() if weighted else None
+    loss, stats = hip.ce_dice_fwd(tok, B, C, h, w, H, W, tg, 255, cwd, True)
+    go = torch.full((1,), 1.7, device='cuda')
+    monkeypatch.setenv('SEGFAC_LOSS_BAND_ROWS', '8')           # several segments also on the small maps
+    band = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats, go)
+    band2 = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats, go)
+    monkeypatch.delenv('SEGFAC_LOSS_BAND_ROWS')
+    band3 = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats, go)
+    monkeypatch.setenv('SEGFAC_LOSS_NO_BAND', '1')
+    tile = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats, go)
+    torch.cuda.synchronize()
+    assert torch.equal(band, band2)
+    assert band.shape == (B * h * w, ld) and not band[:, C:].any() and not band3[:, C:].any()
+    want = lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C)
+    scale = want.abs().max().item()
+    for got in (band, band3, tile):
+        err = (got[:, :C].float().cpu() - want).abs().max().item()
+        assert err < 1e-2 * scale, (err, scale)                  # bf16 storage of the gradient: 2^-8 relative
+    # the segment length only changes which wave computes a tap, never the arithmetic of a tap
+    assert torch.equal(band, band3)
+
+
+def test_loss_backward_band_kernel_hands_over_on_underflow():
+    """Logit spreads beyond exp2's range: the band kernel must raise the retry flag and the exact-maximum pass must deliver."""
+    from oracle import loss as OL
+    from segmentation_factory_amd import hip
+    B, C, h, w = 2, 150, 8, 8
+    H, W = 4 * h, 4 * w
+    g = torch.Generator().manual_seed(12)
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    lo = (torch.randn(B, C, h, w, generator=g) * 150).to(torch.bfloat16)
+    lr = lo.float().requires_grad_(True)
+    up = F.interpolate(lr, size=(H, W), mode='bilinear', align_corners=False)
+    OL.criterion_closed_form(up, t, None, num_classes=C, dice=True, ignore_index=255).backward()
+    buf = torch.zeros(B * h * w, 160, dtype=torch.bfloat16, device='cuda')
+    buf[:, :C] = lo.permute(0, 2, 3, 1).reshape(B * h * w, C).cuda()
+    loss, stats = hip.ce_dice_fwd(buf[:, :C], B, C, h, w, H, W, t.cuda(), 255, None, True)
+    d = hip.ce_dice_bwd(buf[:, :C], B, C, h, w, H, W, t.cuda(), 255, None, True, stats, torch.ones(1, device='cuda'))
+    torch.cuda.synchronize()
+    assert stats[-4:].view(torch.int32)[0].item() != 0
+    want = lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C)
+    assert (d[:, :C].float().cpu() - want).abs().max().item() < 1e-2 * want.abs().max().item()
+
+
 def test_argmax_confmat_and_metrics_golden(golden_dir):
     from segmentation_factory_amd import utils
     from segmentation_factory_amd.metrics import Metrics
