@@ -1159,7 +1159,12 @@ static bool loss_use_mfma(int sc) { return sc == 4 && !getenv("SEGFAC_LOSS_NO_MF
 template <typename T>
 static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                        int64_t ignore_index, const float* cw, float* partial, int* retry) {
-    if (loss_use_mfma(sc)) {
+    bool band = false;
+    if constexpr (sizeof(T) == 2) {
+        if (loss_use_mfma(sc)) band = loss_band_fwd_launch((const bf16_t*)logits, g, target, ignore_index, cw, partial, retry, st);
+    }
+    if (band) {}
+    else if (loss_use_mfma(sc)) {
 #define CALLM(NT) hipLaunchKernelGGL((ce_dice_fwd_mfma4_kernel<T, NT>), grid, dim3(LS_THREADS), 0, st, logits, g, target, ignore_index, cw, partial, retry)
         LS_NT_DISPATCH(g.C, CALLM);
 #undef CALLM

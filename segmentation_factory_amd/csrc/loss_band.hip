@@ -383,6 +383,203 @@ __global__ void __launch_bounds__(LS_THREADS, BAND_OCC) ce_dice_bwd_band_kernel(
     if (__any(slow) && lane == 0) atomicOr(retry, 1);
 }
 
+// ---- forward ------------------------------------------------------------------------------------------------------
+// Same cell front end (vector tap loads, interpolation MFMA with the scale and the stabiliser folded in, one exp2 per
+// (pixel, class)); cells need no neighbours here, so a wave simply strides over the cells of its image.  The per-class sums
+// P_c = sum_pixels p_pc are a contraction over pixels = one more scatter-type MFMA per pair of cells (A row 0 = ok_p / S_p, B =
+// the exp tiles in bf16), instead of four multiply-adds per class tile and cell on the VALU; I_c, T_c and the CE sum stay fp32
+// (shared-memory adds of the label path, fixed order).  Output: per-(workgroup, image) partials in ce_dice_fwd_mfma4_kernel's layout.
+template <int NT, bool FULL0>
+__global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16_t* __restrict__ logits, LossGeom g,
+                                                                      const int64_t* __restrict__ target, int64_t ignore_index,
+                                                                      const float* __restrict__ cw, float* __restrict__ partial,
+                                                                      int* __restrict__ retry) {
+    using BP = BandParts<NT>;
+    constexpr int NCOL = NT * 16;
+    __shared__ float hI[4][NCOL], hT[4][NCOL], redP[4][NCOL], redS[4][4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, gq = lane >> 4;
+    const int b = blockIdx.y;
+    for (int i = lane; i < NCOL; i += 64) { hI[wave][i] = 0.f; hT[wave][i] = 0.f; redP[wave][i] = 0.f; }
+    const float wAL = tap_weight(gq, ((c >> 2) + 0.5f) * 0.25f, ((c & 3) + 0.5f) * 0.25f) * LS_LOG2E;
+    const int kl = c & 3, pc = c >> 2;
+    const bool lo8 = c < 8, even4 = (pc & 1) == 0;
+    const float wL = tap_weight(kl, (gq + 0.5f) * 0.25f, (pc + 0.5f) * 0.25f);
+    const bf16_t* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+    const int64_t* tg = target + (int64_t)b * g.H * g.W;
+    const char* imgb = reinterpret_cast<const char*>(img);
+    const char* tgb = reinterpret_cast<const char*>(tg);
+    const uint32_t ldlb = 2u * (uint32_t)g.ldl;
+    uint32_t coffb[3];
+    {
+        const int o0 = BP::P0 * c, o1 = 16 * BP::P0 + BP::P1 * c, o2 = 16 * (BP::P0 + BP::P1) + BP::P2 * c;
+        coffb[0] = 2u * (o0 + BP::P0 <= (int)g.ldl ? o0 : 0);
+        coffb[1] = 2u * (o1 + BP::P1 <= (int)g.ldl ? o1 : 0);
+        coffb[2] = 2u * (o2 + BP::P2 <= (int)g.ldl ? o2 : 0);
+    }
+    bool cmask[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cmask[t] = band_class<NT>(c, t) < g.C;
+    const int ncx = g.w + 1, ncell = (g.h + 1) * ncx;
+    const int pc8 = 8 * pc;
+
+    struct CellGeo { int cj, ck; };
+    auto geo = [&](int cell) { CellGeo G; G.cj = cell / ncx - 1; G.ck = cell - (G.cj + 1) * ncx - 1; return G; };
+    auto issue = [&](BandLoads<NT>& L, const CellGeo& G) {
+        const int y0 = G.cj < 0 ? 0 : G.cj, y1 = G.cj + 1 > g.h - 1 ? g.h - 1 : G.cj + 1;
+        const int x0 = G.ck < 0 ? 0 : G.ck, x1 = G.ck + 1 > g.w - 1 ? g.w - 1 : G.ck + 1;
+        const uint32_t t00 = (uint32_t)(y0 * g.w + x0) * ldlb, t01 = (uint32_t)(y0 * g.w + x1) * ldlb;     // scalar
+        const uint32_t t10 = (uint32_t)(y1 * g.w + x0) * ldlb, t11 = (uint32_t)(y1 * g.w + x1) * ldlb;
+        const uint32_t tap = (gq >> 1) ? ((gq & 1) ? t11 : t10) : ((gq & 1) ? t01 : t00);
+        band_load_part<BP::P0>(reinterpret_cast<const bf16_t*>(imgb + (tap + coffb[0])), L.raw + BP::W0);
+        if constexpr (BP::P1 > 0) band_load_part<BP::P1>(reinterpret_cast<const bf16_t*>(imgb + (tap + coffb[1])), L.raw + BP::W1);
+        if constexpr (BP::P2 > 0) band_load_part<BP::P2>(reinterpret_cast<const bf16_t*>(imgb + (tap + coffb[2])), L.raw + BP::W2);
+        int Y = 4 * G.cj + 2 + gq;
+        Y = Y < 0 ? 0 : (Y > g.H - 1 ? g.H - 1 : Y);
+        int X8 = 8 * (4 * G.ck + 2) + pc8;
+        X8 = X8 < 0 ? 0 : (X8 > 8 * (g.W - 1) ? 8 * (g.W - 1) : X8);
+        L.traw = *reinterpret_cast<const int64_t*>(tgb + ((uint32_t)(Y * g.W) * 8u + (uint32_t)X8));
+    };
+
+    lossf4 D[NT];                                        // row 0: sum over pixels of p for the classes of this column
+    uint32_t Bp[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        D[t] = lossf4{0.f, 0.f, 0.f, 0.f};
+        Bp[t][0] = 0u; Bp[t][1] = 0u; Bp[t][2] = 0u; Bp[t][3] = 0u;
+    }
+    float cel = 0.f, wsum = 0.f, nvalid = 0.f;
+    bool bad = false, slow = false;
+    const int stride = gridDim.x * 4;
+    int cell = blockIdx.x * 4 + wave;
+    BandLoads<NT> nx;
+    if (cell < ncell) issue(nx, geo(cell));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (; cell < ncell; cell += 2 * stride) {
+        uint32_t Apk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int cidx = cell + s * stride;
+            if (cidx >= ncell) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { Bp[t][2 * s] = 0u; Bp[t][2 * s + 1] = 0u; }
+                continue;
+            }
+            const CellGeo G = geo(cidx);
+            const BandLoads<NT> cur = nx;
+            const int y0 = G.cj < 0 ? 0 : G.cj, y1 = G.cj + 1 > g.h - 1 ? g.h - 1 : G.cj + 1;
+            const int x0 = G.ck < 0 ? 0 : G.ck, x1 = G.ck + 1 > g.w - 1 ? g.w - 1 : G.ck + 1;
+            const int Y = 4 * G.cj + 2 + gq, X = 4 * G.ck + 2 + pc;
+            const bool inside = Y >= 0 && Y < g.H && X >= 0 && X < g.W;
+            const bool inrange = (uint64_t)cur.traw < (uint64_t)g.C;
+            const bool skip = !inside || cur.traw == ignore_index;
+            const bool valid0 = !skip && inrange;
+            bad |= !skip && !inrange;
+            const int tt = valid0 ? (int)cur.traw : 0;
+            const uint32_t g00 = (uint32_t)(y0 * g.w + x0) * ldlb, g01 = (uint32_t)(y0 * g.w + x1) * ldlb;
+            const uint32_t g10 = (uint32_t)(y1 * g.w + x0) * ldlb, g11 = (uint32_t)(y1 * g.w + x1) * ldlb;
+            const uint32_t uloff = ((kl >> 1) ? ((kl & 1) ? g11 : g10) : ((kl & 1) ? g01 : g00)) + 2u * (uint32_t)tt;
+            uint32_t ulbits = *reinterpret_cast<const uint32_t*>(imgb + (uloff & ~3u));
+            {
+                const int nidx = cidx + stride;
+                issue(nx, geo(nidx < ncell ? nidx : cidx));
+            }
+            float u[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int p = BP::part(t), k = t - BP::tbase(p);
+                const uint32_t wd = cur.raw[BP::wbase(p) + (k >> 1)];
+                u[t] = __uint_as_float((k & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                if (!(FULL0 && p == 0)) u[t] = cmask[t] ? u[t] : -1e30f;
+            }
+            float mx = u[0];
+#pragma unroll
+            for (int t = 1; t < NT; ++t) asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(u[t]));
+            const float mb = wave_max_all_fast(mx);
+            const float nmb = -mb * LS_LOG2E;
+            const lossf4 cin = {nmb, nmb, nmb, nmb};
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const lossf4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(wAL, u[t], cin, 0, 0, 0);
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(z[r]); s4[r] += e[r]; }
+                Bp[t][2 * s] = pack2bf(e[0], e[1]); Bp[t][2 * s + 1] = pack2bf(e[2], e[3]);
+            }
+            float tot = row_sum16_own(s4, lo8, even4);
+            asm volatile("" : "+v"(ulbits), "+v"(tot));
+            const float ulraw = __uint_as_float((uloff & 2u) ? (ulbits & 0xffff0000u) : (ulbits << 16));
+            float zt = wL * ((ulraw - mb) * LS_LOG2E);
+            zt += dpp_mov<DPP_XOR1>(zt); zt += dpp_mov<DPP_XOR2>(zt);
+            const bool under = valid0 && !(tot > 1e-30f);
+            slow |= under;
+            const bool ok = valid0 && !under;
+            const float inv = ok ? __builtin_amdgcn_rcpf(fmaxf(tot, 1e-30f)) : 0.f;
+            if (ok && kl == 0) {
+                const float wt = cw ? cw[tt] : 1.f;
+                atomicAdd(&hI[wave][tt], __builtin_amdgcn_exp2f(zt) * inv);
+                atomicAdd(&hT[wave][tt], 1.f);
+                cel = fmaf(wt, __builtin_amdgcn_logf(tot) - zt, cel);
+                wsum += wt; nvalid += 1.f;
+            }
+            // A operand row 0 (lanes with c == 0): ok / S of pixels (gq, 0..3) = this lane and lanes c = 4, 8, 12 of the row group
+            const float a1 = dpp_mov<0x104>(inv), a2 = dpp_mov<0x108>(inv), a3 = dpp_mov<0x10C>(inv);
+            const uint32_t p01 = pack2bf(inv, a1), p23 = pack2bf(a2, a3);
+            Apk[2 * s] = c == 0 ? p01 : 0u; Apk[2 * s + 1] = c == 0 ? p23 : 0u;
+        }
+        union { uint32_t u[4]; lossbf8 v; } Av;
+        Av.u[0] = Apk[0]; Av.u[1] = Apk[1]; Av.u[2] = Apk[2]; Av.u[3] = Apk[3];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            union { uint32_t u[4]; lossbf8 v; } Bv;
+            Bv.u[0] = Bp[t][0]; Bv.u[1] = Bp[t][1]; Bv.u[2] = Bp[t][2]; Bv.u[3] = Bp[t][3];
+            D[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Av.v, Bv.v, D[t], 0, 0, 0);
+        }
+    }
+    if (__any(slow) && lane == 0) atomicOr(retry, 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (gq == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) redP[wave][band_class<NT>(c, t)] = D[t][0];
+    }
+    const float ce = LS_LN2 * wave_sum_all(cel), ws = wave_sum_all(wsum), nv = wave_sum_all(nvalid);
+    if (lane == 0) { redS[wave][0] = ce; redS[wave][1] = ws; redS[wave][2] = nv; redS[wave][3] = __any(bad) ? 1.f : 0.f; }
+    __syncthreads();
+    float* dst = partial + ((int64_t)blockIdx.x * g.B + b) * (3 * g.C + 4);
+    for (int i = threadIdx.x; i < NCOL; i += LS_THREADS) {
+        if (i < g.C) {
+            dst[i] = (hI[0][i] + hI[1][i]) + (hI[2][i] + hI[3][i]);
+            dst[g.C + i] = (redP[0][i] + redP[1][i]) + (redP[2][i] + redP[3][i]);
+            dst[2 * g.C + i] = (hT[0][i] + hT[1][i]) + (hT[2][i] + hT[3][i]);
+        }
+    }
+    if (threadIdx.x < 4) dst[3 * g.C + threadIdx.x] = (redS[0][threadIdx.x] + redS[1][threadIdx.x]) + (redS[2][threadIdx.x] + redS[3][threadIdx.x]);
+}
+
+bool loss_band_fwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw,
+                          float* partial, int* retry, hipStream_t st) {
+    if (getenv("SEGFAC_LOSS_NO_BAND") || getenv("SEGFAC_LOSS_NO_BAND_FWD")) return false;
+    if (g.H != 4 * g.h || g.W != 4 * g.w || g.C > 192) return false;
+    const int nt = (g.C + 15) / 16;
+    const int NTb = nt <= 2 ? 2 : (nt <= 4 ? 4 : (nt <= 10 ? 10 : 12));
+    if (g.ldl % 8 || g.ldl < g.C || ((uintptr_t)logits & 15)) return false;
+    if ((int64_t)g.h * g.w * g.ldl >= (1ll << 30) || (int64_t)g.H * g.W >= (1ll << 28)) return false;
+    const dim3 grid(LS_NBLK, g.B);
+#define BAND_CALL(NT, FULL) hipLaunchKernelGGL((ce_dice_fwd_band_kernel<NT, FULL>), grid, dim3(LS_THREADS), 0, st, logits, g, target, \
+                                               ignore_index, cw, partial, retry)
+    if (NTb == 2) { if (g.C >= 32) BAND_CALL(2, true); else BAND_CALL(2, false); }
+    else if (NTb == 4) { if (g.C >= 64) BAND_CALL(4, true); else BAND_CALL(4, false); }
+    else if (NTb == 10) { if (g.C >= 128) BAND_CALL(10, true); else BAND_CALL(10, false); }
+    else { if (g.C >= 128) BAND_CALL(12, true); else BAND_CALL(12, false); }
+#undef BAND_CALL
+    return true;
+}
+
 static int band_seg_rows(int B, int h, int nbands) {
     if (const char* e = getenv("SEGFAC_LOSS_BAND_ROWS")) { const int v = atoi(e); if (v > 0) return v; }
     // enough wave tasks for several rounds of the chip (256 CUs x 8 resident waves of this kernel) so that the tail evens out;

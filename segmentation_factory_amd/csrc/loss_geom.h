@@ -42,3 +42,5 @@ __device__ __forceinline__ void dice_coef_one(const float* __restrict__ stats, i
 // loss_band.hip: band-sweep backward for ratio 4 / bf16; returns false when the configuration is not covered
 bool loss_band_bwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw, int dice,
                           const float* stats, const float* grad_out, bf16_t* dlow, int64_t ldd, int* retry, hipStream_t st);
+bool loss_band_fwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw,
+                          float* partial, int* retry, hipStream_t st);

@@ -380,6 +380,20 @@ def test_loss_backward_band_kernel_vs_tile_kernel_and_oracle(cfg, monkeypatch):
     tok, tg = buf[:, :C], t.cuda()
     cwd = cw.cuda() if weighted else None
     loss, stats = hip.ce_dice_fwd(tok, B, C, h, w, H, W, tg, 255, cwd, True)
+    # forward: the strided-cell kernel of loss_band.hip (per-class P sums on the matrix pipe from bf16 exp tiles) against the
+    # oracle and against the tile kernel; reproducible; label counts exact
+    loss_again, stats_again = hip.ce_dice_fwd(tok, B, C, h, w, H, W, tg, 255, cwd, True)
+    monkeypatch.setenv('SEGFAC_LOSS_NO_BAND_FWD', '1')
+    loss_tile, stats_tile = hip.ce_dice_fwd(tok, B, C, h, w, H, W, tg, 255, cwd, True)
+    monkeypatch.delenv('SEGFAC_LOSS_NO_BAND_FWD')
+    n = B * (3 * C + 4)
+    assert torch.equal(loss, loss_again) and torch.equal(stats[:n], stats_again[:n])
+    assert abs(loss[0].item() - ref.item()) < 1e-4 * max(1, abs(ref.item())), (loss[0].item(), ref.item())
+    assert abs(loss_tile[0].item() - ref.item()) < 2e-5 * max(1, abs(ref.item()))
+    sb, st = stats[:n].view(B, 3 * C + 4), stats_tile[:n].view(B, 3 * C + 4)
+    assert torch.equal(sb[:, 2 * C:3 * C], st[:, 2 * C:3 * C]) and torch.equal(sb[:, 3 * C + 1:], st[:, 3 * C + 1:])    # T, weights, counts
+    assert (sb[:, :C] - st[:, :C]).abs().max().item() <= 1e-5 * st[:, :C].abs().max().item() + 1e-6                    # I: fp32 both
+    assert (sb[:, C:2 * C] - st[:, C:2 * C]).abs().max().item() <= 2e-3 * st[:, C:2 * C].abs().max().item()          # P: bf16 tiles
     go = torch.full((1,), 1.7, device='cuda')
     monkeypatch.setenv('SEGFAC_LOSS_BAND_ROWS', '8')           # several segments also on the small maps
     band = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats, go)

@@ -16,7 +16,19 @@ def run(B, nc, h, w, ld, seed=0, ign_rows=2, weighted=False):
     tgt = torch.randint(0, nc, (B, H, W), device=dev, generator=g)
     tgt[:, :ign_rows] = 255
     cw = (torch.rand(nc, device=dev, generator=g) + 0.5) if weighted else None
+    os.environ['SEGFAC_LOSS_NO_BAND_FWD'] = '1'
+    loss0, stats0 = hip.ce_dice_fwd(lo, B, nc, h, w, H, W, tgt, 255, cw, True)
+    os.environ.pop('SEGFAC_LOSS_NO_BAND_FWD')
     loss, stats = hip.ce_dice_fwd(lo, B, nc, h, w, H, W, tgt, 255, cw, True)
+    loss_b, stats_b = hip.ce_dice_fwd(lo, B, nc, h, w, H, W, tgt, 255, cw, True)
+    torch.cuda.synchronize()
+    n = B * (3 * nc + 4) + 4
+    assert torch.equal(stats[:n], stats_b[:n]) and torch.equal(loss, loss_b), 'band forward not reproducible'
+    st0, st1 = stats0[:n - 4].view(B, 3 * nc + 4), stats[:n - 4].view(B, 3 * nc + 4)
+    relP = ((st0[:, nc:2 * nc] - st1[:, nc:2 * nc]).abs().max() / st0[:, nc:2 * nc].abs().max()).item()
+    relI = ((st0[:, :nc] - st1[:, :nc]).abs().max() / st0[:, :nc].abs().max().clamp_min(1e-30)).item()
+    eqT = torch.equal(st0[:, 2 * nc:3 * nc], st1[:, 2 * nc:3 * nc])
+    print(f'   fwd: loss tile {loss0[0].item():.7f} band {loss[0].item():.7f} relP {relP:.2e} relI {relI:.2e} T equal {eqT} tails {st0[:, 3 * nc:].sum(0).tolist()} {st1[:, 3 * nc:].sum(0).tolist()}')
     go = torch.full((1,), 1.7, device=dev)
     outs = {}
     for name, env in (('tile', '1'), ('band', None)):
@@ -52,6 +64,16 @@ if __name__ == '__main__':
     tgt[:, :8] = 255
     loss, stats = hip.ce_dice_fwd(lo, B, nc, h, h, 512, 512, tgt, 255, None, True)
     go = torch.ones(1, device=dev)
+    for name, envs in (('fwd tile', {'SEGFAC_LOSS_NO_BAND_FWD': '1'}), ('fwd band', {})):
+        os.environ.pop('SEGFAC_LOSS_NO_BAND_FWD', None)
+        os.environ.update(envs)
+        for _ in range(3): hip.ce_dice_fwd(lo, B, nc, h, h, 512, 512, tgt, 255, None, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10): hip.ce_dice_fwd(lo, B, nc, h, h, 512, 512, tgt, 255, None, True)
+        torch.cuda.synchronize()
+        print(f'{name}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms (incl. finalize kernels)', flush=True)
+    os.environ.pop('SEGFAC_LOSS_NO_BAND_FWD', None)
     for name, envs in (('tile', {'SEGFAC_LOSS_NO_BAND': '1'}), ('band', {}), ('band rows16', {'SEGFAC_LOSS_BAND_ROWS': '16'}),
                        ('band rows32', {'SEGFAC_LOSS_BAND_ROWS': '32'}), ('band rows64', {'SEGFAC_LOSS_BAND_ROWS': '64'}),
                        ('band rows128', {'SEGFAC_LOSS_BAND_ROWS': '128'})):
