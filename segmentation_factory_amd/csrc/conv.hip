@@ -106,6 +106,173 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const T* __restrict__ x,
     }
 }
 
+// ---- vertical-walk form -------------------------------------------------------------------------------------------
+// The strip kernel above loads the 3 x 6 input window of every 4-pixel strip anew: 18 loads per strip, every input element 4.5
+// times through the L1 (HBM sees it about once).  Here a thread owns a 4-channel chunk and a 4-pixel-wide column and WALKS DOWN
+// the image: every incoming input row (6 loads, 1.5 x) is unpacked once and scattered into the accumulators of the three
+// output rows it touches (above: ky = 2, same: ky = 1, below: ky = 0); the row above is then complete and is finished and
+// stored.  Same multiply-adds, a third of the load instructions, no window in registers.  The three accumulator rows rotate
+// by unrolling the walk three times (no register moves).  Rows per segment R: each segment re-reads two rows.
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { float4 a; };
+template <> struct Raw4<bf16_t> { uint2 u; };
+template <typename T> __device__ __forceinline__ Raw4<T> load4_raw(const T* p);
+template <> __device__ __forceinline__ Raw4<float> load4_raw<float>(const float* p) { Raw4<float> r; r.a = *reinterpret_cast<const float4*>(p); return r; }
+template <> __device__ __forceinline__ Raw4<bf16_t> load4_raw<bf16_t>(const bf16_t* p) { Raw4<bf16_t> r; r.u = *reinterpret_cast<const uint2*>(p); return r; }
+__device__ __forceinline__ void unpack4v(const Raw4<float>& r, bool ok, f32x2_t (&v)[2]) {
+    v[0] = ok ? f32x2_t{r.a.x, r.a.y} : f32x2_t{0.f, 0.f}; v[1] = ok ? f32x2_t{r.a.z, r.a.w} : f32x2_t{0.f, 0.f};
+}
+__device__ __forceinline__ void unpack4v(const Raw4<bf16_t>& r, bool ok, f32x2_t (&v)[2]) {
+    const uint32_t a = ok ? r.u.x : 0u, b = ok ? r.u.y : 0u;
+    v[0] = f32x2_t{__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u)};
+    v[1] = f32x2_t{__uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+}
+__device__ __forceinline__ void store4v(float* p, const f32x2_t (&v)[2]) { *reinterpret_cast<float4*>(p) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y); }
+__device__ __forceinline__ void store4v(bf16_t* p, const f32x2_t (&v)[2]) {
+    uint2 u; u.x = pack2bf(v[0].x, v[0].y); u.y = pack2bf(v[1].x, v[1].y);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) dwconv3x3_walk_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int apply_gelu,
+                                                              const T* __restrict__ dy, T* __restrict__ y, int B, int H, int W, int C,
+                                                              int R, int nseg) {
+    const int nchunk = C / 4;
+    const int wg = (W + DW_PIX - 1) / DW_PIX;
+    const int units = B * nseg * wg;
+    const int64_t g = (int64_t)xcd_block() * 256 + threadIdx.x;
+    const int ustep = (int)(((int64_t)gridDim.x * 256) / nchunk);
+    const int c0 = (int)(g % nchunk) * 4;
+    f32x2_t wk[9][2], bs[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk) {
+            const int ks = MODE == 1 ? 8 - kk : kk;
+            wk[kk][jj] = f32x2_t{w[(c0 + 2 * jj) * 9 + ks], w[(c0 + 2 * jj + 1) * 9 + ks]};
+        }
+        bs[jj] = (MODE != 1 && bias) ? f32x2_t{bias[c0 + 2 * jj], bias[c0 + 2 * jj + 1]} : f32x2_t{0.f, 0.f};
+    }
+    const int steps = (R + 2 + 2) / 3;                    // walk length R + 2 input rows, rounded up to whole rotations
+    for (int u = (int)(g / nchunk); u < units; u += ustep) {
+        const int xg = u % wg;
+        const int t = u / wg;
+        const int seg = t % nseg;
+        const int b = t / nseg;
+        const int x0 = xg * DW_PIX;
+        const int ya = seg * R, yb = ya + R < H ? ya + R : H;
+        const T* xb = x + (int64_t)b * H * W * C + c0;
+        const T* gb = MODE == 2 ? dy + (int64_t)b * H * W * C + c0 : nullptr;
+        T* yo_b = y + (int64_t)b * H * W * C + c0;
+        int coff[DW_PIX + 2];
+        bool cok[DW_PIX + 2];
+#pragma unroll
+        for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+            const int ix = x0 + cx - 1;
+            cok[cx] = ix >= 0 && ix < W;
+            coff[cx] = (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;
+        }
+        f32x2_t acc[3][DW_PIX][2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int p = 0; p < DW_PIX; ++p) { acc[a][p][0] = bs[0]; acc[a][p][1] = bs[1]; }
+        Raw4<T> nxt[DW_PIX + 2], gnx[DW_PIX];
+        auto load_row = [&](int yin, Raw4<T> (&dst)[DW_PIX + 2]) {
+            const int yc = yin < 0 ? 0 : (yin >= H ? H - 1 : yin);
+            const T* row = xb + (int64_t)yc * W * C;
+#pragma unroll
+            for (int cx = 0; cx < DW_PIX + 2; ++cx) dst[cx] = load4_raw<T>(row + coff[cx]);
+        };
+        auto load_grow = [&](int yo, Raw4<T> (&dst)[DW_PIX]) {
+            const int yc = yo < 0 ? 0 : (yo >= H ? H - 1 : yo);
+            const T* row = gb + (int64_t)yc * W * C;
+#pragma unroll
+            for (int p = 0; p < DW_PIX; ++p) dst[p] = load4_raw<T>(row + coff[p + 1]);
+        };
+        load_row(ya - 1, nxt);
+        if (MODE == 2) load_grow(ya - 2, gnx);
+        int yin = ya - 1;
+        for (int st = 0; st < steps; ++st) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j, ++yin) {
+                // roles of the accumulator rows in this sub-step: P = output row yin - 1 (completes), Cc = row yin, N = row yin + 1
+                constexpr int dummy = 0; (void)dummy;
+                f32x2_t (&P)[DW_PIX][2] = acc[j % 3];
+                f32x2_t (&Cc)[DW_PIX][2] = acc[(j + 1) % 3];
+                f32x2_t (&N)[DW_PIX][2] = acc[(j + 2) % 3];
+                Raw4<T> cur[DW_PIX + 2], gcur[DW_PIX];
+#pragma unroll
+                for (int cx = 0; cx < DW_PIX + 2; ++cx) cur[cx] = nxt[cx];
+                load_row(yin + 1, nxt);
+                if (MODE == 2) {
+#pragma unroll
+                    for (int p = 0; p < DW_PIX; ++p) gcur[p] = gnx[p];
+                    load_grow(yin, gnx);
+                }
+                const bool vy = yin >= 0 && yin < H && yin <= yb;
+#pragma unroll
+                for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                    f32x2_t v[2];
+                    unpack4v(cur[cx], vy && cok[cx], v);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int p = cx - kx;
+                        if (p >= 0 && p < DW_PIX) {
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                P[p][jj] = wk[6 + kx][jj] * v[jj] + P[p][jj];
+                                Cc[p][jj] = wk[3 + kx][jj] * v[jj] + Cc[p][jj];
+                                N[p][jj] = wk[kx][jj] * v[jj] + N[p][jj];
+                            }
+                        }
+                    }
+                }
+                const int yo = yin - 1;
+                if (yo >= ya && yo < yb) {
+                    T* orow = yo_b + (int64_t)yo * W * C;
+                    // two pixels x four channels at a time through the eight-wide GELU helpers
+#pragma unroll
+                    for (int h = 0; h < DW_PIX / 2; ++h) {
+                        f32x2_t a8[4] = {P[2 * h][0], P[2 * h][1], P[2 * h + 1][0], P[2 * h + 1][1]};
+                        if (MODE == 0 && apply_gelu) gelu_erf8<false>(a8, nullptr);
+                        if (MODE == 2) {
+                            f32x2_t gy[4], g0[2], g1[2];
+                            unpack4v(gcur[2 * h], true, g0); unpack4v(gcur[2 * h + 1], true, g1);
+                            gy[0] = g0[0]; gy[1] = g0[1]; gy[2] = g1[0]; gy[3] = g1[1];
+                            if (apply_gelu) gelu_erf8<true>(a8, gy);
+                            else { a8[0] = gy[0]; a8[1] = gy[1]; a8[2] = gy[2]; a8[3] = gy[3]; }
+                        }
+                        const f32x2_t o0[2] = {a8[0], a8[1]}, o1[2] = {a8[2], a8[3]};
+                        if (cok[2 * h + 1]) store4v(orow + coff[2 * h + 1], o0);
+                        if (cok[2 * h + 2]) store4v(orow + coff[2 * h + 2], o1);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < DW_PIX; ++p) { P[p][0] = bs[0]; P[p][1] = bs[1]; }       // becomes row yin + 2 of the next sub-step
+            }
+        }
+    }
+}
+
+static inline void dw_walk_plan(int H, int& R, int& nseg) {
+    // segments of at most 64 rows (two re-read rows per segment), equal length
+    nseg = (H + 63) / 64;
+    if (const char* e = getenv("SEGFAC_DW_WALK_ROWS")) { const int v = atoi(e); if (v > 0) nseg = (H + v - 1) / v; }
+    R = (H + nseg - 1) / nseg;
+}
+static inline bool dw_use_walk() { return !getenv("SEGFAC_DW_NO_WALK"); }
+template <typename T, int MODE>
+static inline void dw_walk_launch(hipStream_t st, const T* x, const float* w, const float* bias, int apply_gelu, const T* dy, T* y,
+                                  int B, int H, int W, int C) {
+    int R, nseg;
+    dw_walk_plan(H, R, nseg);
+    const int64_t units = (int64_t)B * nseg * ((W + DW_PIX - 1) / DW_PIX);
+    const int blocks = colfixed_blocks(units, C / 4, 1, 32768);
+    hipLaunchKernelGGL((dwconv3x3_walk_kernel<T, MODE>), dim3(blocks), dim3(256), 0, st, x, w, bias, apply_gelu, dy, y, B, H, W, C, R, nseg);
+}
+
 static inline int dw_blocks(int B, int H, int W, int C) {
     // 8 strips per thread: the 72 per-channel weights a thread keeps in registers are loaded once per 8 strips
     return colfixed_blocks((int64_t)B * H * ((W + DW_PIX - 1) / DW_PIX), C / 8, 8, 16384);
@@ -119,6 +286,8 @@ extern "C" int segf_dwconv3x3_gelu_fwd(int dt, int B, int H, int W, int C, const
     hipStream_t st = (hipStream_t)stream;
     const int blocks = dw_blocks(B, H, W, C);
     SEGF_DISPATCH_DT(dt, T, {
+        if (dw_use_walk()) dw_walk_launch<T, 0>(st, (const T*)x, w, bias, apply_gelu, (const T*)nullptr, (T*)y, B, H, W, C);
+        else
         hipLaunchKernelGGL((dwconv3x3_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, bias, apply_gelu,
                            (const T*)nullptr, (T*)y, B, H, W, C);
     })
@@ -162,10 +331,13 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_kernel(const T* __restric
     for (int o = 0; o < 10; ++o)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
-    const int u0 = xcd_block() * units_per_blk;
-    const int u1 = u0 + units_per_blk < units ? u0 + units_per_blk : units;
+    // units are dealt to the workgroups round-robin in groups of rl strips (not as one contiguous range each): the workgroups
+    // that run at the same time on an XCD then walk ADJACENT image rows, and the two re-reads of every input row (as the row
+    // above / below of its neighbours) hit that XCD's L2.  With contiguous ranges every workgroup streamed its own 16 rows,
+    // 128 of them per 4 MB L2, and FETCH_SIZE showed x fetched three times (2.13 GB for 1.07 GB at [128,128,128,128]).
+    (void)units_per_blk;
     if (active) {
-        for (int u = u0 + ty; u < u1; u += rl) {
+        for (int u = (int)xcd_block() * rl + ty; u < units; u += (int)gridDim.x * rl) {
             const int xg = u % wg;
             const int t = u / wg;
             const int yy = t % H;
@@ -225,6 +397,147 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_kernel(const T* __restric
     colreduce_block_tail<10>(acc, active, ty == 0 && c0 < C, tx, ch, rl, c0, 8, C, partial, red);
 }
 
+// Weight / bias gradient in the vertical-walk form: thread = (4-channel chunk, 4-pixel-wide column, row segment).  Every input
+// row is loaded once (6 chunks) and meets the three gradient rows it pairs with (du rows yin + 1, yin, yin - 1 for ky = 0, 1, 2),
+// which rotate through registers unpacked; 10 loads per row of strips instead of 22, and x is fetched once (the strip form's
+// FETCH_SIZE was 2 x the algorithmic bytes even after the round-robin dealing).
+struct DwwPlan { int ch, rl, slabs, nblk, R, nseg; };
+static inline DwwPlan dww_plan(int B, int H, int W, int C) {
+    DwwPlan p;
+    const int nchunk = C / 4;
+    // channel chunks per workgroup: the split into slabs that leaves the fewest of the 256 threads idle (160 chunks: one
+    // slab would use 160 threads, two slabs of 80 use 240)
+    double best = -1.0;
+    p.ch = 1; p.slabs = nchunk;
+    for (int sl = 1; sl <= 8; ++sl) {
+        const int ch = (nchunk + sl - 1) / sl;
+        if (ch > 256) continue;
+        const double util = (double)(ch * (256 / ch)) / 256.0 * (double)nchunk / (double)(ch * sl);
+        if (util > best + 1e-9) { best = util; p.ch = ch; p.slabs = sl; }
+    }
+    p.rl = 256 / p.ch;
+    dw_walk_plan(H, p.R, p.nseg);
+    const int64_t units = (int64_t)B * p.nseg * ((W + DW_PIX - 1) / DW_PIX);
+    int64_t want = cdiv64(units, p.rl);
+    int cap = 2 * DWG_MAX_BLOCKS / p.slabs;
+    if (cap < 1) cap = 1;
+    p.nblk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    return p;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) dwconv3x3_wgrad_walk_kernel(const T* __restrict__ x, const T* __restrict__ du,
+                                                                    float* __restrict__ partial, int B, int H, int W, int C, int ch,
+                                                                    int rl, int R, int nseg) {
+    __shared__ float red[256 * 4];
+    const int tx = threadIdx.x % ch, ty = threadIdx.x / ch;
+    const int chunk = blockIdx.y * ch + tx;
+    const int c0 = chunk * 4;
+    const bool active = ty < rl && c0 < C;
+    const int wg = (W + DW_PIX - 1) / DW_PIX;
+    const int units = B * nseg * wg;
+    f32x2_t acc[10][2];
+#pragma unroll
+    for (int o = 0; o < 10; ++o) { acc[o][0] = f32x2_t{0.f, 0.f}; acc[o][1] = f32x2_t{0.f, 0.f}; }
+    const int steps = (R + 2 + 2) / 3;
+    if (active) {
+        for (int u = (int)xcd_block() * rl + ty; u < units; u += (int)gridDim.x * rl) {
+            const int xg = u % wg;
+            const int t = u / wg;
+            const int seg = t % nseg;
+            const int b = t / nseg;
+            const int x0 = xg * DW_PIX;
+            const int ya = seg * R, yb = ya + R < H ? ya + R : H;
+            const T* xb = x + (int64_t)b * H * W * C + c0;
+            const T* gb = du + (int64_t)b * H * W * C + c0;
+            int coff[DW_PIX + 2];
+            bool cok[DW_PIX + 2];
+#pragma unroll
+            for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                const int ix = x0 + cx - 1;
+                cok[cx] = ix >= 0 && ix < W;
+                coff[cx] = (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;
+            }
+            f32x2_t gw[3][DW_PIX][2];                    // gradient rows yin - 1, yin, yin + 1 (rotating roles)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int p = 0; p < DW_PIX; ++p) { gw[a][p][0] = f32x2_t{0.f, 0.f}; gw[a][p][1] = f32x2_t{0.f, 0.f}; }
+            Raw4<T> nxt[DW_PIX + 2], gnx[DW_PIX];
+            auto load_row = [&](int yin, Raw4<T> (&dst)[DW_PIX + 2]) {
+                const int yc = yin < 0 ? 0 : (yin >= H ? H - 1 : yin);
+                const T* row = xb + (int64_t)yc * W * C;
+#pragma unroll
+                for (int cx = 0; cx < DW_PIX + 2; ++cx) dst[cx] = load4_raw<T>(row + coff[cx]);
+            };
+            auto load_grow = [&](int yo, Raw4<T> (&dst)[DW_PIX]) {
+                const int yc = yo < 0 ? 0 : (yo >= H ? H - 1 : yo);
+                const T* row = gb + (int64_t)yc * W * C;
+#pragma unroll
+                for (int p = 0; p < DW_PIX; ++p) dst[p] = load4_raw<T>(row + coff[p + 1]);
+            };
+            load_row(ya - 1, nxt);
+            load_grow(ya, gnx);                           // gradient rows run one row ahead of the input rows
+            int yin = ya - 1;
+            for (int st = 0; st < steps; ++st) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j, ++yin) {
+                    f32x2_t (&GP)[DW_PIX][2] = gw[j % 3];            // row yin - 1  (pairs with ky = 2)
+                    f32x2_t (&GC)[DW_PIX][2] = gw[(j + 1) % 3];      // row yin      (ky = 1)
+                    f32x2_t (&GN)[DW_PIX][2] = gw[(j + 2) % 3];      // row yin + 1  (ky = 0): arrives now
+                    Raw4<T> cur[DW_PIX + 2], gcur[DW_PIX];
+#pragma unroll
+                    for (int cx = 0; cx < DW_PIX + 2; ++cx) cur[cx] = nxt[cx];
+#pragma unroll
+                    for (int p = 0; p < DW_PIX; ++p) gcur[p] = gnx[p];
+                    load_row(yin + 1, nxt);
+                    load_grow(yin + 2, gnx);
+                    const bool gok = yin + 1 >= ya && yin + 1 < yb;
+#pragma unroll
+                    for (int p = 0; p < DW_PIX; ++p) {
+                        unpack4v(gcur[p], gok && cok[p + 1], GN[p]);
+                        acc[9][0] += GN[p][0]; acc[9][1] += GN[p][1];
+                    }
+                    const bool vy = yin >= 0 && yin < H;
+#pragma unroll
+                    for (int cx = 0; cx < DW_PIX + 2; ++cx) {
+                        f32x2_t v[2];
+                        unpack4v(cur[cx], vy && cok[cx], v);
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int p = cx - kx;
+                            if (p >= 0 && p < DW_PIX) {
+#pragma unroll
+                                for (int jj = 0; jj < 2; ++jj) {
+                                    acc[6 + kx][jj] = GP[p][jj] * v[jj] + acc[6 + kx][jj];
+                                    acc[3 + kx][jj] = GC[p][jj] * v[jj] + acc[3 + kx][jj];
+                                    acc[kx][jj] = GN[p][jj] * v[jj] + acc[kx][jj];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // block tail: sum over the rl unit lanes in fixed order, partial[blockIdx.x][o][c0 .. c0 + 4)
+    for (int o = 0; o < 10; ++o) {
+        __syncthreads();
+        red[threadIdx.x * 4 + 0] = active ? acc[o][0].x : 0.f; red[threadIdx.x * 4 + 1] = active ? acc[o][0].y : 0.f;
+        red[threadIdx.x * 4 + 2] = active ? acc[o][1].x : 0.f; red[threadIdx.x * 4 + 3] = active ? acc[o][1].y : 0.f;
+        __syncthreads();
+        if (ty == 0 && c0 < C) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int yy = 0; yy < rl; ++yy)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s4[j] += red[(yy * ch + tx) * 4 + j];
+            float* dst = partial + ((int64_t)blockIdx.x * 10 + o) * C + c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = s4[j];
+        }
+    }
+}
+
 // [10][C] sums -> dw[C][9], db[C]
 __global__ void dw_scatter_kernel(const float* __restrict__ sums, int C, float* __restrict__ dw, float* __restrict__ db) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,7 +548,8 @@ __global__ void dw_scatter_kernel(const float* __restrict__ sums, int C, float* 
 
 extern "C" int64_t segf_dwconv3x3_bwd_ws(int B, int H, int W, int C) {
     DwgPlan p = dwg_plan(B, H, W, C > 0 ? C : 8);
-    return (int64_t)p.nblk * 10 * C + 10 * (int64_t)C;
+    DwwPlan q = dww_plan(B, H > 0 ? H : 1, W > 0 ? W : 1, C > 0 ? C : 8);
+    return (int64_t)(p.nblk > q.nblk ? p.nblk : q.nblk) * 10 * C + 10 * (int64_t)C;
 }
 
 extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
@@ -248,14 +562,25 @@ extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const
     if (!ws) return SEGF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     DwgPlan p = dwg_plan(B, H, W, C);
+    const DwwPlan q = dww_plan(B, H, W, C);
+    const bool walk = dw_use_walk();
+    if (walk) p.nblk = q.nblk;
     float* sums = ws + (int64_t)p.nblk * 10 * C;
     const int blocks = dw_blocks(B, H, W, C);
     SEGF_DISPATCH_DT(dt, T, {
         // A: du = dy * gelu'(conv(x) + b);  B: dw / db partial sums;  C: dx = conv^T(du)
+        if (dw_use_walk()) dw_walk_launch<T, 2>(st, (const T*)x, w, bias, apply_gelu, (const T*)dy, (T*)du, B, H, W, C);
+        else
         hipLaunchKernelGGL((dwconv3x3_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, (const T*)x, w, bias, apply_gelu,
                            (const T*)dy, (T*)du, B, H, W, C);
+        if (walk)
+        hipLaunchKernelGGL((dwconv3x3_wgrad_walk_kernel<T>), dim3(q.nblk, q.slabs), dim3(256), 0, st, (const T*)x, (const T*)du, ws,
+                           B, H, W, C, q.ch, q.rl, q.R, q.nseg);
+        else
         hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<T>), dim3(p.nblk, p.slabs), dim3(256), 0, st, (const T*)x, (const T*)du, ws,
                            B, H, W, C, p.ch, p.rl, p.units_per_blk);
+        if (dw_use_walk()) dw_walk_launch<T, 1>(st, (const T*)du, w, (const float*)nullptr, 0, (const T*)nullptr, (T*)dx, B, H, W, C);
+        else
         hipLaunchKernelGGL((dwconv3x3_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)du, w, (const float*)nullptr, 0,
                            (const T*)nullptr, (T*)dx, B, H, W, C);
     })
@@ -375,10 +700,13 @@ __global__ void __launch_bounds__(256) dwconv7x7_wgrad_kernel(const T* __restric
     for (int o = 0; o < 8; ++o)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) ap[o][jj] = f32x2_t{0.f, 0.f};
-    const int u0 = xcd_block() * units_per_blk;
-    const int u1 = u0 + units_per_blk < units ? u0 + units_per_blk : units;
+    // units are dealt to the workgroups round-robin in groups of rl strips (not as one contiguous range each): the workgroups
+    // that run at the same time on an XCD then walk ADJACENT image rows, and the two re-reads of every input row (as the row
+    // above / below of its neighbours) hit that XCD's L2.  With contiguous ranges every workgroup streamed its own 16 rows,
+    // 128 of them per 4 MB L2, and FETCH_SIZE showed x fetched three times (2.13 GB for 1.07 GB at [128,128,128,128]).
+    (void)units_per_blk;
     if (active) {
-        for (int u = u0 + ty; u < u1; u += rl) {
+        for (int u = (int)xcd_block() * rl + ty; u < units; u += (int)gridDim.x * rl) {
             const int xg = u % wg;
             const int t = u / wg;
             const int yy = t % H;

@@ -96,6 +96,10 @@ def main():
             report(f'dwconv3x3+gelu fwd [{B},{H},{H},{C}]', ms, nbytes=4 * B * H * H * C)
             ms = timeit(lambda: hip.dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, H, C, True))
             report(f'dwconv3x3+gelu bwd [{B},{H},{H},{C}]', ms, nbytes=14 * B * H * H * C)
+            ms = timeit(lambda: hip.dwconv3x3_gelu_fwd(x, w9, bias, B, H, H, C, False))
+            report(f'dwconv3x3 (no gelu) fwd [{B},{H},{H},{C}]', ms, nbytes=4 * B * H * H * C)
+            ms = timeit(lambda: hip.dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, H, C, False))
+            report(f'dwconv3x3 (no gelu) bwd [{B},{H},{H},{C}]', ms, nbytes=14 * B * H * H * C)
     if want('attn'):
         for N, heads in ((16384, 1), (4096, 2), (1024, 5), (256, 8)):
             C = heads * 32
