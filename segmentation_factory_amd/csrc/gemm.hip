@@ -930,8 +930,185 @@ static bool gemm_skinny_launch(int ks, int nt, dim3 grid, hipStream_t st, const 
     return false;
 }
 
+// ---- streaming weight gradient for small outputs -----------------------------------------------------------------------------
+// dW[M,N] = A^T B over K ~ 10^5..10^6 tokens with M, N <= a few hundred (the MiT stage-1/2 linears, the patch embedding) is
+// pure streaming of the two token-major operands; the 128^2-tile kernel spends most of each tile on padding (a [32 x 147] output
+// ran at 20 % of its HBM time).  Here a WAVE owns a K slice: it walks 32-token groups, stages the two row blocks in its own LDS
+// slab (16-byte chunks as they lie in memory; the next group's loads are in flight meanwhile), reads both operands back through
+// ds_read_b64_tr_b16 (tokens become the contiguous k of the fragments) and keeps the whole [16 MT x 16 NT] output block in
+// MFMA accumulators; no workgroup barrier anywhere.  Every wave writes one split-K slice [z][M][N] (summed by
+// splitk_reduce_kernel in fixed order); the bias gradient rides along as an all-ones column at index N.
+// grid = (slices / 4, column blocks, row blocks).
+__device__ __forceinline__ bf16x8 frag_tok_tr(const unsigned char* tile, int rowbytes, int cb, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const unsigned char* a0 = tile + (8 * g + q) * rowbytes + (cb + 4 * p) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * rowbytes));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int MT, int NT, bool CSUM>
+__global__ void __launch_bounds__(256) gemm_dw_skinny_kernel(GemmArgs a, int slices) {
+    constexpr int RA = 32 * MT + 16, RB = 32 * NT + 16;                  // row bytes of the staged blocks (+16: bank spread)
+    constexpr int CA = 2 * MT, CB = 2 * NT;                               // 16-byte chunks per staged row
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][32 * (RA + RB)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int z = blockIdx.x * 4 + wave;
+    if (z >= slices) return;
+    const int64_t m0 = (int64_t)blockIdx.z * (16 * MT), n0 = (int64_t)blockIdx.y * (16 * NT);
+    unsigned char* ta = slab[wave];
+    unsigned char* tb = ta + 32 * RA;
+    const int64_t k0 = (int64_t)z * a.kchunk;
+    const int64_t kend = k0 + a.kchunk < a.K ? k0 + a.kchunk : a.K;      // host: (kend - k0) % 32 == 0
+    // Per-lane chunk offsets, fixed for the whole walk (bytes from the first token of a group).  No masks anywhere: columns
+    // past M / N (row padding, or a clamped chunk when the block overhangs the row) only ever reach accumulator rows / columns
+    // that are never stored, and the host guarantees whole 32-token groups.
+    uint32_t oa[MT], ob[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ci = lane + 64 * i, row = ci / CA, c = ci - row * CA;
+        const int64_t col = m0 + 8 * c;
+        oa[i] = (uint32_t)((row * a.lda + (col + 8 <= a.lda ? col : 0)) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int ci = lane + 64 * i, row = ci / CB, c = ci - row * CB;
+        const int64_t col = n0 + 8 * c;
+        ob[i] = (uint32_t)((row * a.ldb + (col + 8 <= a.ldb ? col : 0)) * 2);
+    }
+    f32x4 acc[MT][NT], accs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // B fragment of all ones: MFMA(A fragment, ones) = the column sums of dy = the bias gradient, in every output column
+    const uint4 ones4 = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    const bf16x8 fones = __builtin_bit_cast(bf16x8, ones4);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));       // (native vectors: arrays of HIP's uint4 class stayed in scratch)
+    u32x4 ra[MT], rb[NT];
+    const char* pa0 = reinterpret_cast<const char*>(a.A);
+    const char* pb0 = reinterpret_cast<const char*>(a.B);
+    {
+        const char* pa_ = pa0 + k0 * a.lda * 2;
+        const char* pb_ = pb0 + k0 * a.ldb * 2;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(pa_ + oa[i]);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pb_ + ob[i]);
+    }
+    for (int64_t kg = k0; kg < kend; kg += 32) {
+        // stage the group (the previous group's fragment reads are complete: same-wave LDS operations execute in order)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int ci = lane + 64 * i, row = ci / CA, c = ci - row * CA;
+            *reinterpret_cast<u32x4*>(ta + row * RA + 16 * c) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int ci = lane + 64 * i, row = ci / CB, c = ci - row * CB;
+            *reinterpret_cast<u32x4*>(tb + row * RB + 16 * c) = rb[i];
+        }
+        {
+            const int64_t kn = kg + 32 < kend ? kg + 32 : kg;        // unconditional: the loads stay countable (the last one is a re-read)
+            const char* pa_ = pa0 + kn * a.lda * 2;
+            const char* pb_ = pb0 + kn * a.ldb * 2;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) ra[i] = *reinterpret_cast<const u32x4*>(pa_ + oa[i]);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pb_ + ob[i]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 fa[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            fa[i] = frag_tok_tr(ta, RA, 16 * i, lane);
+            if (CSUM) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fones, accs[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const bf16x8 fb = frag_tok_tr(tb, RB, 16 * j, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // accumulator (i, j): rows m0 + 16 i + 4 (lane >> 4) + r, column n0 + 16 j + (lane & 15)
+    float* wsz = a.ws + (int64_t)z * a.M * a.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int64_t n = n0 + 16 * j + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + 16 * i + 4 * (lane >> 4) + r;
+                if (m < a.M && n < a.N) wsz[m * a.N + n] = acc[i][j][r];
+            }
+        }
+        if (CSUM && blockIdx.y == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + 16 * i + 4 * (lane >> 4) + r;
+                if (m < a.M) a.colsum_ws[(int64_t)z * a.M + m] = accs[i][r];
+            }
+        }
+    }
+}
+
+// Shapes the streaming weight-gradient kernel takes and its blocking; slices = waves along K
+struct DwSkinny { int mt, nt, rowblocks, colblocks, slices; };
+static bool gemm_dw_skinny_plan(int64_t M, int64_t N, int64_t K, bool colsum, DwSkinny& p) {
+    if (getenv("SEGFAC_GEMM_NO_DW_SKINNY")) return false;
+    if (K < 65536 || M > 256 || N > 288) return false;
+    (void)colsum;                                 // the bias gradient costs no output column (all-ones B fragment)
+    if (K % 32) return false;                     // whole 32-token groups only (no masking in the kernel)
+    const int tm = (int)cdiv64(M, 16), tn = (int)cdiv64(N, 16);
+    // row blocks of 2 / 4 / 8 tiles, column blocks of 2 / 4 / 8 / 10 tiles, at most 32 accumulator tiles per wave
+    static const int mts[] = {2, 4, 8}, nts[] = {2, 4, 8, 10};
+    int64_t best = -1;
+    for (int mt : mts)
+        for (int nt : nts) {
+            if (mt * nt > 32 || (mt == 8 && nt > 2)) continue;
+            const int rbk = (tm + mt - 1) / mt, cbk = (tn + nt - 1) / nt;
+            // bytes streamed per token: A row blocks are re-read per column block and vice versa (padding included)
+            const int64_t cost = (int64_t)cbk * rbk * (16 * mt + 16 * nt);
+            if (best < 0 || cost < best) { best = cost; p.mt = mt; p.nt = nt; p.rowblocks = rbk; p.colblocks = cbk; }
+        }
+    if (best < 0 || p.rowblocks * p.colblocks > 1) return false;       // blocked outputs re-read an operand: measured no better than
+                                                                       // the tiled kernel ([64 x 256]: 108 vs 94 us, [256 x 64]: 89 vs 93)
+    int64_t sl = K / 512;                                                // >= 16 groups of 32 tokens per wave
+    int64_t capw = 2048;
+    if (const char* e = getenv("SEGFAC_DW_SKINNY_SLICES")) { const int v = atoi(e); if (v > 0) { capw = v; sl = K / 128; } }
+    const int64_t cap = capw / ((int64_t)p.rowblocks * p.colblocks);
+    if (sl > cap) sl = cap;
+    if (sl < 4) return false;
+    // the slice count gemm_impl arrives at from this request (K chunks are whole 64-token steps)
+    const int64_t kchunk = cdiv64(cdiv64(K, sl), 64) * 64;
+    p.slices = (int)cdiv64(K, kchunk);
+    return true;
+}
+template <int MT>
+static bool gemm_dw_skinny_launch_nt(int nt, dim3 grid, hipStream_t st, const GemmArgs& a, int slices) {
+#define DS(NT_) if (nt == NT_) { if (a.colsum_ws) hipLaunchKernelGGL((gemm_dw_skinny_kernel<MT, NT_, true>), grid, dim3(256), 0, st, a, slices); \
+                            else hipLaunchKernelGGL((gemm_dw_skinny_kernel<MT, NT_, false>), grid, dim3(256), 0, st, a, slices); return true; }
+    DS(2)
+    if constexpr (MT <= 4) { DS(4) DS(8) }
+    if constexpr (MT == 2) { DS(10) }
+#undef DS
+    return false;
+}
+
 extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     // layout 2 (weight gradient): K = token count.  Aim for >= 512 workgroups, >= 4 K-steps per slice.
+    {   // small outputs: the streaming kernel's slice count (one slice per wave); the bias-gradient column is assumed
+        DwSkinny p;
+        if (gemm_dw_skinny_plan(M, N, K, true, p)) return p.slices;
+    }
     const bool big = gemm_use_big(2, M, N, K);
     const int64_t tiles = big ? cdiv64(M, GG_B) * cdiv64(N, GG_B) : cdiv64(M, GB_BM) * cdiv64(N, GB_BN);
     // one wave of workgroups: 256 CUs x (1 big-tile | 2 small-tile) resident workgroups.  Rounded DOWN: 3 tiles x 86 slices =
@@ -971,7 +1148,11 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
                                void* C, int c_dt, int64_t ldc, int split_k, float* ws, float* dbias, void* stream) {
     if (!dbias || !ws) return SEGF_ERR_WORKSPACE;
     if (split_k < 1) split_k = 1;
-    const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (N % GB_BN) != 0 && !gemm_use_big(2, M, N, K) &&
+    DwSkinny sk;
+    const bool skinny = dt == SEGF_BF16 && c_dt == SEGF_F32 && gemm_dw_skinny_plan(M, N, K, true, sk) && sk.slices == split_k &&
+                        (uintptr_t)A % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)B % 16 == 0 && (ldb * 2) % 16 == 0 &&
+                        !(getenv("SEGFAC_GEMM_NO_TR") && getenv("SEGFAC_GEMM_NO_TR")[0] == '1');
+    const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (skinny || ((N % GB_BN) != 0 && !gemm_use_big(2, M, N, K))) &&
                        !getenv("SEGFAC_GEMM_NO_FUSED_DB");
     if (!fused) {       // big-tile / fp32 kernels: separate column reduction (still one C-ABI call)
         const int rc = gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, nullptr, stream);
@@ -1056,6 +1237,18 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                 const bool ok = layout == 0 ? gemm_skinny_launch<0>((int)(K / 32), nt, grid, st, a)
                                             : gemm_skinny_launch<1>((int)(K / 32), nt, grid, st, a);
                 if (ok) { SEGF_CHECK_LAUNCH(); return 0; }
+            }
+        }
+        if (layout == 2 && !pro && a.ws && c_dt == SEGF_F32 && a.use_tr && (a.a_vec & 1) && (a.b_vec & 1) && !bias && !residual) {
+            DwSkinny p;
+            // the caller sized ws for split_k slices (segf_gemm_pick_splitk gives this kernel's count): take it only then
+            if (gemm_dw_skinny_plan(M, N, K, true, p) && p.slices == split_k && kchunk % 32 == 0 && lda * 2 * 32 < (1ll << 31) && ldb * 2 * 32 < (1ll << 31)) {
+                if (!colsum) { a.colsum = nullptr; a.colsum_ws = nullptr; }
+                const dim3 gridk((unsigned)((p.slices + 3) / 4), (unsigned)p.colblocks, (unsigned)p.rowblocks);
+                const bool ok = p.mt == 2 ? gemm_dw_skinny_launch_nt<2>(p.nt, gridk, st, a, p.slices)
+                              : p.mt == 4 ? gemm_dw_skinny_launch_nt<4>(p.nt, gridk, st, a, p.slices)
+                                          : gemm_dw_skinny_launch_nt<8>(p.nt, gridk, st, a, p.slices);
+                if (ok) { SEGF_CHECK_LAUNCH(); goto reduce; }
             }
         }
         if (gemm_use_big(layout, M, N, K) && a.use_tr) {

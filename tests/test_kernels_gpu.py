@@ -736,6 +736,41 @@ def test_gemm_big_tile_variant(hipmod, layout):
         assert err <= 1.2e-2 * full.abs().max().item()       # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize('shape', [(32, 147, 131072, 152), (32, 32, 65536, 32), (32, 128, 65536, 128), (128, 32, 98304, 32),
+                                   (64, 256, 65536, 256), (256, 64, 65536, 64), (64, 64, 65536 + 4096, 72), (40, 100, 70000, 104)])
+def test_gemm_streaming_weight_gradient(hipmod, shape, monkeypatch):
+    """dW = dy^T x and db = column sums of dy for small outputs over many tokens (gemm_dw_skinny_kernel: a wave per K slice, both
+    operands transposed through ds_read_b64_tr_b16, bias gradient as an all-ones column) against fp64 on the bf16-rounded
+    operands; ragged K, padded rows, row / column blocking, and bitwise agreement of two runs.  The last shape's K does not
+    divide into the kernel's slices evenly; whichever kernel takes it must still be right."""
+    M, N, K, ldx = shape
+    g = torch.Generator().manual_seed(77)
+    dy = (torch.randn(K, M, generator=g) * 0.5).bfloat16()
+    xb = torch.zeros(K, ldx).bfloat16()
+    xb[:, :N] = torch.randn(K, N, generator=g).bfloat16()
+    if ldx > N:
+        xb[:, N:] = 7.0                      # padding columns must not leak into the product
+    ref = dy.double().t() @ xb[:, :N].double()
+    refb = dy.double().sum(0)
+    dyd, xd = dy.cuda(), xb.cuda()
+    split = hipmod.pick_splitk(M, N, K)
+    dw, db = hipmod.gemm_dw_db(dyd, xd[:, :N], M, N, K, split_k=split)
+    dw2, db2 = hipmod.gemm_dw_db(dyd, xd[:, :N], M, N, K, split_k=split)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    scale = ref.abs().max().item()
+    assert (dw.double().cpu() - ref).abs().max().item() <= 2e-5 * scale + 1e-3, (dw.double().cpu() - ref).abs().max().item()
+    assert (db.double().cpu() - refb).abs().max().item() <= 2e-5 * refb.abs().max().item() + 1e-3
+    # the same through the tiled kernel (switch) and through plain segf_gemm layout 2
+    monkeypatch.setenv('SEGFAC_GEMM_NO_DW_SKINNY', '1')
+    split_t = hipmod.pick_splitk(M, N, K)
+    dwt, dbt = hipmod.gemm_dw_db(dyd, xd[:, :N], M, N, K, split_k=split_t)
+    monkeypatch.delenv('SEGFAC_GEMM_NO_DW_SKINNY')
+    assert (dwt.double().cpu() - ref).abs().max().item() <= 2e-5 * scale + 1e-3
+    plain = hipmod.gemm(2, dyd, xd[:, :N], M, N, K, split_k=split, out_dtype=torch.float32)
+    assert (plain.double().cpu() - ref).abs().max().item() <= 2e-5 * scale + 1e-3
+
+
 @pytest.mark.parametrize('layout', [0, 1])
 @pytest.mark.parametrize('shape', [(16391, 32, 32), (20000, 128, 32), (16400, 32, 128), (16384, 64, 64), (16390, 768, 32),
                                    (16384, 256, 64), (16392, 64, 128)])
