@@ -92,22 +92,23 @@ __global__ void __launch_bounds__(256) gemm_fp8_kernel(Fp8Args a) {
     const int64_t m0 = (int64_t)(L / (unsigned)tn) * F8_BM, n0 = (int64_t)(L % (unsigned)tn) * F8_BN;
     // staging: thread t moves 4 x 16 bytes of each operand tile per K step: rows t/8 + 32 i, byte column 16 (t % 8)
     const int srow = threadIdx.x >> 3, scol = (threadIdx.x & 7) * 16;
-    int4 ra[4], rb[4];
+    typedef int i32x4 __attribute__((ext_vector_type(4)));      // native vectors: arrays of HIP's int4 class were kept in scratch
+    i32x4 ra[4], rb[4];
     auto gload = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int64_t m = m0 + srow + 32 * i, n = n0 + srow + 32 * i;
             m = m < a.M ? m : a.M - 1;                          // clamped rows: their products land in rows / columns that are never stored
             n = n < a.N ? n : a.N - 1;
-            ra[i] = *reinterpret_cast<const int4*>(a.A + m * a.lda + k0 + scol);
-            rb[i] = *reinterpret_cast<const int4*>(a.B + n * a.ldb + k0 + scol);
+            ra[i] = *reinterpret_cast<const i32x4*>(a.A + m * a.lda + k0 + scol);
+            rb[i] = *reinterpret_cast<const i32x4*>(a.B + n * a.ldb + k0 + scol);
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<int4*>(la + (srow + 32 * i) * F8_LD + scol) = ra[i];
-            *reinterpret_cast<int4*>(lb + (srow + 32 * i) * F8_LD + scol) = rb[i];
+            *reinterpret_cast<i32x4*>(la + (srow + 32 * i) * F8_LD + scol) = ra[i];
+            *reinterpret_cast<i32x4*>(lb + (srow + 32 * i) * F8_LD + scol) = rb[i];
         }
     };
     fp8_v4f acc[4][4];
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(256) gemm_fp8_kernel(Fp8Args a) {
         __syncthreads();                                        // the previous step's fragment reads are done
         lstore();
         __syncthreads();
-        if (k0 + F8_BK < a.K) gload(k0 + F8_BK);                // next tile in flight during the MFMAs
+        gload(k0 + F8_BK < a.K ? k0 + F8_BK : k0);              // next tile in flight during the MFMAs (unconditional: countable loads)
         fp8_v8i fa[4], fb[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
