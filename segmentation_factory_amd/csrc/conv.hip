@@ -256,9 +256,11 @@ __global__ void __launch_bounds__(256) dwconv3x3_walk_kernel(const T* __restrict
     }
 }
 
-static inline void dw_walk_plan(int H, int& R, int& nseg) {
-    // segments of at most 64 rows (two re-read rows per segment), equal length
+static inline void dw_walk_plan(int H, int& R, int& nseg, int64_t columns = 0) {
+    // segments of at most 64 rows (two re-read rows per segment), equal length; shorter ones when the launch would otherwise
+    // have too few threads to fill the chip (columns = batch x 4-pixel strips x channel chunks; small batches)
     nseg = (H + 63) / 64;
+    while (columns > 0 && columns * nseg < 131072 && (H + nseg - 1) / nseg > 8) nseg *= 2;
     if (const char* e = getenv("SEGFAC_DW_WALK_ROWS")) { const int v = atoi(e); if (v > 0) nseg = (H + v - 1) / v; }
     R = (H + nseg - 1) / nseg;
 }
@@ -267,7 +269,7 @@ template <typename T, int MODE>
 static inline void dw_walk_launch(hipStream_t st, const T* x, const float* w, const float* bias, int apply_gelu, const T* dy, T* y,
                                   int B, int H, int W, int C) {
     int R, nseg;
-    dw_walk_plan(H, R, nseg);
+    dw_walk_plan(H, R, nseg, (int64_t)B * ((W + DW_PIX - 1) / DW_PIX) * (C / 4));
     const int64_t units = (int64_t)B * nseg * ((W + DW_PIX - 1) / DW_PIX);
     const int blocks = colfixed_blocks(units, C / 4, 1, 32768);
     hipLaunchKernelGGL((dwconv3x3_walk_kernel<T, MODE>), dim3(blocks), dim3(256), 0, st, x, w, bias, apply_gelu, dy, y, B, H, W, C, R, nseg);
@@ -416,7 +418,7 @@ static inline DwwPlan dww_plan(int B, int H, int W, int C) {
         if (util > best + 1e-9) { best = util; p.ch = ch; p.slabs = sl; }
     }
     p.rl = 256 / p.ch;
-    dw_walk_plan(H, p.R, p.nseg);
+    dw_walk_plan(H, p.R, p.nseg, (int64_t)B * ((W + DW_PIX - 1) / DW_PIX) * (C / 4));
     const int64_t units = (int64_t)B * p.nseg * ((W + DW_PIX - 1) / DW_PIX);
     int64_t want = cdiv64(units, p.rl);
     int cap = 2 * DWG_MAX_BLOCKS / p.slabs;

@@ -19,6 +19,7 @@ for b in 4 16 32; do python3 bench.py --batch $b --no-cpu-baseline > $O/${TAG}_b
 python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline > $O/${TAG}_bench_cfg3_b32.json 2>> $O/bench.err
 python3 bench.py --config cfg4 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_cfg4_b16.json 2>> $O/bench.err
 python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline > $O/${TAG}_bench_cfg5_b8.json 2>> $O/bench.err
+python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline --fp8 > $O/${TAG}_bench_cfg5_b8_fp8.json 2>> $O/bench.err
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 ls -la $O; cat $O/stats_top.txt | cut -c1-140; cat $O/pmc_top.txt | head -12; for f in $O/*bench*.json; do python3 -c "
 import json,sys
