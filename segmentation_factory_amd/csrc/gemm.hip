@@ -553,11 +553,17 @@ __device__ __forceinline__ void pro_apply(uint4& r, const float (&sc)[8], const 
     r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
 }
 
-template <int LAYOUT, typename OutT, bool CONV, bool PRO = false>
+// SHAPE 0: the 8 waves as 2 (M) x 4 (N), wave tile 128 x 64.  SHAPE 1 (N <= 160, layout 0): 4 x 2 waves, wave tile 64 x 80 -- only
+// the first 160 columns of the 256-wide B tile are multiplied (the classifier's 150 -> 160 classes fill 10 of its 16 column
+// tiles: 37.5 % of the MFMA work of SHAPE 0 was padding).  SHAPE 2 (M <= 160, layout 2): 2 x 4 waves, wave tile 80 x 64.
+// The loaders and the LDS image are the same for all three.
+template <int LAYOUT, typename OutT, bool CONV, bool PRO = false, int SHAPE = 0>
 __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GG_TILE_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave & 1, wn = wave >> 1;              // wave tile: rows [128 wm, +128), columns [64 wn, +64)
+    constexpr int TM = SHAPE == 1 ? 4 : (SHAPE == 2 ? 5 : 8), TN = SHAPE == 1 ? 5 : 4;      // 16 x 16 tiles per wave
+    const int wm = SHAPE == 1 ? (wave & 3) : (wave & 1), wn = SHAPE == 1 ? (wave >> 2) : (wave >> 1);
+    const int wrow = wm * (16 * TM), wcol = wn * (16 * TN);       // wave tile origin inside the workgroup tile
     const unsigned gx = gridDim.x, gy = gridDim.y;
     const unsigned nwg = gx * gy * gridDim.z;
     const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
@@ -570,11 +576,11 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
     const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
 
-    f32x4 acc[4][8];   // [tn][tm]
+    f32x4 acc[TN][TM];   // [tn][tm]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[4], rb[4];
     ConvState cst;
@@ -629,25 +635,26 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         const unsigned char* tb = smem[buf][1];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 fb[4];
+            bf16x8 fb[TN];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int nb = wn * 64 + t * 16;
+            for (int t = 0; t < TN; ++t) {
+                const int nb = wcol + t * 16;
                 fb[t] = LAYOUT == 0 ? frag_kc(tb, nb, s, lane) : frag_rm_tr_t<GG_B>(tb, nb, s, lane);
             }
+            constexpr int MG = TM == 8 ? 4 : TM;       // row tiles per group (SHAPE 0: the 8 row tiles in two groups of 4: 8 live fragments instead of 12)
 #pragma unroll
-            for (int hm = 0; hm < 2; ++hm) {           // the 8 row tiles in two groups of 4: 8 live fragments instead of 12
-                bf16x8 fa[4];
+            for (int hm = 0; hm < TM / MG; ++hm) {
+                bf16x8 fa[MG];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int mb = wm * 128 + (hm * 4 + t) * 16;
+                for (int t = 0; t < MG; ++t) {
+                    const int mb = wrow + (hm * MG + t) * 16;
                     fa[t] = LAYOUT == 2 ? frag_rm_tr_t<GG_B>(ta, mb, s, lane) : frag_kc(ta, mb, s, lane);
                 }
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[tn][hm * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[t], acc[tn][hm * 4 + t], 0, 0, 0);
+                    for (int t = 0; t < MG; ++t)
+                        acc[tn][hm * MG + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[t], acc[tn][hm * MG + t], 0, 0, 0);
             }
         }
         if (kt + 1 < nk) swrite(buf ^ 1);
@@ -663,13 +670,13 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         const bool full = ncol + 8 <= a.N;
         for (int pass = 0; pass < 4; ++pass) {              // 64 rows per pass
             if (pass) __syncthreads();
-            if (wm == (pass >> 1)) {
+            if (SHAPE == 1 ? wm == pass : wm == (pass >> 1)) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        *reinterpret_cast<f32x4*>(stg + (t * 16 + (lane & 15)) * GG_STG_LD + wn * 64 + tn * 16 + 4 * (lane >> 4)) =
-                            acc[tn][(pass & 1) * 4 + t];
+                    for (int tn = 0; tn < TN; ++tn)
+                        *reinterpret_cast<f32x4*>(stg + (t * 16 + (lane & 15)) * GG_STG_LD + wcol + tn * 16 + 4 * (lane >> 4)) =
+                            acc[tn][SHAPE == 1 ? t : (pass & 1) * 4 + t];
             }
             __syncthreads();
 #pragma unroll
@@ -706,11 +713,11 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         return;
     }
 #pragma unroll
-    for (int tm = 0; tm < 8; ++tm) {
-        const int64_t m = m0 + wm * 128 + tm * 16 + (lane & 15);
+    for (int tm = 0; tm < TM; ++tm) {
+        const int64_t m = m0 + wrow + tm * 16 + (lane & 15);
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int64_t n = n0 + wn * 64 + tn * 16 + 4 * (lane >> 4);
+        for (int tn = 0; tn < TN; ++tn) {
+            const int64_t n = n0 + wcol + tn * 16 + 4 * (lane >> 4);
             float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
             gemm_epilogue4<bf16_t, OutT>(a, m, n, v, bz);
         }
@@ -1260,11 +1267,20 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
         if (f32o) hipLaunchKernelGGL((gemm_bf16_big_kernel<L, float, false>), gridb, dim3(GG_THREADS), 0, st, a);  \
         else hipLaunchKernelGGL((gemm_bf16_big_kernel<L, bf16_t, false>), gridb, dim3(GG_THREADS), 0, st, a);      \
     } while (0)
+            // partly filled workgroup tiles: the narrow wave shapes (see the kernel's header)
+            const bool narrow_n = layout == 0 && !f32o && N <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
+            const bool narrow_m = layout == 2 && f32o && M <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
             if (a.pro_scale) {
-                if (layout == 0 && !f32o) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
-                else if (layout == 2 && f32o) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
-                else return SEGF_ERR_SHAPE;
-            } else
+                if (layout == 0 && !f32o) {
+                    if (narrow_n) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true, 1>), gridb, dim3(GG_THREADS), 0, st, a);
+                    else hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
+                } else if (layout == 2 && f32o) {
+                    if (narrow_m) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, true, 2>), gridb, dim3(GG_THREADS), 0, st, a);
+                    else hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
+                } else return SEGF_ERR_SHAPE;
+            } else if (narrow_n) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);
+            else if (narrow_m) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, false, 2>), gridb, dim3(GG_THREADS), 0, st, a);
+            else
             if (layout == 0) LAUNCH_G(0); else if (layout == 1) LAUNCH_G(1); else LAUNCH_G(2);
 #undef LAUNCH_G
             SEGF_CHECK_LAUNCH();

@@ -736,6 +736,50 @@ def test_gemm_big_tile_variant(hipmod, layout):
         assert err <= 1.2e-2 * full.abs().max().item()       # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize('case', [(0, 256 * 40 + 72, 150, 768, 160), (0, 256 * 33, 160, 200, 160), (0, 256 * 34 + 8, 137, 136, 144),
+                                  (2, 150, 768, 36000, 160), (2, 160, 392, 20000, 160), (2, 131, 520, 9000, 136)])
+def test_gemm_big_tile_narrow_shapes(hipmod, case, monkeypatch):
+    """The 256-tile kernel's narrow wave shapes (N <= 160 in layout 0: 4 x 2 waves of 64 x 80; M <= 160 in layout 2: 2 x 4 waves of
+    80 x 64 -- the classifier's 150 -> 160 classes) against fp64 and against the full-shape kernel (switch); padded row strides,
+    ragged M / K, bias + residual epilogue (layout 0) and split-K partials (layout 2)."""
+    layout, M, N, K, ld = case
+    g = torch.Generator().manual_seed(5 + layout)
+    if layout == 0:
+        a = torch.randn(M, K, generator=g).bfloat16()
+        wb = torch.zeros(ld, K).bfloat16()
+        wb[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+        bias, res = torch.randn(N, generator=g), torch.randn(M, ld, generator=g).bfloat16()
+        ref = a.double() @ wb[:N].double().t() + bias.double() + res[:, :N].double()
+        ad, wd = a.cuda(), wb.cuda()
+        outs = []
+        for env in (None, '1'):
+            if env: monkeypatch.setenv('SEGFAC_GEMM_NO_NARROW', env)
+            out = torch.full((M, ld), 3.0, dtype=torch.bfloat16, device='cuda')
+            hipmod.gemm(0, ad, wd[:N], M, N, K, out=out[:, :N], bias=bias.cuda(), residual=res.cuda()[:, :N])
+            outs.append(out.clone())
+        monkeypatch.delenv('SEGFAC_GEMM_NO_NARROW')
+        for out in outs:
+            assert (out[:, :N].double().cpu() - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+            assert (out[:, N:] == 3.0).all()                      # columns past N are not the kernel's to touch
+        assert torch.equal(outs[0], outs[1])                      # same products in the same order, only dealt to other waves
+    else:
+        dy = torch.zeros(K, ld).bfloat16()
+        dy[:, :M] = torch.randn(K, M, generator=g).bfloat16()
+        dy[:, M:] = 5.0
+        x = torch.randn(K, N, generator=g).bfloat16()
+        ref = dy[:, :M].double().t() @ x.double()
+        dyd, xd = dy.cuda(), x.cuda()
+        split = hipmod.pick_splitk(M, N, K)
+        outs = []
+        for env in (None, '1'):
+            if env: monkeypatch.setenv('SEGFAC_GEMM_NO_NARROW', env)
+            outs.append(hipmod.gemm(2, dyd[:, :M], xd, M, N, K, out_dtype=torch.float32, split_k=split).clone())
+        monkeypatch.delenv('SEGFAC_GEMM_NO_NARROW')
+        for out in outs:
+            assert (out.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
+        assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize('shape', [(32, 147, 131072, 152), (32, 32, 65536, 32), (32, 128, 65536, 128), (128, 32, 98304, 32),
                                    (64, 256, 65536, 256), (256, 64, 65536, 64), (64, 64, 65536 + 4096, 72), (40, 100, 70000, 104)])
 def test_gemm_streaming_weight_gradient(hipmod, shape, monkeypatch):
