@@ -737,7 +737,7 @@ def test_gemm_big_tile_variant(hipmod, layout):
 
 
 @pytest.mark.parametrize('case', [(0, 256 * 40 + 72, 150, 768, 160), (0, 256 * 33, 160, 200, 160), (0, 256 * 34 + 8, 137, 136, 144),
-                                  (2, 150, 768, 36000, 160), (2, 160, 392, 20000, 160), (2, 131, 520, 9000, 136)])
+                                  (2, 150, 768, 70000, 160), (2, 160, 392, 66000, 160), (2, 131, 520, 65536 + 8, 136), (2, 200, 392, 70000, 200)])
 def test_gemm_big_tile_narrow_shapes(hipmod, case, monkeypatch):
     """The 256-tile kernel's narrow wave shapes (N <= 160 in layout 0: 4 x 2 waves of 64 x 80; M <= 160 in layout 2: 2 x 4 waves of
     80 x 64 -- the classifier's 150 -> 160 classes) against fp64 and against the full-shape kernel (switch); padded row strides,
