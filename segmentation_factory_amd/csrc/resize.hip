@@ -624,7 +624,7 @@ template <typename T> __device__ __forceinline__ void store4v(T* p, const f32x2_
 }
 template <typename T>
 __global__ void __launch_bounds__(256, 2) bilinear_bwd_248_kernel(const T* __restrict__ dy, int64_t ldo, T* __restrict__ d2, T* __restrict__ d4,
-                                                                T* __restrict__ d8, int B, int H, int W, int C) {
+                                                                T* __restrict__ d8, int B, int H, int W, int C, int getenv_noflip) {
     constexpr int CW = 4;
     const int h8 = H / 8, w8 = W / 8, h4 = H / 4, w4 = W / 4, h2 = H / 2, w2 = W / 2;
     const int nch = C / CW;
@@ -692,8 +692,14 @@ __global__ void __launch_bounds__(256, 2) bilinear_bwd_248_kernel(const T* __res
         const T* src = dy + (b * H * W) * ldo + c0;
         // the row loop is NOT unrolled (16 x 16 hoisted addresses would not fit the register file): rows outside an output's
         // support simply carry weight 0 in its y-update
+        // Odd x8 rows walk their window bottom-up: an x8 row shares its upper 8 window rows with the row above and its lower 8
+        // with the row below (other workgroups, dispatched next to this one on the same XCD); with opposite walking directions
+        // both neighbours touch a shared band during the same half of their loops, which keeps it in the 4 MB L2 between the two
+        // reads (all top-down the reuse distance was 8 row steps = 8 MB streamed per XCD: FETCH_SIZE 1.7x the gradient)
+        const bool up = (y8 & 1) && !getenv_noflip;
 #pragma unroll 1
-        for (int i = 0; i < 16; ++i) {
+        for (int ii = 0; ii < 16; ++ii) {
+            const int i = up ? 15 - ii : ii;
             const int Y = Y0 + i, Yc = Y < 0 ? 0 : (Y >= H ? H - 1 : Y);
             const T* row = src + (int64_t)Yc * W * ldo;
             Raw4<T> raw[16];
@@ -770,7 +776,8 @@ extern "C" int segf_bilinear_bwd_248(int dt, int B, int H, int W, int C, const v
     const int64_t total = (int64_t)B * (H / 8) * (W / 8) * (C / 4);
     const int blocks = (int)imin64(cdiv64(total, 256), 32768);
     SEGF_DISPATCH_DT(dt, T, {
-        hipLaunchKernelGGL((bilinear_bwd_248_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)dout, ldo, (T*)d2, (T*)d4, (T*)d8, B, H, W, C);
+        hipLaunchKernelGGL((bilinear_bwd_248_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)dout, ldo, (T*)d2, (T*)d4, (T*)d8, B, H, W, C,
+                           getenv("SEGFAC_BWD248_NO_FLIP") ? 1 : 0);
     })
     SEGF_CHECK_LAUNCH();
     return 0;
