@@ -280,7 +280,7 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int
 // (the stage-1 MiT linears and the folded head products, K = 32 / 64) need no second buffer; 34 KB of LDS lets 4 workgroups
 // share a CU, which is what hides the load -> MFMA -> store latency chain of these purely HBM-bound launches.
 template <int LAYOUT, typename OutT, bool TR, bool CONV = false, int NBUF = 2>
-__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
+__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
     constexpr int SMEM_BYTES = NBUF == 2 ? 4 * GB_TILE_BYTES : (64 * GB_STG_LD * 4 > 2 * GB_TILE_BYTES ? 64 * GB_STG_LD * 4 : 2 * GB_TILE_BYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
     unsigned char (*smem)[2][GB_TILE_BYTES] = reinterpret_cast<unsigned char (*)[2][GB_TILE_BYTES]>(smem_raw);
@@ -312,6 +312,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
     // bias gradient riding on the weight gradient (layout 2, a.colsum): the first unused column of the last column tile is
     // staged as all-ones, so its accumulator column is sum_k A(k, m); csn = that column's index inside this tile (or -1)
     const int csn = (LAYOUT == 2 && !CONV && a.colsum != nullptr && a.N >= n0 && a.N < n0 + GB_BN) ? (int)(a.N - n0) : -1;
+    // ... and when N fills its last column tile (no spare column anywhere: N % 128 == 0) the column sums come from four extra
+    // MFMAs per K step against an all-ones B fragment, in the waves that hold the first 64 columns of the first column tile
+    // (wave-uniform): still one pass over dy, no separate column-reduction launch
+    const bool cs_mfma = LAYOUT == 2 && !CONV && a.colsum != nullptr && (a.N % GB_BN) == 0 && bx == 0 && wn == 0;
+    f32x4 accs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16x8 fones = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
     uint4 ra[4], rb[4];
     ConvState cst;
     if (CONV && LAYOUT == 0) conv_state_init_kc(cst, a, m0, threadIdx.x >> 3, 32, kbeg + (threadIdx.x & 7) * 8);
@@ -374,9 +382,21 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+            if (LAYOUT == 2 && !CONV && cs_mfma) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) accs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fones, fa[tm], accs[tm], 0, 0, 0);
+            }
         }
         if (kt + 1 < nk) swrite(buf ^ 1);
         __syncthreads();
+    }
+    if (LAYOUT == 2 && !CONV && cs_mfma && (lane >> 4) == 0) {          // every product row holds the sums: row 0 = register 0 of lanes 0..15
+        float* cdst = a.colsum_ws ? a.colsum_ws + (int64_t)bz * a.M : a.colsum;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int64_t m = m0 + wm * 64 + tm * 16 + (lane & 15);
+            if (m < a.M) cdst[m] = accs[tm][0];
+        }
     }
     // D[i][j]: i (rows, 4*(lane>>4)+r) <-> n, j (cols, lane&15) <-> m
     if (sizeof(OutT) == 2 && !a.ws && a.c_vec16) {
@@ -1160,7 +1180,9 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
     const bool skinny = dt == SEGF_BF16 && c_dt == SEGF_F32 && gemm_dw_skinny_plan(M, N, K, true, sk) && sk.slices == split_k &&
                         (uintptr_t)A % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)B % 16 == 0 && (ldb * 2) % 16 == 0 &&
                         !(getenv("SEGFAC_GEMM_NO_TR") && getenv("SEGFAC_GEMM_NO_TR")[0] == '1');
-    const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (skinny || ((N % GB_BN) != 0 && !gemm_use_big(2, M, N, K))) &&
+    // fused in the streaming kernel (all-ones fragment), in the 128-tile kernel (all-ones column when N leaves one free, extra
+    // MFMAs when it does not); the 256-tile kernel has no registers to spare for it
+    const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (skinny || !gemm_use_big(2, M, N, K)) &&
                        !getenv("SEGFAC_GEMM_NO_FUSED_DB");
     if (!fused) {       // big-tile / fp32 kernels: separate column reduction (still one C-ABI call)
         const int rc = gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, nullptr, stream);

@@ -811,6 +811,8 @@ def test_gemm_streaming_weight_gradient(hipmod, shape, monkeypatch):
     dwt, dbt = hipmod.gemm_dw_db(dyd, xd[:, :N], M, N, K, split_k=split_t)
     monkeypatch.delenv('SEGFAC_GEMM_NO_DW_SKINNY')
     assert (dwt.double().cpu() - ref).abs().max().item() <= 2e-5 * scale + 1e-3
+    # (tiled kernel: bias gradient from an all-ones column when N leaves one free, from extra MFMAs when N % 128 == 0)
+    assert (dbt.double().cpu() - refb).abs().max().item() <= 2e-5 * refb.abs().max().item() + 1e-3
     plain = hipmod.gemm(2, dyd, xd[:, :N], M, N, K, split_k=split, out_dtype=torch.float32)
     assert (plain.double().cpu() - ref).abs().max().item() <= 2e-5 * scale + 1e-3
 
