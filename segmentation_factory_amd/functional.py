@@ -17,9 +17,35 @@ def _rowmajor(t):
     return t if t.stride(-1) == 1 else t.contiguous()
 
 
+# bf16 shadow of the optimizer's flat parameter buffer (graph.GraphedTrainStep): inside `shadow_scope` a parameter that lives in
+# the flat buffer is not cast per use -- the step casts the whole buffer with ONE launch at its start and `_w` hands out views
+# (45 five-microsecond cast launches per SegFormer-B0 step otherwise).  Only active while the step function runs (warm-up,
+# capture): outside, e.g. in evaluate() between epochs, the shadow would be one optimizer update behind.
+_SHADOW = None
+
+
+class shadow_scope:
+    def __init__(self, table):
+        self.table = table
+
+    def __enter__(self):
+        global _SHADOW
+        self.prev, _SHADOW = _SHADOW, self.table
+        return self
+
+    def __exit__(self, *exc):
+        global _SHADOW
+        _SHADOW = self.prev
+        return False
+
+
 def _w(param, dtype):
     """fp32 master parameter -> compute dtype copy (bf16 cast kernel; identity in fp32 mode)."""
     p = param.detach()
+    if _SHADOW is not None and dtype == torch.bfloat16 and p.is_contiguous():
+        v = _SHADOW.get(p.data_ptr())
+        if v is not None and v.numel() == p.numel():
+            return v.view(p.shape)
     p = p if p.is_contiguous() else p.contiguous()
     return hip.cast(p, dtype) if dtype != torch.float32 else p
 

@@ -16,9 +16,13 @@ keeps executing the rest of backward on the compute stream.  Same arithmetic as 
 the loss gradient is pre-scaled by 1/world and the collective sums), same bucket idea, no per-parameter Python hooks.
 BatchNorm stays per-rank, as in the reference (plain nn.BatchNorm2d, no SyncBN).
 """
+import contextlib
+import os
+
 import torch
 import torch.distributed as dist
 
+from . import functional as Fh
 from . import hip
 from .optim import FusedAGCAdamW
 
@@ -89,6 +93,14 @@ class GraphedTrainStep:
                     self._pending[self.opt._grad_views[i].data_ptr()] = k
             self._left = [0] * len(self.buckets)
             self.comm = torch.cuda.Stream()
+        # bf16 shadow of the flat parameter buffer, refreshed by one cast at the start of every step (functional.shadow_scope)
+        self._shadow, self._shadow_map = None, None
+        if any(p.dtype == torch.float32 for p in self.opt._params) and not os.environ.get('SEGFAC_NO_WEIGHT_SHADOW'):
+            flat = self.opt.flat_params
+            self._shadow = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+            self._shadow_map = {}
+            for p, o in zip(self.opt._params, self.opt._offsets):
+                self._shadow_map[p.data_ptr()] = self._shadow[o:o + p.numel()]
         self.opt.enable_direct_grads(self._on_grad_written if (self.world > 1 and overlap) else None)
         self._seed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.static_inputs[0].device)
         s = torch.cuda.Stream()
@@ -120,9 +132,15 @@ class GraphedTrainStep:
 
     # ---- pieces --------------------------------------------------------------------------------------------------------
     def _forward_backward_eager(self):
-        loss = self.loss_fn(self.model, *self.static_inputs)
-        # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
-        loss.backward(gradient=self._seed if self.world > 1 else None)
+        if self._shadow is not None:
+            hip.cast_into(self.opt.flat_params, self._shadow)
+            scope = Fh.shadow_scope(self._shadow_map)
+        else:
+            scope = contextlib.nullcontext()
+        with scope:
+            loss = self.loss_fn(self.model, *self.static_inputs)
+            # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
+            loss.backward(gradient=self._seed if self.world > 1 else None)
         return loss
 
     def _reset_pending(self):

@@ -160,6 +160,14 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return dst
 
 
+def cast_into(src: torch.Tensor, dst: torch.Tensor):
+    """dst.flat[i] = src.flat[i] with dtype conversion, both contiguous (one launch; dst is reused across graph replays)."""
+    _need_cuda(src, dst)
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    _chk(lib().segf_cast(_ptr(src), dt_of(src), _ptr(dst), dt_of(dst), src.numel(), _stream()), 'segf_cast')
+    return dst
+
+
 def cast2d(src: torch.Tensor, dst: torch.Tensor):
     """dst[r, c] = src[r, c] with dtype conversion; both 2-D with unit inner stride (any row stride), or 1-D."""
     _need_cuda(src, dst)
