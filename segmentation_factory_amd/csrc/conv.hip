@@ -178,7 +178,9 @@ __global__ void __launch_bounds__(256) dwconv3x3_walk_kernel(const T* __restrict
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int p = 0; p < DW_PIX; ++p) { acc[a][p][0] = bs[0]; acc[a][p][1] = bs[1]; }
-        Raw4<T> nxt[DW_PIX + 2], gnx[DW_PIX];
+        // three raw-row buffers rotating with the accumulator roles: the loads run TWO rows ahead of the arithmetic (with one row
+        // ahead a wave had 3 KB in flight, 24 KB per CU at two waves per SIMD: latency-bound at 3.6 TB/s)
+        Raw4<T> rawb[3][DW_PIX + 2], grawb[3][DW_PIX];
         auto load_row = [&](int yin, Raw4<T> (&dst)[DW_PIX + 2]) {
             const int yc = yin < 0 ? 0 : (yin >= H ? H - 1 : yin);
             const T* row = xb + (int64_t)yc * W * C;
@@ -191,31 +193,26 @@ __global__ void __launch_bounds__(256) dwconv3x3_walk_kernel(const T* __restrict
 #pragma unroll
             for (int p = 0; p < DW_PIX; ++p) dst[p] = load4_raw<T>(row + coff[p + 1]);
         };
-        load_row(ya - 1, nxt);
-        if (MODE == 2) load_grow(ya - 2, gnx);
+        load_row(ya - 1, rawb[0]);
+        load_row(ya, rawb[1]);
+        if (MODE == 2) { load_grow(ya - 2, grawb[0]); load_grow(ya - 1, grawb[1]); }
         int yin = ya - 1;
         for (int st = 0; st < steps; ++st) {
 #pragma unroll
             for (int j = 0; j < 3; ++j, ++yin) {
                 // roles of the accumulator rows in this sub-step: P = output row yin - 1 (completes), Cc = row yin, N = row yin + 1
-                constexpr int dummy = 0; (void)dummy;
                 f32x2_t (&P)[DW_PIX][2] = acc[j % 3];
                 f32x2_t (&Cc)[DW_PIX][2] = acc[(j + 1) % 3];
                 f32x2_t (&N)[DW_PIX][2] = acc[(j + 2) % 3];
-                Raw4<T> cur[DW_PIX + 2], gcur[DW_PIX];
-#pragma unroll
-                for (int cx = 0; cx < DW_PIX + 2; ++cx) cur[cx] = nxt[cx];
-                load_row(yin + 1, nxt);
-                if (MODE == 2) {
-#pragma unroll
-                    for (int p = 0; p < DW_PIX; ++p) gcur[p] = gnx[p];
-                    load_grow(yin, gnx);
-                }
+                Raw4<T> (&curc)[DW_PIX + 2] = rawb[j % 3];                // input row yin (loaded two sub-steps ago)
+                Raw4<T> (&gcurc)[DW_PIX] = grawb[j % 3];                  // MODE 2: dy row yin - 1
+                load_row(yin + 2, rawb[(j + 2) % 3]);
+                if (MODE == 2) load_grow(yin + 1, grawb[(j + 2) % 3]);
                 const bool vy = yin >= 0 && yin < H && yin <= yb;
 #pragma unroll
                 for (int cx = 0; cx < DW_PIX + 2; ++cx) {
                     f32x2_t v[2];
-                    unpack4v(cur[cx], vy && cok[cx], v);
+                    unpack4v(curc[cx], vy && cok[cx], v);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int p = cx - kx;
@@ -239,7 +236,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_walk_kernel(const T* __restrict
                         if (MODE == 0 && apply_gelu) gelu_erf8<false>(a8, nullptr);
                         if (MODE == 2) {
                             f32x2_t gy[4], g0[2], g1[2];
-                            unpack4v(gcur[2 * h], true, g0); unpack4v(gcur[2 * h + 1], true, g1);
+                            unpack4v(gcurc[2 * h], true, g0); unpack4v(gcurc[2 * h + 1], true, g1);
                             gy[0] = g0[0]; gy[1] = g0[1]; gy[2] = g1[0]; gy[3] = g1[1];
                             if (apply_gelu) gelu_erf8<true>(a8, gy);
                             else { a8[0] = gy[0]; a8[1] = gy[1]; a8[2] = gy[2]; a8[3] = gy[3]; }
@@ -465,7 +462,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_walk_kernel(const T* __re
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int p = 0; p < DW_PIX; ++p) { gw[a][p][0] = f32x2_t{0.f, 0.f}; gw[a][p][1] = f32x2_t{0.f, 0.f}; }
-            Raw4<T> nxt[DW_PIX + 2], gnx[DW_PIX];
+            Raw4<T> rawb[3][DW_PIX + 2], grawb[3][DW_PIX];       // rotating: loads run two rows ahead (see dwconv3x3_walk_kernel)
             auto load_row = [&](int yin, Raw4<T> (&dst)[DW_PIX + 2]) {
                 const int yc = yin < 0 ? 0 : (yin >= H ? H - 1 : yin);
                 const T* row = xb + (int64_t)yc * W * C;
@@ -478,8 +475,8 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_walk_kernel(const T* __re
 #pragma unroll
                 for (int p = 0; p < DW_PIX; ++p) dst[p] = load4_raw<T>(row + coff[p + 1]);
             };
-            load_row(ya - 1, nxt);
-            load_grow(ya, gnx);                           // gradient rows run one row ahead of the input rows
+            load_row(ya - 1, rawb[0]); load_row(ya, rawb[1]);
+            load_grow(ya, grawb[0]); load_grow(ya + 1, grawb[1]);       // gradient rows run one row ahead of the input rows
             int yin = ya - 1;
             for (int st = 0; st < steps; ++st) {
 #pragma unroll
@@ -487,13 +484,10 @@ __global__ void __launch_bounds__(256) dwconv3x3_wgrad_walk_kernel(const T* __re
                     f32x2_t (&GP)[DW_PIX][2] = gw[j % 3];            // row yin - 1  (pairs with ky = 2)
                     f32x2_t (&GC)[DW_PIX][2] = gw[(j + 1) % 3];      // row yin      (ky = 1)
                     f32x2_t (&GN)[DW_PIX][2] = gw[(j + 2) % 3];      // row yin + 1  (ky = 0): arrives now
-                    Raw4<T> cur[DW_PIX + 2], gcur[DW_PIX];
-#pragma unroll
-                    for (int cx = 0; cx < DW_PIX + 2; ++cx) cur[cx] = nxt[cx];
-#pragma unroll
-                    for (int p = 0; p < DW_PIX; ++p) gcur[p] = gnx[p];
-                    load_row(yin + 1, nxt);
-                    load_grow(yin + 2, gnx);
+                    Raw4<T> (&cur)[DW_PIX + 2] = rawb[j % 3];
+                    Raw4<T> (&gcur)[DW_PIX] = grawb[j % 3];
+                    load_row(yin + 2, rawb[(j + 2) % 3]);
+                    load_grow(yin + 3, grawb[(j + 2) % 3]);
                     const bool gok = yin + 1 >= ya && yin + 1 < yb;
 #pragma unroll
                     for (int p = 0; p < DW_PIX; ++p) {
