@@ -577,9 +577,15 @@ __device__ __forceinline__ void pro_apply(uint4& r, const float (&sc)[8], const 
 // the first 160 columns of the 256-wide B tile are multiplied (the classifier's 150 -> 160 classes fill 10 of its 16 column
 // tiles: 37.5 % of the MFMA work of SHAPE 0 was padding).  SHAPE 2 (M <= 160, layout 2): 2 x 4 waves, wave tile 80 x 64.
 // The loaders and the LDS image are the same for all three.
-template <int LAYOUT, typename OutT, bool CONV, bool PRO = false, int SHAPE = 0>
+// DEEP (layout 0, full 64-deep K steps, vector-aligned operands): TWO K steps of operand tiles are in flight in registers while one
+// is multiplied (register sets alternate; every load unconditional so that the compiler can wait for one set and leave the other
+// in flight).  With one workgroup per CU and one 52 KB step in flight the classifier product was latency-bound at 2.9 TB/s.
+template <int LAYOUT, typename OutT, bool CONV, bool PRO = false, int SHAPE = 0, bool DEEP = false>
 __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GG_TILE_BYTES];
+    // DEEP + PRO: the operand affine of this workgroup's sample, staged once (K <= 1024 features): read from global memory
+    // inside the K loop, the table loads are younger than the tile loads in flight and waiting for them drains the queue
+    __shared__ __attribute__((aligned(16))) float pro_lds[(PRO && DEEP) ? 2 * 1024 : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int TM = SHAPE == 1 ? 4 : (SHAPE == 2 ? 5 : 8), TN = SHAPE == 1 ? 5 : 4;      // 16 x 16 tiles per wave
     const int wm = SHAPE == 1 ? (wave & 3) : (wave & 1), wn = SHAPE == 1 ? (wave >> 2) : (wave >> 1);
@@ -633,8 +639,15 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
             const int64_t grp = (LAYOUT == 0 ? m0 : pro_k0) / a.pro_rpg;
             int64_t f0 = LAYOUT == 0 ? pro_k0 + (threadIdx.x & 7) * 8 : n0 + (threadIdx.x % (GG_B / 8)) * 8;
             f0 = f0 + 8 <= a.pro_ld ? f0 : a.pro_ld - 8;
+            if (PRO && DEEP) {
+                const float4 s0 = *reinterpret_cast<const float4*>(pro_lds + f0), s1 = *reinterpret_cast<const float4*>(pro_lds + f0 + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(pro_lds + 1024 + f0), h1 = *reinterpret_cast<const float4*>(pro_lds + 1024 + f0 + 4);
+                psc[0] = s0.x; psc[1] = s0.y; psc[2] = s0.z; psc[3] = s0.w; psc[4] = s1.x; psc[5] = s1.y; psc[6] = s1.z; psc[7] = s1.w;
+                psh[0] = h0.x; psh[1] = h0.y; psh[2] = h0.z; psh[3] = h0.w; psh[4] = h1.x; psh[5] = h1.y; psh[6] = h1.z; psh[7] = h1.w;
+            } else {
             load8f(a.pro_scale + grp * a.pro_ld + f0, psc);
             load8f(a.pro_shift + grp * a.pro_ld + f0, psh);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) pro_apply(LAYOUT == 0 ? ra[i] : rb[i], psc, psh, a.pro_act);
         }
@@ -643,14 +656,7 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
     };
 
     const int nk = (int)((kend - kbeg + GB_BK - 1) / GB_BK);
-    if (nk > 0) {
-        gload(kbeg);
-        swrite(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * GB_BK);
+    auto compute = [&](int buf) {
         const unsigned char* ta = smem[buf][0];
         const unsigned char* tb = smem[buf][1];
 #pragma unroll
@@ -677,8 +683,70 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
                         acc[tn][hm * MG + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[t], acc[tn][hm * MG + t], 0, 0, 0);
             }
         }
-        if (kt + 1 < nk) swrite(buf ^ 1);
+    };
+    if (DEEP && LAYOUT == 0 && !CONV) {
+        if (PRO) {
+            const int64_t grp = m0 / a.pro_rpg;
+            for (int f = threadIdx.x; f < (int)a.pro_ld; f += GG_THREADS) {
+                pro_lds[f] = a.pro_scale[grp * a.pro_ld + f];
+                pro_lds[1024 + f] = a.pro_shift[grp * a.pro_ld + f];
+            }
+            __syncthreads();
+        }
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 sa0[4], sb0[4], sa1[4], sb1[4];
+        const int c8 = (threadIdx.x & 7) * 8, r0 = threadIdx.x >> 3;
+        // unconditional tile loads (rows clamped; K steps past the end re-read the last one and are never multiplied)
+#define DEEP_LOAD(SA, SB, T_)                                                                                          \
+        do {                                                                                                           \
+            const int64_t k_ = kbeg + (int64_t)((T_) < nk ? (T_) : nk - 1) * GB_BK + c8;                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
+                const int64_t ra_ = m0 + r0 + (GG_THREADS / 8) * i_, rb_ = n0 + r0 + (GG_THREADS / 8) * i_;            \
+                SA[i_] = *reinterpret_cast<const u32x4*>(A + (ra_ < a.M ? ra_ : a.M - 1) * a.lda + k_);                \
+                SB[i_] = *reinterpret_cast<const u32x4*>(B + (rb_ < a.N ? rb_ : a.N - 1) * a.ldb + k_);                \
+            }                                                                                                          \
+        } while (0)
+#define DEEP_WRITE(SA, SB, T_, BUF)                                                                                    \
+        do {                                                                                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
+                ra[i_] = make_uint4(SA[i_][0], SA[i_][1], SA[i_][2], SA[i_][3]);                                       \
+                rb[i_] = make_uint4(SB[i_][0], SB[i_][1], SB[i_][2], SB[i_][3]);                                       \
+            }                                                                                                          \
+            pro_k0 = kbeg + (int64_t)((T_) < nk ? (T_) : nk - 1) * GB_BK;                                              \
+            swrite(BUF);                                                                                               \
+        } while (0)
+        DEEP_LOAD(sa0, sb0, 0);
+        DEEP_WRITE(sa0, sb0, 0, 0);
+        DEEP_LOAD(sa1, sb1, 1);
+        DEEP_LOAD(sa0, sb0, 2);
         __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            compute(0);
+            DEEP_WRITE(sa1, sb1, kt + 1, 1);
+            DEEP_LOAD(sa1, sb1, kt + 3);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                compute(1);
+                DEEP_WRITE(sa0, sb0, kt + 2, 0);
+                DEEP_LOAD(sa0, sb0, kt + 4);
+                __syncthreads();
+            }
+        }
+#undef DEEP_LOAD
+#undef DEEP_WRITE
+    } else {
+        if (nk > 0) {
+            gload(kbeg);
+            swrite(0);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) gload(kbeg + (int64_t)(kt + 1) * GB_BK);
+            compute(buf);
+            if (kt + 1 < nk) swrite(buf ^ 1);
+            __syncthreads();
+        }
     }
     if (sizeof(OutT) == 2 && !a.ws && a.c_vec16) {
         float* stg = reinterpret_cast<float*>(&smem[0][0][0]);     // [64][GG_STG_LD] floats = 66.5 KB
@@ -1293,15 +1361,19 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
             // partly filled workgroup tiles: the narrow wave shapes (see the kernel's header)
             const bool narrow_n = layout == 0 && !f32o && N <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
             const bool narrow_m = layout == 2 && f32o && M <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
+            const bool deep = layout == 0 && split_k == 1 && (a.a_vec & 2) && (a.b_vec & 2) && K % GB_BK == 0 && K >= 2 * GB_BK &&
+                              (!a.pro_scale || a.pro_ld <= 1024) && !getenv("SEGFAC_GEMM_NO_DEEP");
             if (a.pro_scale) {
                 if (layout == 0 && !f32o) {
-                    if (narrow_n) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true, 1>), gridb, dim3(GG_THREADS), 0, st, a);
+                    if (narrow_n && deep) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true, 1, true>), gridb, dim3(GG_THREADS), 0, st, a);
+                    else if (narrow_n) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true, 1>), gridb, dim3(GG_THREADS), 0, st, a);
                     else hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
                 } else if (layout == 2 && f32o) {
                     if (narrow_m) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, true, 2>), gridb, dim3(GG_THREADS), 0, st, a);
                     else hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, true>), gridb, dim3(GG_THREADS), 0, st, a);
                 } else return SEGF_ERR_SHAPE;
-            } else if (narrow_n) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);
+            } else if (narrow_n && deep) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, false, 1, true>), gridb, dim3(GG_THREADS), 0, st, a);
+            else if (narrow_n) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);
             else if (narrow_m) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, false, 2>), gridb, dim3(GG_THREADS), 0, st, a);
             else
             if (layout == 0) LAUNCH_G(0); else if (layout == 1) LAUNCH_G(1); else LAUNCH_G(2);
