@@ -914,9 +914,19 @@ __global__ void __launch_bounds__(256) im2col_nchw_rows_kernel(const float* __re
         T* dst = rows + (int64_t)rr * W + x4;
         stf<T>(dst, v.x); stf<T>(dst + 1, v.y); stf<T>(dst + 2, v.z); stf<T>(dst + 3, v.w);
     }
-    __syncthreads();
+    // column -> (staged row offset, kx): the two divisions by run-time constants per output VALUE made this kernel VALU-bound
+    // (0.49 ms for the 7x7 stem at batch 128); they depend on the column only, so a 1 KB table per workgroup replaces them
+    __shared__ int ktab[2][256];
     const int nch = (int)(ldcol / 8), K = kh * kw * Cin;
+    for (int kcol = threadIdx.x; kcol < nch * 8 && kcol < 256; kcol += 256) {
+        const int kk = kcol / Cin, ci = kcol - kk * Cin;
+        const int ky = kk / kw, kx = kk - ky * kw;
+        ktab[0][kcol] = kcol < K ? (ky * Cin + ci) * W : -1;
+        ktab[1][kcol] = kx;
+    }
+    __syncthreads();
     T* out = col + ((int64_t)b * Ho + oy) * Wo * ldcol;
+    const bool tab_ok = nch * 8 <= 256;
     for (int i = threadIdx.x; i < Wo * nch; i += 256) {
         const int ox = i / nch, ch = i - ox * nch;
         const int ix0 = ox * stride - pad;
@@ -924,11 +934,17 @@ __global__ void __launch_bounds__(256) im2col_nchw_rows_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int kcol = ch * 8 + j;
-            const int kk = kcol / Cin, ci = kcol - kk * Cin;
-            const int ky = kk / kw, kx = kk - ky * kw;
+            int ro, kx;
+            if (tab_ok) { ro = ktab[0][kcol]; kx = ktab[1][kcol]; }
+            else {
+                const int kk = kcol / Cin, ci = kcol - kk * Cin;
+                const int ky = kk / kw;
+                kx = kk - ky * kw;
+                ro = kcol < K ? (ky * Cin + ci) * W : -1;
+            }
             const int ix = ix0 + kx;
-            const bool ok = kcol < K && ix >= 0 && ix < W;
-            v[j] = ok ? ldf<T>(rows + (int64_t)(ky * Cin + ci) * W + ix) : 0.f;
+            const bool ok = ro >= 0 && ix >= 0 && ix < W;
+            v[j] = ok ? ldf<T>(rows + ro + ix) : 0.f;
         }
         store8<T>(out + (int64_t)ox * ldcol + ch * 8, v);
     }
