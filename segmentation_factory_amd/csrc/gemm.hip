@@ -953,6 +953,13 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
         for (int r = 0; r < 4; ++r) bv[nt][r] = a.bias ? a.bias[n0 + 32 * (nt >> 1) + 8 * g + 4 * (nt & 1) + r] : 0.f;
     const int64_t ngroups = (a.M + 15) / 16, gstride = (int64_t)gridDim.x * 4;
     int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    // output staging: the accumulator layout gives a lane 16 bytes of one token, so a store instruction wrote 64-byte pieces of
+    // 16 rows (half cache lines: the [2M x 32] -> 768 projection ran at 3.1 TB/s where a plain fill reaches 6.8).  The wave's
+    // 16 x (16 NT) tile goes through its own LDS slab and leaves as whole 32 NT-byte row runs, 16 bytes per lane.
+    // (Dealing the column chunks of the same rows to neighbouring workgroups on top of this measured no better.)
+    constexpr int SROW = 32 * NT + 16;                                  // staged row bytes (+16: bank spread)
+    __shared__ __attribute__((aligned(16))) unsigned char ostage[4][16 * SROW];
+    unsigned char* ost = ostage[wave];
     uint4 xa[KS], xb[KS];
     auto load_rows = [&](int64_t gp, uint4 (&x)[KS]) {
         int64_t m = gp * 16 + mi;
@@ -982,7 +989,6 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], __builtin_bit_cast(bf16x8, xa[s]), acc[nt], 0, 0, 0);
         }
         const float rs = a.rscale ? a.rscale[(mok ? m : 0) / a.rpg] : 1.f;
-        bf16_t* cp = C + m * a.ldc + n0 + 8 * g;
 #pragma unroll
         for (int q = 0; q < NT / 2; ++q) {
             float v[8];
@@ -997,12 +1003,24 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
                     v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u) + rs * v[2 * j + 1];
                 }
             }
-            if (mok) {
-                uint4 o;
-                o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-                *reinterpret_cast<uint4*>(cp + 32 * q) = o;
+            uint4 o;
+            o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+            *reinterpret_cast<uint4*>(ost + mi * SROW + (32 * q + 8 * g) * 2) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            constexpr int CPR = 2 * NT;                                  // 16-byte chunks per staged row
+#pragma unroll
+            for (int i = 0; i < (16 * CPR) / 64; ++i) {
+                const int idx = lane + 64 * i, row = idx / CPR, cc = idx - row * CPR;
+                const uint4 o = *reinterpret_cast<const uint4*>(ost + row * SROW + 16 * cc);
+                const int64_t mr = grp * 16 + row;
+                if (mr < a.M) *reinterpret_cast<uint4*>(C + mr * a.ldc + n0 + 8 * cc) = o;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < KS; ++s) xa[s] = xb[s];
     }
