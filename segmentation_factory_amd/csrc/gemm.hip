@@ -10,6 +10,7 @@
 //   of one output row m -> 8-byte (bf16) / 16-byte (f32) row-contiguous stores.
 // f32 path: exact-fp32 FMA kernel (64x64x16 tile, 4x4 per thread) used by the parity mode.
 #include <stdlib.h>
+#include <type_traits>
 #include "colreduce.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -918,6 +919,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // (lane (m = l & 15, g = l >> 4) loads the 16 bytes x[m][32 s + 8 g ..]), no LDS at all; the accumulator rows (features)
 // are permuted through the weight-row order so that every lane ends up with runs of 8 consecutive output features of one
 // token and stores them with 16-byte writes that tile whole 64-byte segments.  N > 16*NT is covered by blockIdx.y chunks (x is re-read from L2, it is the small side).
+__device__ const float skinny_one = 1.f;
 template <int LAYOUT, int KS, int NT>
 __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -960,25 +962,49 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
     constexpr int SROW = 32 * NT + 16;                                  // staged row bytes (+16: bank spread)
     __shared__ __attribute__((aligned(16))) unsigned char ostage[4][16 * SROW];
     unsigned char* ost = ostage[wave];
-    uint4 xa[KS], xb[KS];
-    auto load_rows = [&](int64_t gp, uint4 (&x)[KS]) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 xa[KS], xb[KS];
+    auto rowptr = [&](int64_t gp) {
         int64_t m = gp * 16 + mi;
         m = m < a.M ? m : a.M - 1;
-        const bf16_t* p = A + m * a.lda + 8 * g;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) x[s] = *reinterpret_cast<const uint4*>(p + 32 * s);
+        return A + m * a.lda + 8 * g;
     };
-    if (grp < ngroups) load_rows(grp, xa);
-    for (; grp < ngroups; grp += gstride) {
-        const int64_t nxt = grp + gstride;
-        if (nxt < ngroups) load_rows(nxt, xb);
-        const int64_t m = grp * 16 + mi;
-        const bool mok = m < a.M;
-        uint4 rres[(NT + 1) / 2];
-        if (R) {
+    {
+        const bf16_t* p = rowptr(grp < ngroups ? grp : 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xa[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
+    }
+    // per-sample DropPath scale of the residual form, one group ahead like the rows (a null table reads a constant 1)
+    const float* rsp = a.rscale ? a.rscale : &skinny_one;
+    float rsn;
+    {
+        const int64_t m0_ = (grp < ngroups ? grp : 0) * 16 + mi;
+        rsn = rsp[a.rscale ? (m0_ < a.M ? m0_ : a.M - 1) / a.rpg : 0];
+    }
+    // One group of 16 tokens.  FULL = every row exists and HASR = a residual operand are compile-time: all loads and stores of
+    // the main loop are unconditional, so the compiler waits for the prefetched rows with a counted vmcnt and the group's stores
+    // stay in flight (a guarded store or load forces vmcnt(0): the wave drained its stores before every next group).
+    auto one_group = [&](int64_t gp, auto full_tag, auto r_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, HASR = decltype(r_tag)::value;
+        {
+            const int64_t nxt = gp + gstride;
+            const bf16_t* p = rowptr(nxt < ngroups ? nxt : gp);           // unconditional (the last one re-reads)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
+            SEGF_LOADS_ISSUED();                                          // (or the scheduler sinks the prefetch down to the stores)
+        }
+        const int64_t m = gp * 16 + mi;
+        const bool mok = FULL || m < a.M;
+        const float rs = rsn;                                             // this group's DropPath scale (loaded one group ahead)
+        if (HASR) {
+            const int64_t nxt = gp + gstride, mn = (nxt < ngroups ? nxt : gp) * 16 + mi;
+            rsn = rsp[a.rscale ? (mn < a.M ? mn : a.M - 1) / a.rpg : 0];
+        }
+        u32x4 rres[(NT + 1) / 2];
+        if (HASR) {
             const bf16_t* rp = R + (mok ? m : a.M - 1) * a.ldr + n0 + 8 * g;
 #pragma unroll
-            for (int q = 0; q < (NT + 1) / 2; ++q) rres[q] = *reinterpret_cast<const uint4*>(rp + 32 * q);
+            for (int q = 0; q < (NT + 1) / 2; ++q) rres[q] = *reinterpret_cast<const u32x4*>(rp + 32 * q);
         }
         f32x4 acc[NT];
 #pragma unroll
@@ -988,15 +1014,13 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
             for (int s = 0; s < KS; ++s)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], __builtin_bit_cast(bf16x8, xa[s]), acc[nt], 0, 0, 0);
         }
-        const float rs = a.rscale ? a.rscale[(mok ? m : 0) / a.rpg] : 1.f;
 #pragma unroll
         for (int q = 0; q < NT / 2; ++q) {
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][r] + bv[2 * q][r]; v[4 + r] = acc[2 * q + 1][r] + bv[2 * q + 1][r]; }
-            if (R) {
-                const uint4 u = rres[q];
-                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            if (HASR) {
+                const u32x4 w = rres[q];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     v[2 * j] = __uint_as_float(w[j] << 16) + rs * v[2 * j];
@@ -1015,15 +1039,137 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs a) {
             for (int i = 0; i < (16 * CPR) / 64; ++i) {
                 const int idx = lane + 64 * i, row = idx / CPR, cc = idx - row * CPR;
                 const uint4 o = *reinterpret_cast<const uint4*>(ost + row * SROW + 16 * cc);
-                const int64_t mr = grp * 16 + row;
-                if (mr < a.M) *reinterpret_cast<uint4*>(C + mr * a.ldc + n0 + 8 * cc) = o;
+                const int64_t mr = gp * 16 + row;
+                if (FULL || mr < a.M) *reinterpret_cast<uint4*>(C + mr * a.ldc + n0 + 8 * cc) = o;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xa[s] = xb[s];
+        for (int s = 0; s < KS; ++s) {
+            xa[s] = xb[s];
+            asm volatile("" : "+v"(xa[s]));       // keep the copy (and its counted wait) here, behind this group's stores
+        }
+    };
+    const int64_t nfull = a.M / 16;                                       // groups whose 16 rows all exist
+    // everything loaded so far is consumed here once: otherwise its first use sits inside the loop and the loop header gets a
+    // vmcnt(0) that also waits for the previous group's stores on every trip
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) asm volatile("" : "+v"(Wf[nt][s2]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bv[nt][r]));
     }
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) asm volatile("" : "+v"(xa[s2]));
+    asm volatile("" : "+v"(rsn));
+    if (R) {
+        for (; grp < nfull; grp += gstride) one_group(grp, std::true_type{}, std::true_type{});
+        if (grp < ngroups) one_group(grp, std::false_type{}, std::true_type{});
+    } else {
+        for (; grp < nfull; grp += gstride) one_group(grp, std::true_type{}, std::false_type{});
+        if (grp < ngroups) one_group(grp, std::false_type{}, std::false_type{});     // at most one ragged group, in one wave
+    }
+}
+
+// Wide-output form of the streaming product (layout 0, N = NCH chunks of 128 features, e.g. the folded head's [2M x 32] -> 768
+// projection): with the column chunks as separate workgroups every output row was written in six 256-byte pieces at six
+// different times (847 us = 3.9 TB/s for a product that is 96 % stores).  Here the whole weight matrix sits in LDS in fragment
+// order (N x K bf16 <= 48 KB), a wave loops over the chunks for its 16 tokens, stages the [16 x N] result in its own LDS slab and
+// writes WHOLE rows (N * 2 bytes contiguous per token, 16 bytes per lane).  No residual operand (bias only).
+template <int KS, int NCH>
+__global__ void __launch_bounds__(256) gemm_skinny_rows_kernel(GemmArgs a) {
+    constexpr int NT = 8, NF = NCH * NT * KS;                         // fragments of 1 KB
+    constexpr int SROW = NCH * 256 + 16;                              // staged output row bytes
+    __shared__ __attribute__((aligned(16))) unsigned char wlds[NF * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char ostage[4][16 * SROW];
+    __shared__ float blds[NCH * 128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mi = lane & 15, g = lane >> 4;
+    const bf16_t* __restrict__ A = static_cast<const bf16_t*>(a.A);
+    const bf16_t* __restrict__ B = static_cast<const bf16_t*>(a.B);
+    bf16_t* __restrict__ C = static_cast<bf16_t*>(a.C);
+    // fragment (chunk c, tile nt, step s), lane (mi, g): 16 bytes of weight row n = 128 c + 32 (nt >> 1) + 8 (mi >> 2) + 4 (nt & 1) + (mi & 3)
+    for (int f = wave; f < NF; f += 4) {
+        const int s = f % KS, nt = (f / KS) % NT, c = f / (KS * NT);
+        const int n = 128 * c + 32 * (nt >> 1) + 8 * (mi >> 2) + 4 * (nt & 1) + (mi & 3);
+        *reinterpret_cast<uint4*>(wlds + f * 1024 + lane * 16) = *reinterpret_cast<const uint4*>(B + (int64_t)n * a.ldb + 32 * s + 8 * g);
+    }
+    for (int i = threadIdx.x; i < NCH * 128; i += 256) blds[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+    unsigned char* ost = ostage[wave];
+    const int64_t ngroups = (a.M + 15) / 16, gstride = (int64_t)gridDim.x * 4;
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 xa[KS], xb[KS];
+    auto rowptr = [&](int64_t gp) {
+        int64_t m = gp * 16 + mi;
+        m = m < a.M ? m : a.M - 1;
+        return A + m * a.lda + 8 * g;
+    };
+    {
+        const bf16_t* p = rowptr(grp < ngroups ? grp : 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xa[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
+    }
+    // One group of 16 tokens.  FULL = every row exists: all loads and stores unconditional, so that the compiler can count them
+    // and wait for the prefetched rows with vmcnt(#stores) -- with a guarded store it waits vmcnt(0), i.e. for the 24 KB of stores
+    // of the group to DRAIN, before every next group (the wave then alternates between computing and draining: 4.5 TB/s).
+    auto one_group = [&](int64_t gp, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        {
+            const int64_t nxt = gp + gstride;
+            const bf16_t* p = rowptr(nxt < ngroups ? nxt : gp);           // unconditional (the last one re-reads)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
+            SEGF_LOADS_ISSUED();                                          // (or the scheduler sinks the prefetch down to the stores)
+        }
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wlds + ((c * NT + nt) * KS + s) * 1024 + lane * 16));
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xa[s]), acc[nt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NT / 2; ++q) {
+                const float4 b0 = *reinterpret_cast<const float4*>(blds + 128 * c + 32 * q + 8 * g);
+                const float4 b1 = *reinterpret_cast<const float4*>(blds + 128 * c + 32 * q + 8 * g + 4);
+                uint4 o;
+                o.x = pack2bf(acc[2 * q][0] + b0.x, acc[2 * q][1] + b0.y); o.y = pack2bf(acc[2 * q][2] + b0.z, acc[2 * q][3] + b0.w);
+                o.z = pack2bf(acc[2 * q + 1][0] + b1.x, acc[2 * q + 1][1] + b1.y); o.w = pack2bf(acc[2 * q + 1][2] + b1.z, acc[2 * q + 1][3] + b1.w);
+                *reinterpret_cast<uint4*>(ost + mi * SROW + (128 * c + 32 * q + 8 * g) * 2) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            constexpr int CPR = NCH * 16;                                 // 16-byte chunks per output row
+#pragma unroll
+            for (int i = 0; i < (16 * CPR) / 64; ++i) {
+                const int idx = lane + 64 * i, row = idx / CPR, cc = idx - row * CPR;
+                const uint4 o = *reinterpret_cast<const uint4*>(ost + row * SROW + 16 * cc);
+                const int64_t mr = gp * 16 + row;
+                if (FULL || mr < a.M) *reinterpret_cast<uint4*>(C + mr * a.ldc + 8 * cc) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xa[s] = xb[s];
+            asm volatile("" : "+v"(xa[s]));
+        }
+    };
+    const int64_t nfull = a.M / 16;                                       // groups whose 16 rows all exist
+    for (; grp < nfull; grp += gstride) one_group(grp, std::true_type{});
+    if (grp < ngroups) one_group(grp, std::false_type{});                 // at most one ragged group, in one wave
 }
 
 // shapes the streaming kernel takes: bf16 in/out, layouts 0/1, K in {32, 64, 128}, N a multiple of the chunk width,
@@ -1344,6 +1490,14 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     if (dt == SEGF_BF16) {
         if (!pro && c_dt == SEGF_BF16 && split_k == 1 && a.a_vec && a.c_vec16 && (!residual || a.r_vec) &&
             (layout == 1 || a.b_vec) && !getenv("SEGFAC_GEMM_NO_SKINNY")) {
+            if (layout == 0 && !residual && K == 32 && N == 768 && M >= 65536 && a.b_vec && !getenv("SEGFAC_GEMM_NO_SKINNY_ROWS")) {
+                const int64_t groups = cdiv64(M, 16);
+                int64_t gx = cdiv64(groups, 4 * 8);
+                if (gx > 1024) gx = 1024;
+                hipLaunchKernelGGL((gemm_skinny_rows_kernel<1, 6>), dim3((unsigned)gx), dim3(256), 0, st, a);
+                SEGF_CHECK_LAUNCH();
+                return 0;
+            }
             const int nt = gemm_skinny_nt(layout, M, N, K);
             if (nt) {
                 const int64_t groups = cdiv64(M, 16);

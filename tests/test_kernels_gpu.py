@@ -736,6 +736,27 @@ def test_gemm_big_tile_variant(hipmod, layout):
         assert err <= 1.2e-2 * full.abs().max().item()       # one bf16 rounding of the output
 
 
+def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
+    """[M x 32] -> 768 with M >= 65536 (the folded head's stage-1 projection): the whole-row form (weights in LDS, a wave writes
+    complete 1536-byte rows) against fp64 and against the column-chunk form (switch): identical products, identical rounding."""
+    M, K, N = 65536 + 16 * 37 + 5, 32, 768
+    g = torch.Generator().manual_seed(91)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    out = hipmod.gemm(0, ad, wd, M, N, K, bias=bd)
+    monkeypatch.setenv('SEGFAC_GEMM_NO_SKINNY_ROWS', '1')
+    out2 = hipmod.gemm(0, ad, wd, M, N, K, bias=bd)
+    monkeypatch.delenv('SEGFAC_GEMM_NO_SKINNY_ROWS')
+    nob = hipmod.gemm(0, ad, wd, M, N, K)
+    torch.cuda.synchronize()
+    assert (out.double().cpu() - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+    assert torch.equal(out, out2)
+    assert (nob.double().cpu() - (ref - bias.double())).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('case', [(0, 256 * 40 + 72, 150, 768, 160), (0, 256 * 33, 160, 200, 160), (0, 256 * 34 + 8, 137, 136, 144),
                                   (2, 150, 768, 70000, 160), (2, 160, 392, 66000, 160), (2, 131, 520, 65536 + 8, 136), (2, 200, 392, 70000, 200)])
 def test_gemm_big_tile_narrow_shapes(hipmod, case, monkeypatch):
