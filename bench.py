@@ -253,8 +253,10 @@ def main():
             for kname, v in pmc['kernels'].items():
                 if kname.startswith('ce_dice_bwd'):        # the retry kernel shares the prefix and moves no data: keep the larger
                     traffic['loss_bwd'] = max(traffic.get('loss_bwd', 0), v['total_bytes'])
-                if kname.startswith('gemm_bf16_big_kernel<0') and kname.rstrip('>').endswith('true'):
-                    traffic['gemm_pro'] = v['total_bytes']
+                if kname.startswith('gemm_bf16_big_kernel<0'):        # template arguments: layout, out type, CONV, PRO, SHAPE, DEEP
+                    targs = [t.strip() for t in kname[kname.index('<') + 1:kname.rindex('>')].split(',')]
+                    if len(targs) > 3 and targs[3] == 'true':
+                        traffic['gemm_pro'] = max(traffic.get('gemm_pro', 0), v['total_bytes'])
     except (OSError, ValueError, KeyError):
         pass
     if rank == 0:
@@ -292,7 +294,7 @@ def main():
                          "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~3 VALU "
                                  "ops; interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
-            "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true> (segf_gemm_pro, the in-graph variant): classifier 1x1 conv "
+            "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true, SHAPE=1, DEEP=true> (segf_gemm_pro, the in-graph variant; narrow 64x80 wave tiles, two K steps in flight): classifier 1x1 conv "
                                         f"[B*{hq}*{wq},768]x[768,{ld}] with BatchNorm + ReLU + Dropout2d applied on the operand load" if use_pro else
                                         f"gemm_bf16_big_kernel<0>: classifier 1x1 conv [B*{hq}*{wq},768]x[768,{ld}]",
                               "bound": "hbm", "achieved": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
