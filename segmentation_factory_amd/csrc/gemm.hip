@@ -1532,6 +1532,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     } while (0)
             // partly filled workgroup tiles: the narrow wave shapes (see the kernel's header)
             const bool narrow_n = layout == 0 && !f32o && N <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
+            const bool narrow_n1 = layout == 1 && !f32o && !a.pro_scale && N <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
             const bool narrow_m = layout == 2 && f32o && M <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
             const bool deep = layout == 0 && split_k == 1 && (a.a_vec & 2) && (a.b_vec & 2) && K % GB_BK == 0 && K >= 2 * GB_BK &&
                               (!a.pro_scale || a.pro_ld <= 1024) && !getenv("SEGFAC_GEMM_NO_DEEP");
@@ -1547,6 +1548,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
             } else if (narrow_n && deep) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, false, 1, true>), gridb, dim3(GG_THREADS), 0, st, a);
             else if (narrow_n) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);
             else if (narrow_m) hipLaunchKernelGGL((gemm_bf16_big_kernel<2, float, false, false, 2>), gridb, dim3(GG_THREADS), 0, st, a);
+            else if (narrow_n1) hipLaunchKernelGGL((gemm_bf16_big_kernel<1, bf16_t, false, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);
             else
             if (layout == 0) LAUNCH_G(0); else if (layout == 1) LAUNCH_G(1); else LAUNCH_G(2);
 #undef LAUNCH_G

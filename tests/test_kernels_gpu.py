@@ -758,6 +758,7 @@ def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
 
 
 @pytest.mark.parametrize('case', [(0, 256 * 40 + 72, 150, 768, 160), (0, 256 * 33, 160, 200, 160), (0, 256 * 34 + 8, 137, 136, 144),
+                                  (1, 256 * 50 + 24, 160, 640, 160), (1, 256 * 49, 152, 328, 152),
                                   (2, 150, 768, 70000, 160), (2, 160, 392, 66000, 160), (2, 131, 520, 65536 + 8, 136), (2, 200, 392, 70000, 200)])
 def test_gemm_big_tile_narrow_shapes(hipmod, case, monkeypatch):
     """The 256-tile kernel's narrow wave shapes (N <= 160 in layout 0: 4 x 2 waves of 64 x 80; M <= 160 in layout 2: 2 x 4 waves of
@@ -765,7 +766,21 @@ def test_gemm_big_tile_narrow_shapes(hipmod, case, monkeypatch):
     ragged M / K, bias + residual epilogue (layout 0) and split-K partials (layout 2)."""
     layout, M, N, K, ld = case
     g = torch.Generator().manual_seed(5 + layout)
-    if layout == 0:
+    if layout == 1:
+        # dx = dy W with W [K][N] (reduction-major second operand), N <= 160
+        a = torch.randn(M, K, generator=g).bfloat16()
+        wb = (torch.randn(K, ld, generator=g) / K ** 0.5).bfloat16()
+        ref = a.double() @ wb[:, :N].double()
+        ad, wd = a.cuda(), wb.cuda()
+        outs = []
+        for env in (None, '1'):
+            if env: monkeypatch.setenv('SEGFAC_GEMM_NO_NARROW', env)
+            outs.append(hipmod.gemm(1, ad, wd[:, :N], M, N, K).clone())
+        monkeypatch.delenv('SEGFAC_GEMM_NO_NARROW')
+        for out in outs:
+            assert (out.double().cpu() - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+        assert torch.equal(outs[0], outs[1])
+    elif layout == 0:
         a = torch.randn(M, K, generator=g).bfloat16()
         wb = torch.zeros(ld, K).bfloat16()
         wb[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
