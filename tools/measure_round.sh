@@ -15,6 +15,8 @@ python3 $R/tools/rocpd_summary.py $O/prof/stats_results.db --csv $O/${TAG}_bench
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
 cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch 128 --out $O/pmc_traffic_b128.json > $O/pmc_top.txt 2>&1
+# the default line once more with the counter file just taken (same sources: bench.py reports roofline.traffic from it)
+cp $O/pmc_traffic_b128.json $R/profiles/pmc_traffic_b128.json && python3 bench.py > $O/${TAG}_bench_b128_final.json 2>> $O/bench.err
 for b in 4 16 32; do python3 bench.py --batch $b --no-cpu-baseline > $O/${TAG}_bench_b${b}.json 2>> $O/bench.err; done
 python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline > $O/${TAG}_bench_cfg3_b32.json 2>> $O/bench.err
 python3 bench.py --config cfg4 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_cfg4_b16.json 2>> $O/bench.err
