@@ -62,9 +62,8 @@ class Attention(nn.Module):
 
     def tokens(self, h, B, H, W, residual, rscale):
         N = H * W
-        h, h2 = Fh.fork(h, 2)                        # two consumers (q and the key / value path): gradients joined by segf_add
-        q = Fh.linear(h, self.q.weight, self.q.bias)
-        h = h2
+        # two consumers (q and the key / value path): the key / value path's gradient joins inside q's data-gradient product
+        q, h = Fh.linear_fork(h, self.q.weight, self.q.bias)
         if self.sr_ratio > 1:
             sr = self.sr_ratio
             xr = Fh.conv_patch(h, self.sr.weight, self.sr.bias, (B, H, W, self.dim, sr, sr, 0))

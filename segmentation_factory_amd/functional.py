@@ -204,6 +204,48 @@ class LinearFn(Function):
         return dx, dw, db, dres, None, None, None, None
 
 
+@direct_grads(1, 2)
+class LinearForkFn(Function):
+    """(y, x') = (x W^T + bias, x): a Linear whose input has a second consumer (MiT attention: q = Linear(h) while h also feeds
+    the key / value path, mit.py:52-53).  The second consumer's gradient arrives as an argument of this backward and rides into
+    the data-gradient product as its residual operand, dx = dx' + dy W, instead of a separate add launch per block."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _rowmajor(x)
+        M, K = x.shape
+        N = weight.shape[0]
+        w = _w(weight.reshape(N, -1), x.dtype)
+        y = hip.gemm(0, x, w, M, N, K, bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(x, w)
+        ctx.meta = (M, N, K, bias is not None, weight.shape)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dx2):
+        x, w = ctx.saved_tensors
+        M, N, K, has_bias, wshape = ctx.meta
+        dy = _rowmajor(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.gemm(1, dy, w, M, K, N, residual=_rowmajor(dx2) if dx2 is not None else None)
+        gw, gb = gslot(ctx, 1, (N, K)), gslot(ctx, 2)
+        if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
+            dw, db = hip.gemm_dw_db(dy, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)
+            dw = dw.view(wshape)
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = hip.gemm(2, dy, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dy, out=gb)
+        return dx, dw, db
+
+
+def linear_fork(x, weight, bias=None):
+    """(Linear(x), alias of x for a second consumer) -- see LinearForkFn"""
+    return LinearForkFn.apply(x, weight, bias)
+
+
 def linear(x, weight, bias=None, residual=None, rscale=None, rows_per_group=None, pad_to=None, fp8=False):
     return LinearFn.apply(x, weight, bias, residual, rscale, rows_per_group, pad_to, fp8)
 
