@@ -417,15 +417,16 @@ class ConvPatchFn(Function):
         M = B * Ho * Wo
         dy = _rowmajor(dy)
         dx = dw = db = None
+        gw, gb = gslot(ctx, 1), gslot(ctx, 2)                # flat-gradient views: the permute / column sum write in place
         if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
-            dwm, db = hip.gemm_dw_db(dy, col, O, K, M, split_k=_splitk(O, K, M))                      # [O][(ky,kx)][ci]
-            dw = hip.permute021(dwm, O, k * k, Cin, torch.float32).view(wshape)
+            dwm, db = hip.gemm_dw_db(dy, col, O, K, M, split_k=_splitk(O, K, M), db_out=gb)           # [O][(ky,kx)][ci]
+            dw = hip.permute021(dwm, O, k * k, Cin, torch.float32, out=gw).view(wshape)
         else:
             if ctx.needs_input_grad[1]:
                 dwm = hip.gemm(2, dy, col, O, K, M, out_dtype=torch.float32, split_k=_splitk(O, K, M))
-                dw = hip.permute021(dwm, O, k * k, Cin, torch.float32).view(wshape)
+                dw = hip.permute021(dwm, O, k * k, Cin, torch.float32, out=gw).view(wshape)
             if has_bias and ctx.needs_input_grad[2]:
-                db = hip.colsum(dy)
+                db = hip.colsum(dy, out=gb)
         if ctx.needs_input_grad[0] and not image:
             dcol = hip.gemm(1, dy, wmat, M, K, O)
             dx = hip.col2im(dcol, B, H, W, Cin, k, k, stride, pad, Ho, Wo)
@@ -484,7 +485,8 @@ class DWConvGeluFn(Function):
         x, w9, b = ctx.saved_tensors
         B, H, W, Cc, apply_gelu, wshape = ctx.meta
         dy = dy if dy.is_contiguous() else dy.contiguous()
-        dx, dw, db = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, apply_gelu)
+        gw, gb = gslot(ctx, 1), (gslot(ctx, 2) if b is not None else None)       # flat-gradient views: written in place, no copy
+        dx, dw, db = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, apply_gelu, dw_out=gw, db_out=gb)
         return dx, dw.view(wshape), (db if b is not None else None), None, None, None, None
 
 

@@ -180,11 +180,14 @@ def cast2d(src: torch.Tensor, dst: torch.Tensor):
     return dst
 
 
-def permute021(x: torch.Tensor, A: int, Bd: int, Cd: int, out_dtype: torch.dtype, ld_out=None) -> torch.Tensor:
-    """out[a][c][b] = in[a][b][c]; last dim zero-padded to ld_out."""
+def permute021(x: torch.Tensor, A: int, Bd: int, Cd: int, out_dtype: torch.dtype, ld_out=None, out=None) -> torch.Tensor:
+    """out[a][c][b] = in[a][b][c]; last dim zero-padded to ld_out.  out: optional contiguous destination of A * Cd * ld_out elements."""
     _need_cuda(x)
     ld_out = Bd if ld_out is None else ld_out
-    out = torch.empty((A, Cd, ld_out), dtype=out_dtype, device=x.device)
+    if out is None:
+        out = torch.empty((A, Cd, ld_out), dtype=out_dtype, device=x.device)
+    else:
+        assert out.is_contiguous() and out.numel() == A * Cd * ld_out and out.dtype == out_dtype
     _chk(lib().segf_permute021(_ptr(x), dt_of(x), _ptr(out), BF16 if out_dtype == torch.bfloat16 else F32,
                                A, Bd, Cd, ld_out, _stream()), 'segf_permute021')
     return out
@@ -531,11 +534,12 @@ def dwconv3x3_gelu_fwd(x, w9, bias, B, H, W, Cc, apply_gelu=True):
     return y
 
 
-def dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, Cc, apply_gelu=True):
+def dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, Cc, apply_gelu=True, dw_out=None, db_out=None):
     du = torch.empty_like(x)
     dx = torch.empty_like(x)
-    dw = torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
-    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dw = dw_out if dw_out is not None else torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
+    db = db_out if db_out is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)
+    assert dw.is_contiguous() and dw.numel() == Cc * 9 and db.is_contiguous() and db.numel() == Cc and dw.dtype == db.dtype == torch.float32
     ws = _f32(lib().segf_dwconv3x3_bwd_ws(B, H, W, Cc), x.device)
     _chk(lib().segf_dwconv3x3_gelu_bwd(dt_of(x), B, H, W, Cc, _ptr(x), _ptr(w9), _ptr(bias), int(apply_gelu), _ptr(dy),
                                        _ptr(du), _ptr(dx), _ptr(dw), _ptr(db), _ptr(ws), _stream()),
