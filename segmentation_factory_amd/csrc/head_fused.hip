@@ -57,6 +57,16 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
     // buffered, one barrier per 32 tokens) instead of once per wave -- with per-wave global loads the dy rows crossed the
     // L2 -> CU path 24 times per pass and cost 1.5 of the 4.0 ms (measured by removing them).
     __shared__ __attribute__((aligned(16))) bf16_t tile[2][TOK][RS];
+    // x (and dx in pass 2) also travel through LDS, cooperatively and in whole 512-byte row runs: a wave owns 32 features, so
+    // its own accesses were 64-byte pieces of 16 rows per instruction; with contiguous accesses both passes measured 2.60 -> 1.78 ms
+    // (upper bound, wrong layout), the staged form below is what that buys with the LDS round trip and the second barrier.
+    constexpr int XW = 32 * HF_WAVES;                       // features per workgroup
+    constexpr int XRS = XW + 8;                             // LDS row stride in bf16
+    constexpr int XCH = TOK * (XW / 8);                     // 16-byte chunks of one x tile
+    constexpr int XPT = XCH / (64 * HF_WAVES);              // per thread
+    static_assert(XCH % (64 * HF_WAVES) == 0, "x tile chunks must divide evenly over the workgroup");
+    __shared__ __attribute__((aligned(16))) bf16_t xt[2][TOK][XRS];
+    __shared__ __attribute__((aligned(16))) bf16_t ot[PASS == 2 ? TOK : 1][XRS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mi = lane & 15, g = lane >> 4;
     // 1-D grid, XCD-aware logical id L = (token chunk, feature slice) with the slice fastest: the workgroups that cover the whole
@@ -139,21 +149,31 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
         if (CPT > 1) stash_one(bufi, (int)threadIdx.x + 64 * HF_WAVES, stg1);
         if (CPT > 2) stash_one(bufi, (int)threadIdx.x + 128 * HF_WAVES, stg2);
     };
-    uint4 xa[HF_U], xb[HF_U];
-    auto load_x = [&](int gp, uint4 (&xv)[HF_U]) {
+    typedef uint32_t hf_u32x4 __attribute__((ext_vector_type(4)));
+    hf_u32x4 xs[XPT];                                        // this thread's chunks of the NEXT x tile
+    const int wg_f0 = slice * XW;                            // first feature of the workgroup
+    auto fetch_x = [&](int gp) {
 #pragma unroll
-        for (int u = 0; u < HF_U; ++u) {
-            int64_t m = row0 + (int64_t)(gp + u) * 16 + mi;
+        for (int i = 0; i < XPT; ++i) {
+            const int q = (int)threadIdx.x + 64 * HF_WAVES * i, tk = q / (XW / 8), c16 = q % (XW / 8);
+            int64_t m = row0 + (int64_t)gp * 16 + tk;
             m = m <= last_row ? m : last_row;
-            xv[u] = *reinterpret_cast<const uint4*>(a.x + m * a.C + f0);
+            xs[i] = *reinterpret_cast<const hf_u32x4*>(a.x + m * a.C + wg_f0 + 8 * c16);
         }
     };
-    if (gbeg < gend) { fetch_tile(gbeg); load_x(gbeg, xa); stash_tile(0); }
+    auto stash_x = [&](int bufi) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int q = (int)threadIdx.x + 64 * HF_WAVES * i, tk = q / (XW / 8), c16 = q % (XW / 8);
+            *reinterpret_cast<hf_u32x4*>(&xt[bufi][tk][8 * c16]) = xs[i];
+        }
+    };
+    if (gbeg < gend) { fetch_tile(gbeg); fetch_x(gbeg); stash_tile(0); stash_x(0); }
     __syncthreads();
     int bufi = 0;
     for (int gp = gbeg; gp < gend; gp += HF_U) {
         const bool more = gp + HF_U < gend;
-        if (more) { fetch_tile(gp + HF_U); load_x(gp + HF_U, xb); }
+        if (more) { fetch_tile(gp + HF_U); fetch_x(gp + HF_U); }
 #pragma unroll
         for (int u = 0; u < HF_U; ++u) {
             hf_f32x4 acc[NT];
@@ -166,7 +186,8 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], yv, acc[nt], 0, 0, 0);
             }
             const bool live = gp + u < gend;
-            const uint32_t xw[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w};
+            const hf_u32x4 xv4 = *reinterpret_cast<const hf_u32x4*>(&xt[bufi][16 * u + mi][32 * wave + 8 * g]);
+            const uint32_t xw[4] = {xv4[0], xv4[1], xv4[2], xv4[3]};
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -182,10 +203,9 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
                     o[j] = fmaf(E[j], gm, -fmaf(xv, Q[j], P[j]));
                 }
             }
-            if (PASS == 2 && live) {
-                uint4 ov;
-                ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]); ov.z = pack2bf(o[4], o[5]); ov.w = pack2bf(o[6], o[7]);
-                *reinterpret_cast<uint4*>(a.dx + (row0 + (int64_t)(gp + u) * 16 + mi) * a.C + f0) = ov;
+            if (PASS == 2) {
+                const hf_u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+                *reinterpret_cast<hf_u32x4*>(&ot[16 * u + mi][32 * wave + 8 * g]) = ov;
             }
         }
         // keep the LDS writes of the prefetched tile BELOW the arithmetic: hoisted above it (the compiler sees no dependence) they
@@ -194,10 +214,19 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
         asm volatile("" ::: "memory");
         if (more) {
             stash_tile(bufi ^ 1);
-#pragma unroll
-            for (int u = 0; u < HF_U; ++u) xa[u] = xb[u];
+            stash_x(bufi ^ 1);
         }
-        __syncthreads();                 // the next tile is complete, and nobody still reads the buffer that gets overwritten next
+        __syncthreads();                 // the next tiles are complete, and nobody still reads the buffers that get overwritten next
+        if (PASS == 2) {                 // the dx tile leaves in whole 512-byte row runs (rows of dead groups are dropped)
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int q = (int)threadIdx.x + 64 * HF_WAVES * i, tk = q / (XW / 8), c16 = q % (XW / 8);
+                const hf_u32x4 ov = *reinterpret_cast<const hf_u32x4*>(&ot[tk][8 * c16]);
+                if (gp + (tk >> 4) < gend)
+                    *reinterpret_cast<hf_u32x4*>(a.dx + (row0 + (int64_t)gp * 16 + tk) * a.C + wg_f0 + 8 * c16) = ov;
+            }
+            __syncthreads();             // ot is free again
+        }
         bufi ^= 1;
     }
     if (PASS == 1) {
