@@ -356,7 +356,8 @@ def test_upsample_ce_dice_retry_and_reproducible():
 
 
 @pytest.mark.parametrize('cfg', [(2, 150, 16, 23, 160, False), (2, 19, 32, 64, 32, True), (1, 171, 9, 7, 176, False), (2, 40, 9, 30, 40, True),
-                                 (1, 2, 5, 5, 8, False), (2, 150, 40, 40, 152, True)])
+                                 (1, 2, 5, 5, 8, False), (2, 150, 40, 40, 152, True), (1, 64, 8, 8, 64, False), (1, 32, 8, 13, 32, True),
+                                 (1, 192, 8, 8, 192, False), (2, 128, 10, 9, 128, True), (1, 16, 3, 50, 16, False)])
 def test_loss_backward_band_kernel_vs_tile_kernel_and_oracle(cfg, monkeypatch):
     """bf16, ratio 4: the band-sweep backward (loss_band.hip) against the tile kernel it replaces (same library, env switch) and
     against the fp32 oracle on the same bf16-rounded logits; two runs bitwise equal; pad columns exactly zero.  Shapes cover
@@ -755,6 +756,36 @@ def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
     assert (out.double().cpu() - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
     assert torch.equal(out, out2)
     assert (nob.double().cpu() - (ref - bias.double())).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 70, 9, 8, True), (1, 5, 131, 16, True), (3, 16, 16, 40, False), (1, 130, 6, 136, True)])
+def test_dwconv3x3_walk_equals_strip_form(dtype, shape, monkeypatch):
+    """Depthwise 3x3 (+GELU) forward and backward: the vertical-walk kernels against the strip kernels they replace (switch), on
+    heights that do not divide into the row segments, widths that are no multiple of the 4-pixel column and few / many channels.
+    Same multiply-adds in another order: fp32 agrees to rounding, bf16 to one ulp of the stored result."""
+    from segmentation_factory_amd import hip
+    B, H, W, C, gelu = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B * H * W, C, generator=g).to(dtype).cuda()
+    dy = torch.randn(B * H * W, C, generator=g).to(dtype).cuda()
+    w9 = (torch.randn(C, 9, generator=g) * 0.3).cuda()
+    bias = torch.randn(C, generator=g).cuda()
+    outs = {}
+    for name, env, rows in (('walk', None, None), ('walk5', None, '5'), ('strip', '1', None)):
+        if env: monkeypatch.setenv('SEGFAC_DW_NO_WALK', env)
+        if rows: monkeypatch.setenv('SEGFAC_DW_WALK_ROWS', rows)
+        y = hip.dwconv3x3_gelu_fwd(x, w9, bias, B, H, W, C, gelu)
+        dx, dw, db = hip.dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, C, gelu)
+        torch.cuda.synchronize()
+        outs[name] = [t.float().cpu().clone() for t in (y, dx, dw, db)]
+        monkeypatch.delenv('SEGFAC_DW_NO_WALK', raising=False)
+        monkeypatch.delenv('SEGFAC_DW_WALK_ROWS', raising=False)
+    tol = 2e-5 if dtype == torch.float32 else 1.6e-2
+    for name in ('walk', 'walk5'):
+        for a, b_, what in zip(outs[name], outs['strip'], ('y', 'dx', 'dw', 'db')):
+            scale = b_.abs().max().item() + 1e-6
+            assert (a - b_).abs().max().item() <= tol * scale, (name, what, (a - b_).abs().max().item(), scale)
 
 
 @pytest.mark.parametrize('case', [(0, 256 * 40 + 72, 150, 768, 160), (0, 256 * 33, 160, 200, 160), (0, 256 * 34 + 8, 137, 136, 144),
