@@ -1429,7 +1429,10 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
 // layout 2 = dW = dy^T act(x s + t).  Only the 256-tile kernel implements it: ask segf_gemm_pro_supported first.
 extern "C" int segf_gemm_pro_supported(int dt, int layout, int64_t M, int64_t N, int64_t K, int64_t rows_per_group) {
     if (dt != SEGF_BF16 || (layout != 0 && layout != 2) || rows_per_group <= 0) return 0;
-    if (!gemm_use_big(layout, M, N, K) || K % GB_BK) return 0;
+    // (the 256-tile kernel is used whenever the prologue is requested, also for outputs narrower than its usual threshold: the
+    // 19-class heads of the Cityscapes configurations run its narrow wave shapes with some waves idle, which a product that
+    // streams a [tokens x 768] operand does not notice)
+    if ((layout == 0 ? M : K) < 4096 || K % GB_BK || (layout == 2 && K < 32768)) return 0;
     { const char* e = getenv("SEGFAC_GEMM_NO_TR"); if (e && e[0] == '1') return 0; }
     if (getenv("SEGFAC_GEMM_NO_PRO")) return 0;
     if (layout == 0) return (rows_per_group % GG_B == 0 && K % 8 == 0) ? 1 : 0;
@@ -1521,7 +1524,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                 if (ok) { SEGF_CHECK_LAUNCH(); goto reduce; }
             }
         }
-        if (gemm_use_big(layout, M, N, K) && a.use_tr) {
+        if ((gemm_use_big(layout, M, N, K) || pro) && a.use_tr) {
             dim3 gridb((unsigned)cdiv64(N, GG_B), (unsigned)cdiv64(M, GG_B), (unsigned)split_k);
             if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
             const bool f32o = c_dt == SEGF_F32 || a.ws;
