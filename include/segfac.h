@@ -313,6 +313,37 @@ int segf_agc_adamw(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float clip_factor, float agc_eps, void* stream);
 
+/* ---- device-side input pipeline over decoded uint8 images resident in HBM ---------------------------
+ * segf_input_train: ExtRandomCrop -> ExtColorJitter -> ExtRandomHorizontalFlip -> ExtToTensor -> ExtNormalize
+ * (datasets/build_datasets.py:14-22; datasets/extra_transform.py:319-392, 426-509, 196-214, 259-281, 288-313) and the dataset
+ * classes' label table + .long() (datasets/ade.py:122-124, cityscapes.py:159, coco_stuff.py:95-100) for a batch of B samples
+ * cropped to H x W.  Pillow's uint8 arithmetic (ImagingBlend, rgb2l, ImageStat mean) bit for bit; the float tail
+ * ((u8 / 255) / 255 - mean) / std keeps the reference's second / 255 (quirk Q11).  One segf_input_sample per image: packed RGB
+ * rows (img_stride bytes apart) and uint8 label rows; the crop window starts at (top, left) and reads 0 outside the source
+ * (Image.crop); `order` lists the jitter steps in application order, 2 bits each (1 brightness, 2 contrast, 3 saturation,
+ * 0 end), factor[k] belongs to step k; the random values are drawn by the caller.  lsum_ws: B x uint64 (luma sums for the
+ * contrast means); label_lut nullable (int64[256]; identity when null).  out_img fp32 [B][3][H][W], out_lbl int64 [B][H][W]. */
+typedef struct {
+    const uint8_t* img;
+    const uint8_t* lbl;
+    int64_t img_stride, lbl_stride;
+    int32_t src_h, src_w, top, left;
+    int32_t flip, order;
+    float factor[3];
+    int32_t reserved;
+} segf_input_sample;                                                     /* 72 bytes */
+int segf_input_train(const segf_input_sample* samples /*device [B]*/, int B, int H, int W, uint64_t* lsum_ws, const float* mean3,
+                     const float* std3, const int64_t* label_lut, float* out_img, int64_t* out_lbl, void* stream);
+/* segf_input_val: ExtResize -> ExtToTensor -> ExtNormalize (build_datasets.py:24-29; extra_transform.py:395-419) for ONE image:
+ * Image.resize((out_w, out_h), BILINEAR) = ImagingResample's horizontal then vertical pass in 22-bit fixed point, each rounded to
+ * uint8, and Image.resize(..., NEAREST) for the label (ImagingScaleAffine's accumulated source index); the caller computes
+ * (out_h, out_w) (smaller edge -> size, other edge int(size * long / short)).  ws: segf_input_val_ws(...) BYTES, 16-byte aligned.
+ * out_img fp32 [3][out_h][out_w], out_lbl int64 [out_h][out_w]. */
+int64_t segf_input_val_ws(int src_h, int src_w, int out_h, int out_w);
+int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, int64_t lbl_stride, int src_h, int src_w, int out_h,
+                   int out_w, void* ws, const float* mean3, const float* std3, const int64_t* label_lut, float* out_img,
+                   int64_t* out_lbl, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

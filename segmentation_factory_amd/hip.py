@@ -87,6 +87,9 @@ _PROTOS = {
     'segf_quant_rows_fp8': (_i, [_i, _l, _i, _p, _l, _p, _l, _p, _p]),
     'segf_gemm_fp8_supported': (_i, [_l, _l, _l]),
     'segf_gemm_fp8': (_i, [_l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p, _l, _p]),
+    'segf_input_train': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_input_val_ws': (_l, [_i, _i, _i, _i]),
+    'segf_input_val': (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     'segf_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'segf_event_destroy': (_i, [_p]),
     'segf_event_record': (_i, [_p, _p, _i]),
@@ -656,6 +659,47 @@ def nearest_up(x, B, h, w, Cc, H, W, base=None, bwd=False):
     out = torch.empty(((B * h * w) if bwd else (B * H * W), Cc), dtype=x.dtype, device=x.device)
     _chk(lib().segf_nearest_up(dt_of(x), int(bwd), B, h, w, Cc, H, W, _ptr(x), _ptr(base), _ptr(out), _stream()), 'segf_nearest_up')
     return out
+
+
+class InputSample(C.Structure):
+    """segf_input_sample of include/segfac.h (72 bytes)."""
+    _fields_ = [('img', C.c_uint64), ('lbl', C.c_uint64), ('img_stride', C.c_int64), ('lbl_stride', C.c_int64),
+                ('src_h', C.c_int32), ('src_w', C.c_int32), ('top', C.c_int32), ('left', C.c_int32),
+                ('flip', C.c_int32), ('order', C.c_int32), ('factor', C.c_float * 3), ('reserved', C.c_int32)]
+
+
+def input_train(samples, B, H, W, mean3, std3, label_lut, out_img=None, out_lbl=None):
+    """segf_input_train: `samples` = uint8 device tensor holding B packed InputSample records (their image / label pointers must
+    stay alive until the stream has run the kernels) -> (fp32 [B, 3, H, W], int64 [B, H, W])."""
+    _need_cuda(samples, mean3, std3, label_lut)
+    assert samples.dtype == torch.uint8 and samples.numel() == B * C.sizeof(InputSample)
+    assert mean3.dtype == torch.float32 and std3.dtype == torch.float32 and mean3.numel() == 3 and std3.numel() == 3
+    assert label_lut is None or (label_lut.dtype == torch.int64 and label_lut.numel() == 256)
+    dev = samples.device
+    if out_img is None:
+        out_img = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+    if out_lbl is None:
+        out_lbl = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    assert out_img.is_contiguous() and out_lbl.is_contiguous() and out_img.numel() == B * 3 * H * W and out_lbl.numel() == B * H * W
+    lsum = torch.empty(max(B, 2), dtype=torch.int64, device=dev)
+    _chk(lib().segf_input_train(_ptr(samples), B, H, W, _ptr(lsum), _ptr(mean3), _ptr(std3), _ptr(label_lut), _ptr(out_img),
+                                _ptr(out_lbl), _stream()), 'segf_input_train')
+    return out_img, out_lbl
+
+
+def input_val(img, lbl, out_h, out_w, mean3, std3, label_lut):
+    """segf_input_val: img uint8 [h, w, 3], lbl uint8 [h, w] (device) -> (fp32 [3, out_h, out_w], int64 [out_h, out_w])."""
+    _need_cuda(img, lbl, mean3, std3, label_lut)
+    assert img.dtype == torch.uint8 and lbl.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 3 and img.stride(2) == 1 \
+        and img.stride(1) == 3 and lbl.stride(1) == 1 and lbl.shape == img.shape[:2]
+    assert label_lut is None or (label_lut.dtype == torch.int64 and label_lut.numel() == 256)
+    h, w = int(img.shape[0]), int(img.shape[1])
+    ws = torch.empty(int(lib().segf_input_val_ws(h, w, out_h, out_w)) + 16, dtype=torch.uint8, device=img.device)
+    out_img = torch.empty((3, out_h, out_w), dtype=torch.float32, device=img.device)
+    out_lbl = torch.empty((out_h, out_w), dtype=torch.int64, device=img.device)
+    _chk(lib().segf_input_val(_ptr(img), img.stride(0), _ptr(lbl), lbl.stride(0), h, w, out_h, out_w, _ptr(ws), _ptr(mean3),
+                              _ptr(std3), _ptr(label_lut), _ptr(out_img), _ptr(out_lbl), _stream()), 'segf_input_val')
+    return out_img, out_lbl
 
 
 def bilinear_bwd_248(dout, B, H, W, Cc):
