@@ -236,9 +236,36 @@ def main():
                 hip.gemm(0, A_, W_, M, ld, K, bias=b_)
     esz = A_.element_size()
     loss_bytes = args.batch * (2 * hq * wq * ld * esz + H * W * 8)           # logits read + gradient written + labels
-    loss_exps = float(args.batch) * H * W * (16 * ((NC + 15) // 16)) * (81.0 / 64.0)   # per pixel and padded class; 9x9 cells per 8x8-tap tile
+    loss_exps = float(args.batch) * H * W * (16 * ((NC + 15) // 16)) * (8.0 / 7.0) * (17.0 / 16.0)   # per pixel and padded class; band sweep: 8 cells per 7 tap columns, one lead-in row per 16-row segment
     gemm_bytes = esz * (M * K + ld * K + M * ld)
     del A_, W_, lo_
+
+    # input-pipeline leg: one batch of the reference's train transform stack (crop, Pillow colour jitter, flip,
+    # ToTensor, Normalize, label table) from decoded uint8 images resident in HBM -- reported beside the step, not part of `value`
+    inp = None
+    if rank == 0 and H % 4 == 0:
+        import random as _random
+        from segmentation_factory_amd.transforms import DeviceTrainTransform, label_table
+        gen_ = torch.Generator(device=dev).manual_seed(0)
+        srcs_ = [(H + 40 + (k % 7) * 13, W + 60 + (k % 5) * 29) for k in range(args.batch)]
+        imgs_ = [torch.randint(0, 256, (h_, w_, 3), dtype=torch.uint8, device=dev, generator=gen_) for h_, w_ in srcs_]
+        lbls_ = [torch.randint(0, 256, (h_, w_), dtype=torch.uint8, device=dev, generator=gen_) for h_, w_ in srcs_]
+        tr_ = DeviceTrainTransform((H, W), label_lut=label_table({255: 0}, dev), device=dev, rng=_random.Random(0))
+        smp_ = tr_.pack(imgs_, lbls_, [tr_.draw(h_, w_) for h_, w_ in srcs_])
+        oi_, ol_ = hip.input_train(smp_, args.batch, H, W, tr_.mean, tr_.std, tr_.label_lut)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+            hip.input_train(smp_, args.batch, H, W, tr_.mean, tr_.std, tr_.label_lut, oi_, ol_)
+        ev1.record()
+        torch.cuda.synchronize()
+        inp_ms = ev0.elapsed_time(ev1) / 10
+        inp_bytes = args.batch * H * W * 24                      # 3 + 1 bytes read, 12 + 8 written per output pixel
+        inp = {"kernels": "input_lsum_kernel + input_train_kernel (segf_input_train)", "ms_per_batch": round(inp_ms, 4),
+               "images_per_sec": round(args.batch / inp_ms * 1e3), "algorithmic_bytes_per_batch": inp_bytes,
+               "achieved_GBps": round(inp_bytes / inp_ms / 1e6, 1), "frac_of_hbm_peak": round(inp_bytes / (inp_ms * 1e-3) / HBM_PEAK, 4),
+               "note": "bit-exact against Pillow + torch CPU (tests/test_input_pipeline.py); sources ~(H+80) x (W+120) uint8"}
+        del imgs_, lbls_, oi_, ol_
 
     # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command,
     # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/): reported only for the batch it was measured at
@@ -303,6 +330,8 @@ def main():
                               "avg_launch_ms": round(gemm_ms, 4), "algorithmic_bytes_per_launch": gemm_bytes,
                               "flops_per_launch": 2.0 * M * ld * K},
         }
+        if inp is not None:
+            out["input_pipeline"] = inp
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -230,3 +230,24 @@ def test_device_batch_loader_feeds_train_one_epoch_shapes():
             assert img.shape == (2, 3, 64, 64) and img.dtype == torch.float32 and img.is_cuda
             assert lbl.shape == (2, 64, 64) and lbl.dtype == torch.int64 and int(lbl.max()) < 150
             assert torch.isfinite(img).all()
+
+
+@pytest.mark.gpu
+def test_train_gpu_cli_with_device_input(tmp_path):
+    """train_gpu.py --device-input --hip-graph: the captured step fed by the device pipeline, end to end, loss falling."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'train_gpu.py'), '--dataset', 'synthetic', '--data_len', '16', '--image_size', '64',
+           '--nb_classes', '5', '--backbone', 'MiT-B0', '--heads', 'SegFormerHead', '--batch-size', '4', '--val_batch_size', '2',
+           '--epochs', '3', '--save_weights_dir', str(tmp_path / 'out'), '--writer_output', str(tmp_path), '--train_print_freq', '1',
+           '--val_print_freq', '1', '--lr', '2e-3', '--device-input', '--hip-graph']
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'Val_mIOU' in r.stdout
+    import glob
+    res = glob.glob(str(tmp_path / 'results*.txt'))                                # train_gpu.py:344-352: per-epoch results file
+    assert res, r.stdout[-2000:]
+    losses = [float(v) for v in re.findall(r'train_loss: ([0-9.]+)', open(res[0]).read())]
+    assert len(losses) == 3 and losses[-1] < losses[0], losses

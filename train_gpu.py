@@ -114,6 +114,10 @@ def get_args_parser():
     # MI355X-path extras
     parser.add_argument('--compute-dtype', default='bf16', choices=['bf16', 'fp32'], help='activation storage (fp32 = exact-parity mode)')
     parser.add_argument('--hip-graph', action='store_true', help='replay each train step as one hipGraph')
+    parser.add_argument('--device-input', action='store_true',
+                        help='training batches from the device-side input pipeline (segmentation_factory_amd/transforms.py): the '
+                             'decoded uint8 training set is uploaded once and the transform stack of datasets/build_datasets.py:14-22 '
+                             'runs as HIP kernels')
     return parser
 
 
@@ -151,6 +155,34 @@ def build_dataset(args):
     return ref_build_dataset(args)
 
 
+def _decode_only(image, label):
+    """Stands where the reference's train_transform stands (datasets/*.py `self.transform(image, label)`): hands back the decoded
+    PIL pair as uint8 tensors, untouched, so the dataset classes of the reference do the file handling and decoding."""
+    return torch.from_numpy(np.array(image, dtype=np.uint8)), torch.from_numpy(np.array(label, dtype=np.uint8))
+
+
+def build_device_loader(args, train_set):
+    """--device-input: every training sample is decoded ONCE into HBM; each batch is then two kernel launches."""
+    from segmentation_factory_amd.transforms import DeviceBatchLoader, DeviceDataset, DeviceTrainTransform
+    ds = DeviceDataset(args.device)
+    if args.dataset == 'synthetic':                 # uint8 photographs-to-be: block-pattern labels, colours that encode them
+        for i in range(len(train_set)):
+            rng = np.random.default_rng(args.seed * 100003 + i)
+            s = args.image_size + 32 + 8 * (i % 5)
+            blk = max(args.image_size // 8, 1)
+            coarse = rng.integers(0, args.nb_classes, (s // blk + 1, s // blk + 1))
+            lbl = np.kron(coarse, np.ones((blk, blk), dtype=np.int64))[:s, :s]
+            img = (lbl[..., None] * np.array([255, 127, 63]) // max(args.nb_classes - 1, 1) + rng.integers(0, 32, (s, s, 3))) % 256
+            ds.add(img.astype(np.uint8), lbl.astype(np.uint8))
+    else:                                           # the reference's dataset class decodes; its own label mapping has been applied
+        train_set.transform = _decode_only
+        for i in range(len(train_set)):
+            img, lbl = train_set[i]
+            ds.add(img, lbl.to(torch.uint8))
+    tf = DeviceTrainTransform(args.image_size, device=args.device)
+    return DeviceBatchLoader(ds, args.batch_size, tf, shuffle=True, seed=args.seed, rank=utils.get_rank(), world=utils.get_world_size())
+
+
 class _NullWriter:
     def add_scalar(self, *a, **k):
         pass
@@ -182,6 +214,8 @@ def main(args):
         sampler_val = torch.utils.data.SequentialSampler(valid_set)
     trainloader = DataLoader(train_set, batch_size=args.batch_size, num_workers=args.num_workers, drop_last=True,
                              pin_memory=args.pin_mem, sampler=sampler_train)
+    if args.device_input:
+        trainloader = build_device_loader(args, train_set)
     valloader = DataLoader(valid_set, batch_size=args.val_batch_size, num_workers=args.num_workers, drop_last=True,
                            pin_memory=args.pin_mem, sampler=sampler_val)
 
@@ -260,7 +294,9 @@ def main(args):
 
     print(f"Start training for {args.epochs} epochs")
     for epoch in range(args.epochs):
-        if args.distributed:
+        if args.device_input:
+            trainloader.set_epoch(epoch)
+        elif args.distributed:
             trainloader.sampler.set_epoch(epoch)
         mean_loss, lr = train_one_epoch(model, optimizer, trainloader, epoch, device, args.train_print_freq, args.clip_grad,
                                         args.clip_mode, loss_scaler, writer, args)
