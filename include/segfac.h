@@ -313,6 +313,12 @@ int segf_agc_adamw(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float clip_factor, float agc_eps, void* stream);
 
+/* The other --clip-mode values of the reference (train_gpu.py:99-102 -> timm.utils.dispatch_clip_grad) on the flat gradient buffer:
+ * mode 0 'norm' = torch.nn.utils.clip_grad_norm_(params, value, 2.0): g *= min(1, value / (||g||_2 + 1e-6));
+ * mode 1 'value' = clip_grad_value_: g = clamp(g, -value, value).  ws: segf_clip_grad_ws() floats (mode 0).  No host read. */
+int64_t segf_clip_grad_ws(void);
+int segf_clip_grad(float* grad, int64_t n, int mode, float value, float* ws, void* stream);
+
 /* ---- device-side input pipeline over decoded uint8 images resident in HBM ---------------------------
  * segf_input_train: ExtRandomCrop -> ExtColorJitter -> ExtRandomHorizontalFlip -> ExtToTensor -> ExtNormalize
  * (datasets/build_datasets.py:14-22; datasets/extra_transform.py:319-392, 426-509, 196-214, 259-281, 288-313) and the dataset

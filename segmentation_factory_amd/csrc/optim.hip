@@ -60,3 +60,62 @@ extern "C" int segf_agc_adamw(float* param, const float* grad, float* exp_avg, f
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- the other two --clip-mode values of the reference (train_gpu.py:99-102 -> timm.utils.dispatch_clip_grad) over the flat
+// gradient buffer, device-only (no host read of the norm, graph-capturable):
+//   'norm'  = torch.nn.utils.clip_grad_norm_(parameters, value, norm_type=2.0): g *= min(1, value / (||g||_2 + 1e-6))
+//   'value' = torch.nn.utils.clip_grad_value_(parameters, value):               g = clamp(g, -value, value)
+// The norm is a fixed-order reduction (per-workgroup partials over fixed slices, then every workgroup re-reduces the partials in
+// the same order in double): bitwise reproducible, and independent of how the buffer is cut into parameters.
+constexpr int CLIP_BLOCKS = 1024;
+
+__global__ void __launch_bounds__(256) grad_sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    float acc = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const float v = g[i]; acc = fmaf(v, v, acc); }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) grad_scale_by_norm_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ partial,
+                                                                  int nparts, float max_norm) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float total = (float)sqrt(red[0]);
+    const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
+    if (coef >= 1.f) return;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) g[i] *= coef;
+}
+
+__global__ void __launch_bounds__(256) grad_clamp_kernel(float* __restrict__ g, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) g[i] = fminf(fmaxf(g[i], -v), v);
+}
+
+extern "C" int64_t segf_clip_grad_ws(void) { return CLIP_BLOCKS; }
+
+extern "C" int segf_clip_grad(float* grad, int64_t n, int mode, float value, float* ws, void* stream) {
+    if (n <= 0) return 0;
+    if (!grad || (mode != 0 && mode != 1) || !(value >= 0.f)) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)imin64(cdiv64(n, 4096), CLIP_BLOCKS);
+    if (mode == 0) {
+        if (!ws) return SEGF_ERR_WORKSPACE;
+        hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, st, grad, n, ws);
+        hipLaunchKernelGGL(grad_scale_by_norm_kernel, dim3(blocks), dim3(256), 0, st, grad, n, ws, blocks, value);
+    } else {
+        hipLaunchKernelGGL(grad_clamp_kernel, dim3(blocks), dim3(256), 0, st, grad, n, value);
+    }
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -74,9 +74,7 @@ class GraphedTrainStep:
         self.static_inputs = [t.clone() for t in example_inputs]
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.group = process_group
-        if clip_grad is not None and clip_mode != 'agc':
-            raise NotImplementedError("clip_mode='agc' is the fused mode (engine.py:52-53 default)")
-        self.opt.agc_clip = float(clip_grad) if clip_grad is not None else 0.0
+        self.opt.set_clipping(clip_grad, clip_mode)      # 'agc' in the AdamW kernel; 'norm' / 'value' as kernels right before it
         # parameters are re-homed into the flat buffer BEFORE capture, laid out in registration order (bucket = suffix)
         self.opt.ensure_built(order=list(model.parameters()))
         broadcast_flat_(self.opt.flat_params, 0, self.group)     # DDP's initial parameter broadcast from rank 0

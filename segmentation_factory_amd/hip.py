@@ -80,6 +80,8 @@ _PROTOS = {
     'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
     'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),
+    'segf_clip_grad_ws': (_l, []),
+    'segf_clip_grad': (_i, [_p, _l, _i, _f, _p, _p]),
     'segf_zero': (_i, [_p, _l, _p]),
     'segf_add_i64': (_i, [_p, _l, _p]),
     'segf_bernoulli_scale': (_i, [_p, _p, _l, _l, _p, _p]),
@@ -796,6 +798,17 @@ def confmat_pairs(gt, pred, Cc, ignore_label, mat, hist, flag):
     _need_cuda(gt, pred)
     _chk(lib().segf_confmat_pairs(_ptr(gt), _ptr(pred), gt.numel(), Cc, int(ignore_label), _ptr(mat), _ptr(hist),
                                   _ptr(flag), _stream()), 'segf_confmat_pairs')
+
+
+def clip_grad(grad, mode, value, ws=None):
+    """segf_clip_grad on a flat fp32 gradient buffer, in place: mode 'norm' (clip_grad_norm_, L2) or 'value' (clip_grad_value_)."""
+    _need_cuda(grad)
+    assert grad.dtype == torch.float32 and grad.is_contiguous()
+    m = {'norm': 0, 'value': 1}[mode]
+    if m == 0 and ws is None:
+        ws = _f32(lib().segf_clip_grad_ws(), grad.device)
+    _chk(lib().segf_clip_grad(_ptr(grad), grad.numel(), m, float(value), _ptr(ws), _stream()), 'segf_clip_grad')
+    return grad
 
 
 def agc_adamw(param, grad, exp_avg, exp_avg_sq, unit_off, unit_len, unit_flags, lr, beta1, beta2, eps, weight_decay,

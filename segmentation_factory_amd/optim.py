@@ -67,6 +67,15 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         self._flags = torch.tensor(flags, dtype=torch.uint8, device=dev)
         self.direct = False
 
+    def set_clipping(self, clip_grad, clip_mode):
+        """timm.utils.dispatch_clip_grad(parameters, value=clip_grad, mode=clip_mode) as part of the optimizer step: 'agc' inside
+        the AdamW kernel, 'norm' / 'value' as kernels over the flat gradient buffer right before it (segf_clip_grad)."""
+        if clip_grad is not None and clip_mode not in ('agc', 'norm', 'value'):
+            raise AssertionError(f"Unknown clip mode ({clip_mode}).")          # timm's wording
+        self.clip_mode = clip_mode if clip_grad is not None else 'agc'
+        self.clip_value = None if clip_grad is None else float(clip_grad)
+        self.agc_clip = float(clip_grad) if (clip_grad is not None and clip_mode == 'agc') else 0.0
+
     def ensure_built(self, order=None):
         if self._flat is None:
             self._build(order)
@@ -130,8 +139,13 @@ class FusedAGCAdamW(torch.optim.Optimizer):
             raise NotImplementedError(f'FusedAGCAdamW: one non-zero weight decay for all decayed groups, got {sorted(wds)}')
         wd = max(pg['weight_decay'] for pg in self.param_groups)
         self._step += 1
+        mode, value = getattr(self, 'clip_mode', 'agc'), getattr(self, 'clip_value', None)
+        if mode in ('norm', 'value') and value is not None:      # timm dispatch_clip_grad's other modes, on the flat buffer
+            if getattr(self, '_clip_ws', None) is None:
+                self._clip_ws = torch.empty(int(hip.lib().segf_clip_grad_ws()), dtype=torch.float32, device=self._grad.device)
+            hip.clip_grad(self._grad, mode, value, self._clip_ws)
         hip.agc_adamw(self._flat, self._grad, self._m, self._v, self._off, self._len, self._flags, g['lr'], g['betas'][0],
-                      g['betas'][1], g['eps'], wd, self._step, float(self.agc_clip))
+                      g['betas'][1], g['eps'], wd, self._step, float(self.agc_clip) if mode == 'agc' else 0.0)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -206,9 +220,7 @@ class NativeScaler:
         if not need_update:
             return
         if isinstance(optimizer, FusedAGCAdamW):
-            optimizer.agc_clip = float(clip_grad) if (clip_grad is not None and clip_mode == 'agc') else 0.0
-            if clip_grad is not None and clip_mode != 'agc':
-                raise NotImplementedError("FusedAGCAdamW fuses clip_mode='agc' only")
+            optimizer.set_clipping(clip_grad, clip_mode)
         elif clip_grad is not None:
             raise NotImplementedError('gradient clipping is fused into FusedAGCAdamW; use it or pass clip_grad=None')
         optimizer.step()

@@ -234,7 +234,8 @@ def test_device_batch_loader_feeds_train_one_epoch_shapes():
 
 @pytest.mark.gpu
 def test_train_gpu_cli_with_device_input(tmp_path):
-    """train_gpu.py --device-input --hip-graph: the captured step fed by the device pipeline, end to end, loss falling."""
+    """train_gpu.py --device-input --hip-graph --clip-mode norm: the captured step fed by the device pipeline (and the L2-norm
+    clipping of the reference's --clip-mode norm in front of the optimizer kernel), end to end, loss falling."""
     import re
     import subprocess
     import sys
@@ -242,7 +243,7 @@ def test_train_gpu_cli_with_device_input(tmp_path):
     cmd = [sys.executable, os.path.join(root, 'train_gpu.py'), '--dataset', 'synthetic', '--data_len', '16', '--image_size', '64',
            '--nb_classes', '5', '--backbone', 'MiT-B0', '--heads', 'SegFormerHead', '--batch-size', '4', '--val_batch_size', '2',
            '--epochs', '3', '--save_weights_dir', str(tmp_path / 'out'), '--writer_output', str(tmp_path), '--train_print_freq', '1',
-           '--val_print_freq', '1', '--lr', '2e-3', '--device-input', '--hip-graph']
+           '--val_print_freq', '1', '--lr', '2e-3', '--device-input', '--hip-graph', '--clip-mode', 'norm', '--clip-grad', '1.0']
     r = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'Val_mIOU' in r.stdout

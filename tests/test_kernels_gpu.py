@@ -566,6 +566,48 @@ def test_agc_adamw_known_answers(hipmod):
         assert (b.detach().cpu() - pb).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize('mode,value', [('norm', 0.5), ('norm', 1e4), ('value', 0.3)])
+def test_clip_modes_norm_and_value_vs_torch(hipmod, mode, value):
+    """The reference's other --clip-mode values (train_gpu.py:99-102 -> timm dispatch_clip_grad = torch.nn.utils.clip_grad_norm_ /
+    clip_grad_value_) through NativeScaler + FusedAGCAdamW, against torch's own clipping + torch.optim.AdamW on the CPU; and the
+    flat-buffer kernel alone on a buffer large enough to use every workgroup slice (bitwise reproducible)."""
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler
+    g = torch.Generator().manual_seed(5)
+    shapes = [(6, 10), (6,), (3, 4, 2, 2), (17,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt = FusedAGCAdamW([{'params': [p for p in ps if p.ndim <= 1], 'weight_decay': 0.},
+                         {'params': [p for p in ps if p.ndim > 1], 'weight_decay': 0.05}], lr=1e-2)
+    ropt = torch.optim.AdamW([{'params': [p for p in ref if p.ndim <= 1], 'weight_decay': 0.},
+                              {'params': [p for p in ref if p.ndim > 1], 'weight_decay': 0.05}], lr=1e-2)
+    scaler = NativeScaler()
+    for step in range(3):
+        coefs = [torch.randn(*s, generator=g) * 2 for s in shapes]
+        opt.zero_grad()
+        loss = sum((p * c.cuda()).sum() for p, c in zip(ps, coefs))
+        scaler(loss, opt, clip_grad=value, clip_mode=mode, parameters=ps)
+        rloss = sum((p * c).sum() for p, c in zip(ref, coefs))
+        ropt.zero_grad()
+        rloss.backward()
+        if mode == 'norm':
+            torch.nn.utils.clip_grad_norm_(ref, value, norm_type=2.0)
+        else:
+            torch.nn.utils.clip_grad_value_(ref, value)
+        ropt.step()
+        for p, r in zip(ps, ref):
+            assert (p.detach().cpu() - r.detach()).abs().max() < 2e-6, (mode, step)
+    big = torch.randn(5_000_011, generator=g)
+    want = big.clone()
+    if mode == 'norm':
+        want *= min(1.0, value / (float(torch.linalg.vector_norm(big.double())) + 1e-6))
+    else:
+        want.clamp_(-value, value)
+    a = hipmod.clip_grad(big.cuda(), mode, value).cpu()
+    b = hipmod.clip_grad(big.cuda(), mode, value).cpu()
+    assert torch.equal(a, b)
+    assert (a - want).abs().max() <= 1e-6 * want.abs().max()
+
+
 # ---- ConvNeXt / UPerNet kernels ------------------------------------------------------------------------------------
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('geom', [(2, 9, 13, 32), (1, 16, 16, 96), (2, 5, 3, 8), (1, 1, 1, 64)])
