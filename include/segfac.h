@@ -163,6 +163,17 @@ int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy
                     const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                     const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma, float* dbeta,
                     float* ws, void* stream);
+/* The same with the NEXT backward step's weight-gradient product riding on pass 2: dx is the gradient of the folded SegFormerHead's
+ * stride-4 map y = sum_i resize_i(x_i G_i^T) (heads/segformer.py:42-56); its stage-1 term needs dG_1 = dx^T x1 and colsum(dx), a
+ * [C x C1] product over all M tokens.  dG: fp32 [C][C1 + 8] = [dx^T x1 | colsum(dx) | 0 x 7], accumulated from the bf16 dx tile each
+ * workgroup has on chip (bit-identical operands to a separate product over the stored dx; saves one 2 M C byte pass).  C1 == 32,
+ * K <= 160: ask segf_bn_cls_bwd_dw_supported.  ws >= segf_bn_cls_bwd_dw_ws floats. */
+int segf_bn_cls_bwd_dw_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample, int C1);
+int64_t segf_bn_cls_bwd_dw_ws(int64_t M, int C, int64_t rows_per_sample);
+int segf_bn_cls_bwd_dw(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
+                       const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                       const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
+                       float* dbeta, float* ws, const void* x1, int64_t ldx1, int C1, float* dG, void* stream);
 
 /* ---- Global Response Normalization (ConvNeXtV2 GRN, convnextv2.py:68-80) on NHWC rows, B images of rows_per_sample rows:
  * y = gamma * (x * Nx) + beta + x, Nx = ||x||_2(H,W) / (mean_c ||x||_2 + 1e-6).  sumsq_out [B][C] is saved for the backward. */

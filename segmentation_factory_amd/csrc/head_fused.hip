@@ -30,7 +30,23 @@ struct HeadFusedArgs {
     bf16_t* dx;                           // pass 2
     float* partial;                       // pass 1: [gridDim.x][2][C]
     int64_t M; int C; int64_t rps; int groups_per_sample, chunks_per_sample; int act, eval_mode;
+    const bf16_t* x1; int64_t ldx1;       // DW: [M][>= 32] second operand of the riding weight-gradient product
+    float* dwpart;                        // DW: [gridDim.x / ny][C][DW_LD] per-workgroup partials of dx^T [x1 | 1]
 };
+#define DW_C1 32                          // channels of x1 (MiT-B0's stage-1 width)
+#define DW_LD 40                          // row length of the product: 32 channels, the all-ones column (= column sums of dx), 7 x 0
+
+// fragment of a row-major [token][column] bf16 LDS tile with the tokens as the contraction index: lane (i = lane & 15, g = lane >> 4)
+// gets column cb + i of tokens 8 g .. 8 g + 7 (ds_read_b64_tr_b16, two 4-row blocks)
+__device__ __forceinline__ hf_bf16x8 hf_frag_tok_tr(const unsigned char* tile, int rowbytes, int cb, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short hf_s16x4;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const unsigned char* a0 = tile + (8 * g + q) * rowbytes + (cb + 4 * p) * 2;
+    const hf_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hf_s16x4*)a0);
+    const hf_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hf_s16x4*)(a0 + 4 * rowbytes));
+    const hf_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(hf_bf16x8, v);
+}
 
 __device__ __forceinline__ float hf_row_sum16(float v) {
     v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
@@ -46,7 +62,13 @@ __device__ __forceinline__ float hf_row_sum16(float v) {
 #ifndef HF_U
 #define HF_U 4                     // 16-token groups per iteration (2 -> 4: twice the bytes in flight per CU, -5 %)
 #endif
-template <int PASS, int KS>
+// DW (pass 2 only): the weight-gradient product of the NEXT backward step rides along.  dx is the gradient of the folded
+// SegFormerHead's stride-4 map; its producer x1 G1^T (stage-1 tokens x1 [M][32]) needs dG1 = dx^T x1 and the column sums of dx --
+// a [C x 32] product over all M tokens that, as its own launch, re-reads the 3.2 GB dx tensor (0.81 ms at cfg2, batch 128).
+// Here each wave multiplies its 32 features of the finished dx tile (read back transposed from the staging tile `ot`: exactly the
+// bf16 values that go to memory) with the tokens' x1 rows [x1 | 1 | 0] staged beside it: 2 x 3 accumulator tiles, 12 MFMAs per
+// 64 tokens.  Per-workgroup partials [C][DW_LD] are summed in fixed order by colreduce_finalize.
+template <int PASS, int KS, bool DW = false>
 __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadFusedArgs a) {
     constexpr int NT = 2;                                   // 32 features per wave
     constexpr int TOK = 16 * HF_U;                          // tokens per iteration
@@ -67,6 +89,9 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
     static_assert(XCH % (64 * HF_WAVES) == 0, "x tile chunks must divide evenly over the workgroup");
     __shared__ __attribute__((aligned(16))) bf16_t xt[2][TOK][XRS];
     __shared__ __attribute__((aligned(16))) bf16_t ot[PASS == 2 ? TOK : 1][XRS];
+    static_assert(!DW || (PASS == 2 && HF_WAVES == 8 && TOK == 64), "the riding weight gradient belongs to pass 2");
+    constexpr int X1RS = DW_C1 + 16 + 8;                    // [x1 (32) | 1 | 0 x 15 | pad]: 112-byte rows
+    __shared__ __attribute__((aligned(16))) bf16_t x1t[DW ? 2 : 1][DW ? TOK : 1][X1RS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mi = lane & 15, g = lane >> 4;
     // 1-D grid, XCD-aware logical id L = (token chunk, feature slice) with the slice fastest: the workgroups that cover the whole
@@ -168,12 +193,44 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
             *reinterpret_cast<hf_u32x4*>(&xt[bufi][tk][8 * c16]) = xs[i];
         }
     };
-    if (gbeg < gend) { fetch_tile(gbeg); fetch_x(gbeg); stash_tile(0); stash_x(0); }
+    // x1 rows of the token tile: threads 0..255 carry one 16-byte chunk each (4 per token); threads 256..383 write the ones /
+    // zero columns.  Rows of dead groups (odd tail of the chunk) are staged as zeros so that they drop out of the product.
+    hf_u32x4 x1s = {0u, 0u, 0u, 0u};
+    auto fetch_x1 = [&](int gp) {
+        if (DW) {
+            const int q = (int)threadIdx.x & 255, tk = q >> 2, c16 = q & 3;
+            int64_t m = row0 + (int64_t)gp * 16 + tk;
+            m = m <= last_row ? m : last_row;
+            x1s = *reinterpret_cast<const hf_u32x4*>(a.x1 + m * a.ldx1 + 8 * c16);
+        }
+    };
+    auto stash_x1 = [&](int bufi, int gp) {
+        if (DW) {
+            const int t = (int)threadIdx.x;
+            if (t < 256) {
+                const int tk = t >> 2, c16 = t & 3;
+                const bool live = gp + (tk >> 4) < gend;
+                const hf_u32x4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<hf_u32x4*>(&x1t[bufi][tk][8 * c16]) = live ? x1s : z;
+            } else if (t < 384) {
+                const int r = t - 256, tk = r >> 1, half = r & 1;
+                const bool live = gp + (tk >> 4) < gend;
+                const hf_u32x4 v = {(half == 0 && live) ? 0x00003f80u : 0u, 0u, 0u, 0u};      // bf16 1.0 in column 32
+                *reinterpret_cast<hf_u32x4*>(&x1t[bufi][tk][DW_C1 + 8 * half]) = v;
+            }
+        }
+    };
+    hf_f32x4 accw[DW ? 2 : 1][DW ? 3 : 1];
+#pragma unroll
+    for (int i = 0; i < (DW ? 2 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (DW ? 3 : 1); ++j) accw[i][j] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (gbeg < gend) { fetch_tile(gbeg); fetch_x(gbeg); fetch_x1(gbeg); stash_tile(0); stash_x(0); stash_x1(0, gbeg); }
     __syncthreads();
     int bufi = 0;
     for (int gp = gbeg; gp < gend; gp += HF_U) {
         const bool more = gp + HF_U < gend;
-        if (more) { fetch_tile(gp + HF_U); fetch_x(gp + HF_U); }
+        if (more) { fetch_tile(gp + HF_U); fetch_x(gp + HF_U); fetch_x1(gp + HF_U); }
 #pragma unroll
         for (int u = 0; u < HF_U; ++u) {
             hf_f32x4 acc[NT];
@@ -215,8 +272,23 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
         if (more) {
             stash_tile(bufi ^ 1);
             stash_x(bufi ^ 1);
+            stash_x1(bufi ^ 1, gp + HF_U);
         }
         __syncthreads();                 // the next tiles are complete, and nobody still reads the buffers that get overwritten next
+        if (DW) {                        // dG1 partial += dx_tile^T [x1 | 1]: tokens are the contraction index of both operands
+#pragma unroll
+            for (int ks = 0; ks < TOK / 32; ++ks) {
+                const unsigned char* ob = reinterpret_cast<const unsigned char*>(&ot[32 * ks][0]);
+                const unsigned char* xb = reinterpret_cast<const unsigned char*>(&x1t[bufi][32 * ks][0]);
+                const hf_bf16x8 fa0 = hf_frag_tok_tr(ob, XRS * 2, 32 * wave, lane), fa1 = hf_frag_tok_tr(ob, XRS * 2, 32 * wave + 16, lane);
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    const hf_bf16x8 fb = hf_frag_tok_tr(xb, X1RS * 2, 16 * nt, lane);
+                    accw[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb, accw[0][nt], 0, 0, 0);
+                    accw[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb, accw[1][nt], 0, 0, 0);
+                }
+            }
+        }
         if (PASS == 2) {                 // the dx tile leaves in whole 512-byte row runs (rows of dead groups are dropped)
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
@@ -228,6 +300,20 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
             __syncthreads();             // ot is free again
         }
         bufi ^= 1;
+    }
+    if (DW) {
+        // accumulator (mt, nt): rows = features wg_f0 + 32 wave + 16 mt + 4 (lane >> 4) + r, column = 16 nt + (lane & 15)
+        float* dst = a.dwpart + ((int64_t)blk * a.C + wg_f0 + 32 * wave) * DW_LD;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const int cc = 16 * nt + mi;
+                if (cc < DW_LD) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(16 * mt + 4 * g + r) * DW_LD + cc] = accw[mt][nt][r];
+                }
+            }
     }
     if (PASS == 1) {
         // tokens of a group sit in the 16 lanes of a row group: DPP row sums, then lane mi == 0 of each (wave, g) writes its 8 features
@@ -267,10 +353,42 @@ extern "C" int64_t segf_bn_cls_bwd_ws(int64_t M, int C, int64_t rows_per_sample)
     return (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / (32 * HF_WAVES)) * 2 * C + 2 * C;
 }
 
+extern "C" int segf_bn_cls_bwd_dw_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample, int C1) {
+    if (getenv("SEGFAC_NO_HEAD_FUSED_DW")) return 0;
+    return segf_bn_cls_bwd_supported(dt, M, C, K, rows_per_sample) && C1 == DW_C1 && K <= 160;     // K = 192: the tiles pass 160 KB of LDS
+}
+extern "C" int64_t segf_bn_cls_bwd_dw_ws(int64_t M, int C, int64_t rows_per_sample) {
+    const int B = (int)(M / rows_per_sample);
+    return segf_bn_cls_bwd_ws(M, C, rows_per_sample) +
+           (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / (32 * HF_WAVES)) * C * DW_LD;
+}
+
+static int bn_cls_bwd_impl(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                           const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
+                           float* dbeta, float* ws, const void* x1, int64_t ldx1, float* dG, void* stream);
+
 extern "C" int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
                                const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                                const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
                                float* dbeta, float* ws, void* stream) {
+    return bn_cls_bwd_impl(dt, M, C, K, dy, ldy, w, ldw, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode, dx,
+                           dgamma, dbeta, ws, nullptr, 0, nullptr, stream);
+}
+extern "C" int segf_bn_cls_bwd_dw(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                  const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
+                                  float* dbeta, float* ws, const void* x1, int64_t ldx1, int C1, float* dG, void* stream) {
+    if (!segf_bn_cls_bwd_dw_supported(dt, M, C, K, rows_per_sample, C1) || !x1 || !dG || ldx1 < C1 || ldx1 % 8 || ((uintptr_t)x1 % 16))
+        return SEGF_ERR_SHAPE;
+    return bn_cls_bwd_impl(dt, M, C, K, dy, ldy, w, ldw, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode, dx,
+                           dgamma, dbeta, ws, x1, ldx1, dG, stream);
+}
+
+static int bn_cls_bwd_impl(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                           const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
+                           float* dbeta, float* ws, const void* x1, int64_t ldx1, float* dG, void* stream) {
     if (!segf_bn_cls_bwd_supported(dt, M, C, K, rows_per_sample) || ldy < K || ldw < C || act < 0 || act > 2) return SEGF_ERR_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) % 16 || (ldy % 8)) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
@@ -279,8 +397,9 @@ extern "C" int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, 
     const int chunks = hf_chunks(B, gps, ny);
     const int nblk = B * chunks;
     float* sums = ws + (int64_t)nblk * 2 * C;
+    float* dwpart = sums + 2 * C;                       // (only with x1) [nblk][C][DW_LD]
     HeadFusedArgs a{(const bf16_t*)dy, ldy, (const bf16_t*)w, ldw, (const bf16_t*)x, mean, rstd, gamma, beta, chan_scale, sums,
-                    (bf16_t*)dx, ws, M, C, rows_per_sample, gps, chunks, act, eval_mode};
+                    (bf16_t*)dx, ws, M, C, rows_per_sample, gps, chunks, act, eval_mode, (const bf16_t*)x1, ldx1, dwpart};
     const dim3 grid((unsigned)(nblk * ny));
 #define HF_LAUNCH(PASS)                                                                                                  \
     do {                                                                                                                 \
@@ -297,7 +416,19 @@ extern "C" int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, 
     SEGF_CHECK_LAUNCH();
     colreduce_finalize_launch(ws, nblk, 2 * (int64_t)C, sums, st);
     SEGF_CHECK_LAUNCH();
-    HF_LAUNCH(2);
+    if (x1) {
+        switch (K / 32) {
+        case 1: hipLaunchKernelGGL((bn_cls_bwd_kernel<2, 1, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((bn_cls_bwd_kernel<2, 2, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((bn_cls_bwd_kernel<2, 3, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((bn_cls_bwd_kernel<2, 4, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        default: hipLaunchKernelGGL((bn_cls_bwd_kernel<2, 5, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        }
+        SEGF_CHECK_LAUNCH();
+        colreduce_finalize_launch(dwpart, nblk, (int64_t)C * DW_LD, dG, st);
+    } else {
+        HF_LAUNCH(2);
+    }
     SEGF_CHECK_LAUNCH();
 #undef HF_LAUNCH
     hipLaunchKernelGGL(hf_split_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);

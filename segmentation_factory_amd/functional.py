@@ -542,7 +542,8 @@ class BnActLinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rps, weight, bias, Np,
-                pre_sums):
+                pre_sums, fold_slot=None):
+        ctx.fold_slot = fold_slot
         x = x if x.is_contiguous() else x.contiguous()
         M, K = x.shape
         N = weight.shape[0]
@@ -580,11 +581,18 @@ class BnActLinearFn(Function):
         if hip.bn_cls_bwd_supported(x.dtype, M, K, Np, rps):
             # da = dyp W is recomputed inside both BatchNorm passes (K = #classes terms per element) instead of being written
             # once and read twice: 19.8 -> 10.9 GB at cfg2, batch 128 (head_fused.hip)
-            dx, dg, dbeta = hip.bn_cls_bwd(dyp, w, x, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
+            slot = ctx.fold_slot
+            x1 = slot.get('x1') if slot is not None else None
+            if x1 is not None and x1.shape[0] == M and hip.bn_cls_bwd_dw_supported(x.dtype, M, K, Np, rps, x1.shape[1]):
+                # x is the folded SegFormerHead's stride-4 map: the weight-gradient product of its stage-1 term (dx^T x1 and the
+                # column sums of dx) rides on the second BatchNorm pass, which has the dx tile on chip (one 3.2 GB pass less)
+                dx, dg, dbeta, slot['dG'] = hip.bn_cls_bwd_dw(dyp, w, x, mean, rstd, g, b, act, chan_scale, rps, eval_mode, x1)
+            else:
+                dx, dg, dbeta = hip.bn_cls_bwd(dyp, w, x, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
         else:
             da = hip.gemm(1, dyp, w, M, K, Np)               # gradient w.r.t. the (never materialised) normalised tensor
             dx, dg, dbeta = hip.bn_bwd(x, da, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
-        return dx, dg, dbeta, None, None, None, None, None, None, None, None, dw, db, None, None
+        return dx, dg, dbeta, None, None, None, None, None, None, None, None, dw, db, None, None, None
 
 
 def bn_act_linear(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample, weight,
@@ -598,7 +606,7 @@ def bn_act_linear(x, gamma, beta, running_mean, running_var, training, momentum,
     if (x.dtype == torch.bfloat16 and act in (0, 1) and M % rps == 0 and hip.gemm_pro_supported(x.dtype, 0, M, Np, K, rps)
             and hip.gemm_pro_supported(x.dtype, 2, Np, K, M, rps)):
         return BnActLinearFn.apply(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rps,
-                                   weight, bias, Np, pre_sums)
+                                   weight, bias, Np, pre_sums, getattr(x, '_segf_fold', None))
     y = batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, act, chan_scale, rows_per_sample,
                        pre_sums=pre_sums)
     return linear(y, weight, bias, pad_to=pad_to)
@@ -672,6 +680,7 @@ class SegformerFoldedFuseFn(Function):
     @staticmethod
     def forward(ctx, geoms, *args):
         feats, weights, biases, wf = args[0:4], args[4:8], args[8:12], args[12]
+        ctx.fold_slot = args[13] if len(args) > 13 else None
         B, H1, W1 = geoms[0]
         E = weights[0].shape[0]
         dtype = feats[0].dtype
@@ -695,6 +704,8 @@ class SegformerFoldedFuseFn(Function):
             _, h, w = geoms[i]
             ts.append(hip.gemm(0, x, G, B * h * w, E, Ci, bias=beta_i))   # a constant row passes through the resize unchanged
             saved += [x, G, Wp]
+            if i == 0 and ctx.fold_slot is not None and dtype == torch.bfloat16:
+                ctx.fold_slot['x1'] = x           # BnActLinearFn.backward may compute dG_1 while it has the gradient tile on chip
         y, sums = hip.upsample_add_stats(ts[0], [(ts[i], geoms[i][1], geoms[i][2]) for i in range(1, 4)], B, H1, W1, E)
         if sums is None:
             sums = torch.empty(0, device=y.device)          # geometry without the fused statistics: the consumer runs its own pass
@@ -725,8 +736,16 @@ class SegformerFoldedFuseFn(Function):
             M, Ci = x.shape
             dt = dy if i == 0 else (dts[i - 1] if dts is not None else hip.bilinear_bwd(dy, B, h, w, E, H1, W1, align_corners=False))
             dxs.append(hip.gemm(1, dt, G, M, Ci, E) if ctx.needs_input_grad[1 + i] else None)
-            dGp = hip.zeros((E, Ci + 8), torch.float32, dev)                                # d [G_i | beta_i | 0]
-            if i == 0:
+            pre = ctx.fold_slot.pop('dG', None) if (i == 0 and ctx.fold_slot is not None) else None
+            if pre is not None and tuple(pre.shape) == (E, Ci + 8):
+                dGp = pre                          # [dy^T x_1 | colsum(dy) | 0] arrived with dy (segf_bn_cls_bwd_dw)
+                dbeta = torch.empty(E, dtype=torch.float32, device=dev)
+                hip.cast2d(dGp[:, Ci:Ci + 1], dbeta.unsqueeze(1))
+            else:
+                dGp = hip.zeros((E, Ci + 8), torch.float32, dev)                            # d [G_i | beta_i | 0]
+            if pre is not None and tuple(pre.shape) == (E, Ci + 8):
+                pass
+            elif i == 0:
                 _, dbeta = hip.gemm_dw_db(dt, x, E, Ci, M, split_k=_splitk(E, Ci, M), out=dGp[:, :Ci])
             else:
                 hip.gemm(2, dt, x, E, Ci, M, out=dGp[:, :Ci], split_k=_splitk(E, Ci, M))
@@ -737,13 +756,17 @@ class SegformerFoldedFuseFn(Function):
             dWp = hip.gemm(2, Fi, dGc, E, Ci + 8, E, out_dtype=torch.float32)               # [dW_i | db_i | 0] = F_i^T dG'_i
             dws.append(dWp[:, :Ci])
             dbs.append(dWp[:, Ci])
-        return (None, *dxs, *dws, *dbs, dwf.view(E, 4 * E, 1, 1))
+        if ctx.fold_slot is not None:
+            ctx.fold_slot.clear()
+        return (None, *dxs, *dws, *dbs, dwf.view(E, 4 * E, 1, 1), None)
 
 
 def segformer_folded_fuse(feats, weights, biases, fuse_weight, geoms):
     """-> (y [B*H1*W1, E], sums): sums = fp32 [2, E] per-channel (sum, sum of squares) of y for the BatchNorm that follows, or
     None when the geometry did not take the fused kernel."""
-    y, sums = SegformerFoldedFuseFn.apply(tuple(geoms), *feats, *weights, *biases, fuse_weight)
+    slot = {}
+    y, sums = SegformerFoldedFuseFn.apply(tuple(geoms), *feats, *weights, *biases, fuse_weight, slot)
+    y._segf_fold = slot          # read by bn_act_linear: its backward can compute this function's stage-1 weight gradient in passing
     return y, (sums if sums.numel() else None)
 
 

@@ -44,6 +44,9 @@ _PROTOS = {
     'segf_bn_cls_bwd_supported': (_i, [_i, _l, _i, _i, _l]),
     'segf_bn_cls_bwd_ws': (_l, [_l, _i, _l]),
     'segf_bn_cls_bwd': (_i, [_i, _l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p]),
+    'segf_bn_cls_bwd_dw_supported': (_i, [_i, _l, _i, _i, _l, _i]),
+    'segf_bn_cls_bwd_dw_ws': (_l, [_l, _i, _l]),
+    'segf_bn_cls_bwd_dw': (_i, [_i, _l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
     'segf_grn_ws': (_l, [_i, _l, _i, _i]),
     'segf_grn_fwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_grn_bwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -487,6 +490,30 @@ def bn_cls_bwd(dy, w, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_samp
                                _ptr(gamma), _ptr(beta), act, _ptr(chan_scale), rows_per_sample, int(eval_mode), _ptr(dx),
                                _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream()), 'segf_bn_cls_bwd')
     return dx, dgamma, dbeta
+
+
+def bn_cls_bwd_dw_supported(dtype, M, Cc, K, rps, C1):
+    return dtype == torch.bfloat16 and bool(lib().segf_bn_cls_bwd_dw_supported(BF16, M, Cc, K, rps, C1))
+
+
+def bn_cls_bwd_dw(dy, w, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode, x1):
+    """bn_cls_bwd plus the product that the consumer of dx needs next: dG fp32 [C, C1 + 8] = [dx^T x1 | colsum(dx) | 0]
+    (segf_bn_cls_bwd_dw; x1: [M, C1] bf16, the stage-1 tokens of the folded SegFormerHead).  -> (dx, dgamma, dbeta, dG)."""
+    _need_cuda(dy, w, x, x1)
+    M, Cc = x.shape
+    K, C1 = w.shape[0], x1.shape[1]
+    assert dy.shape[0] == M and dy.stride(1) == 1 and dy.stride(0) >= K and w.shape[1] == Cc and w.is_contiguous() and x.is_contiguous()
+    assert x1.shape[0] == M and x1.stride(1) == 1 and x1.dtype == torch.bfloat16
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dG = torch.empty((Cc, C1 + 8), dtype=torch.float32, device=x.device)
+    ws = _f32(lib().segf_bn_cls_bwd_dw_ws(M, Cc, rows_per_sample), x.device)
+    _chk(lib().segf_bn_cls_bwd_dw(BF16, M, Cc, K, _ptr(dy), dy.stride(0), _ptr(w), w.stride(0), _ptr(x), _ptr(mean), _ptr(rstd),
+                                  _ptr(gamma), _ptr(beta), act, _ptr(chan_scale), rows_per_sample, int(eval_mode), _ptr(dx),
+                                  _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(x1), x1.stride(0), C1, _ptr(dG), _stream()),
+         'segf_bn_cls_bwd_dw')
+    return dx, dgamma, dbeta, dG
 
 
 def grn_fwd(x, gamma, beta, B, rps):

@@ -1097,7 +1097,8 @@ def test_bilinear_bwd_248_equals_three_transposed_resizes(hipmod, dtype, geom):
 
 
 @pytest.mark.parametrize('cfg', [(2, 128, 128, 768, 150, 1, True, False), (2, 64, 128, 256, 19, 1, False, False),
-                                 (1, 128, 128, 512, 21, 0, True, True), (3, 96, 64, 768, 171, 2, False, False)])
+                                 (1, 128, 128, 512, 21, 0, True, True), (3, 96, 64, 768, 171, 2, False, False),
+                                 (5, 72, 72, 768, 150, 1, True, False)])
 def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
     """segf_bn_cls_bwd (head_fused.hip: both BatchNorm-backward passes recompute da = dy W on the matrix pipe, da is never
     materialised) against fp32 autograd of  a = act(bn(x)) * drop;  y = a W^T  on the CPU, and against the two-launch path
@@ -1142,6 +1143,24 @@ def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
     dx2, dg2, db2 = hip.bn_bwd(args[2], da, args[3], args[4], args[5], args[6], act, args[8], h * w, eval_mode)
     assert (dx.float() - dx2.float()).abs().max().item() <= 3e-2 * scale
     assert (dg - dg2).abs().max().item() <= 2e-2 * dg2.abs().max().item() + 1e-6
+    # segf_bn_cls_bwd_dw: the same launches with the consumer's weight-gradient product riding on pass 2:
+    # dG = [dx^T x1 | colsum(dx) | 0] from the bf16 dx tile on chip -- dx / dgamma / dbeta must not change by a bit, dG must equal
+    # the fp32 product over the STORED dx (fp32 accumulation order aside), and two runs must agree bitwise
+    C1 = 32
+    if hip.bn_cls_bwd_dw_supported(torch.bfloat16, M, C, K, h * w, C1):
+        x1 = (torch.randn(M, C1 + 8, generator=g) * 0.7).to(torch.bfloat16)
+        x1d = x1.cuda()[:, :C1]                                                   # row stride 40: a column slice of a wider buffer
+        dxw, dgw, dbw, dG = hip.bn_cls_bwd_dw(*args, x1d)
+        assert torch.equal(dxw, dx) and torch.equal(dgw, dg) and torch.equal(dbw, db)
+        assert dG.shape == (C, C1 + 8) and dG.dtype == torch.float32
+        dxf = dx.float().cpu().double()
+        want = dxf.t() @ x1[:, :C1].double()
+        tol = 1e-5 * (dxf.abs().t() @ x1[:, :C1].double().abs()).max().item() + 1e-12
+        assert (dG[:, :C1].cpu().double() - want).abs().max().item() <= tol
+        assert (dG[:, C1].cpu().double() - dxf.sum(0)).abs().max().item() <= 1e-5 * dxf.abs().sum(0).max().item() + 1e-12
+        assert float(dG[:, C1 + 1:].abs().max()) == 0.0
+        dG2 = hip.bn_cls_bwd_dw(*args, x1d)[3]
+        assert torch.equal(dG, dG2)
 
 
 @pytest.mark.parametrize('shape', [(300, 256, 128), (1000, 768, 3072), (4096, 1536, 384), (129, 40, 256)])
