@@ -1175,8 +1175,9 @@ __global__ void __launch_bounds__(256) gemm_skinny_rows_kernel(GemmArgs a) {
 // shapes the streaming kernel takes: bf16 in/out, layouts 0/1, K in {32, 64, 128}, N a multiple of the chunk width,
 // 16-byte aligned rows on every operand, enough tokens to amortise the register-resident weights
 static int gemm_skinny_nt(int layout, int64_t M, int64_t N, int64_t K) {
-    if (layout > 1 || M < 16384 || (K != 32 && K != 64 && K != 128)) return 0;
+    if (layout > 1 || M < 16384 || (K != 32 && K != 64 && K != 128 && !(K == 160 && layout == 0))) return 0;
     const int ks = (int)(K / 32);
+    if (ks == 5) return N % 32 == 0 ? 2 : 0;    // K = 160: the stem's 7 x 7 x 3 = 147 im2col columns padded to whole 32-steps
     int nt = 16 / ks;                       // NT * KS <= 16 fragments
     if (nt > 8) nt = 8;
     while (nt >= 2 && N % (16 * nt)) nt >>= 1;
@@ -1185,7 +1186,7 @@ static int gemm_skinny_nt(int layout, int64_t M, int64_t N, int64_t K) {
 template <int LAYOUT>
 static bool gemm_skinny_launch(int ks, int nt, dim3 grid, hipStream_t st, const GemmArgs& a) {
 #define SK(KS_, NT_) if (ks == KS_ && nt == NT_) { hipLaunchKernelGGL((gemm_skinny_kernel<LAYOUT, KS_, NT_>), grid, dim3(256), 0, st, a); return true; }
-    SK(1, 2) SK(1, 4) SK(1, 8) SK(2, 2) SK(2, 4) SK(2, 8) SK(4, 2) SK(4, 4)
+    SK(1, 2) SK(1, 4) SK(1, 8) SK(2, 2) SK(2, 4) SK(2, 8) SK(4, 2) SK(4, 4) SK(5, 2)
 #undef SK
     return false;
 }

@@ -398,11 +398,23 @@ class ConvPatchFn(Function):
         Wo = (W + 2 * pad - k) // stride + 1
         K = k * k * Cin
         ld = (K + 7) // 8 * 8
+        # the stem (7 x 7 x 3 = 147 columns, 2 M tokens at cfg2): columns padded to whole 32-steps (160) so that the forward
+        # product takes the streaming kernel (rows are its MFMA operand as they lie in memory); the pad columns are zeros on
+        # both sides.  The tiled kernel spent 392 us on this [2M x 147] -> 32 product, 75 % of its tile columns empty
+        stream_form = (image and dtype == torch.bfloat16 and K % 32 != 0 and (K + 31) // 32 * 32 == 160 and O % 32 == 0
+                       and B * Ho * Wo >= 16384)
+        if stream_form:
+            ld = 160
         x = x if x.is_contiguous() else x.contiguous()
         col = hip.im2col(x, dtype, image, B, H, W, Cin, k, k, stride, pad, Ho, Wo, ld)
         wmat = hip.permute021(weight.detach().contiguous(), O, Cin, k * k, dtype).view(O, K)   # [O][(ky,kx)][ci]
         b = bias.detach() if bias is not None else None
-        y = hip.gemm(0, col, wmat, B * Ho * Wo, O, K, bias=b)
+        if stream_form:
+            wpad = hip.zeros((O, ld), dtype, x.device)
+            hip.cast2d(wmat, wpad[:, :K])
+            y = hip.gemm(0, col, wpad, B * Ho * Wo, O, ld, bias=b)
+        else:
+            y = hip.gemm(0, col, wmat, B * Ho * Wo, O, K, bias=b)
         # the im2col matrix itself is kept for the weight gradient (k*k/stride^2 <= 3.1x the conv input, < 1 GB in total
         # for SegFormer-B0 at batch 64 out of 288 GB): rebuilding it in backward costs a second pass over the image
         ctx.save_for_backward(col, wmat)

@@ -800,6 +800,38 @@ def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
     assert (nob.double().cpu() - (ref - bias.double())).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
 
 
+def test_stem_conv_streaming_form(hipmod, monkeypatch):
+    """PatchEmbed's k7 s4 p3 conv of the fp32 NCHW image (mit.py:105) at a token count that takes the streaming forward product:
+    im2col columns padded 147 -> 160 (zeros on both sides), gemm_skinny_kernel<0, 5, 2>.  Against F.conv2d on the bf16-rounded
+    operands, and against the tiled kernel on the same padded operands (switch): forward, weight and bias gradients."""
+    from segmentation_factory_amd import functional as Fh
+    g = torch.Generator().manual_seed(17)
+    B, H, W, O = 2, 384, 400, 32                                     # 2 * 96 * 100 = 19200 tokens (ragged last 16-token group: none)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(O, 3, 7, 7, generator=g) * 0.1
+    b = torch.randn(O, generator=g) * 0.1
+    dy = torch.randn(B, O, H // 4, W // 4, generator=g)
+    wr, br = _q(w, torch.bfloat16).requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(_q(x, torch.bfloat16), wr, br, stride=4, padding=3)
+    ref.backward(_q(dy, torch.bfloat16))
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, O)             # noqa: E731
+
+    def run():
+        wd, bd = _dev(w).requires_grad_(True), _dev(b).requires_grad_(True)
+        y = Fh.conv_patch(_dev(x), wd, bd, (B, H, W, 3, 7, 4, 3), image=True, dtype=torch.bfloat16)
+        y.backward(_dev(tok(dy), torch.bfloat16))
+        return y.detach(), wd.grad, bd.grad
+    y, dw, db = run()
+    _close(y, tok(ref), torch.bfloat16)
+    _close(dw, wr.grad, torch.bfloat16, fac=4)
+    _close(db, br.grad, torch.bfloat16, fac=4)
+    monkeypatch.setenv('SEGFAC_GEMM_NO_SKINNY', '1')
+    y2, dw2, db2 = run()
+    monkeypatch.delenv('SEGFAC_GEMM_NO_SKINNY')
+    assert (y.float() - y2.float()).abs().max().item() <= 2e-2 * y2.float().abs().max().item()
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2, 70, 9, 8, True), (1, 5, 131, 16, True), (3, 16, 16, 40, False), (1, 130, 6, 136, True)])
 def test_dwconv3x3_walk_equals_strip_form(dtype, shape, monkeypatch):
