@@ -888,17 +888,22 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 
 // ---- split-K reduction: C = sum_z ws[z] (fixed order): 16 outputs x 16 slice-lanes per workgroup, slice lane s adds
 // z = s, s+16, ... with independent loads in flight, then the 16 lane sums are added in fixed order --------------------
+// The workgroups past `main_blocks` reduce the bias-gradient slices that ride on the same product (cs_ws [split][cs_n] ->
+// cs_out [cs_n], the arithmetic of colreduce_finalize_kernel): one launch per weight gradient instead of two.
 template <typename OutT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
-                                                             OutT* __restrict__ C, int64_t ldc) {
+                                                             OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                             const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
     __shared__ float red[16][17];
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int64_t total = M * N;
-    const int64_t i = (int64_t)blockIdx.x * 16 + o;
+    const bool cs = blockIdx.x >= main_blocks;
+    const int64_t total = cs ? cs_n : M * N;
+    const float* __restrict__ src = cs ? cs_ws : ws;
+    const int64_t i = (int64_t)(cs ? blockIdx.x - main_blocks : blockIdx.x) * 16 + o;
     float acc = 0.f;
     if (i < total) {
 #pragma unroll 4
-        for (int z = sl; z < split; z += 16) acc += ws[(int64_t)z * total + i];
+        for (int z = sl; z < split; z += 16) acc += src[(int64_t)z * total + i];
     }
     red[sl][o] = acc;
     __syncthreads();
@@ -906,8 +911,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][o];
-        const int64_t m = i / N, n = i - m * N;
-        stf<OutT>(C + m * ldc + n, t);
+        if (cs) {
+            cs_out[i] = t;
+        } else {
+            const int64_t m = i / N, n = i - m * N;
+            stf<OutT>(C + m * ldc + n, t);
+        }
     }
 }
 
@@ -1587,15 +1596,14 @@ reduce:
     if (a.ws) {
         const int64_t total = M * N;
         const unsigned blocks = (unsigned)cdiv64(total, 16);
+        const unsigned csb = a.colsum_ws ? (unsigned)cdiv64(M, 16) : 0u;        // the bias gradient's slices: same launch
         if (c_dt == SEGF_F32)
-            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (float*)C, ldc);
+            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks + csb), dim3(256), 0, st, ws, split_k, M, N, (float*)C, ldc,
+                               blocks, a.colsum_ws, a.colsum, M);
         else
-            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, (bf16_t*)C, ldc);
+            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks + csb), dim3(256), 0, st, ws, split_k, M, N, (bf16_t*)C, ldc,
+                               blocks, a.colsum_ws, a.colsum, M);
         SEGF_CHECK_LAUNCH();
-        if (a.colsum_ws) {
-            colreduce_finalize_launch(a.colsum_ws, split_k, M, a.colsum, st);     // 16 slices in parallel per output, fixed order
-            SEGF_CHECK_LAUNCH();
-        }
     }
     return 0;
 }
@@ -1665,8 +1673,8 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
 reduce3:
     if (a.ws) {
         const unsigned blocks = (unsigned)cdiv64(a.M * a.N, 16);
-        if (y_dt == SEGF_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (float*)y, ldy);
-        else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (bf16_t*)y, ldy);
+        if (y_dt == SEGF_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (float*)y, ldy, blocks, (const float*)nullptr, (float*)nullptr, (int64_t)0);
+        else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (bf16_t*)y, ldy, blocks, (const float*)nullptr, (float*)nullptr, (int64_t)0);
         SEGF_CHECK_LAUNCH();
     }
     return 0;
