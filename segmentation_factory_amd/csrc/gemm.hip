@@ -1183,6 +1183,91 @@ __global__ void __launch_bounds__(256) gemm_skinny_rows_kernel(GemmArgs a) {
 
 // shapes the streaming kernel takes: bf16 in/out, layouts 0/1, K in {32, 64, 128}, N a multiple of the chunk width,
 // 16-byte aligned rows on every operand, enough tokens to amortise the register-resident weights
+// ---- streaming data gradient with a WIDE reduction: dx[M][32] = dy[M][K] G[K][32], M ~ 10^6 tokens, K = 256 .. 1024 ------------
+// (the folded SegFormerHead's stage-1 term: K = 768, 3.2 GB of dy per launch at cfg2; the tiled kernel fills a quarter of its
+// 128 output columns and ran at 3.8 TB/s).  The four waves of a workgroup split K: wave w keeps the weight fragments of its
+// K / 4 columns in registers and, per 16-token group, loads its 16-byte pieces of the rows straight into the MFMA B operand (as
+// gemm_skinny_kernel does: transposed product, no LDS on the way in; next group's loads in flight).  The four partial
+// [16 x 32] tiles meet in LDS (two slabs, one barrier per group) and are added in fixed order wave 0..3 by all 256 threads,
+// which then write the group's 1 KB of bf16 output (row runs of 64 bytes).
+template <int KS>
+__global__ void __launch_bounds__(256) gemm_skinny_k_kernel(GemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mi = lane & 15, g = lane >> 4;
+    const bf16_t* __restrict__ A = static_cast<const bf16_t*>(a.A);
+    const bf16_t* __restrict__ B = static_cast<const bf16_t*>(a.B);
+    bf16_t* __restrict__ C = static_cast<bf16_t*>(a.C);
+    const int k0 = wave * (32 * KS);
+    // weight fragments (B stored [K][N]): MFMA row i of tile nt carries feature 8 (i >> 2) + 4 nt + (i & 3), so that lane group g
+    // ends up with the 8 consecutive features 8 g .. 8 g + 7 of token mi (tile 0: + r, tile 1: + 4 + r)
+    bf16x8 Wf[2][KS];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = 8 * (mi >> 2) + 4 * nt + (mi & 3);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            s16x8 w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = (short)B[(int64_t)(k0 + 32 * s + 8 * g + j) * a.ldb + n];
+            Wf[nt][s] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    __shared__ __attribute__((aligned(16))) float part[2][4][16][36];   // [slab][wave][token][feature (+4: bank spread)]
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 xa[KS], xb[KS];
+    const int64_t ngroups = (a.M + 15) / 16, gstride = gridDim.x;
+    auto rowptr = [&](int64_t gp) {
+        int64_t m = gp * 16 + mi;
+        m = m < a.M ? m : a.M - 1;
+        return A + m * a.lda + k0 + 8 * g;
+    };
+    int64_t grp = blockIdx.x;
+    {
+        const bf16_t* p = rowptr(grp < ngroups ? grp : 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xa[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
+    }
+    const int ot = threadIdx.x >> 4, of = 2 * (threadIdx.x & 15);        // this thread's output: token ot, features of, of + 1
+    int slab = 0;
+    for (; grp < ngroups; grp += gstride) {
+        {
+            const int64_t nxt = grp + gstride;
+            const bf16_t* p = rowptr(nxt < ngroups ? nxt : grp);          // unconditional (the last one re-reads)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
+            SEGF_LOADS_ISSUED();
+        }
+        f32x4 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], __builtin_bit_cast(bf16x8, xa[s]), acc[nt], 0, 0, 0);
+        }
+        float* pw = &part[slab][wave][mi][8 * g];
+        *reinterpret_cast<float4*>(pw) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+        *reinterpret_cast<float4*>(pw + 4) = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+        __syncthreads();                 // (the other slab is free again: its readers passed the previous barrier's successor)
+        {
+            const float2 p0 = *reinterpret_cast<const float2*>(&part[slab][0][ot][of]);
+            const float2 p1 = *reinterpret_cast<const float2*>(&part[slab][1][ot][of]);
+            const float2 p2 = *reinterpret_cast<const float2*>(&part[slab][2][ot][of]);
+            const float2 p3 = *reinterpret_cast<const float2*>(&part[slab][3][ot][of]);
+            const float v0 = ((p0.x + p1.x) + p2.x) + p3.x, v1 = ((p0.y + p1.y) + p2.y) + p3.y;
+            const int64_t mr = grp * 16 + ot;
+            if (mr < a.M) *reinterpret_cast<uint32_t*>(C + mr * a.ldc + of) = pack2bf(v0, v1);
+        }
+        slab ^= 1;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xa[s] = xb[s];
+    }
+}
+static bool gemm_skinny_k_ok(int layout, int64_t M, int64_t N, int64_t K) {
+    if (getenv("SEGFAC_GEMM_NO_SKINNY_K")) return false;
+    return layout == 1 && N == 32 && M >= 65536 && K % 128 == 0 && K >= 256 && K <= 1024;
+}
+
 static int gemm_skinny_nt(int layout, int64_t M, int64_t N, int64_t K) {
     if (layout > 1 || M < 16384 || (K != 32 && K != 64 && K != 128 && !(K == 160 && layout == 0))) return 0;
     const int ks = (int)(K / 32);
@@ -1508,6 +1593,21 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                 int64_t gx = cdiv64(groups, 4 * 8);
                 if (gx > 1024) gx = 1024;
                 hipLaunchKernelGGL((gemm_skinny_rows_kernel<1, 6>), dim3((unsigned)gx), dim3(256), 0, st, a);
+                SEGF_CHECK_LAUNCH();
+                return 0;
+            }
+            if (!bias && !residual && gemm_skinny_k_ok(layout, M, N, K) && ldc % 2 == 0) {
+                const int64_t groups = cdiv64(M, 16);
+                const unsigned gx = (unsigned)imin64(groups, 256 * 12);     // three workgroups per CU, several rounds of groups each
+                switch ((int)(K / 128)) {
+                case 2: hipLaunchKernelGGL((gemm_skinny_k_kernel<2>), dim3(gx), dim3(256), 0, st, a); break;
+                case 3: hipLaunchKernelGGL((gemm_skinny_k_kernel<3>), dim3(gx), dim3(256), 0, st, a); break;
+                case 4: hipLaunchKernelGGL((gemm_skinny_k_kernel<4>), dim3(gx), dim3(256), 0, st, a); break;
+                case 5: hipLaunchKernelGGL((gemm_skinny_k_kernel<5>), dim3(gx), dim3(256), 0, st, a); break;
+                case 6: hipLaunchKernelGGL((gemm_skinny_k_kernel<6>), dim3(gx), dim3(256), 0, st, a); break;
+                case 7: hipLaunchKernelGGL((gemm_skinny_k_kernel<7>), dim3(gx), dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((gemm_skinny_k_kernel<8>), dim3(gx), dim3(256), 0, st, a); break;
+                }
                 SEGF_CHECK_LAUNCH();
                 return 0;
             }

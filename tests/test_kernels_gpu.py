@@ -800,6 +800,30 @@ def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
     assert (nob.double().cpu() - (ref - bias.double())).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize('K', [256, 768, 1024])
+def test_gemm_streaming_wide_k_data_gradient(hipmod, monkeypatch, K):
+    """dx[M][32] = dy[M][K] G[K][32] with M >= 65536 (the folded head's stage-1 data gradient): gemm_skinny_k_kernel (four waves
+    split K, partial tiles added in fixed order) against fp64, against the tiled kernel (switch), ragged last group, twice
+    (bitwise reproducible)."""
+    M, N = 65536 + 16 * 11 + 7, 32
+    g = torch.Generator().manual_seed(92)
+    dy = torch.randn(M, K, generator=g).bfloat16()
+    G = (torch.randn(K, N, generator=g) / K ** 0.5).bfloat16()
+    ref = dy.double() @ G.double()
+    dyd, Gd = dy.cuda(), G.cuda()
+    out = hipmod.gemm(1, dyd, Gd, M, N, K)
+    out_b = hipmod.gemm(1, dyd, Gd, M, N, K)
+    monkeypatch.setenv('SEGFAC_GEMM_NO_SKINNY_K', '1')
+    out2 = hipmod.gemm(1, dyd, Gd, M, N, K)
+    monkeypatch.delenv('SEGFAC_GEMM_NO_SKINNY_K')
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_b)
+    tol = 1.2e-2 * ref.abs().max().item()                                          # one bf16 rounding of the output
+    assert (out.double().cpu() - ref).abs().max().item() <= tol
+    assert (out2.double().cpu() - ref).abs().max().item() <= tol
+    assert (out.float() - out2.float()).abs().max().item() <= tol
+
+
 def test_stem_conv_streaming_form(hipmod, monkeypatch):
     """PatchEmbed's k7 s4 p3 conv of the fp32 NCHW image (mit.py:105) at a token count that takes the streaming forward product:
     im2col columns padded 147 -> 160 (zeros on both sides), gemm_skinny_kernel<0, 5, 2>.  Against F.conv2d on the bf16-rounded
