@@ -1183,36 +1183,45 @@ __global__ void __launch_bounds__(256) gemm_skinny_rows_kernel(GemmArgs a) {
 
 // shapes the streaming kernel takes: bf16 in/out, layouts 0/1, K in {32, 64, 128}, N a multiple of the chunk width,
 // 16-byte aligned rows on every operand, enough tokens to amortise the register-resident weights
-// ---- streaming data gradient with a WIDE reduction: dx[M][32] = dy[M][K] G[K][32], M ~ 10^6 tokens, K = 256 .. 1024 ------------
-// (the folded SegFormerHead's stage-1 term: K = 768, 3.2 GB of dy per launch at cfg2; the tiled kernel fills a quarter of its
-// 128 output columns and ran at 3.8 TB/s).  The four waves of a workgroup split K: wave w keeps the weight fragments of its
-// K / 4 columns in registers and, per 16-token group, loads its 16-byte pieces of the rows straight into the MFMA B operand (as
+// ---- streaming products with a WIDE reduction and a narrow output: y[M][N] = x[M][K] W, N = 32 / 64, K = 256 .. 1024, M ~ 10^6 --
+// (the folded SegFormerHead's stage-1 / stage-2 data gradients: K = 768, 3.2 GB of dy per launch at cfg2; the stage-2 MLP's
+// fc2 forward and fc1 data gradient: K = 256.  The tiled kernel fills a quarter / half of its 128 output columns and ran the
+// head's term at 3.8 TB/s.)  The four waves of a workgroup split K: wave w keeps the weight fragments of its K / 4 columns in
+// registers and, per 16-token group, loads its 16-byte pieces of the rows straight into the MFMA B operand (as
 // gemm_skinny_kernel does: transposed product, no LDS on the way in; next group's loads in flight).  The four partial
-// [16 x 32] tiles meet in LDS (two slabs, one barrier per group) and are added in fixed order wave 0..3 by all 256 threads,
-// which then write the group's 1 KB of bf16 output (row runs of 64 bytes).
-template <int KS>
-__global__ void __launch_bounds__(256) gemm_skinny_k_kernel(GemmArgs a) {
+// [16 x N] tiles meet in LDS (two slabs, one barrier per group) and are added in fixed order wave 0..3 by all 256 threads, which
+// apply the epilogue (bias, residual + per-sample DropPath scale) and write the group's bf16 rows in whole runs.
+// LAYOUT 0: W stored [N][K] (forward); LAYOUT 1: W stored [K][N] (data gradient).
+template <int LAYOUT, int KS, int NT>
+__global__ void __launch_bounds__(256, 2) gemm_skinny_k_kernel(GemmArgs a) {
+    static_assert(NT == 2 || NT == 4, "32 or 64 output features");
+    constexpr int NF = 16 * NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mi = lane & 15, g = lane >> 4;
     const bf16_t* __restrict__ A = static_cast<const bf16_t*>(a.A);
     const bf16_t* __restrict__ B = static_cast<const bf16_t*>(a.B);
     bf16_t* __restrict__ C = static_cast<bf16_t*>(a.C);
+    const bf16_t* __restrict__ R = static_cast<const bf16_t*>(a.residual);
     const int k0 = wave * (32 * KS);
-    // weight fragments (B stored [K][N]): MFMA row i of tile nt carries feature 8 (i >> 2) + 4 nt + (i & 3), so that lane group g
-    // ends up with the 8 consecutive features 8 g .. 8 g + 7 of token mi (tile 0: + r, tile 1: + 4 + r)
-    bf16x8 Wf[2][KS];
+    // weight fragments: MFMA row i of tile nt carries feature 32 (nt >> 1) + 8 (i >> 2) + 4 (nt & 1) + (i & 3), so that lane group g
+    // ends up with the 8 consecutive features 32 q + 8 g .. + 7 of token mi from the tile pair (2 q, 2 q + 1)
+    bf16x8 Wf[NT][KS];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = 8 * (mi >> 2) + 4 * nt + (mi & 3);
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = 32 * (nt >> 1) + 8 * (mi >> 2) + 4 * (nt & 1) + (mi & 3);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            s16x8 w;
+            if (LAYOUT == 0) {
+                Wf[nt][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(B + (int64_t)n * a.ldb + k0 + 32 * s + 8 * g));
+            } else {
+                s16x8 w;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = (short)B[(int64_t)(k0 + 32 * s + 8 * g + j) * a.ldb + n];
-            Wf[nt][s] = __builtin_bit_cast(bf16x8, w);
+                for (int j = 0; j < 8; ++j) w[j] = (short)B[(int64_t)(k0 + 32 * s + 8 * g + j) * a.ldb + n];
+                Wf[nt][s] = __builtin_bit_cast(bf16x8, w);
+            }
         }
     }
-    __shared__ __attribute__((aligned(16))) float part[2][4][16][36];   // [slab][wave][token][feature (+4: bank spread)]
+    __shared__ __attribute__((aligned(16))) float part[2][4][16][NF + 4];   // [slab][wave][token][feature (+4: bank spread)]
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 xa[KS], xb[KS];
     const int64_t ngroups = (a.M + 15) / 16, gstride = gridDim.x;
@@ -1227,7 +1236,13 @@ __global__ void __launch_bounds__(256) gemm_skinny_k_kernel(GemmArgs a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) xa[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
     }
-    const int ot = threadIdx.x >> 4, of = 2 * (threadIdx.x & 15);        // this thread's output: token ot, features of, of + 1
+    // this thread's outputs of a group: token ot, features of .. of + NF / 16 - 1 (2 or 4 consecutive ones)
+    constexpr int FPT = NF / 16;
+    const int ot = threadIdx.x >> 4, of = FPT * (threadIdx.x & 15);
+    float bv[FPT];
+#pragma unroll
+    for (int j = 0; j < FPT; ++j) bv[j] = a.bias ? a.bias[of + j] : 0.f;
+    const float* rsp = a.rscale ? a.rscale : &skinny_one;
     int slab = 0;
     for (; grp < ngroups; grp += gstride) {
         {
@@ -1237,26 +1252,51 @@ __global__ void __launch_bounds__(256) gemm_skinny_k_kernel(GemmArgs a) {
             for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
             SEGF_LOADS_ISSUED();
         }
-        f32x4 acc[2];
+        f32x4 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[nt][s], __builtin_bit_cast(bf16x8, xa[s]), acc[nt], 0, 0, 0);
         }
-        float* pw = &part[slab][wave][mi][8 * g];
-        *reinterpret_cast<float4*>(pw) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-        *reinterpret_cast<float4*>(pw + 4) = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
-        __syncthreads();                 // (the other slab is free again: its readers passed the previous barrier's successor)
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+            float* pw = &part[slab][wave][mi][32 * q + 8 * g];
+            *reinterpret_cast<float4*>(pw) = make_float4(acc[2 * q][0], acc[2 * q][1], acc[2 * q][2], acc[2 * q][3]);
+            *reinterpret_cast<float4*>(pw + 4) = make_float4(acc[2 * q + 1][0], acc[2 * q + 1][1], acc[2 * q + 1][2], acc[2 * q + 1][3]);
+        }
+        const int64_t mr = grp * 16 + ot;
+        const int64_t mc = mr < a.M ? mr : a.M - 1;
+        // residual row piece and DropPath scale of this thread's outputs: issued before the barrier, consumed after it
+        uint32_t rraw[FPT / 2];
+        float rs = 1.f;
+        if (R) {
+            const bf16_t* rp = R + mc * a.ldr + of;
+#pragma unroll
+            for (int j = 0; j < FPT / 2; ++j) rraw[j] = *reinterpret_cast<const uint32_t*>(rp + 2 * j);
+            rs = rsp[a.rscale ? mc / a.rpg : 0];
+        }
+        __syncthreads();                 // (the other slab is free again: its readers have all arrived here)
         {
-            const float2 p0 = *reinterpret_cast<const float2*>(&part[slab][0][ot][of]);
-            const float2 p1 = *reinterpret_cast<const float2*>(&part[slab][1][ot][of]);
-            const float2 p2 = *reinterpret_cast<const float2*>(&part[slab][2][ot][of]);
-            const float2 p3 = *reinterpret_cast<const float2*>(&part[slab][3][ot][of]);
-            const float v0 = ((p0.x + p1.x) + p2.x) + p3.x, v1 = ((p0.y + p1.y) + p2.y) + p3.y;
-            const int64_t mr = grp * 16 + ot;
-            if (mr < a.M) *reinterpret_cast<uint32_t*>(C + mr * a.ldc + of) = pack2bf(v0, v1);
+            float v[FPT];
+#pragma unroll
+            for (int j = 0; j < FPT; ++j) {
+                const float p0 = part[slab][0][ot][of + j], p1 = part[slab][1][ot][of + j], p2 = part[slab][2][ot][of + j],
+                            p3 = part[slab][3][ot][of + j];
+                v[j] = (((p0 + p1) + p2) + p3) + bv[j];
+            }
+            if (R) {
+#pragma unroll
+                for (int j = 0; j < FPT / 2; ++j) {
+                    v[2 * j] = __uint_as_float(rraw[j] << 16) + rs * v[2 * j];
+                    v[2 * j + 1] = __uint_as_float(rraw[j] & 0xffff0000u) + rs * v[2 * j + 1];
+                }
+            }
+            if (mr < a.M) {
+                if constexpr (FPT == 2) *reinterpret_cast<uint32_t*>(C + mr * a.ldc + of) = pack2bf(v[0], v[1]);
+                else *reinterpret_cast<uint2*>(C + mr * a.ldc + of) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            }
         }
         slab ^= 1;
 #pragma unroll
@@ -1265,7 +1305,20 @@ __global__ void __launch_bounds__(256) gemm_skinny_k_kernel(GemmArgs a) {
 }
 static bool gemm_skinny_k_ok(int layout, int64_t M, int64_t N, int64_t K) {
     if (getenv("SEGFAC_GEMM_NO_SKINNY_K")) return false;
-    return layout == 1 && N == 32 && M >= 65536 && K % 128 == 0 && K >= 256 && K <= 1024;
+    if (N == 64 && K > 768) return false;       // 64 outputs: the weight fragments of K / 4 > 192 columns pass the register file
+    return (layout == 0 || layout == 1) && (N == 32 || N == 64) && M >= 65536 && K % 128 == 0 && K >= 256 && K <= 1024;
+}
+template <int LAYOUT, int NT>
+static void gemm_skinny_k_launch(int ks, unsigned gx, hipStream_t st, const GemmArgs& a) {
+    switch (ks) {
+    case 2: hipLaunchKernelGGL((gemm_skinny_k_kernel<LAYOUT, 2, NT>), dim3(gx), dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((gemm_skinny_k_kernel<LAYOUT, 3, NT>), dim3(gx), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((gemm_skinny_k_kernel<LAYOUT, 4, NT>), dim3(gx), dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((gemm_skinny_k_kernel<LAYOUT, 5, NT>), dim3(gx), dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((gemm_skinny_k_kernel<LAYOUT, 6, NT>), dim3(gx), dim3(256), 0, st, a); break;
+    case 7: hipLaunchKernelGGL((gemm_skinny_k_kernel<LAYOUT, 7, NT>), dim3(gx), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_skinny_k_kernel<LAYOUT, 8, NT>), dim3(gx), dim3(256), 0, st, a); break;
+    }
 }
 
 static int gemm_skinny_nt(int layout, int64_t M, int64_t N, int64_t K) {
@@ -1596,18 +1649,12 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                 SEGF_CHECK_LAUNCH();
                 return 0;
             }
-            if (!bias && !residual && gemm_skinny_k_ok(layout, M, N, K) && ldc % 2 == 0) {
+            if (gemm_skinny_k_ok(layout, M, N, K) && ldc % 4 == 0 && (!residual || ldr % 2 == 0)) {
                 const int64_t groups = cdiv64(M, 16);
-                const unsigned gx = (unsigned)imin64(groups, 256 * 12);     // three workgroups per CU, several rounds of groups each
-                switch ((int)(K / 128)) {
-                case 2: hipLaunchKernelGGL((gemm_skinny_k_kernel<2>), dim3(gx), dim3(256), 0, st, a); break;
-                case 3: hipLaunchKernelGGL((gemm_skinny_k_kernel<3>), dim3(gx), dim3(256), 0, st, a); break;
-                case 4: hipLaunchKernelGGL((gemm_skinny_k_kernel<4>), dim3(gx), dim3(256), 0, st, a); break;
-                case 5: hipLaunchKernelGGL((gemm_skinny_k_kernel<5>), dim3(gx), dim3(256), 0, st, a); break;
-                case 6: hipLaunchKernelGGL((gemm_skinny_k_kernel<6>), dim3(gx), dim3(256), 0, st, a); break;
-                case 7: hipLaunchKernelGGL((gemm_skinny_k_kernel<7>), dim3(gx), dim3(256), 0, st, a); break;
-                default: hipLaunchKernelGGL((gemm_skinny_k_kernel<8>), dim3(gx), dim3(256), 0, st, a); break;
-                }
+                const unsigned gx = (unsigned)imin64(groups, 256 * 12);     // several rounds of 16-token groups per workgroup
+                const int ks = (int)(K / 128);
+                if (layout == 0) { if (N == 32) gemm_skinny_k_launch<0, 2>(ks, gx, st, a); else gemm_skinny_k_launch<0, 4>(ks, gx, st, a); }
+                else { if (N == 32) gemm_skinny_k_launch<1, 2>(ks, gx, st, a); else gemm_skinny_k_launch<1, 4>(ks, gx, st, a); }
                 SEGF_CHECK_LAUNCH();
                 return 0;
             }

@@ -800,21 +800,30 @@ def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
     assert (nob.double().cpu() - (ref - bias.double())).abs().max().item() <= 1.2e-2 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize('K', [256, 768, 1024])
-def test_gemm_streaming_wide_k_data_gradient(hipmod, monkeypatch, K):
-    """dx[M][32] = dy[M][K] G[K][32] with M >= 65536 (the folded head's stage-1 data gradient): gemm_skinny_k_kernel (four waves
-    split K, partial tiles added in fixed order) against fp64, against the tiled kernel (switch), ragged last group, twice
-    (bitwise reproducible)."""
-    M, N = 65536 + 16 * 11 + 7, 32
+@pytest.mark.parametrize('cfg', [(1, 256, 32, False), (1, 768, 32, False), (1, 1024, 32, False), (1, 768, 64, False),
+                                 (1, 256, 64, True), (0, 256, 64, True), (0, 512, 32, True), (0, 768, 64, False)])
+def test_gemm_streaming_wide_k(hipmod, monkeypatch, cfg):
+    """y[M][N] = x[M][K] W with N = 32 / 64, K = 256 .. 1024, M >= 65536 (the folded head's stage-1 / stage-2 data gradients, the
+    stage-2 MLP's fc2 forward with bias + residual + DropPath scale): gemm_skinny_k_kernel (four waves split K, partial tiles
+    added in fixed order) against fp64, against the tiled kernel (switch), ragged last group, twice (bitwise reproducible)."""
+    layout, K, N, epi = cfg
+    M, rpg = 65536 + 16 * 11 + 7, 4096
     g = torch.Generator().manual_seed(92)
-    dy = torch.randn(M, K, generator=g).bfloat16()
-    G = (torch.randn(K, N, generator=g) / K ** 0.5).bfloat16()
-    ref = dy.double() @ G.double()
-    dyd, Gd = dy.cuda(), G.cuda()
-    out = hipmod.gemm(1, dyd, Gd, M, N, K)
-    out_b = hipmod.gemm(1, dyd, Gd, M, N, K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(*((N, K) if layout == 0 else (K, N)), generator=g) / K ** 0.5).bfloat16()
+    ref = x.double() @ (W.double().t() if layout == 0 else W.double())
+    kw = {}
+    if epi:
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g).bfloat16()
+        rsc = torch.rand((M + rpg - 1) // rpg, generator=g) * 2
+        ref = res.double() + rsc.double().repeat_interleave(rpg)[:M, None] * (ref + bias.double())
+        kw = dict(bias=bias.cuda(), residual=res.cuda(), rscale=rsc.cuda(), rows_per_group=rpg)
+    xd, Wd = x.cuda(), W.cuda()
+    out = hipmod.gemm(layout, xd, Wd, M, N, K, **kw)
+    out_b = hipmod.gemm(layout, xd, Wd, M, N, K, **kw)
     monkeypatch.setenv('SEGFAC_GEMM_NO_SKINNY_K', '1')
-    out2 = hipmod.gemm(1, dyd, Gd, M, N, K)
+    out2 = hipmod.gemm(layout, xd, Wd, M, N, K, **kw)
     monkeypatch.delenv('SEGFAC_GEMM_NO_SKINNY_K')
     torch.cuda.synchronize()
     assert torch.equal(out, out_b)
