@@ -92,8 +92,6 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
             Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
         }
     f32x4 O[DT][QW];
-    const float c2 = scale * 1.4426950408889634f;
-    const bool full = (Nkv & 31) == 0;
     float m[QW], l[QW];
 #pragma unroll
     for (int t = 0; t < QW; ++t) {
@@ -119,9 +117,6 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
             for (int d = 0; d < DT; ++d) Vf[d] = ld_frag_tr<HD>(Vs, kb + 4 * g, kb + 16 + 4 * g, 16 * d, lane);
 #pragma unroll
             for (int t = 0; t < QW; ++t) {
-                // softmax in the exp2 domain on the RAW scores: p = exp2(s c2 - m c2), c2 = scale log2(e) (scale > 0, so the running
-                // maximum can be kept on the raw scores): one fma + one v_exp_f32 + one add per score instead of
-                // select / scale / subtract / multiply / exp / add
                 float sv[2][4];
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt) {
@@ -129,33 +124,27 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
 #pragma unroll
                     for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sv[kt][r] = S[r];
-                }
-                if (!full) {                         // ragged key count (wave-uniform): keys past Nkv drop out
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (kc0 + kb + 16 * kt + 4 * g + r >= Nkv) sv[kt][r] = -INFINITY;
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kc0 + kb + 16 * kt + 4 * g + r;
+                        sv[kt][r] = key < Nkv ? S[r] * scale : -INFINITY;
+                    }
                 }
                 float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
                                  fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
                 mx = xgroup_max(mx);
                 const float mnew = fmaxf(m[t], mx);
-                const float alpha = __builtin_amdgcn_exp2f((m[t] - mnew) * c2);
-                const float nm = -mnew * c2;
+                const float alpha = __expf(m[t] - mnew);
                 float ps = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { sv[kt][r] = __builtin_amdgcn_exp2f(fmaf(sv[kt][r], c2, nm)); ps += sv[kt][r]; }
+                    for (int r = 0; r < 4; ++r) { sv[kt][r] = __expf(sv[kt][r] - mnew); ps += sv[kt][r]; }
                 l[t] = l[t] * alpha + ps;
-                const bool moved = __any(mnew > m[t]);        // lazy rescale: after the first steps the maximum rarely moves
                 m[t] = mnew;
                 const bf16x8 Pf = pack_acc(sv[0], sv[1]);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
-                    if (moved) O[d][t] *= alpha;
+                    O[d][t] *= alpha;
                     O[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[d], Pf, O[d][t], 0, 0, 0);
                 }
             }
@@ -174,7 +163,7 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
                 const uint2 u = make_uint2(pack2bf(O[d][t][0] * inv, O[d][t][1] * inv), pack2bf(O[d][t][2] * inv, O[d][t][3] * inv));
                 *reinterpret_cast<uint2*>(Ob + (int64_t)row * ldo + 16 * d + 4 * g) = u;
             }
-            if (g == 0) lse[((int64_t)b * heads + h) * N + row] = m[t] * scale + __logf(lt);
+            if (g == 0) lse[((int64_t)b * heads + h) * N + row] = m[t] + __logf(lt);
         }
     }
 }
@@ -235,15 +224,10 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
         if (g == 0 && row < N) Dbuf[((int64_t)b * heads + h) * N + row] = Dq[t];
     }
     f32x4 dQ[DT][QW];
-    const float c2 = scale * 1.4426950408889634f;
-    const bool full = (Nkv & 31) == 0;
-    float nlq[QW];
 #pragma unroll
-    for (int t = 0; t < QW; ++t) {
-        nlq[t] = -lq[t] * 1.4426950408889634f;
+    for (int t = 0; t < QW; ++t)
 #pragma unroll
         for (int d = 0; d < DT; ++d) dQ[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
     for (int kc0 = 0; kc0 < Nkv; kc0 += AM_KC) {
         const int nk = Nkv - kc0 < AM_KC ? Nkv - kc0 : AM_KC;
         const int nk32 = (nk + 31) & ~31;
@@ -276,9 +260,9 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float p = __builtin_amdgcn_exp2f(fmaf(S[r], c2, nlq[t]));         // exp(s scale - lse)
-                        if (!full) p = (kc0 + kb + 16 * kt + 4 * g + r < Nkv) ? p : 0.f;
-                        ds[kt][r] = p * (dP[r] - Dq[t]);                                   // (x scale: applied to dQ once, below)
+                        const int key = kc0 + kb + 16 * kt + 4 * g + r;
+                        const float p = key < Nkv ? __expf(S[r] * scale - lq[t]) : 0.f;
+                        ds[kt][r] = p * (dP[r] - Dq[t]) * scale;
                     }
                 }
                 const bf16x8 dSf = pack_acc(ds[0], ds[1]);
@@ -295,7 +279,7 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
         if (row < N) {
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                const uint2 u = make_uint2(pack2bf(dQ[d][t][0] * scale, dQ[d][t][1] * scale), pack2bf(dQ[d][t][2] * scale, dQ[d][t][3] * scale));
+                const uint2 u = make_uint2(pack2bf(dQ[d][t][0], dQ[d][t][1]), pack2bf(dQ[d][t][2], dQ[d][t][3]));
                 *reinterpret_cast<uint2*>(dQb + (int64_t)row * lddq + 16 * d + 4 * g) = u;
             }
         }
@@ -340,7 +324,6 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             Vf[kt][s] = ld_frag_global(Vb + (int64_t)key * ldv + 32 * s + 8 * g, key < Nkv);
         }
     f32x4 dK[DT][KW], dV[DT][KW];
-    const float c2 = scale * 1.4426950408889634f;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -368,7 +351,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             }
             float lr[4], dr[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { lr[r] = -Ls[16 * qt + 4 * g + r] * 1.4426950408889634f; dr[r] = Ds[16 * qt + 4 * g + r]; }
+            for (int r = 0; r < 4; ++r) { lr[r] = Ls[16 * qt + 4 * g + r]; dr[r] = Ds[16 * qt + 4 * g + r]; }
 #pragma unroll
             for (int kt = 0; kt < KW; ++kt) {
                 f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -379,9 +362,9 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[r], c2, lr[r]));        // exp(s scale - lse); lr = -lse log2(e)
+                    const float p = __expf(S[r] * scale - lr[r]);
                     P[qt][kt][r] = p;
-                    dS[qt][kt][r] = p * (dP[r] - dr[r]);                                   // (x scale: applied to dK once, below)
+                    dS[qt][kt][r] = p * (dP[r] - dr[r]) * scale;
                 }
             }
         }
@@ -412,7 +395,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             float* row = sb + ((int64_t)b * Nkv + key) * 2 * C + h * HD;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                *reinterpret_cast<float4*>(row + 16 * d + 4 * g) = make_float4(dK[d][kt][0] * scale, dK[d][kt][1] * scale, dK[d][kt][2] * scale, dK[d][kt][3] * scale);
+                *reinterpret_cast<float4*>(row + 16 * d + 4 * g) = make_float4(dK[d][kt][0], dK[d][kt][1], dK[d][kt][2], dK[d][kt][3]);
                 *reinterpret_cast<float4*>(row + C + 16 * d + 4 * g) = make_float4(dV[d][kt][0], dV[d][kt][1], dV[d][kt][2], dV[d][kt][3]);
             }
         }
