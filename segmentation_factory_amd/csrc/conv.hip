@@ -895,12 +895,17 @@ __global__ void __launch_bounds__(256) im2col_nchw_kernel(const float* __restric
 // coalesced, into LDS (as T); the row's Wo x ldcol/8 chunks are then assembled from LDS and stored with 16-byte writes.  The
 // gather form above reads every image element ~k*k/stride^2 times through uncoalesced 4-byte loads and runs at ~2 TB/s of
 // output; this one is bound by the 16-byte stores.  Needs kh * Cin * W * sizeof(T) of LDS (21 KB for the 7x7 stride-4 stem).
+#define IM2COL_ROW_PAD 2      // elements (one dword for bf16)
 template <typename T>
 __global__ void __launch_bounds__(256) im2col_nchw_rows_kernel(const float* __restrict__ x, T* __restrict__ col, int64_t ldcol, int B,
                                                                 int H, int W, int Cin, int kh, int kw, int stride, int pad, int Ho,
                                                                 int Wo) {
     extern __shared__ unsigned char im2col_lds[];
-    T* rows = reinterpret_cast<T*>(im2col_lds);                 // [ky][ci][W]
+    T* rows = reinterpret_cast<T*>(im2col_lds);                 // [ky][ci][W + IM2COL_ROW_PAD]
+    // (rows W * sizeof(T) = a multiple of 256 bytes apart put the same column of every (ky, ci) row on the same LDS bank: the
+    // 20 chunk lanes of one output pixel read 8 values each from ~7 x 3 rows -> 5-way conflicts; one extra dword per row
+    // moves row r to bank r)
+    const int WP = W + IM2COL_ROW_PAD;
     const int bo = xcd_block();
     const int oy = bo % Ho, b = bo / Ho;
     const int iy0 = oy * stride - pad;
@@ -911,7 +916,7 @@ __global__ void __launch_bounds__(256) im2col_nchw_rows_kernel(const float* __re
         const int iy = iy0 + ky;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (iy >= 0 && iy < H) v = *reinterpret_cast<const float4*>(x + (((int64_t)b * Cin + ci) * H + iy) * W + x4);
-        T* dst = rows + (int64_t)rr * W + x4;
+        T* dst = rows + (int64_t)rr * WP + x4;
         stf<T>(dst, v.x); stf<T>(dst + 1, v.y); stf<T>(dst + 2, v.z); stf<T>(dst + 3, v.w);
     }
     // column -> (staged row offset, kx): the two divisions by run-time constants per output VALUE made this kernel VALU-bound
@@ -921,12 +926,40 @@ __global__ void __launch_bounds__(256) im2col_nchw_rows_kernel(const float* __re
     for (int kcol = threadIdx.x; kcol < nch * 8 && kcol < 256; kcol += 256) {
         const int kk = kcol / Cin, ci = kcol - kk * Cin;
         const int ky = kk / kw, kx = kk - ky * kw;
-        ktab[0][kcol] = kcol < K ? (ky * Cin + ci) * W : -1;
+        ktab[0][kcol] = kcol < K ? (ky * Cin + ci) * WP : -1;
         ktab[1][kcol] = kx;
     }
     __syncthreads();
     T* out = col + ((int64_t)b * Ho + oy) * Wo * ldcol;
     const bool tab_ok = nch * 8 <= 256;
+    if (sizeof(T) == 2 && tab_ok && nch <= 256) {
+        // column-fixed form: a thread keeps ONE 16-byte chunk of the row (its 8 (staged-row offset, kx) pairs live in registers)
+        // and walks the output pixels ppp at a time; the bf16 values go from LDS to the store as raw halfwords.  (With the chunk
+        // changing per iteration the loop spent ~150 instructions per store on a division, 16 table reads and two conversions.)
+        const int ppp = 256 / nch;                                        // pixels per pass
+        const int ch = (int)threadIdx.x % nch, p0 = (int)threadIdx.x / nch;
+        int ro[8], kxs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ro[j] = ktab[0][ch * 8 + j]; kxs[j] = ktab[1][ch * 8 + j]; }
+        const uint16_t* rows16 = reinterpret_cast<const uint16_t*>(rows);
+        if (p0 < ppp) {
+            for (int ox = p0; ox < Wo; ox += ppp) {
+                const int ix0 = ox * stride - pad;
+                uint32_t h[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ix = ix0 + kxs[j];
+                    const bool ok = ro[j] >= 0 && ix >= 0 && ix < W;
+                    const uint32_t raw = rows16[ok ? ro[j] + ix : 0];
+                    h[j] = ok ? raw : 0u;
+                }
+                uint4 o;
+                o.x = h[0] | (h[1] << 16); o.y = h[2] | (h[3] << 16); o.z = h[4] | (h[5] << 16); o.w = h[6] | (h[7] << 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out) + (int64_t)ox * ldcol + ch * 8) = o;
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < Wo * nch; i += 256) {
         const int ox = i / nch, ch = i - ox * nch;
         const int ix0 = ox * stride - pad;
@@ -940,7 +973,7 @@ __global__ void __launch_bounds__(256) im2col_nchw_rows_kernel(const float* __re
                 const int kk = kcol / Cin, ci = kcol - kk * Cin;
                 const int ky = kk / kw;
                 kx = kk - ky * kw;
-                ro = kcol < K ? (ky * Cin + ci) * W : -1;
+                ro = kcol < K ? (ky * Cin + ci) * WP : -1;
             }
             const int ix = ix0 + kx;
             const bool ok = ro >= 0 && ix >= 0 && ix < W;
@@ -971,7 +1004,7 @@ extern "C" int segf_im2col(int dt, int in_nchw_f32, int B, int H, int W, int Cin
     if (in_nchw_f32) {
         const int64_t esz0 = dt == SEGF_BF16 ? 2 : 4;
         if (ldcol % 8 || ((uintptr_t)col % 16) || ((ldcol * esz0) % 16)) return SEGF_ERR_SHAPE;
-        const int64_t lds_bytes = (int64_t)kh * Cin * W * esz0;
+        const int64_t lds_bytes = (int64_t)kh * Cin * (W + IM2COL_ROW_PAD) * esz0;
         if (W % 4 == 0 && ((uintptr_t)x % 16) == 0 && lds_bytes <= 64 * 1024 && (int64_t)B * Ho <= 0x7fffffff &&
             !getenv("SEGFAC_IM2COL_GATHER")) {
             SEGF_DISPATCH_DT(dt, T, {
