@@ -1324,7 +1324,7 @@ static void gemm_skinny_k_launch(int ks, unsigned gx, hipStream_t st, const Gemm
 static int gemm_skinny_nt(int layout, int64_t M, int64_t N, int64_t K) {
     if (layout > 1 || M < 16384 || (K != 32 && K != 64 && K != 128 && !(K == 160 && layout == 0))) return 0;
     const int ks = (int)(K / 32);
-    if (ks == 5) return N % 32 == 0 ? 2 : 0;    // K = 160: the stem's 7 x 7 x 3 = 147 im2col columns padded to whole 32-steps
+    if (ks == 5) return N == 32 ? 2 : 0;    // K = 160: ONLY the stem (7 x 7 x 3 = 147 im2col columns padded to whole 32-steps, 32 outputs); MiT stage 3's 160-wide products would re-read x once per 32 output columns
     int nt = 16 / ks;                       // NT * KS <= 16 fragments
     if (nt > 8) nt = 8;
     while (nt >= 2 && N % (16 * nt)) nt >>= 1;
