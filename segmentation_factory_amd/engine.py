@@ -75,6 +75,8 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
                 gs = GraphedTrainStep(core, optimizer, loss_fn, (img, lbl), clip_grad=clip_grad, clip_mode=clip_mode)
                 gs.key = key
                 core._graphed_step = gs
+            if getattr(dataloader, 'bind_output', None) is not None and getattr(dataloader, 'out', None) is None:
+                dataloader.bind_output(gs.static_inputs)    # device-side input pipeline: later batches land in the step's buffers
             loss = gs.step(img, lbl)
             loss_value = loss.item()
             if not math.isfinite(loss_value):

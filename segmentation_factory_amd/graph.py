@@ -176,10 +176,16 @@ class GraphedTrainStep:
         for w in works:
             w.wait()                                           # the compute stream waits for the collective's result
 
+    def _feed(self, inputs):
+        # zero-copy feed: a producer that writes the batch straight into `static_inputs` (transforms.DeviceBatchLoader.bind_output,
+        # bench.py) passes those very tensors back and nothing is copied; anything else is copied into them
+        for dst, src in zip(self.static_inputs, inputs):
+            if src.data_ptr() != dst.data_ptr() or src.shape != dst.shape:
+                dst.copy_(src, non_blocking=True)
+
     def step(self, *inputs):
         """One optimisation step; returns the (device) loss tensor of this step."""
-        for dst, src in zip(self.static_inputs, inputs):
-            dst.copy_(src, non_blocking=True)
+        self._feed(inputs)
         self._main = torch.cuda.current_stream()
         self.graph.replay()
         if self.world > 1:
@@ -189,7 +195,6 @@ class GraphedTrainStep:
 
     def forward_backward(self, *inputs):
         """Replay without the exchange / optimizer (forward + loss + backward only)."""
-        for dst, src in zip(self.static_inputs, inputs):
-            dst.copy_(src, non_blocking=True)
+        self._feed(inputs)
         self.graph.replay()
         return self.loss

@@ -110,13 +110,15 @@ class DeviceTrainTransform(_Base):
         host = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
         return host.to(self.device, non_blocking=False)
 
-    def __call__(self, images, labels, params=None):
+    def __call__(self, images, labels, params=None, out=None):
         """images: list of uint8 [h, w, 3] device tensors, labels: list of uint8 [h, w] -> (fp32 [B, 3, S, S], int64 [B, S, S]).
-        ``params`` overrides the draws (one (top, left, ops, flip) per sample)."""
+        ``params`` overrides the draws (one (top, left, ops, flip) per sample); ``out`` = (image, label) tensors to fill in place
+        (e.g. the input buffers of a captured train step: zero-copy feed)."""
         if params is None:
             params = [self.draw(int(i.shape[0]), int(i.shape[1])) for i in images]
         samples = self.pack(images, labels, params)
-        return hip.input_train(samples, len(images), self.size[0], self.size[1], self.mean, self.std, self.label_lut)
+        oi, ol = out if out is not None else (None, None)
+        return hip.input_train(samples, len(images), self.size[0], self.size[1], self.mean, self.std, self.label_lut, oi, ol)
 
 
 class DeviceValTransform(_Base):
@@ -168,6 +170,19 @@ class DeviceBatchLoader:
     def __init__(self, dataset, batch_size, transform, shuffle=True, seed=0, rank=0, world=1):
         self.dataset, self.batch_size, self.transform = dataset, int(batch_size), transform
         self.shuffle, self.seed, self.rank, self.world, self.epoch = shuffle, seed, rank, world, 0
+        self.out = None
+
+    def bind_output(self, buffers):
+        """From now on every batch is written into `buffers` = (image fp32 [B, 3, S, S], label int64 [B, S, S]) -- the input
+        buffers of a captured train step (graph.GraphedTrainStep.static_inputs) -- and those tensors are what the loader yields:
+        the step then has nothing to copy.  The consumer must be done with a batch before asking for the next (stream order
+        guarantees it for the replayed step)."""
+        img, lbl = buffers
+        S = self.transform.size
+        if tuple(img.shape) != (self.batch_size, 3, S[0], S[1]) or tuple(lbl.shape) != (self.batch_size, S[0], S[1]) \
+                or img.dtype != torch.float32 or lbl.dtype != torch.int64 or not img.is_contiguous() or not lbl.is_contiguous():
+            raise ValueError('bind_output: buffers do not match the batches of this loader')
+        self.out = (img, lbl)
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -186,5 +201,5 @@ class DeviceBatchLoader:
         order = order[self.rank:(n // self.world) * self.world:self.world]
         for b in range(len(self)):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
-            yield self.transform([self.dataset.images[i] for i in idx], [self.dataset.labels[i] for i in idx])
+            yield self.transform([self.dataset.images[i] for i in idx], [self.dataset.labels[i] for i in idx], out=self.out)
 

@@ -233,6 +233,57 @@ def test_device_batch_loader_feeds_train_one_epoch_shapes():
 
 
 @pytest.mark.gpu
+def test_zero_copy_feed_into_the_captured_step():
+    """DeviceBatchLoader.bind_output: after the step is captured, batches are produced INSIDE its input buffers (the loader yields
+    those very tensors, step() copies nothing), and what the step sees is exactly what an unbound loader with the same seeds
+    yields."""
+    import types
+    from oracle import weights as OW
+    from segmentation_factory_amd import SegmentationModel, engine
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler
+    from segmentation_factory_amd.transforms import DeviceBatchLoader, DeviceDataset, DeviceTrainTransform
+    rng = np.random.default_rng(3)
+    ds = DeviceDataset()
+    for k in range(8):
+        ds.add(rng.integers(0, 256, (80 + k, 90, 3), dtype=np.uint8), rng.integers(0, 5, (80 + k, 90), dtype=np.uint8))
+
+    def make_loader():
+        return DeviceBatchLoader(ds, 2, DeviceTrainTransform(64, rng=random.Random(11)), shuffle=True, seed=5)
+    want = []
+    ref_loader = make_loader()
+    for ep in range(2):
+        ref_loader.set_epoch(ep)
+        want += [(a.clone(), b.clone()) for a, b in ref_loader]
+    model = SegmentationModel('MiT-B0', num_classes=5, seg_head='SegFormerHead', compute_dtype=torch.bfloat16).cuda()
+    model.load_state_dict(OW.make_state_dict('MiT-B0', 'SegFormerHead', 5, 7))
+    model.train()
+    opt = FusedAGCAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    loader = make_loader()
+    seen, losses = [], []
+
+    class Rec:
+        def add_scalar(self, name, v, it=None):
+            if name == 'train_loss':                       # called right after the step: what did the step read?
+                gs = model._graphed_step
+                seen.append((gs.static_inputs[0].clone(), gs.static_inputs[1].clone()))
+                losses.append(float(v))
+    args = types.SimpleNamespace(nb_classes=5, dice=True, ignore_index=255, ignore_label=255, local_rank=0, device='cuda', hip_graph=True)
+    for ep in range(2):
+        loader.set_epoch(ep)
+        engine.train_one_epoch(model, opt, loader, ep, 'cuda', 1, 0.02, 'agc', NativeScaler(), Rec(), args)
+    gs = model._graphed_step
+    assert loader.out is not None and loader.out[0].data_ptr() == gs.static_inputs[0].data_ptr() \
+        and loader.out[1].data_ptr() == gs.static_inputs[1].data_ptr()
+    assert len(seen) == len(want) == 8 and all(np.isfinite(losses))
+    for (si, sl), (wi, wl) in zip(seen, want):
+        assert torch.equal(si, wi) and torch.equal(sl, wl)
+    # the bound loader yields the step's own tensors: nothing left to copy
+    it = iter(loader)
+    bi, bl = next(it)
+    assert bi.data_ptr() == gs.static_inputs[0].data_ptr() and bl.data_ptr() == gs.static_inputs[1].data_ptr()
+
+
+@pytest.mark.gpu
 def test_train_gpu_cli_with_device_input(tmp_path):
     """train_gpu.py --device-input --hip-graph --clip-mode norm: the captured step fed by the device pipeline (and the L2-norm
     clipping of the reference's --clip-mode norm in front of the optimizer kernel), end to end, loss falling."""
