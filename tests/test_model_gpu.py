@@ -443,6 +443,44 @@ def test_other_variants_fp32_vs_oracle(backbone, head):
     assert checked > 50
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_nb_classes_151_as_the_reference_cli_admits(dtype):
+    """ADE20K through the reference's CLI is --nb_classes 151 (datasets/build_datasets.py:32; SURVEY 8(d) 'nc 150 and 151'): 151
+    classes pad to 160 columns in the head, run the 10-tile band loss kernels with one live column in the last tile, and the fused
+    BatchNorm backward with K = 160.  MiT-B0 + SegFormerHead at 128 x 128 against the CPU oracle: logits, loss, every gradient."""
+    from segmentation_factory_amd import criterion_lowres
+    backbone, head, nc, B, H, W, seed = 'MiT-B0', 'SegFormerHead', 151, 2, 128, 128, 33
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    x, y = OW.synthetic_batch(B, H, W, nc, seed)
+    assert int(y[y != 255].max()) == nc - 1                      # the last class occurs
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var')))
+           for k, v in sd.items()}
+    o, _ = ON.model_forward(sdg, x, backbone, head, training=True, lowres=True)
+    up = torch.nn.functional.interpolate(o, size=(H, W), mode='bilinear', align_corners=False)
+    ref_loss = OL.criterion_closed_form(up, y, None, num_classes=nc, dice=True, ignore_index=255)
+    ref_loss.backward()
+    model = _build(backbone, head, nc, sd, dtype, B).train()
+    lo = model.forward_lowres(x.cuda())
+    loss = criterion_lowres(lo, y.cuda(), (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+    loss.backward()
+    got = lo.nchw().float().cpu()
+    fp32 = dtype == torch.float32
+    assert got.shape == o.shape
+    assert (got - o.detach()).abs().max() <= (1e-3 if fp32 else 4e-2) * o.detach().abs().max()
+    assert abs(loss.item() - ref_loss.item()) <= (2e-4 if fp32 else 1e-2) * abs(ref_loss.item())
+    params = dict(model.named_parameters())
+    gmax = max(v.grad.abs().max().item() for v in sdg.values() if v.grad is not None)
+    checked = 0
+    for k, v in sdg.items():
+        if v.grad is None or k not in params:
+            continue
+        g, r = params[k].grad.float().cpu(), v.grad
+        tol = (5e-2 if fp32 else 2.5e-1) * (r.abs().max().item() + 0.1 * gmax)
+        assert (g - r).abs().max().item() <= tol, (k, (g - r).abs().max().item(), r.abs().max().item())
+        checked += 1
+    assert checked > 50
+
+
 @pytest.mark.gpu
 def test_single_image_inference_matches_reference_pipeline():
     """inference.SemSeg (estimate_model.py:53-123 restated for tensors): HIP resizes + arg max against the reference's op
