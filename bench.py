@@ -325,8 +325,8 @@ def main():
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note,
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
-                         "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~3 VALU "
-                                 "ops; interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
+                         "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~6 other VALU "
+                                 "instructions (ISA count: 248 VALU + 41 transcendental + 20 MFMA per 16-pixel cell); interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
             "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true, SHAPE=1, DEEP=true> (segf_gemm_pro, the in-graph variant; narrow 64x80 wave tiles, two K steps in flight): classifier 1x1 conv "
                                         f"[B*{hq}*{wq},768]x[768,{ld}] with BatchNorm + ReLU + Dropout2d applied on the operand load" if use_pro else
