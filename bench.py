@@ -5,11 +5,12 @@ loss + backward + AGC/AdamW step) of SegFormer-B0 *as the reference builds it* (
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W          (one rank per GPU; each rank replays its hipGraph, then ONE RCCL
-                                                       all-reduce of the flat gradient buffer, then the fused optimizer)
+      bench.py --gpus N --steps K --warmup W          (one rank per GPU; each rank replays its hipGraph, whose in-graph event
+                                                       nodes release the bucketed RCCL gradient exchange on a communication
+                                                       stream while the backward is still running; then the fused optimizer)
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with a `roofline` object for the dominant kernel
-(gemm_bf16_kernel<0>, heaviest launch = the HBM-bound classifier GEMM; HIP-event timed on its launch stream) and a
+(ce_dice_bwd_band_kernel; HIP-event timed on its launch stream; `roofline_gemm` = the heaviest HBM-bound GEMM launch) and a
 `cpu_baseline` object (the CPU oracle port of the reference path timed on this host's cores, bounded sample).
 """
 import argparse
@@ -240,7 +241,9 @@ def main():
             else:
                 hip.gemm(0, A_, W_, M, ld, K, bias=b_)
     esz = A_.element_size()
-    loss_bytes = args.batch * (2 * hq * wq * ld * esz + H * W * 8)           # logits read + gradient written + labels
+    # SURVEY 8(d), loss kernel: low-res logits read + their gradient written (NC classes, not the padded row) + int64 labels read
+    loss_bytes = args.batch * (2 * hq * wq * NC * esz + H * W * 8)
+    loss_bytes_padded = args.batch * (2 * hq * wq * ld * esz + H * W * 8)      # what the rows occupy in memory (class pad columns)
     loss_exps = float(args.batch) * H * W * (16 * ((NC + 15) // 16)) * (8.0 / 7.0) * (17.0 / 16.0)   # per pixel and padded class; band sweep: 8 cells per 7 tap columns, one lead-in row per 16-row segment
     gemm_bytes = esz * (M * K + ld * K + M * ld)
     del A_, W_, lo_
@@ -325,6 +328,7 @@ def main():
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note,
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
+                         "padded_row_bytes_per_launch": loss_bytes_padded,
                          "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~6 other VALU "
                                  "instructions (ISA count: 248 VALU + 41 transcendental + 20 MFMA per 16-pixel cell); interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},

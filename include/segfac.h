@@ -317,11 +317,14 @@ int segf_confmat_pairs(const int64_t* gt, const int64_t* pred, int64_t n, int C,
 
 /* ---- optimizer step (engine.py:52-53 -> timm NativeScaler -> AGC clip -> AdamW) over flat fp32
  * param/grad/state buffers.  A "unit" is one dim-0 row of a >=2-D weight or a whole 1-D tensor:
- * unit_offset[u], unit_len[u] (elements), unit_flags[u] bit0 = apply weight decay.  clip_factor <= 0
+ * unit_offset[u], unit_len[u] (elements), unit_flags[u] bit0 = apply weight decay, bit1 = the parameter got no gradient
+ * this step: the unit is skipped entirely, as torch.optim.AdamW skips `p.grad is None` (train_gpu.py:269).  unit_step
+ * (nullable): per-unit step counts kept on the device and advanced by the kernel for every unit it updates -- torch's per-parameter
+ * state['step'], which sets the bias corrections; when null the host scalar `step` is used for all units.  clip_factor <= 0
  * disables AGC.  See oracle/optim.py for the restated arithmetic (timm 0.9.2; "parity unpinned").   */
 int segf_agc_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                   const int64_t* unit_offset, const int32_t* unit_len, const uint8_t* unit_flags, int nunits,
-                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   const int64_t* unit_offset, const int32_t* unit_len, const uint8_t* unit_flags, int32_t* unit_step,
+                   int nunits, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float clip_factor, float agc_eps, void* stream);
 
 /* The other --clip-mode values of the reference (train_gpu.py:99-102 -> timm.utils.dispatch_clip_grad) on the flat gradient buffer:

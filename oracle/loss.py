@@ -27,27 +27,37 @@ def _dice_target(target, num_classes, ignore_index):
     return oh.permute(0, 3, 1, 2)
 
 
+def _dice_coeff_loops(x, target, ignore_index, epsilon=EPS):
+    # util/losses.py:141-161: x, target are ONE class's [B,H,W] slices; the batch loop runs inside
+    d = 0.
+    batch_size = x.shape[0]
+    for i in range(batch_size):
+        x_i = x[i].reshape(-1)
+        t_i = target[i].reshape(-1)
+        if ignore_index >= 0:
+            roi = torch.ne(t_i, ignore_index)
+            x_i = x_i[roi]
+            t_i = t_i[roi]
+        inter = torch.dot(x_i, t_i)
+        sets = torch.sum(x_i) + torch.sum(t_i)
+        if sets == 0:
+            sets = 2 * inter
+        d += (2 * inter + epsilon) / (sets + epsilon)
+    return d / batch_size
+
+
 def criterion_loops(inputs, target, loss_weight=None, num_classes=2, dice=True, ignore_index=-100):
+    """Same autograd graph shape as the reference: the channel is sliced ONCE per class in the outer loop
+    (util/losses.py:164-170: ``x[:, channel, ...]``) and the batch is indexed inside (``x[i]``, :146-159), so the
+    backward materialises one full-size zero tensor per class (not per (image, class) pair)."""
     loss = F.cross_entropy(inputs, target, ignore_index=ignore_index, weight=loss_weight)
     if dice is True:
         tgt = _dice_target(target, num_classes, ignore_index)
-        prob = F.softmax(inputs, dim=1)
+        prob = F.softmax(inputs, dim=1)                # losses.py:175
         total = 0.
-        for c in range(prob.shape[1]):                 # losses.py:164-170
-            d = 0.
-            for i in range(prob.shape[0]):             # losses.py:146-159
-                x_i = prob[i, c].reshape(-1)
-                t_i = tgt[i, c].reshape(-1)
-                if ignore_index >= 0:
-                    roi = t_i != ignore_index
-                    x_i, t_i = x_i[roi], t_i[roi]
-                inter = torch.dot(x_i, t_i)
-                sets = x_i.sum() + t_i.sum()
-                if sets == 0:
-                    sets = 2 * inter
-                d = d + (2 * inter + EPS) / (sets + EPS)
-            total = total + d / prob.shape[0]
-        loss = loss + (1 - total / prob.shape[1])
+        for channel in range(prob.shape[1]):           # losses.py:167-168
+            total += _dice_coeff_loops(prob[:, channel, ...], tgt[:, channel, ...], ignore_index)
+        loss += 1 - total / prob.shape[1]              # losses.py:170,177; engine.py:14
     return loss
 
 

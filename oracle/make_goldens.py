@@ -331,7 +331,50 @@ def scheduler_cases():
         json.dump(out, fh, indent=1)
 
 
+def cpu_cost_check(out_path=None):
+    """The bench's cpu_baseline times oracle.loss.criterion_loops in place of the reference's criterion (engine.py:10-15), which
+    cannot travel to the GPU box.  Check HERE that the port has the reference's cost structure: forward + backward of the
+    criterion alone on cfg2-size logits (batch 2, 150 classes, 512 x 512; the criterion is ~80 % of the reference's CPU step),
+    same threads, same tensors -- the port must stay within 1.3x of the imported reference (it was 2.7x slower
+    when it indexed prob[i, c] inside a double loop).  The measured pair is kept in profiles/ for the record."""
+    import json
+    import time
+    ref = ref_shim.load()
+    torch.manual_seed(0)
+    x, y = OW.synthetic_batch(2, 512, 512, 150, 0)
+    logits = torch.randn(2, 150, 512, 512)
+
+    def once(fn):
+        lg = logits.clone().requires_grad_(True)
+        t0 = time.time()
+        fn(lg, y, None, num_classes=150, dice=True, ignore_index=255).backward()
+        return time.time() - t0, lg.grad
+    # interleaved, best of 3 each (single runs scatter by 2x in this container: page faults of the 157 MB temporaries)
+    t_ref = t_port = 1e9
+    for _ in range(3):
+        t, g_port = once(OL.criterion_loops)
+        t_port = min(t_port, t)
+        t, g_ref = once(ref.engine.criterion)
+        t_ref = min(t_ref, t)
+    assert torch.equal(g_ref, g_port), 'criterion_loops no longer has the reference\'s gradient bit for bit'
+    ratio = t_port / t_ref
+    print(f'[cpu_cost] criterion fwd+bwd, batch 2 x 150 x 512^2, {torch.get_num_threads()} threads: reference {t_ref:.2f} s, '
+          f'oracle port {t_port:.2f} s, ratio {ratio:.2f}')
+    assert ratio < 1.3, f'oracle criterion_loops is {ratio:.2f}x the reference\'s cost'
+    rec = {'what': 'criterion forward + backward on [2,150,512,512] fp32 logits, interleaved, best of 3 each',
+           'threads': torch.get_num_threads(), 'reference_s': round(t_ref, 3), 'oracle_port_s': round(t_port, 3),
+           'ratio': round(ratio, 3), 'gradients_bit_identical': True}
+    if out_path:
+        with open(out_path, 'w') as fh:
+            json.dump(rec, fh, indent=1)
+    return rec
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'cpu-cost':
+        torch.set_num_threads(8)
+        cpu_cost_check(os.path.join(os.path.dirname(OUT), '..', 'profiles', 'r03_cpu_cost_check.json'))
+        return 0
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -349,6 +392,7 @@ def main():
     train_loop_case()
     train_overfit_case()
     scheduler_cases()
+    cpu_cost_check()
     print('goldens written to', OUT)
 
 

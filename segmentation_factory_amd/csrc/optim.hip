@@ -7,21 +7,31 @@
 //   max_norm = max(||p_unit||, agc_eps) * clip_factor;  g <- g * max_norm / max(||g_unit||, 1e-6)  if ||g_unit|| >= max_norm
 //   p <- p * (1 - lr * wd);  m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2;
 //   p <- p - lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// unit_flags: bit 0 = weight decay applies, bit 1 = the unit's parameter received no gradient this step (skipped entirely).
 // One wave per unit: two streaming passes over the unit (norms, then update); 7 x 4 B per parameter of HBM traffic.
 #include "common.h"
 
 __global__ void __launch_bounds__(256) agc_adamw_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          const int64_t* __restrict__ unit_off, const int32_t* __restrict__ unit_len,
-                                                         const uint8_t* __restrict__ unit_flags, int nunits, float lr, float b1,
-                                                         float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                         float clip_factor, float agc_eps) {
+                                                         const uint8_t* __restrict__ unit_flags, int32_t* __restrict__ unit_step,
+                                                         int nunits, float lr, float b1, float b2, float eps, float wd, float bc1_,
+                                                         float bc2_sqrt_, float clip_factor, float agc_eps) {
     const int lane = threadIdx.x & 63;
     const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t u = wave_global; u < nunits; u += nwaves) {
         const int64_t off = unit_off[u];
         const int len = unit_len[u];
+        const int uflags = unit_flags[u];
+        if (uflags & 2) continue;          // no gradient this step: torch.optim.AdamW skips `p.grad is None` (no decay, no moments)
+        float bc1 = bc1_, bc2_sqrt = bc2_sqrt_;
+        if (unit_step) {                   // per-parameter step count, as torch keeps it (state['step']): a skipped step does not count
+            const int t = unit_step[u] + 1;      // every lane reads before lane 0 writes (same wave, program order)
+            bc1 = 1.f - powf(b1, (float)t);
+            bc2_sqrt = sqrtf(1.f - powf(b2, (float)t));
+            if (lane == 0) unit_step[u] = t;
+        }
         float gscale = 1.f;
         if (clip_factor > 0.f) {
             float pn = 0.f, gn = 0.f;
@@ -33,7 +43,7 @@ __global__ void __launch_bounds__(256) agc_adamw_kernel(float* __restrict__ para
             const float max_norm = fmaxf(pn, agc_eps) * clip_factor;
             if (!(gn < max_norm)) gscale = max_norm / fmaxf(gn, 1e-6f);
         }
-        const float decay = (unit_flags[u] & 1) ? 1.f - lr * wd : 1.f;
+        const float decay = (uflags & 1) ? 1.f - lr * wd : 1.f;
         const float step = lr / bc1;
         for (int i = lane; i < len; i += 64) {
             const float g = grad[off + i] * gscale;
@@ -47,16 +57,17 @@ __global__ void __launch_bounds__(256) agc_adamw_kernel(float* __restrict__ para
 }
 
 extern "C" int segf_agc_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* unit_offset,
-                              const int32_t* unit_len, const uint8_t* unit_flags, int nunits, float lr, float beta1, float beta2,
-                              float eps, float weight_decay, int step, float clip_factor, float agc_eps, void* stream) {
+                              const int32_t* unit_len, const uint8_t* unit_flags, int32_t* unit_step, int nunits, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, float clip_factor, float agc_eps,
+                              void* stream) {
     if (nunits <= 0) return 0;
-    if (step < 1) return SEGF_ERR_SHAPE;
+    if (step < 1 && !unit_step) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     const int blocks = imin((nunits + 3) / 4, 4096);
     hipLaunchKernelGGL(agc_adamw_kernel, dim3(blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, unit_offset, unit_len,
-                       unit_flags, nunits, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, clip_factor, agc_eps);
+                       unit_flags, unit_step, nunits, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, clip_factor, agc_eps);
     SEGF_CHECK_LAUNCH();
     return 0;
 }

@@ -72,7 +72,8 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
                 def loss_fn(m, x, y, _lw=loss_weight, _hw=tuple(img.shape[2:])):
                     return criterion_lowres(m.forward_lowres(x), y, _hw, _lw, num_classes=args.nb_classes, dice=args.dice,
                                             ignore_index=args.ignore_index)
-                gs = GraphedTrainStep(core, optimizer, loss_fn, (img, lbl), clip_grad=clip_grad, clip_mode=clip_mode)
+                gs = GraphedTrainStep(core, optimizer, loss_fn, (img, lbl), clip_grad=clip_grad, clip_mode=clip_mode,
+                                      exchange=getattr(args, 'grad_exchange', None), payload=getattr(args, 'grad_payload', None))
                 gs.key = key
                 core._graphed_step = gs
             if getattr(dataloader, 'bind_output', None) is not None and getattr(dataloader, 'out', None) is None:

@@ -64,16 +64,65 @@ def plan_buckets(numels, bucket_elems):
     return buckets
 
 
+def comm_ranges(buckets, total, align):
+    """Element ranges the collectives run over, one per bucket, in completion order.  Bucket k = [L_k, L_(k-1)) of the flat
+    buffer completes when its last gradient is written; its collective covers [up(L_k), up(L_(k-1))) with up() = round up to a
+    multiple of `align` (the top end: `total` rounded up -- the flat buffers carry that much slack).  The ranges tile the padded
+    buffer exactly once; the few elements [L_k, up(L_k)) of a bucket travel with the NEXT (later-completing) bucket's range, and a
+    range only reaches into gradients that were complete earlier.  Every range is a multiple of `align` = world x 16 elements,
+    so reduce-scatter / all-gather shards are whole and 64-byte aligned."""
+    up = lambda v: -(-v // align) * align
+    return [(up(lo), up(hi) if hi < total else up(total)) for lo, hi in buckets]
+
+
+EXCHANGE_MODES = ('all_reduce', 'rs_ag')
+
+
+def sum_over_ranks_(buf, mode='all_reduce', group=None):
+    """Sum the flat tensor `buf` (a whole number of world-size elements) over the ranks, in place, asynchronously on the current
+    stream; returns the work handles.  'all_reduce': one collective, RCCL picks the algorithm.  'rs_ag': in-place reduce-scatter
+    (this rank's shard is reduced where it lies) followed by an in-place all-gather."""
+    if mode == 'all_reduce':
+        return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    assert buf.numel() % world == 0, (buf.numel(), world)
+    n = buf.numel() // world
+    shard = buf[rank * n:(rank + 1) * n]
+    w1 = dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    if dist.get_backend(group) != 'nccl':
+        w1.wait()            # RCCL orders the two on its stream; gloo's worker threads do not
+    w2 = dist.all_gather_into_tensor(buf, shard, group=group, async_op=True)
+    return [w1, w2]
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer: FusedAGCAdamW, loss_fn, example_inputs, clip_grad=None, clip_mode='agc',
-                 warmup: int = 2, process_group=None, bucket_mb: float = 25.0, overlap: bool = True):
+                 warmup: int = 2, process_group=None, bucket_mb: float = 25.0, overlap: bool = True,
+                 exchange: str = None, payload: str = None, force_exchange: bool = None):
         """loss_fn(model, *inputs) -> scalar loss tensor.  ``example_inputs`` fix the shapes; their storage becomes
-        the static input buffers (``step(*new_inputs)`` copies into them)."""
-        assert isinstance(optimizer, FusedAGCAdamW), 'the graphed step drives the fused AGC/AdamW kernel'
+        the static input buffers (``step(*new_inputs)`` copies into them).
+
+        exchange: 'all_reduce' (default; RCCL picks the algorithm) or 'rs_ag' = in-place reduce-scatter + all-gather per bucket
+        (on a fully connected xGMI node both halves use all 7 links of every GPU directly).  payload: 'fp32'
+        (default) or 'bf16' (the bucket is cast to a bf16 staging buffer, exchanged, and cast back: half the bytes per link;
+        changes the arithmetic, see the loss-curve test).  force_exchange: run the exchange even in a 1-rank process group
+        (exercises the whole event -> communication stream -> collective -> optimizer chain on one GPU).  Environment overrides:
+        SEGFAC_EXCHANGE, SEGFAC_GRAD_PAYLOAD, SEGFAC_FORCE_EXCHANGE."""
+        if not isinstance(optimizer, FusedAGCAdamW):
+            raise TypeError('GraphedTrainStep drives the fused AGC/AdamW kernel over flat buffers: pass a FusedAGCAdamW '
+                            '(create_optimizer builds one); other optimizers run on the eager path')
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.static_inputs = [t.clone() for t in example_inputs]
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if have_pg else 1
         self.group = process_group
+        self.exchange_mode = exchange or os.environ.get('SEGFAC_EXCHANGE', 'all_reduce')
+        self.payload = payload or os.environ.get('SEGFAC_GRAD_PAYLOAD', 'fp32')
+        if self.exchange_mode not in EXCHANGE_MODES or self.payload not in ('fp32', 'bf16'):
+            raise ValueError(f'exchange {self.exchange_mode!r} / payload {self.payload!r}: expected {EXCHANGE_MODES} / fp32 | bf16')
+        if force_exchange is None:
+            force_exchange = bool(os.environ.get('SEGFAC_FORCE_EXCHANGE'))
+        self.exchanging = have_pg and (self.world > 1 or force_exchange)
         self.opt.set_clipping(clip_grad, clip_mode)      # 'agc' in the AdamW kernel; 'norm' / 'value' as kernels right before it
         # parameters are re-homed into the flat buffer BEFORE capture, laid out in registration order (bucket = suffix)
         self.opt.ensure_built(order=list(model.parameters()))
@@ -81,16 +130,24 @@ class GraphedTrainStep:
         # ---- buckets of the flat gradient buffer, in completion order -------------------------------------------------
         self.buckets, self.events, self._pending = [], [], {}
         self._capturing = False
-        if self.world > 1:
+        if self.exchanging:
             numels = [p.numel() for p in self.opt._params]
-            plan = plan_buckets(numels, int(bucket_mb * (1 << 20) / 4)) if overlap else [(0, sum(numels), 0, len(numels) - 1)]
+            total = sum(numels)
+            plan = plan_buckets(numels, int(bucket_mb * (1 << 20) / 4)) if overlap else [(0, total, 0, len(numels) - 1)]
             for k, (lo, hi, p0, p1) in enumerate(plan):
                 self.buckets.append((lo, hi))
                 self.events.append(hip.GraphEvent() if overlap else None)
                 for i in range(p0, p1 + 1):
                     self._pending[self.opt._grad_views[i].data_ptr()] = k
+            align = self.world * 16
+            if align > self.opt.FLAT_SLACK:
+                raise ValueError(f'world size {self.world}: the flat buffers carry {self.opt.FLAT_SLACK} elements of slack')
+            self.ranges = comm_ranges(self.buckets, total, align)
             self._left = [0] * len(self.buckets)
             self.comm = torch.cuda.Stream()
+            if self.payload == 'bf16':
+                self._stage = torch.empty(max(hi - lo for lo, hi in self.ranges), dtype=torch.bfloat16,
+                                          device=self.opt.flat_grads_padded.device)
         # bf16 shadow of the flat parameter buffer, refreshed by one cast at the start of every step (functional.shadow_scope)
         self._shadow, self._shadow_map = None, None
         if any(p.dtype == torch.float32 for p in self.opt._params) and not os.environ.get('SEGFAC_NO_WEIGHT_SHADOW'):
@@ -99,7 +156,7 @@ class GraphedTrainStep:
             self._shadow_map = {}
             for p, o in zip(self.opt._params, self.opt._offsets):
                 self._shadow_map[p.data_ptr()] = self._shadow[o:o + p.numel()]
-        self.opt.enable_direct_grads(self._on_grad_written if (self.world > 1 and overlap) else None)
+        self.opt.enable_direct_grads(self._on_grad_written if (self.exchanging and overlap) else None)
         self._seed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.static_inputs[0].device)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -115,6 +172,11 @@ class GraphedTrainStep:
                     b.copy_(keep)
             del saved_buffers
         torch.cuda.current_stream().wait_stream(s)
+        # A gradient that still arrives as `.grad` (plugin backbone / head on plain autograd, the case gather_grads exists for) must
+        # be captured as an ASSIGNMENT: with the warm-up passes' .grad tensors left in place autograd would record `grad += new`,
+        # nothing inside the graph zeroes it, and every replay would add to the running sum
+        for p in self.model.parameters():
+            p.grad = None
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread polls events while we capture; in the default global mode that aborts the capture
         self._capturing = True
@@ -123,7 +185,8 @@ class GraphedTrainStep:
             self.loss = self._forward_backward_eager()
             self.opt.gather_grads()          # only gradients that arrived as .grad (foreign plugin modules); normally nothing
         self._capturing = False
-        if self.world > 1 and overlap:
+        self.opt.finish_backward()           # parameters the captured backward never wrote are skipped by the optimizer kernel
+        if self.exchanging and overlap:
             missing = [k for k, n in enumerate(self._left) if n > 0]
             if missing:       # parameters without a gradient (frozen / unused): their buckets are complete when the graph ends
                 self.events = [None if k in missing else e for k, e in enumerate(self.events)]
@@ -135,14 +198,15 @@ class GraphedTrainStep:
             scope = Fh.shadow_scope(self._shadow_map)
         else:
             scope = contextlib.nullcontext()
+        self.opt.begin_backward()
         with scope:
             loss = self.loss_fn(self.model, *self.static_inputs)
             # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
-            loss.backward(gradient=self._seed if self.world > 1 else None)
+            loss.backward(gradient=self._seed if self.exchanging else None)
         return loss
 
     def _reset_pending(self):
-        if self.world > 1:
+        if self.exchanging:
             counts = [0] * len(self.buckets)
             have = {v.data_ptr() for p, v in zip(self.opt._params, self.opt._grad_views)}
             for ptr, k in self._pending.items():
@@ -162,19 +226,33 @@ class GraphedTrainStep:
         if self._left[k] == 0 and self.events[k] is not None:
             self.events[k].record_external()
 
+    def _collective(self, buf):
+        return sum_over_ranks_(buf, self.exchange_mode, self.group)
+
     def _exchange(self):
-        """All-reduce (sum; the gradients carry the 1/world factor) bucket by bucket on the communication stream, each one as
-        soon as its event inside the running graph has fired; the compute stream joins before the optimizer."""
+        """Sum (the gradients carry the 1/world factor) bucket by bucket on the communication stream, each one as soon as its
+        event inside the running graph has fired; the compute stream joins before the optimizer."""
         works = []
+        grads = self.opt.flat_grads_padded
         with torch.cuda.stream(self.comm):
-            for (lo, hi), ev in zip(self.buckets, self.events):
+            for (lo, hi), ev in zip(self.ranges, self.events):
+                if hi <= lo:
+                    continue
                 if ev is not None:
                     ev.wait()                                  # this replay's record node (the graph was launched above)
                 else:
                     self.comm.wait_stream(self._main)          # bucket without an in-graph event: after the whole graph
-                works.append(dist.all_reduce(self.opt.flat_grads[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.payload == 'bf16':
+                    st = self._stage[:hi - lo]
+                    hip.cast_into(grads[lo:hi], st)            # our own cast kernels, on the communication stream
+                    for w in self._collective(st):
+                        w.wait()                               # stream-orders the cast back behind the collective (no host block)
+                    hip.cast_into(st, grads[lo:hi])
+                else:
+                    works += self._collective(grads[lo:hi])
         for w in works:
             w.wait()                                           # the compute stream waits for the collective's result
+        self._main.wait_stream(self.comm)
 
     def _feed(self, inputs):
         # zero-copy feed: a producer that writes the batch straight into `static_inputs` (transforms.DeviceBatchLoader.bind_output,
@@ -188,7 +266,7 @@ class GraphedTrainStep:
         self._feed(inputs)
         self._main = torch.cuda.current_stream()
         self.graph.replay()
-        if self.world > 1:
+        if self.exchanging:
             self._exchange()
         self.opt.apply_flat()
         return self.loss

@@ -82,7 +82,7 @@ _PROTOS = {
     'segf_debug_wave_reduce16': (_i, [_p, _p, _p]),
     'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
-    'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),
+    'segf_agc_adamw': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _i, _f, _f, _p]),
     'segf_clip_grad_ws': (_l, []),
     'segf_clip_grad': (_i, [_p, _l, _i, _f, _p, _p]),
     'segf_zero': (_i, [_p, _l, _p]),
@@ -839,7 +839,7 @@ def clip_grad(grad, mode, value, ws=None):
 
 
 def agc_adamw(param, grad, exp_avg, exp_avg_sq, unit_off, unit_len, unit_flags, lr, beta1, beta2, eps, weight_decay,
-              step, clip_factor, agc_eps=1e-3):
+              step, clip_factor, agc_eps=1e-3, unit_step=None):
     _chk(lib().segf_agc_adamw(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(unit_off), _ptr(unit_len),
-                              _ptr(unit_flags), unit_len.numel(), lr, beta1, beta2, eps, weight_decay, step, clip_factor,
+                              _ptr(unit_flags), _ptr(unit_step) if unit_step is not None else None, unit_len.numel(), lr, beta1, beta2, eps, weight_decay, step, clip_factor,
                               agc_eps, _stream()), 'segf_agc_adamw')

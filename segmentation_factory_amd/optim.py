@@ -11,6 +11,8 @@ from . import hip
 
 
 class FusedAGCAdamW(torch.optim.Optimizer):
+    FLAT_SLACK = 1024        # elements of zero padding behind the flat buffers (collective ranges round up to world x 16, graph.py)
+
     """AdamW whose step (optionally preceded by unit-wise adaptive gradient clipping) runs as a single
     multi-tensor kernel (segf_agc_adamw).  Parameters are re-homed into one flat fp32 buffer (each
     ``p.data`` becomes a view), gradients are gathered into a flat buffer of the same layout."""
@@ -37,7 +39,8 @@ class FusedAGCAdamW(torch.optim.Optimizer):
             ps.sort(key=lambda p: rank.get(id(p), len(rank)))
         dev = ps[0].device
         total = sum(p.numel() for p in ps)
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        store = torch.zeros(total + self.FLAT_SLACK, dtype=torch.float32, device=dev)
+        flat = store[:total]
         offs, lens, flags = [], [], []
         o = 0
         for p in ps:
@@ -54,7 +57,8 @@ class FusedAGCAdamW(torch.optim.Optimizer):
             o += n
         self._params = ps
         self._flat = flat
-        self._grad = torch.zeros_like(flat)
+        self._grad_store = torch.zeros(total + self.FLAT_SLACK, dtype=torch.float32, device=dev)
+        self._grad = self._grad_store[:total]
         self._grad_views, self._offsets, o = [], [], 0
         for p in ps:
             self._grad_views.append(self._grad[o:o + p.numel()].view(p.shape))
@@ -65,7 +69,32 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         self._off = torch.tensor(offs, dtype=torch.int64, device=dev)
         self._len = torch.tensor(lens, dtype=torch.int32, device=dev)
         self._flags = torch.tensor(flags, dtype=torch.uint8, device=dev)
+        # units (rows) of every parameter, for the per-step "received no gradient" bit (flag bit 1): torch.optim.AdamW -- the
+        # reference's optimizer, train_gpu.py:269 -- skips a parameter whose .grad is None entirely (no decay, no moment update)
+        self._unit_range, u = [], 0
+        for p in ps:
+            rows = p.shape[0] if p.ndim > 1 else 1
+            self._unit_range.append((u, u + rows))
+            u += rows
+        self._base_flags = list(flags)
+        self._nograd = frozenset()          # indices (into self._params) of parameters skipped by the current flags
+        self._ustep = torch.zeros(len(flags), dtype=torch.int32, device=dev)   # per-unit step counts (torch's per-parameter state['step'])
+        self._written = {}                  # direct placement: gradient-slot pointer -> deliveries in the current backward
         self.direct = False
+
+    def _set_nograd(self, idx):
+        """Mark the parameters `idx` (indices into the flat layout) as 'no gradient this step': the kernel leaves their
+        parameters and moments untouched.  The flag tensor is rewritten only when the set changes."""
+        idx = frozenset(idx)
+        if idx == self._nograd:
+            return
+        flags = list(self._base_flags)
+        for i in idx:
+            lo, hi = self._unit_range[i]
+            for u in range(lo, hi):
+                flags[u] |= 2
+        self._flags.copy_(torch.tensor(flags, dtype=torch.uint8), non_blocking=False)
+        self._nograd = idx
 
     def set_clipping(self, clip_grad, clip_mode):
         """timm.utils.dispatch_clip_grad(parameters, value=clip_grad, mode=clip_mode) as part of the optimizer step: 'agc' inside
@@ -90,17 +119,45 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         self.ensure_built()
         return self._grad
 
+    @property
+    def flat_grads_padded(self):
+        """The gradient buffer including its FLAT_SLACK zero elements (collectives run over aligned ranges of this)."""
+        self.ensure_built()
+        return self._grad_store
+
     def enable_direct_grads(self, callback=None):
         """Hand every parameter its view of the flat gradient buffer (``p._segf_grad``): the backward formulas of
         segmentation_factory_amd.functional then write parameter gradients in place and ``.grad`` stays None
         (functional.direct_grads).  callback(view) is invoked, in backward order, whenever one gradient is final."""
         self.ensure_built()
         self._grad.zero_()
+        self._user_cb = callback
         for p, view in zip(self._params, self._grad_views):
             p._segf_grad = view
-            p._segf_grad_cb = callback
+            p._segf_grad_cb = self._note_delivery
             p.grad = None
         self.direct = True
+
+    def begin_backward(self):
+        """Direct placement: call before every forward+backward that is run from Python (warm-up, capture, eager steps)."""
+        self._written = {}
+
+    def _note_delivery(self, view):
+        # a slot is an assignment target: a parameter consumed by two Functions in one step (tied weights, a module applied
+        # twice) would keep only the last contribution and release its bucket early -- refuse instead of training on it
+        k = view.data_ptr()
+        if k in self._written:
+            raise RuntimeError('direct gradient placement: a parameter received two gradients in one backward (tied weights / '
+                               'a module applied twice); use the eager path (plain autograd accumulation) for such a model')
+        self._written[k] = 1
+        if self._user_cb is not None:
+            self._user_cb(view)
+
+    def finish_backward(self):
+        """Direct placement: parameters that received neither an in-place gradient nor a .grad in the backward that just ran
+        (e.g. FPNHead.output_convs[0], quirk Q3; frozen-by-construction plugin parts) are skipped by the optimizer kernel."""
+        self._set_nograd(i for i, (p, v) in enumerate(zip(self._params, self._grad_views))
+                         if v.data_ptr() not in self._written and p.grad is None)
 
     def disable_direct_grads(self):
         for p in getattr(self, '_params', []):
@@ -114,15 +171,17 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         """Copy every parameter's .grad into the flat gradient buffer (multi-tensor copy; graph-capturable).  With direct
         placement only gradients that still arrived as ``.grad`` (foreign plugin modules on plain autograd) are copied."""
         self.ensure_built()
-        dst, src = [], []
-        for p, view in zip(self._params, self._grad_views):
+        dst, src, missing = [], [], []
+        for i, (p, view) in enumerate(zip(self._params, self._grad_views)):
             if p.grad is not None:
                 dst.append(view)
                 src.append(p.grad)
             elif not self.direct:
-                view.zero_()
+                missing.append(i)
         if dst:
             torch._foreach_copy_(dst, src)
+        if not self.direct:
+            self._set_nograd(missing)          # torch.optim.AdamW: `if p.grad is None: continue`
 
     @torch.no_grad()
     def apply_flat(self):
@@ -145,7 +204,7 @@ class FusedAGCAdamW(torch.optim.Optimizer):
                 self._clip_ws = torch.empty(int(hip.lib().segf_clip_grad_ws()), dtype=torch.float32, device=self._grad.device)
             hip.clip_grad(self._grad, mode, value, self._clip_ws)
         hip.agc_adamw(self._flat, self._grad, self._m, self._v, self._off, self._len, self._flags, g['lr'], g['betas'][0],
-                      g['betas'][1], g['eps'], wd, self._step, float(self.agc_clip) if mode == 'agc' else 0.0)
+                      g['betas'][1], g['eps'], wd, self._step, float(self.agc_clip) if mode == 'agc' else 0.0, unit_step=self._ustep)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -167,11 +226,14 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         if self._flat is not None and self._step > 0:
             ids = self._packed_ids()
             state, o = {}, 0
-            for p in self._params:
+            usteps = self._ustep.cpu().tolist()
+            for i, p in enumerate(self._params):
                 n = p.numel()
-                state[ids[id(p)]] = {'step': torch.tensor(float(self._step)),
-                                     'exp_avg': self._m[o:o + n].view(p.shape).detach().cpu().clone(),
-                                     'exp_avg_sq': self._v[o:o + n].view(p.shape).detach().cpu().clone()}
+                t = usteps[self._unit_range[i][0]]
+                if t > 0:                       # torch lists state only for parameters that have been stepped
+                    state[ids[id(p)]] = {'step': torch.tensor(float(t)),
+                                         'exp_avg': self._m[o:o + n].view(p.shape).detach().cpu().clone(),
+                                         'exp_avg_sq': self._v[o:o + n].view(p.shape).detach().cpu().clone()}
                 o += n
             sd['state'] = state
         return sd
@@ -185,6 +247,7 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         if fused and fused.get('exp_avg') is not None:
             self.ensure_built()
             self._step = int(fused['step'])
+            self._ustep.fill_(self._step)
             self._m.copy_(fused['exp_avg'])
             self._v.copy_(fused['exp_avg_sq'])
             return
@@ -195,18 +258,21 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         for g in self.param_groups:
             for p in g['params']:
                 by_index[len(by_index)] = p
-        offs, o = {}, 0
-        for p in self._params:
+        offs, o, pos = {}, 0, {}
+        for i, p in enumerate(self._params):
             offs[id(p)] = o
+            pos[id(p)] = i
             o += p.numel()
         for idx, st in state.items():
             p = by_index[int(idx)]
             if id(p) not in offs:
                 continue                        # frozen parameter: not part of the flat buffers
             o, n = offs[id(p)], p.numel()
+            lo, hi = self._unit_range[pos[id(p)]]
+            self._ustep[lo:hi] = int(float(st['step']))
             self._m[o:o + n].copy_(st['exp_avg'].reshape(-1))
             self._v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
-            self._step = int(float(st['step']))
+            self._step = max(self._step, int(float(st['step'])))
 
 
 class NativeScaler:

@@ -164,8 +164,11 @@ class DeviceDataset:
 class DeviceBatchLoader:
     """Iterable of training batches for `engine.train_one_epoch`: what DataLoader(train_set, batch_size, drop_last=True,
     sampler=DistributedSampler / RandomSampler) over the transformed dataset yields (train_gpu.py:211-224), produced on the device.
-    Rank r of `world` takes indices r, r + world, ... of the epoch's permutation (DistributedSampler's partition,
-    torch/utils/data/distributed.py); `set_epoch` reseeds the permutation as `sampler.set_epoch` does (train_gpu.py:323)."""
+    The index order is DistributedSampler's (torch/utils/data/distributed.py, drop_last=False): `randperm(n)` from a generator
+    seeded `seed + epoch`, PADDED with its own head to `ceil(n / world) * world` entries, rank r taking entries r, r + world, ...;
+    `set_epoch` reseeds as `sampler.set_epoch` does (train_gpu.py:323).  train_gpu.py's DistributedSampler is built without a
+    seed, i.e. seed 0: pass seed=0 for its exact order.  (The single-process RandomSampler of the reference draws from torch's
+    global generator instead; the same function with world=1 is used there -- same distribution, not the same sequence.)"""
 
     def __init__(self, dataset, batch_size, transform, shuffle=True, seed=0, rank=0, world=1):
         self.dataset, self.batch_size, self.transform = dataset, int(batch_size), transform
@@ -187,10 +190,14 @@ class DeviceBatchLoader:
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
 
-    def __len__(self):
-        return (len(self.dataset) // self.world) // self.batch_size
+    def num_samples(self):
+        return -(-len(self.dataset) // self.world)             # ceil: DistributedSampler.num_samples with drop_last=False
 
-    def __iter__(self):
+    def __len__(self):
+        return self.num_samples() // self.batch_size           # DataLoader(drop_last=True)
+
+    def indices(self):
+        """This rank's sample indices for the current epoch (DistributedSampler.__iter__)."""
         n = len(self.dataset)
         if self.shuffle:
             g = torch.Generator()
@@ -198,7 +205,14 @@ class DeviceBatchLoader:
             order = torch.randperm(n, generator=g).tolist()
         else:
             order = list(range(n))
-        order = order[self.rank:(n // self.world) * self.world:self.world]
+        total = self.num_samples() * self.world
+        pad = total - len(order)
+        if pad > 0:
+            order += order[:pad] if pad <= len(order) else (order * (-(-pad // len(order))))[:pad]
+        return order[self.rank:total:self.world]
+
+    def __iter__(self):
+        order = self.indices()
         for b in range(len(self)):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
             yield self.transform([self.dataset.images[i] for i in idx], [self.dataset.labels[i] for i in idx], out=self.out)

@@ -1,6 +1,9 @@
 """Child process of tests/test_model_gpu.py::test_two_rank_graphed_step_matches_manual_data_parallel: one data-parallel rank
 driving GraphedTrainStep (hipGraph + bucketed, event-ordered gradient all-reduce + fused AGC/AdamW) on the real model.
-Ranks share this box's one GPU, hence the gloo backend (RCCL refuses duplicate devices); the code path is the product's."""
+Two ranks share this box's one GPU, hence the gloo backend there (RCCL refuses duplicate devices).  With WORLD_SIZE=1 and
+backend 'nccl' the same chain runs over RCCL itself (1-rank communicator, exchange forced on): graph replay -> in-graph event
+nodes -> communication stream -> RCCL collective -> fused optimizer.  The code path is the product's in both cases.
+argv: out_path steps bucket_mb [backend [exchange [payload]]]"""
 import os
 import sys
 
@@ -17,9 +20,12 @@ from segmentation_factory_amd.optim import FusedAGCAdamW, param_groups_weight_de
 
 def main():
     out_path, steps, bucket_mb = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+    backend = sys.argv[4] if len(sys.argv) > 4 else 'gloo'
+    exchange = sys.argv[5] if len(sys.argv) > 5 else 'all_reduce'
+    payload = sys.argv[6] if len(sys.argv) > 6 else 'fp32'
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', init_method='env://', rank=rank, world_size=world)
+    dist.init_process_group(backend, init_method='env://', rank=rank, world_size=world)
     backbone, head, nc, per_rank, H, W, seed = 'MiT-B0', 'SegFormerHead', 19, 2, 64, 64, 17
     sd = OW.make_state_dict(backbone, head, nc, seed + rank)        # DIFFERENT initial weights per rank: rank 0's must win (broadcast)
     x, y = OW.synthetic_batch(per_rank * world, H, W, nc, seed)
@@ -35,12 +41,14 @@ def main():
 
     def loss_fn(m, img, lbl):
         return criterion_lowres(m.forward_lowres(img), lbl, (H, W), None, num_classes=nc, dice=True, ignore_index=255)
-    gs = GraphedTrainStep(model, opt, loss_fn, (x, y), clip_grad=0.02, clip_mode='agc', warmup=1, bucket_mb=bucket_mb)
+    gs = GraphedTrainStep(model, opt, loss_fn, (x, y), clip_grad=0.02, clip_mode='agc', warmup=1, bucket_mb=bucket_mb,
+                          exchange=exchange, payload=payload, force_exchange=True)
     losses = [gs.step(x, y).item() for _ in range(steps)]
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({'losses': losses, 'state': {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                    'n_buckets': len(gs.buckets), 'events': sum(e is not None for e in gs.events)}, out_path)
+                    'n_buckets': len(gs.buckets), 'events': sum(e is not None for e in gs.events), 'ranges': gs.ranges,
+                    'backend': dist.get_backend(), 'exchanging': gs.exchanging}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -125,6 +125,25 @@ assert torch.allclose(flat, torch.arange(6, dtype=torch.float32) * 1.5), flat
 params = torch.full((5,), float(rank + 7))
 broadcast_flat_(params, 0)
 assert torch.all(params == 7.0)
+# the bucketed exchange of the graphed step: aligned collective ranges + both exchange algorithms, fp32 and bf16 payloads
+from segmentation_factory_amd.graph import comm_ranges, plan_buckets, sum_over_ranks_
+numels = [7, 33, 5, 64, 1, 90, 13]
+total = sum(numels)
+plan = plan_buckets(numels, 60)
+buckets = [(lo, hi) for lo, hi, _, _ in plan]
+rng_ = comm_ranges(buckets, total, world * 16)
+assert rng_[0][1] >= total and rng_[-1][0] == 0 and all((hi - lo) % (world * 16) == 0 for lo, hi in rng_)
+assert all(rng_[k][0] == rng_[k + 1][1] for k in range(len(rng_) - 1))          # exact tiling, completion order
+assert all(r[0] >= b[0] for r, b in zip(rng_, buckets))                          # a range never reaches into a later-completing bucket
+for mode in ("all_reduce", "rs_ag"):
+    for dt in (torch.float32, torch.bfloat16):
+        buf = torch.zeros(rng_[0][1], dtype=dt)
+        buf[:total] = (torch.arange(total) % 17).to(dt) * (rank + 1)
+        for lo, hi in rng_:
+            for w in sum_over_ranks_(buf[lo:hi], mode):
+                w.wait()
+        want = torch.zeros_like(buf); want[:total] = (torch.arange(total) % 17).to(dt) * 3
+        assert torch.equal(buf, want), (mode, dt)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -333,3 +352,20 @@ def test_plateau_scheduler_wraps_torch_reduce_on_plateau():
             ref.step(m, ep)
             assert opt.param_groups[0]['lr'] == ref_opt.param_groups[0]['lr']
     assert opt.param_groups[0]['lr'] < 1e-2 and set(sch.state_dict()) == {'best', 'last_epoch'}
+
+
+def test_device_batch_loader_index_order_is_distributed_samplers():
+    """transforms.DeviceBatchLoader.indices() == list(DistributedSampler(...)) (train_gpu.py:212-214: shuffle=True, default seed 0,
+    drop_last=False => padded with the head of the permutation), for dataset sizes that do and do not divide by the world size."""
+    from torch.utils.data.distributed import DistributedSampler
+    from segmentation_factory_amd.transforms import DeviceBatchLoader
+    for n, world in ((10, 2), (11, 2), (7, 3), (2, 3), (64, 8)):
+        data = list(range(n))
+        for rank in range(world):
+            ld = DeviceBatchLoader(data, 2, transform=None, shuffle=True, seed=0, rank=rank, world=world)
+            sm = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True)
+            for epoch in (0, 3):
+                ld.set_epoch(epoch)
+                sm.set_epoch(epoch)
+                assert ld.indices() == list(sm), (n, world, rank, epoch)
+                assert ld.num_samples() == len(sm) and len(ld) == len(sm) // 2

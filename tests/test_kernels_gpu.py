@@ -566,6 +566,35 @@ def test_agc_adamw_known_answers(hipmod):
         assert (b.detach().cpu() - pb).abs().max() < 1e-5
 
 
+def test_fused_adamw_skips_grad_none_like_torch_adamw(hipmod):
+    """torch.optim.AdamW (the reference's optimizer, train_gpu.py:269) does `if p.grad is None: continue`: such a parameter gets
+    no weight decay and no moment update in that step.  Eager path of FusedAGCAdamW (gather_grads sets the kernel's per-unit skip
+    bit), with the set of gradient-less parameters CHANGING between steps."""
+    from segmentation_factory_amd.optim import FusedAGCAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(5, 7), (5,), (4, 3, 2, 2), (9,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    groups = lambda l: [{'params': [p for p in l if p.ndim <= 1], 'weight_decay': 0.}, {'params': [p for p in l if p.ndim > 1], 'weight_decay': 0.1}]
+    opt, ropt = FusedAGCAdamW(groups(ps), lr=1e-2), torch.optim.AdamW(groups(ref), lr=1e-2)
+    opt.set_clipping(None, 'agc')
+    # parameter 2 never gets a gradient; parameter 1 misses one step and then continues with ITS OWN step count (torch keeps
+    # state['step'] per parameter: the kernel keeps per-unit counts on the device and derives the bias corrections from them)
+    for step, have in enumerate([(0, 1, 3), (0, 1, 3), (0, 3), (0, 1, 3)]):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            if i in have:
+                gr = torch.randn(*shapes[i], generator=g)
+                p.grad, r.grad = gr.cuda(), gr.clone()
+            else:
+                p.grad, r.grad = None, None
+        opt.step()
+        ropt.step()
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            assert (p.detach().cpu() - r.detach()).abs().max() < 2e-6, (step, i)
+    assert torch.equal(ps[2].detach().cpu(), ref[2].detach())         # untouched, bit for bit
+    assert len(opt.state_dict()['state']) == 3
+
+
 @pytest.mark.parametrize('mode,value', [('norm', 0.5), ('norm', 1e4), ('value', 0.3)])
 def test_clip_modes_norm_and_value_vs_torch(hipmod, mode, value):
     """The reference's other --clip-mode values (train_gpu.py:99-102 -> timm dispatch_clip_grad = torch.nn.utils.clip_grad_norm_ /

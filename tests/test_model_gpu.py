@@ -279,6 +279,7 @@ def _grad_report(model, ref_grads, skip=()):
 
 
 FULL_SIZE = {   # BASELINE.json configs as the reference builds them, at their full spatial size (batch: what the CPU oracle finishes in ~1 min)
+    'cfg1': ('MobileNetV2', 'FPNHead', 21, 2, 256, 256),     # BASELINE cfg1 exactly: VOC 21 classes, 256 x 256, batch 2 (the reference's CPU / fp32 configuration)
     'cfg2': ('MiT-B0', 'SegFormerHead', 150, 2, 512, 512),
     'cfg3': ('ConvNeXt', 'UPerHead', 150, 4, 512, 512),      # batch 4: PPM's scale-1 BatchNorm sees 4 values per channel (2 is degenerate)
     'cfg4': ('MiT-B2', 'SegFormerHead', 19, 1, 1024, 2048),
@@ -317,8 +318,18 @@ def test_full_size_fp32_and_bf16_vs_oracle(cfg):
         worst, wname, n = _grad_report(model, ref_grads, skip)
         print(f'[{cfg} {str(dtype)[6:]}] oracle {t_oracle:.0f} s; logits {e_log:.2e}, loss {e_loss:.2e}, worst gradient error {worst:.3e} ({wname}), {n} tensors')
         assert n >= 50
-        assert e_log <= (1e-3 if fp32 else 6e-2)
-        assert e_loss <= (1e-4 if fp32 else 2e-2)
+        # cfg1 is the reference's fp32 configuration: fp32 is the pinned mode.  In bf16 MobileNetV2's 52 train-mode BatchNorms over
+        # (near-)dead ReLU6 channels of the random-weight fixture amplify the storage rounding by 1/sigma (see
+        # test_e2e_against_reference_golden): bf16 is a sanity bound there, not a parity claim
+        assert e_log <= (1e-3 if fp32 else (0.6 if cfg == 'cfg1' else 6e-2))
+        assert e_loss <= (1e-4 if fp32 else (6e-2 if cfg == 'cfg1' else 2e-2))
+        if cfg == 'cfg1':
+            assert not fp32 or worst <= 3e-2, (wname, worst)
+            # quirk Q3: FPNHead.output_convs[0] is never evaluated (heads/fpn.py:29-36): no gradient reaches it
+            assert all(p.grad is None for k, p in model.named_parameters() if 'output_convs.0.' in k)
+            del model, lo, loss
+            torch.cuda.empty_cache()
+            continue
         # cfg3: PPM's scale-1 branch feeds a BatchNorm with B samples per channel (quirk Q16), whose Jacobian is
         # ill-conditioned; its neighbours' fp32 gradients move at the 1e-2 level with the summation order
         # measured on the MI355X (fp32 / bf16): cfg2 2.0e-3 / 3.1e-2, cfg3 1.4e-2 / 1.4e-1, cfg4 4.4e-4 / 7.5e-3, cfg5 6.8e-3 / 2.6e-1; ~2x margin
@@ -360,6 +371,104 @@ def test_graphed_step_matches_eager_step():
         curves.append(losses)
     assert curves[0][0] != curves[0][-1]                       # the optimizer actually moved the loss
     np.testing.assert_allclose(curves[1], curves[0], rtol=2e-5)
+
+
+@pytest.mark.parametrize('graphed', [False, True])
+def test_parameters_without_gradient_are_not_stepped(graphed):
+    """torch.optim.AdamW -- the reference's optimizer (train_gpu.py:269) -- skips a parameter whose .grad is None: no weight
+    decay, no moments, no entry in state_dict()['state'].  FPNHead.output_convs[0] (quirk Q3, heads/fpn.py:29-36: built, never
+    evaluated) is such a parameter in BASELINE cfg1's model; the fused kernel must leave it alone, eager and graphed."""
+    from segmentation_factory_amd import criterion_lowres
+    from segmentation_factory_amd.graph import GraphedTrainStep
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler, param_groups_weight_decay
+    backbone, head, nc, B, H, W, seed = 'MobileNetV2', 'FPNHead', 21, 2, 64, 64, 5
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    x, y = OW.synthetic_batch(B, H, W, nc, seed)
+    x, y = x.cuda(), y.cuda()
+    model = _build(backbone, head, nc, sd, torch.float32, B).train()
+    dead = {k: p.detach().clone() for k, p in model.named_parameters() if 'output_convs.0.' in k}
+    live_name = 'decode_head.output_convs.1.conv.weight'
+    live0 = dict(model.named_parameters())[live_name].detach().clone()
+    assert len(dead) >= 2
+
+    def loss_fn(m, img, lbl):
+        return criterion_lowres(m.forward_lowres(img), lbl, (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+
+    opt = FusedAGCAdamW(param_groups_weight_decay(model, 0.1), lr=1e-2)
+    if graphed:
+        gs = GraphedTrainStep(model, opt, loss_fn, (x, y), clip_grad=0.02, clip_mode='agc', warmup=1)
+        for _ in range(3):
+            gs.step(x, y)
+    else:
+        scaler = NativeScaler()
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            scaler(loss_fn(model, x, y), opt, clip_grad=0.02, clip_mode='agc', parameters=model.parameters())
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    for k, v in dead.items():
+        assert torch.equal(params[k].detach(), v), k                 # bit-identical: no decay, no update
+    assert not torch.equal(params[live_name].detach(), live0)
+    st = opt.state_dict()
+    n_params = sum(len(g['params']) for g in st['param_groups'])
+    assert len(st['state']) == n_params - len(dead)                  # torch lists state only for stepped parameters
+    # and the same state dict loads into torch.optim.AdamW over the same parameter groups
+    ref = torch.optim.AdamW(param_groups_weight_decay(model, 0.1), lr=1e-2)
+    ref.load_state_dict(st)
+
+
+def test_graphed_step_with_plain_autograd_plugin_head():
+    """A head registered through register_head that is an ordinary nn.Module on plain autograd (its gradients arrive as .grad and
+    are gathered inside the captured step): three graphed steps must equal three eager steps.  With the warm-up passes' .grad
+    tensors left in place the capture recorded `grad += new` and every replay added to the running sum."""
+    from segmentation_factory_amd import SegmentationModel, criterion_lowres, register_head, head_dict
+    from segmentation_factory_amd.graph import GraphedTrainStep
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler, param_groups_weight_decay
+
+    class PlainHead(torch.nn.Module):
+        def __init__(self, in_channels, channel, num_classes):
+            super().__init__()
+            self.proj = torch.nn.Linear(in_channels[0], num_classes)
+
+        def forward(self, feats):
+            f = feats[0].float().permute(0, 2, 3, 1)                 # NCHW view -> NHWC
+            return self.proj(f).permute(0, 3, 1, 2)
+
+    register_head('PlainHead', PlainHead)
+    try:
+        nc, B, H, W = 5, 2, 64, 64
+        x, y = OW.synthetic_batch(B, H, W, nc, 9)
+        x, y = x.cuda(), y.cuda()
+
+        def loss_fn(m, img, lbl):
+            return criterion_lowres(m.forward_lowres(img), lbl, (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+
+        curves, finals = [], []
+        for graphed in (False, True):
+            torch.manual_seed(0)
+            model = SegmentationModel('MiT-B0', num_classes=nc, seg_head='PlainHead', compute_dtype=torch.float32).cuda().train()
+            for mod in model.backbone.modules():
+                if hasattr(mod, 'drop_prob'):
+                    mod.drop_prob = 0.0
+            opt = FusedAGCAdamW(param_groups_weight_decay(model, 0.025), lr=1e-3)
+            losses = []
+            if graphed:
+                gs = GraphedTrainStep(model, opt, loss_fn, (x, y), clip_grad=0.02, clip_mode='agc', warmup=2)
+                for _ in range(4):
+                    losses.append(gs.step(x, y).item())
+            else:
+                scaler = NativeScaler()
+                for _ in range(4):
+                    opt.zero_grad(set_to_none=True)
+                    loss = loss_fn(model, x, y)
+                    losses.append(loss.item())
+                    scaler(loss, opt, clip_grad=0.02, clip_mode='agc', parameters=model.parameters())
+            curves.append(losses)
+            finals.append(model.decode_head.proj.weight.detach().cpu().clone())
+        np.testing.assert_allclose(curves[1], curves[0], rtol=2e-5)
+        assert (finals[0] - finals[1]).abs().max() <= 1e-5 * finals[0].abs().max() + 1e-7
+    finally:
+        head_dict.pop('PlainHead', None)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -628,8 +737,52 @@ def test_two_rank_eager_ddp_finetune_freeze(tmp_path):
     assert 'Epoch: [0]  [1/2]' in outs[0] and 'Val_mIOU' in outs[0]
 
 
-@pytest.mark.parametrize('bucket_mb', [4.0, 1000.0])
-def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb):
+@pytest.mark.parametrize('exchange,payload', [('all_reduce', 'fp32'), ('rs_ag', 'fp32'), ('all_reduce', 'bf16')])
+def test_one_rank_rccl_exchange_leg(tmp_path, exchange, payload):
+    """The RCCL leg of the data-parallel step on ONE GPU: a fresh child process with a 1-rank `nccl` process group and the
+    exchange forced on drives GraphedTrainStep for three steps -- graph replay, in-graph external event nodes, the communication
+    stream waiting on them, the RCCL collective(s) on each aligned bucket range, the optimizer behind the communication stream
+    (train_gpu.py:211-236's DDP exchange).  A sum over one rank is the identity, so the fp32 modes must reproduce the
+    no-exchange run of the same step in this process exactly; the bf16 payload rounds every gradient once (rel. 2^-9), which the
+    loss curve must tolerate at 1e-3."""
+    import subprocess
+    import sys
+    from segmentation_factory_amd import criterion_lowres
+    from segmentation_factory_amd.graph import GraphedTrainStep
+    from segmentation_factory_amd.optim import FusedAGCAdamW, param_groups_weight_decay
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    steps = 3
+    out = tmp_path / 'rank0.pt'
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29591', WORLD_SIZE='1', RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(out), str(steps), '4.0', 'nccl', exchange, payload],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got = torch.load(str(out), map_location='cpu', weights_only=False)
+    assert got['backend'] == 'nccl' and got['exchanging'] and got['n_buckets'] >= 4 and got['events'] == got['n_buckets']
+    assert all((hi - lo) % 16 == 0 for lo, hi in got['ranges'])
+    backbone, head, nc, B, H, W, seed = 'MiT-B0', 'SegFormerHead', 19, 2, 64, 64, 17
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    x, y = OW.synthetic_batch(B, H, W, nc, seed)
+    x, y = x.cuda(), y.cuda()
+    model = _build(backbone, head, nc, sd, torch.float32, B).train()
+    opt = FusedAGCAdamW(param_groups_weight_decay(model, 0.025), lr=1e-3)
+
+    def loss_fn(m, img, lbl):
+        return criterion_lowres(m.forward_lowres(img), lbl, (H, W), None, num_classes=nc, dice=True, ignore_index=255)
+    gs = GraphedTrainStep(model, opt, loss_fn, (x, y), clip_grad=0.02, clip_mode='agc', warmup=1)
+    assert not gs.exchanging
+    losses = [gs.step(x, y).item() for _ in range(steps)]
+    ref = model.state_dict()
+    if payload == 'fp32':
+        assert got['losses'] == losses
+        for k, v in got['state'].items():
+            assert torch.equal(v, ref[k].detach().cpu()), k
+    else:
+        np.testing.assert_allclose(got['losses'], losses, rtol=1e-3)
+
+
+@pytest.mark.parametrize('bucket_mb,exchange', [(4.0, 'all_reduce'), (1000.0, 'all_reduce'), (4.0, 'rs_ag')])
+def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb, exchange):
     """D1 / collective C1 on the PRODUCT step: two ranks (fresh child processes, gloo, sharing this box's GPU) each drive
     GraphedTrainStep on their shard -- hipGraph replay, per-bucket external events, all-reduce on the communication stream,
     fused AGC/AdamW -- for three steps.  Expected values: data parallelism by hand in this process = per-shard forward /
@@ -644,7 +797,7 @@ def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb)
     steps, world, per_rank = 3, 2, 2
     out = tmp_path / 'rank0.pt'
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29583', WORLD_SIZE=str(world))
-    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(out), str(steps), str(bucket_mb)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(out), str(steps), str(bucket_mb), 'gloo', exchange],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-3000:]

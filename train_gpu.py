@@ -12,8 +12,9 @@ text files, same auto-resume from the first *.pth in --save_weights_dir.  Differ
   * data: the reference's `datasets` package (PIL / torchvision pipelines, out of scope here) is used unchanged when it is
     importable (put the reference checkout on PYTHONPATH); `--dataset synthetic` runs on generated tensors with the same
     tensor contract (fp32 [3,S,S] image, int64 [S,S] label, ignore 255);
-  * --hip-graph replays each step as one hipGraph (segmentation_factory_amd/graph.py); data parallelism is then one RCCL
-    all-reduce of the flat gradient buffer instead of DistributedDataParallel hooks;
+  * --hip-graph replays each step as one hipGraph (segmentation_factory_amd/graph.py); data parallelism is then a bucketed RCCL
+    exchange of the flat gradient buffer released by in-graph events (--grad-exchange, --grad-payload) instead of
+    DistributedDataParallel hooks;
   * --finetune defaults to '' (the reference's default path makes the run fail unless that file exists, quirk Q10).
 
 Launch: `python train_gpu.py ...` or `python -m torch.distributed.run --nproc-per-node N train_gpu.py ...` (RCCL).
@@ -114,6 +115,10 @@ def get_args_parser():
     # MI355X-path extras
     parser.add_argument('--compute-dtype', default='bf16', choices=['bf16', 'fp32'], help='activation storage (fp32 = exact-parity mode)')
     parser.add_argument('--hip-graph', action='store_true', help='replay each train step as one hipGraph')
+    parser.add_argument('--grad-exchange', default='all_reduce', choices=['all_reduce', 'rs_ag'],
+                        help='--hip-graph data parallelism: one all-reduce per gradient bucket, or in-place reduce-scatter + all-gather')
+    parser.add_argument('--grad-payload', default='fp32', choices=['fp32', 'bf16'],
+                        help='--hip-graph data parallelism: exchange gradients as fp32 (reference arithmetic) or rounded to bf16')
     parser.add_argument('--device-input', action='store_true',
                         help='training batches from the device-side input pipeline (segmentation_factory_amd/transforms.py): the '
                              'decoded uint8 training set is uploaded once and the transform stack of datasets/build_datasets.py:14-22 '
@@ -178,9 +183,17 @@ def build_device_loader(args, train_set):
         train_set.transform = _decode_only
         for i in range(len(train_set)):
             img, lbl = train_set[i]
-            ds.add(img, lbl.to(torch.uint8))
+            # the reference's dataset classes differ in what they return here: ADE20K / VOC hand the decoded PIL pair through the
+            # transform (uint8 tensors from _decode_only), Cityscapes returns encode_target(target) = id_to_train_id[np.array(target)],
+            # a numpy int64 array (datasets/cityscapes.py:131,159)
+            lbl = torch.as_tensor(np.asarray(lbl))
+            if lbl.dtype != torch.uint8:
+                assert int(lbl.min()) >= 0 and int(lbl.max()) <= 255, 'label values must fit uint8 (255 = ignore)'
+                lbl = lbl.to(torch.uint8)
+            ds.add(torch.as_tensor(np.asarray(img)), lbl)
     tf = DeviceTrainTransform(args.image_size, device=args.device)
-    return DeviceBatchLoader(ds, args.batch_size, tf, shuffle=True, seed=args.seed, rank=utils.get_rank(), world=utils.get_world_size())
+    # seed 0 = the DistributedSampler of train_gpu.py:212-214 (constructed without a seed)
+    return DeviceBatchLoader(ds, args.batch_size, tf, shuffle=True, seed=0, rank=utils.get_rank(), world=utils.get_world_size())
 
 
 class _NullWriter:
