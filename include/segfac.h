@@ -265,6 +265,18 @@ int segf_upsample_add_stats(int dt, int B, int H, int W, int C, const void* base
                             const void* src0, int h0, int w0, int64_t ld0, const void* src1, int h1, int w1, int64_t ld1,
                             const void* src2, int h2, int w2, int64_t ld2, void* out, int64_t ldo, int align_corners,
                             float* sums, float* ws, void* stream);
+/* The folded SegFormerHead's stride-4 map in one pass on the matrix pipe (heads/segformer.py:42-56 after the fold):
+ *   out[b,Y,X,:] = x1[b,Y,X,:] G1^T + bilinear(t2) + bilinear(t3) + bilinear(t4): the stage-1 product (K = C1 = 32 or 64) and the
+ *   three align_corners=False resizes of the 1/2, 1/4, 1/8 maps t2, t3, t4 ([B*(H/r)*(W/r)][C] bf16, every bias already added:
+ *   bilinear weights sum to one) as ONE accumulated MFMA product per 8 x 8 pixel block -- replaces segf_gemm (x1 G1^T written to
+ *   memory) + segf_upsample_add_stats (read back, interpolated on the VALU).  bf16 only; H, W multiples of 8; C a multiple of 128.
+ *   sums (nullable): fp32 [2][C] per-channel sum / sum of squares of the fp32 results (BatchNorm statistics of the consumer,
+ *   heads/segformer.py:21-29); ws >= segf_fuse_map_248_ws floats when sums is given.  g1: [C][C1] bf16, row stride ldg. */
+int segf_fuse_map_248_supported(int dt, int B, int H, int W, int C, int C1);
+int64_t segf_fuse_map_248_ws(int B, int H, int W, int C);
+int segf_fuse_map_248(int B, int H, int W, int C, int C1, const void* x1, int64_t ldx1, const void* g1, int64_t ldg,
+                      const void* t2, int64_t ld2, const void* t3, int64_t ld3, const void* t4, int64_t ld4,
+                      void* out, int64_t ldo, float* sums, float* ws, void* stream);
 int segf_bn_stats_from_sums(const float* sums, int64_t rows, int C, float* mean, float* rstd, float* running_mean,
                             float* running_var, float momentum, float eps, void* stream);
 /* Nearest-neighbour upsampling by an integer factor on dense NHWC (F.interpolate mode='nearest': the top-down step of FPNHead,

@@ -1,0 +1,306 @@
+// The folded SegFormerHead's stride-4 map in ONE pass, on the matrix pipe.
+//
+// Reference: heads/segformer.py:42-56  (Linear_i -> bilinear resize to stride 4 -> concat [c4,c3,c2,c1] -> 1x1 fuse conv).
+// With the fold of functional.SegformerFoldedFuseFn the map is
+//     fused[b, Y, X, :] = x1[b, Y, X, :] G1^T  +  sum_{i=2,3,4} bilinear_i( t_i )[b, Y, X, :],      t_i = x_i G_i^T + beta_i
+// (the stage-1 bias rides in t_2: bilinear weights sum to one).  Until round 2 this took two launches that wrote / read a
+// [B*H*W, C] tensor twice (gemm_skinny_rows: x1 G1^T -> HBM; upsample_add_248: read it back, add the three interpolated maps on
+// the VALU, write `fused`): 0.63 + 1.78 ms at cfg2 / batch 128.  Here a workgroup owns an 8 x 8 block of stride-4 pixels and a
+// 128-channel slice, and BOTH terms are matrix products accumulated in the same MFMA accumulators:
+//   * x1 G1^T: K = C1 (32 or 64), the x1 rows are the B operand as they lie in memory (one 16-byte load per lane and K step);
+//   * the three bilinear interpolations TOGETHER are one product  W_int [64 pixels x 64 sources] . T_src [64 sources x channels]:
+//     the 8 x 8 block draws on 6 x 6 pixels of the 1/2 map, 4 x 4 of the 1/4 map and 3 x 3 of the 1/8 map (36 + 16 + 9 = 61 <= 64
+//     source rows, K = 64 = two MFMA steps).  W_int depends only on the position inside the block -- border blocks use the same
+//     weights on CLAMPED source addresses, which is exactly ATen's index clamping (area_pixel_compute_source_index) -- so it is
+//     a per-wave constant in registers.  Every weight is (a/16)(b/16), a, b <= 15: exact in bf16; products are exact in fp32.
+//     The source rows are staged in LDS as they lie in memory ([source][channel]) and read as MFMA operands through
+//     ds_read_b64_tr_b16 (the contraction index is the ROW index of that image).
+// The [16 pixels x 128 channels] result of a wave leaves through its own LDS slab as 256-byte row runs; the per-channel sum and
+// sum of squares (BatchNorm statistics of the ConvModule that follows, heads/segformer.py:21-29) are accumulated per lane from
+// the fp32 accumulators and reduced once per workgroup (deterministic partials + colreduce_finalize).
+// HBM traffic: fused written once (3.2 GB at cfg2 / batch 128) + x1 and the three maps read (0.13 + 1.05 GB).
+#include <stdlib.h>
+#include "colreduce.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define FM_SLICE 128                 // channels per workgroup
+#define FM_SROW 272                  // staged output row: 128 bf16 + 16 bytes of padding
+#define FM_NSRC 61                   // live source rows: 6x6 (1/2) + 4x4 (1/4) + 3x3 (1/8)
+#ifndef FM_OCC
+#define FM_OCC 2                     // waves per SIMD the register budget is set for (3: 168 VGPRs, spills 5 dwords with the statistics)
+#endif
+
+struct FuseMapArgs {
+    const bf16_t* x1; int64_t ldx1;
+    const bf16_t* g1; int64_t ldg;                 // [C][C1]
+    const bf16_t *src0, *src1, *src2; int64_t ld0, ld1, ld2;   // 1/2, 1/4, 1/8 maps, token-major [B*h*w][C]
+    bf16_t* out; int64_t ldo;
+    float* partial;                                // [streams][2][C] or nullptr
+    int B, H, W, C;
+    int tiles_x, tiles_per_img; int64_t ntiles;
+    FastDivU32 div_tx, div_tpi;
+    int nslice, nstream;
+};
+
+// same image as gemm.hip's reduction-major operand tile: [64 k rows][128 channels] bf16, 256-byte rows, 16-byte chunk c of row k
+// stored at chunk c ^ swz(k): conflict-free for the 16-byte row writes and for the transposed fragment reads
+__device__ __forceinline__ int fm_swz(int krow) { return 2 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
+__device__ __forceinline__ bf16x8 fm_frag_tr(const unsigned char* tile, int cb, int s, int lane) {
+    // lane (i = lane & 15, g = lane >> 4) receives T[k = 32 s + 8 g + j][channel cb + i], j = 0..7
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int u = (cb >> 2) + p;
+    const int chunk = u >> 1, half = u & 1;
+    s16x4 lo, hi;
+    {
+        const int krow = 32 * s + 8 * g + q;
+        const unsigned char* a = tile + krow * 256 + ((chunk ^ fm_swz(krow)) << 4) + half * 8;
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    }
+    {
+        const int krow = 32 * s + 8 * g + 4 + q;
+        const unsigned char* a = tile + krow * 256 + ((chunk ^ fm_swz(krow)) << 4) + half * 8;
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    }
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// source row r (0..63) of a block: level (0 = 1/2, 1 = 1/4, 2 = 1/8), offset (dy, dx) from the block's first source pixel
+__device__ __forceinline__ void fm_source_of(int r, int& lvl, int& dy, int& dx) {
+    if (r > FM_NSRC - 1) r = FM_NSRC - 1;          // rows 61..63 carry weight 0: any finite data
+    if (r < 36) { lvl = 0; dy = r / 6; dx = r - 6 * dy; }
+    else if (r < 52) { r -= 36; lvl = 1; dy = r >> 2; dx = r & 3; }
+    else { r -= 52; lvl = 2; dy = r / 3; dx = r - 3 * dy; }
+}
+// bilinear weight (align_corners = False) of local source index r for local output pixel p (0..7) at ratio 2 / 4 / 8; the first
+// source pixel of the block is (block origin / ratio) - 1, hence the + 1
+__device__ __forceinline__ float fm_w1(int lvl, int p, int r) {
+    const float ratio = lvl == 0 ? 0.5f : (lvl == 1 ? 0.25f : 0.125f);
+    const float s = (p + 0.5f) * ratio - 0.5f + 1.f;
+    const int i0 = (int)s;
+    const float f = s - (float)i0;
+    return r == i0 ? 1.f - f : (r == i0 + 1 ? f : 0.f);
+}
+__device__ __forceinline__ float fm_weight(int k, int py, int px) {
+    if (k >= FM_NSRC) return 0.f;
+    int lvl, dy, dx;
+    fm_source_of(k, lvl, dy, dx);
+    return fm_w1(lvl, py, dy) * fm_w1(lvl, px, dx);
+}
+
+template <int KS1, bool STATS>
+__global__ void __launch_bounds__(256, FM_OCC) fuse_map_kernel(FuseMapArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char tsrc[64 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char ostage[4][16 * FM_SROW];
+    __shared__ __attribute__((aligned(16))) unsigned char g1lds[8 * KS1 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mi = lane & 15, g = lane >> 4;
+    const unsigned L = xcd_block();
+    const int slice = (int)(L % (unsigned)a.nslice);
+    const int64_t stream = L / (unsigned)a.nslice;
+    const int c0 = slice * FM_SLICE;
+
+    // ---- per-workgroup constants -------------------------------------------------------------------------------------------
+    // G1 slice in fragment order: fragment (nt, s), lane (mi, g) = G1[c0 + 16 nt + mi][32 s + 8 g .. + 7]
+    for (int f = wave; f < 8 * KS1; f += 4) {
+        const int s = f % KS1, nt = f / KS1;
+        *reinterpret_cast<uint4*>(g1lds + f * 1024 + lane * 16) =
+            *reinterpret_cast<const uint4*>(a.g1 + (int64_t)(c0 + 16 * nt + mi) * a.ldg + 32 * s + 8 * g);
+    }
+    // interpolation weights of this wave's 16 pixels (rows 2 wave, 2 wave + 1 of the block): B operand, lane (pixel mi, k group g)
+    bf16x8 wint[2];
+    {
+        const int py = 2 * wave + (mi >> 3), px = mi & 7;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            s16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(fm_weight(32 * s + 8 * g + j, py, px));
+            wint[s] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    // the four source rows this thread stages per block: rows r = tid / 16 + 16 i, 16-byte chunk ck = tid % 16 of the slice
+    const int ck = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    int s_lvl[4], s_dy[4], s_dx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fm_source_of(r0 + 16 * i, s_lvl[i], s_dy[i], s_dx[i]);
+
+    auto tile_coords = [&](int64_t t, int& b, int& ty, int& tx) {
+        b = (int)fastdiv((uint32_t)t, a.div_tpi);
+        const int rem = (int)t - b * a.tiles_per_img;
+        ty = (int)fastdiv((uint32_t)rem, a.div_tx);
+        tx = rem - ty * a.tiles_x;
+    };
+    auto load_sources = [&](int64_t t, u32x4 (&reg)[4]) {
+        int b, ty, tx;
+        tile_coords(t, b, ty, tx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int lv = s_lvl[i], sh = 2 - lv;                     // block origin in source pixels: (8 ty) >> (lv + 1) = ty << (2 - lv)
+            int y = (ty << sh) - 1 + s_dy[i], x = (tx << sh) - 1 + s_dx[i];
+            const int h = a.H >> (lv + 1), w = a.W >> (lv + 1);
+            y = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            x = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+            // (selects, not indexed kernel-argument arrays: those would be copied to scratch)
+            const bf16_t* sp = lv == 0 ? a.src0 : (lv == 1 ? a.src1 : a.src2);
+            const int64_t sl = lv == 0 ? a.ld0 : (lv == 1 ? a.ld1 : a.ld2);
+            const bf16_t* p = sp + (((int64_t)b * h + y) * w + x) * sl + c0 + 8 * ck;
+            reg[i] = *reinterpret_cast<const u32x4*>(p);
+        }
+    };
+    auto pixel_of = [&](int64_t t, int m) -> int64_t {                // flat pixel index of this wave's pixel m (0..15) of block t
+        int b, ty, tx;
+        tile_coords(t, b, ty, tx);
+        return ((int64_t)b * a.H + 8 * ty + 2 * wave + (m >> 3)) * a.W + 8 * tx + (m & 7);
+    };
+    auto load_x1 = [&](int64_t t, u32x4 (&reg)[KS1]) {
+        const bf16_t* p = a.x1 + pixel_of(t, mi) * a.ldx1 + 8 * g;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) reg[s] = *reinterpret_cast<const u32x4*>(p + 32 * s);
+    };
+
+    f32x2_t p1[8][2], p2[8][2];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { p1[nt][h] = f32x2_t{0.f, 0.f}; p2[nt][h] = f32x2_t{0.f, 0.f}; }
+
+    u32x4 sreg[4], xa[KS1], xb[KS1];
+    int64_t t = stream;
+    const int64_t tstep = a.nstream;
+    if (t < a.ntiles) { load_sources(t, sreg); load_x1(t, xa); }
+    unsigned char* ost = ostage[wave];
+    for (; t < a.ntiles; t += tstep) {
+        __syncthreads();                                              // every wave is done with the previous block's source image
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int krow = r0 + 16 * i;
+            *reinterpret_cast<u32x4*>(tsrc + krow * 256 + ((ck ^ fm_swz(krow)) << 4)) = sreg[i];
+        }
+        __syncthreads();
+        {   // next block's operands on their way while this one is multiplied (the last iteration re-reads its own)
+            const int64_t tn = t + tstep < a.ntiles ? t + tstep : t;
+            load_sources(tn, sreg);
+            load_x1(tn, xb);
+            SEGF_LOADS_ISSUED();
+        }
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(g1lds + (nt * KS1 + s) * 1024 + lane * 16));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xa[s]), acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fm_frag_tr(tsrc, 16 * nt, s, lane), wint[s], acc, 0, 0, 0);
+            // acc[r] = fused[pixel mi][channel c0 + 16 nt + 4 g + r]
+            if (STATS) {
+                const f32x2_t lo = {acc[0], acc[1]}, hi = {acc[2], acc[3]};
+                p1[nt][0] += lo; p1[nt][1] += hi;
+                p2[nt][0] += lo * lo; p2[nt][1] += hi * hi;
+            }
+            *reinterpret_cast<uint2*>(ost + mi * FM_SROW + (16 * nt + 4 * g) * 2) =
+                make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {   // 16 rows x 16 chunks of 16 bytes: lane -> (row, chunk), 256-byte runs per pixel
+            const int64_t pix_lo = pixel_of(t, 0), pix_hi = pixel_of(t, 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i, row = idx >> 4, cc = idx & 15;
+                const uint4 o = *reinterpret_cast<const uint4*>(ost + row * FM_SROW + 16 * cc);
+                const int64_t pix = (row < 8 ? pix_lo : pix_hi) + (row & 7);
+                *reinterpret_cast<uint4*>(a.out + pix * a.ldo + c0 + 8 * cc) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            xa[s] = xb[s];
+            asm volatile("" : "+v"(xa[s]));
+        }
+    }
+    if (STATS) {
+        // per-channel sums: over the wave's 16 pixel lanes (DPP row reduction), then over the four waves in fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(tsrc);                 // [wave][2][128]
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v1 = wave_sum(r < 2 ? p1[nt][0][r] : p1[nt][1][r - 2], 16);
+                const float v2 = wave_sum(r < 2 ? p2[nt][0][r] : p2[nt][1][r - 2], 16);
+                if (mi == 0) {
+                    red[(wave * 2 + 0) * 128 + 16 * nt + 4 * g + r] = v1;
+                    red[(wave * 2 + 1) * 128 + 16 * nt + 4 * g + r] = v2;
+                }
+            }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int o = threadIdx.x >> 7, c = threadIdx.x & 127;
+            const float v = ((red[(0 * 2 + o) * 128 + c] + red[(1 * 2 + o) * 128 + c]) + red[(2 * 2 + o) * 128 + c]) + red[(3 * 2 + o) * 128 + c];
+            a.partial[(stream * 2 + o) * a.C + c0 + c] = v;
+        }
+    }
+}
+
+static int fuse_map_streams(int B, int H, int W, int C) {
+    const int64_t ntiles = (int64_t)B * (H / 8) * (W / 8);
+    const int nslice = C / FM_SLICE;
+    int64_t streams = (256 * FM_OCC) / nslice;                       // FM_OCC workgroups per CU resident
+    if (streams < 1) streams = 1;
+    if (streams > ntiles) streams = ntiles;
+    return (int)streams;
+}
+
+extern "C" int segf_fuse_map_248_supported(int dt, int B, int H, int W, int C, int C1) {
+    return dt == SEGF_BF16 && B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0 && C % FM_SLICE == 0 && (C1 == 32 || C1 == 64) &&
+           (int64_t)B * (H / 8) * (W / 8) < (1ll << 31) && !getenv("SEGFAC_NO_FUSE_MAP");
+}
+extern "C" int64_t segf_fuse_map_248_ws(int B, int H, int W, int C) {
+    return (int64_t)fuse_map_streams(B, H, W, C) * 2 * C;
+}
+extern "C" int segf_fuse_map_248(int B, int H, int W, int C, int C1, const void* x1, int64_t ldx1, const void* g1, int64_t ldg,
+                                 const void* t2, int64_t ld2, const void* t3, int64_t ld3, const void* t4, int64_t ld4,
+                                 void* out, int64_t ldo, float* sums, float* ws, void* stream) {
+    if (!segf_fuse_map_248_supported(SEGF_BF16, B, H, W, C, C1)) return SEGF_ERR_SHAPE;
+    const void* ptrs[6] = {x1, g1, t2, t3, t4, out};
+    const int64_t lds[6] = {ldx1, ldg, ld2, ld3, ld4, ldo};
+    const int64_t mins[6] = {C1, C1, C, C, C, C};
+    for (int i = 0; i < 6; ++i)
+        if (!ptrs[i] || ((uintptr_t)ptrs[i] % 16) || ((lds[i] * 2) % 16) || lds[i] < mins[i]) return SEGF_ERR_SHAPE;
+    if (sums && !ws) return SEGF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    FuseMapArgs a;
+    a.x1 = (const bf16_t*)x1; a.ldx1 = ldx1; a.g1 = (const bf16_t*)g1; a.ldg = ldg;
+    a.src0 = (const bf16_t*)t2; a.src1 = (const bf16_t*)t3; a.src2 = (const bf16_t*)t4;
+    a.ld0 = ld2; a.ld1 = ld3; a.ld2 = ld4;
+    a.out = (bf16_t*)out; a.ldo = ldo; a.partial = sums ? ws : nullptr;
+    a.B = B; a.H = H; a.W = W; a.C = C;
+    a.tiles_x = W / 8; a.tiles_per_img = (H / 8) * (W / 8); a.ntiles = (int64_t)B * a.tiles_per_img;
+    a.div_tx = fastdiv_make((uint32_t)a.tiles_x); a.div_tpi = fastdiv_make((uint32_t)a.tiles_per_img);
+    a.nslice = C / FM_SLICE; a.nstream = fuse_map_streams(B, H, W, C);
+    const dim3 grid((unsigned)(a.nstream * a.nslice));
+    if (C1 == 32) {
+        if (sums) hipLaunchKernelGGL((fuse_map_kernel<1, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((fuse_map_kernel<1, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (sums) hipLaunchKernelGGL((fuse_map_kernel<2, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((fuse_map_kernel<2, false>), grid, dim3(256), 0, st, a);
+    }
+    SEGF_CHECK_LAUNCH();
+    if (sums) {
+        colreduce_finalize_launch(ws, a.nstream, 2 * (int64_t)C, sums, st);
+        SEGF_CHECK_LAUNCH();
+    }
+    return 0;
+}

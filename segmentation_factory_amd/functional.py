@@ -700,6 +700,11 @@ class SegformerFoldedFuseFn(Function):
         wf32 = wf.detach().reshape(E, 4 * E)
         wfc = _w(wf32 if wf32.is_contiguous() else wf32.contiguous(), dtype)
         ts, saved = [], []
+        # one launch for the whole stride-4 map (x1 G1^T and the three resizes as one accumulated matrix product per 8 x 8 pixel
+        # block, csrc/fuse_map.hip) when the geometry is the 1/2-1/4-1/8 pyramid; the stage-1 bias then rides in the 1/2 map
+        one_pass = (dtype == torch.bfloat16 and all(geoms[i] == (B, H1 >> i, W1 >> i) for i in (1, 2, 3))
+                    and hip.fuse_map_248_supported(dtype, B, H1, W1, E, feats[0].shape[1]))
+        G1, beta1 = None, None
         for i in range(4):
             x = _rowmajor(feats[i])
             Ci = x.shape[1]
@@ -714,11 +719,20 @@ class SegformerFoldedFuseFn(Function):
             beta_i = torch.empty(E, dtype=torch.float32, device=dev)
             hip.cast2d(Gp[:, Ci:Ci + 1], beta_i.unsqueeze(1))
             _, h, w = geoms[i]
-            ts.append(hip.gemm(0, x, G, B * h * w, E, Ci, bias=beta_i))   # a constant row passes through the resize unchanged
+            if one_pass and i == 0:
+                G1, beta1 = G, beta_i
+                ts.append(None)
+            else:
+                if one_pass and i == 1:
+                    beta_i = hip.add(beta_i.unsqueeze(0), beta1.unsqueeze(0)).squeeze(0)    # a constant passes through the resize
+                ts.append(hip.gemm(0, x, G, B * h * w, E, Ci, bias=beta_i))   # a constant row passes through the resize unchanged
             saved += [x, G, Wp]
             if i == 0 and ctx.fold_slot is not None and dtype == torch.bfloat16:
                 ctx.fold_slot['x1'] = x           # BnActLinearFn.backward may compute dG_1 while it has the gradient tile on chip
-        y, sums = hip.upsample_add_stats(ts[0], [(ts[i], geoms[i][1], geoms[i][2]) for i in range(1, 4)], B, H1, W1, E)
+        if one_pass:
+            y, sums = hip.fuse_map_248(saved[0], G1, ts[1], ts[2], ts[3], B, H1, W1)
+        else:
+            y, sums = hip.upsample_add_stats(ts[0], [(ts[i], geoms[i][1], geoms[i][2]) for i in range(1, 4)], B, H1, W1, E)
         if sums is None:
             sums = torch.empty(0, device=y.device)          # geometry without the fused statistics: the consumer runs its own pass
         ctx.mark_non_differentiable(sums)

@@ -73,6 +73,9 @@ _PROTOS = {
     'segf_upsample_add': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p]),
     'segf_upsample_add_stats_ws': (_l, [_i, _i, _i, _i]),
     'segf_upsample_add_stats': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _p, _i, _i, _l, _p, _i, _i, _l, _p, _i, _i, _l, _p, _l, _i, _p, _p, _p]),
+    'segf_fuse_map_248_supported': (_i, [_i, _i, _i, _i, _i, _i]),
+    'segf_fuse_map_248_ws': (_l, [_i, _i, _i, _i]),
+    'segf_fuse_map_248': (_i, [_i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _p, _p]),
     'segf_bn_stats_from_sums': (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p]),
     'segf_bilinear_to_nchw_f32': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p]),
     'segf_ce_dice_stats_floats': (_l, [_i, _i]),
@@ -773,6 +776,24 @@ def upsample_add_stats(base, srcs, B, H, W, Cc):
     if rc == ERR_SHAPE:
         return upsample_add(base, srcs, B, H, W, Cc), None
     _chk(rc, 'segf_upsample_add_stats')
+    return out, sums
+
+
+def fuse_map_248_supported(dtype, B, H, W, Cc, C1):
+    return dtype == torch.bfloat16 and bool(lib().segf_fuse_map_248_supported(BF16, B, H, W, Cc, C1))
+
+
+def fuse_map_248(x1, g1, t2, t3, t4, B, H, W, with_sums=True):
+    """out [B*H*W, C] = x1 g1^T + bilinear(t2) + bilinear(t3) + bilinear(t4) (1/2, 1/4, 1/8 maps, align_corners=False) and, when
+    asked, sums fp32 [2, C] = per-channel (sum, sum of squares) of the result: the folded SegFormerHead's stride-4 map in one launch."""
+    _need_cuda(x1, g1, t2, t3, t4)
+    Cc, C1 = g1.shape
+    out = torch.empty((B * H * W, Cc), dtype=torch.bfloat16, device=x1.device)
+    sums = torch.empty((2, Cc), dtype=torch.float32, device=x1.device) if with_sums else None
+    ws = _f32(max(1, lib().segf_fuse_map_248_ws(B, H, W, Cc)), x1.device) if with_sums else None
+    _chk(lib().segf_fuse_map_248(B, H, W, Cc, C1, _ptr(x1), x1.stride(0), _ptr(g1), g1.stride(0), _ptr(t2), t2.stride(0),
+                                 _ptr(t3), t3.stride(0), _ptr(t4), t4.stride(0), _ptr(out), Cc,
+                                 _ptr(sums) if with_sums else None, _ptr(ws) if with_sums else None, _stream()), 'segf_fuse_map_248')
     return out, sums
 
 

@@ -1169,6 +1169,42 @@ def test_upsample_add_with_batchnorm_statistics(hipmod, dtype):
     assert sums2 is None and out2.shape == out.shape
 
 
+@pytest.mark.parametrize('geom', [(2, 8, 8, 128, 32), (1, 16, 24, 256, 64), (3, 32, 40, 768, 32), (2, 128, 128, 128, 32)])
+def test_fuse_map_248_one_pass(hipmod, geom):
+    """segf_fuse_map_248 (the folded SegFormerHead's stride-4 map, heads/segformer.py:42-56: x1 G1^T and the three bilinear resizes
+    as ONE accumulated matrix product per 8 x 8 pixel block, with the BatchNorm statistics) against float64 torch on the same bf16
+    operands (x1 @ G1^T + F.interpolate of the 1/2, 1/4, 1/8 maps, align_corners=False), and against the two launches it replaces.
+    8 x 8 maps: every block is a border block (clamped source addresses on every side)."""
+    B, H, W, C, C1 = geom
+    g = torch.Generator().manual_seed(91)
+    bf = torch.bfloat16
+    x1 = torch.randn(B * H * W, C1, generator=g).to(bf)
+    G1 = (torch.randn(C, C1, generator=g) * 0.3).to(bf)
+    sizes = [(H // r, W // r) for r in (2, 4, 8)]
+    ts = [(torch.randn(B * h * w, C, generator=g) * (1 + k)).to(bf) for k, (h, w) in enumerate(sizes)]
+    assert hipmod.fuse_map_248_supported(bf, B, H, W, C, C1)
+    out, sums = hipmod.fuse_map_248(x1.cuda(), G1.cuda(), *[t.cuda() for t in ts], B, H, W)
+    ref = x1.double() @ G1.double().t()
+    for t, (h, w) in zip(ts, sizes):
+        up = F.interpolate(t.double().view(B, h, w, C).permute(0, 3, 1, 2), size=(H, W), mode='bilinear', align_corners=False)
+        ref = ref + up.permute(0, 2, 3, 1).reshape(-1, C)
+    scale = ref.abs().max().item()
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= 2 ** -8 * scale, (err, scale)                      # one bf16 rounding of an fp32-accumulated exact product
+    # statistics: of the fp32 results (before the rounding to bf16)
+    assert torch.allclose(sums[0].double().cpu(), ref.sum(0), rtol=1e-4, atol=1e-3 * scale)
+    assert torch.allclose(sums[1].double().cpu(), (ref * ref).sum(0), rtol=1e-4, atol=1e-3 * scale * scale)
+    # the two launches it replaces (bf16 round trip of x1 G1^T through memory in between)
+    base = hipmod.gemm(0, x1.cuda(), G1.cuda(), B * H * W, C, C1)
+    two, _ = hipmod.upsample_add_stats(base, [(t.cuda(), h, w) for t, (h, w) in zip(ts, sizes)], B, H, W, C)
+    assert (two.double().cpu() - out.double().cpu()).abs().max().item() <= 2 ** -6 * scale
+    # deterministic
+    out2, sums2 = hipmod.fuse_map_248(x1.cuda(), G1.cuda(), *[t.cuda() for t in ts], B, H, W)
+    assert torch.equal(out, out2) and torch.equal(sums, sums2)
+    out3, none = hipmod.fuse_map_248(x1.cuda(), G1.cuda(), *[t.cuda() for t in ts], B, H, W, with_sums=False)
+    assert none is None and torch.equal(out, out3)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('geom', [(2, 16, 24, 16), (1, 8, 8, 40), (1, 32, 16, 8), (2, 128, 128, 64)])
 def test_bilinear_bwd_248_equals_three_transposed_resizes(hipmod, dtype, geom):
