@@ -174,6 +174,15 @@ int segf_bn_cls_bwd_dw(int dt, int64_t M, int C, int K, const void* dy, int64_t 
                        const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                        const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
                        float* dbeta, float* ws, const void* x1, int64_t ldx1, int C1, float* dG, void* stream);
+/* The same with everything that can ride along, each part optional: (x1, dG) as in segf_bn_cls_bwd_dw (pass 2), and dwcls = the
+ * CLASSIFIER's weight gradient fp32 [K][C] = dy^T act(bn(x)) * drop (heads/segformer.py:57-58 backward; act = 0 / 1 only),
+ * formed in pass 1 from the x and dy tiles it already holds -- replaces the layout-2 segf_gemm_pro pass over x.
+ * ws >= segf_bn_cls_bwd_full_ws(M, C, K, rows_per_sample) floats. */
+int64_t segf_bn_cls_bwd_full_ws(int64_t M, int C, int K, int64_t rows_per_sample);
+int segf_bn_cls_bwd_full(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                         const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma, float* dbeta,
+                         float* ws, const void* x1, int64_t ldx1, int C1, float* dG, float* dwcls, void* stream);
 
 /* ---- Global Response Normalization (ConvNeXtV2 GRN, convnextv2.py:68-80) on NHWC rows, B images of rows_per_sample rows:
  * y = gamma * (x * Nx) + beta + x, Nx = ||x||_2(H,W) / (mean_c ||x||_2 + 1e-6).  sumsq_out [B][C] is saved for the backward. */

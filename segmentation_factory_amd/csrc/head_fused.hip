@@ -32,6 +32,7 @@ struct HeadFusedArgs {
     int64_t M; int C; int64_t rps; int groups_per_sample, chunks_per_sample; int act, eval_mode;
     const bf16_t* x1; int64_t ldx1;       // DW: [M][>= 32] second operand of the riding weight-gradient product
     float* dwpart;                        // DW: [gridDim.x / ny][C][DW_LD] per-workgroup partials of dx^T [x1 | 1]
+    float* cwpart;                        // CW: [gridDim.x / ny][32 KS][C] per-workgroup partials of the classifier's weight gradient
 };
 #define DW_C1 32                          // channels of x1 (MiT-B0's stage-1 width)
 #define DW_LD 40                          // row length of the product: 32 channels, the all-ones column (= column sums of dx), 7 x 0
@@ -68,7 +69,14 @@ __device__ __forceinline__ float hf_row_sum16(float v) {
 // Here each wave multiplies its 32 features of the finished dx tile (read back transposed from the staging tile `ot`: exactly the
 // bf16 values that go to memory) with the tokens' x1 rows [x1 | 1 | 0] staged beside it: 2 x 3 accumulator tiles, 12 MFMAs per
 // 64 tokens.  Per-workgroup partials [C][DW_LD] are summed in fixed order by colreduce_finalize.
-template <int PASS, int KS, bool DW = false>
+// CW (pass 1 only): the CLASSIFIER's weight gradient rides along.  dW[class][feature] = sum_tokens dy[token][class] a[token][feature]
+// with a = act(bn(x)) * drop is the product the operand-prologue GEMM (segf_gemm_pro, layout 2) formed in its own pass over x
+// (1.03 ms at cfg2, batch 128): pass 1 already has the x tile and the dy tile on chip.  Each wave writes the normalised
+// activations of its 32 features (bf16, the rounding the GEMM operand had) into its columns of a [TOK][256] LDS tile -- only the
+// wave itself reads them back, so no workgroup barrier is added -- and multiplies dy^T (classes x tokens, transposed read of
+// the staged dy tile) with it: 2 KS x 2 accumulator tiles per wave, 4 KS MFMAs per 32 tokens.  Per-workgroup partials
+// [32 KS][C] are summed in fixed order by colreduce_finalize.
+template <int PASS, int KS, bool DW = false, bool CW = false>
 __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadFusedArgs a) {
     constexpr int NT = 2;                                   // 32 features per wave
     constexpr int TOK = 16 * HF_U;                          // tokens per iteration
@@ -90,6 +98,13 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
     __shared__ __attribute__((aligned(16))) bf16_t xt[2][TOK][XRS];
     __shared__ __attribute__((aligned(16))) bf16_t ot[PASS == 2 ? TOK : 1][XRS];
     static_assert(!DW || (PASS == 2 && HF_WAVES == 8 && TOK == 64), "the riding weight gradient belongs to pass 2");
+    static_assert(!CW || (PASS == 1 && TOK % 32 == 0), "the classifier's weight gradient rides on pass 1");
+    __shared__ __attribute__((aligned(16))) bf16_t at[CW ? TOK : 1][XRS];
+    hf_f32x4 accc[CW ? 2 * KS : 1][CW ? 2 : 1];
+#pragma unroll
+    for (int i = 0; i < (CW ? 2 * KS : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (CW ? 2 : 1); ++j) accc[i][j] = hf_f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int X1RS = DW_C1 + 16 + 8;                    // [x1 (32) | 1 | 0 x 15 | pad]: 112-byte rows
     __shared__ __attribute__((aligned(16))) bf16_t x1t[DW ? 2 : 1][DW ? TOK : 1][X1RS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -144,6 +159,10 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
     for (int j = 0; j < 8; ++j) {
         cs[j] = a.cscale ? a.cscale[(int64_t)b * a.C + f0 + j] : 1.f;
         if (PASS == 2) E[j] *= cs[j];
+        // CW (act = identity / ReLU only): the Dropout2d scale cs >= 0 commutes with the activation, so it is folded into the affine
+        // map: z' = cs z, a = act(z'); the gradient mask z' > 0 is unchanged for cs > 0, and for cs = 0 the sums are multiplied by
+        // cs = 0 at the end anyway.  (Frees eight registers in the loop: the riding product needs 80 accumulators.)
+        if (CW) { zA[j] *= cs[j]; zB[j] *= cs[j]; }
     }
     const int64_t row0 = (int64_t)b * a.rps;
     const int64_t last_row = row0 + (int64_t)gend * 16 - 1;
@@ -231,7 +250,8 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
     for (int gp = gbeg; gp < gend; gp += HF_U) {
         const bool more = gp + HF_U < gend;
         if (more) { fetch_tile(gp + HF_U); fetch_x(gp + HF_U); fetch_x1(gp + HF_U); }
-#pragma unroll
+        constexpr int UNR = CW ? 1 : HF_U;                 // CW: 80 accumulator registers ride along -- one token group at a time
+#pragma unroll UNR
         for (int u = 0; u < HF_U; ++u) {
             hf_f32x4 acc[NT];
 #pragma unroll
@@ -256,14 +276,38 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
                 if (PASS == 1) {                                                       // applied to the sums / folded into E below
                     s1[j] += gm;
                     s2[j] = fmaf(gm, xv, s2[j]);                                       // sum g x; xhat = x hC + hD is applied to the sums
+                    if (CW) o[j] = live ? fmaxf(z, zlo) : 0.f;                         // a = act(bn(x)) * drop (cs folded into z; dead rows: zero)
                 } else {
                     o[j] = fmaf(E[j], gm, -fmaf(xv, Q[j], P[j]));
                 }
+            }
+            if (CW) {
+                const hf_u32x4 av = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+                *reinterpret_cast<hf_u32x4*>(&at[16 * u + mi][32 * wave + 8 * g]) = av;
             }
             if (PASS == 2) {
                 const hf_u32x4 ov = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
                 *reinterpret_cast<hf_u32x4*>(&ot[16 * u + mi][32 * wave + 8 * g]) = ov;
             }
+        }
+        if (CW) {       // dWcls partial += dy_tile^T a_tile: tokens are the contraction index of both operands; this wave's columns only
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ks = 0; ks < TOK / 32; ++ks) {
+                const unsigned char* ab = reinterpret_cast<const unsigned char*>(&at[32 * ks][0]);
+                const unsigned char* yb = reinterpret_cast<const unsigned char*>(&tile[bufi][32 * ks][0]);
+                const hf_bf16x8 fb0 = hf_frag_tok_tr(ab, XRS * 2, 32 * wave, lane), fb1 = hf_frag_tok_tr(ab, XRS * 2, 32 * wave + 16, lane);
+#pragma unroll
+                for (int ct = 0; ct < 2 * KS; ++ct) {
+                    const hf_bf16x8 fa = hf_frag_tok_tr(yb, RS * 2, 16 * ct, lane);
+                    accc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb0, accc[ct][0], 0, 0, 0);
+                    accc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb1, accc[ct][1], 0, 0, 0);
+                    if (ct & 1) __builtin_amdgcn_sched_barrier(0);      // at most two dy fragments live (the scheduler otherwise hoists all 2 KS reads: spills)
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         // keep the LDS writes of the prefetched tile BELOW the arithmetic: hoisted above it (the compiler sees no dependence) they
         // wait for the global loads at the top of the iteration and expose the whole HBM latency
@@ -315,14 +359,26 @@ __global__ void __launch_bounds__(64 * HF_WAVES, HF_OCC) bn_cls_bwd_kernel(HeadF
                 }
             }
     }
+    if (CW) {
+        // accumulator (ct, ft): rows = classes 16 ct + 4 (lane >> 4) + r, column = feature wg_f0 + 32 wave + 16 ft + (lane & 15)
+        float* dst = a.cwpart + (int64_t)blk * (32 * KS) * a.C + wg_f0 + 32 * wave + mi;
+#pragma unroll
+        for (int ct = 0; ct < 2 * KS; ++ct)
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(int64_t)(16 * ct + 4 * g + r) * a.C + 16 * ft] = accc[ct][ft][r];
+    }
     if (PASS == 1) {
         // tokens of a group sit in the 16 lanes of a row group: DPP row sums, then lane mi == 0 of each (wave, g) writes its 8 features
         float* dst = a.partial + (int64_t)blk * 2 * a.C + f0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float r1 = hf_row_sum16(s1[j]), r2 = hf_row_sum16(s2[j]);
-            // sum g = cs sum gm;  sum g xhat = cs (hC sum gm x + hD sum gm)
-            if (mi == 0) { dst[j] = cs[j] * r1; dst[a.C + j] = cs[j] * fmaf(hC[j], r2, hD[j] * r1); }
+            // sum g = cs sum gm;  sum g xhat = cs (hC sum gm x + hD sum gm)   (constants re-read here: not live across the loop)
+            const float csj = a.cscale ? a.cscale[(int64_t)b * a.C + f0 + j] : 1.f;
+            const float hCj = a.rstd[f0 + j], hDj = -a.mean[f0 + j] * hCj;
+            if (mi == 0) { dst[j] = csj * r1; dst[a.C + j] = csj * fmaf(hCj, r2, hDj * r1); }
         }
     }
 }
@@ -335,9 +391,12 @@ __global__ void hf_split_kernel(const float* __restrict__ sums, int C, float* __
     dgamma[c] = sums[C + c];
 }
 
-static int hf_chunks(int B, int groups_per_sample, int ny) {
-    // ~3000 workgroups in flight, at least 8 token groups per workgroup
-    int s = (3072 / ny + B - 1) / B;
+static int hf_chunks(int B, int groups_per_sample, int ny, bool cw = false) {
+    // ~3000 workgroups in flight, at least 8 token groups per workgroup; with the classifier's weight gradient riding on pass 1
+    // every workgroup leaves a [32 KS][256] fp32 partial: three rounds of workgroups (768) keep those at ~0.1 GB
+    const char* e = getenv("SEGFAC_HF_WGS");
+    const int budget = e ? atoi(e) : (cw ? 768 : 3072);
+    int s = (budget / ny + B - 1) / B;
     if (s > groups_per_sample / 8) s = groups_per_sample / 8;
     return s < 1 ? 1 : s;
 }
@@ -353,6 +412,13 @@ extern "C" int64_t segf_bn_cls_bwd_ws(int64_t M, int C, int64_t rows_per_sample)
     return (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / (32 * HF_WAVES)) * 2 * C + 2 * C;
 }
 
+// everything that can ride: x1 / dG (pass 2, nullable pair) and dWcls fp32 [K][C] (pass 1, nullable)
+extern "C" int64_t segf_bn_cls_bwd_full_ws(int64_t M, int C, int K, int64_t rows_per_sample) {
+    const int B = (int)(M / rows_per_sample);
+    const int64_t nblk = (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / (32 * HF_WAVES), true);
+    return nblk * 2 * C + 2 * C + nblk * C * DW_LD + nblk * (int64_t)K * C;
+}
+
 extern "C" int segf_bn_cls_bwd_dw_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample, int C1) {
     if (getenv("SEGFAC_NO_HEAD_FUSED_DW")) return 0;
     return segf_bn_cls_bwd_supported(dt, M, C, K, rows_per_sample) && C1 == DW_C1 && K <= 160;     // K = 192: the tiles pass 160 KB of LDS
@@ -366,7 +432,19 @@ extern "C" int64_t segf_bn_cls_bwd_dw_ws(int64_t M, int C, int64_t rows_per_samp
 static int bn_cls_bwd_impl(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
                            const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                            const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
-                           float* dbeta, float* ws, const void* x1, int64_t ldx1, float* dG, void* stream);
+                           float* dbeta, float* ws, const void* x1, int64_t ldx1, float* dG, void* stream, float* dwcls = nullptr);
+
+extern "C" int segf_bn_cls_bwd_full(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw,
+                                    const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                                    const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
+                                    float* dbeta, float* ws, const void* x1, int64_t ldx1, int C1, float* dG, float* dwcls,
+                                    void* stream) {
+    if (x1 && (!segf_bn_cls_bwd_dw_supported(dt, M, C, K, rows_per_sample, C1) || !dG || ldx1 < C1 || ldx1 % 8 || ((uintptr_t)x1 % 16)))
+        return SEGF_ERR_SHAPE;
+    if (dwcls && K > 192) return SEGF_ERR_SHAPE;
+    return bn_cls_bwd_impl(dt, M, C, K, dy, ldy, w, ldw, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode, dx,
+                           dgamma, dbeta, ws, x1, ldx1, x1 ? dG : nullptr, stream, dwcls);
+}
 
 extern "C" int segf_bn_cls_bwd(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
                                const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
@@ -388,18 +466,19 @@ extern "C" int segf_bn_cls_bwd_dw(int dt, int64_t M, int C, int K, const void* d
 static int bn_cls_bwd_impl(int dt, int64_t M, int C, int K, const void* dy, int64_t ldy, const void* w, int64_t ldw, const void* x,
                            const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
                            const float* chan_scale, int64_t rows_per_sample, int eval_mode, void* dx, float* dgamma,
-                           float* dbeta, float* ws, const void* x1, int64_t ldx1, float* dG, void* stream) {
+                           float* dbeta, float* ws, const void* x1, int64_t ldx1, float* dG, void* stream, float* dwcls) {
     if (!segf_bn_cls_bwd_supported(dt, M, C, K, rows_per_sample) || ldy < K || ldw < C || act < 0 || act > 2) return SEGF_ERR_SHAPE;
     if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) % 16 || (ldy % 8)) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int B = (int)(M / rows_per_sample), gps = (int)(rows_per_sample / 16), ny = C / (32 * HF_WAVES);
-    const int chunks = hf_chunks(B, gps, ny);
+    const int chunks = hf_chunks(B, gps, ny, dwcls != nullptr);
     const int nblk = B * chunks;
     float* sums = ws + (int64_t)nblk * 2 * C;
     float* dwpart = sums + 2 * C;                       // (only with x1) [nblk][C][DW_LD]
+    float* cwpart = dwpart + (int64_t)nblk * C * DW_LD; // (only with dwcls) [nblk][K][C]
     HeadFusedArgs a{(const bf16_t*)dy, ldy, (const bf16_t*)w, ldw, (const bf16_t*)x, mean, rstd, gamma, beta, chan_scale, sums,
-                    (bf16_t*)dx, ws, M, C, rows_per_sample, gps, chunks, act, eval_mode, (const bf16_t*)x1, ldx1, dwpart};
+                    (bf16_t*)dx, ws, M, C, rows_per_sample, gps, chunks, act, eval_mode, (const bf16_t*)x1, ldx1, dwpart, cwpart};
     const dim3 grid((unsigned)(nblk * ny));
 #define HF_LAUNCH(PASS)                                                                                                  \
     do {                                                                                                                 \
@@ -412,7 +491,20 @@ static int bn_cls_bwd_impl(int dt, int64_t M, int C, int K, const void* dy, int6
         default: hipLaunchKernelGGL((bn_cls_bwd_kernel<PASS, 6>), grid, dim3(64 * HF_WAVES), 0, st, a); break;                     \
         }                                                                                                                \
     } while (0)
-    HF_LAUNCH(1);
+    if (dwcls) {
+        switch (K / 32) {
+        case 1: hipLaunchKernelGGL((bn_cls_bwd_kernel<1, 1, false, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((bn_cls_bwd_kernel<1, 2, false, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((bn_cls_bwd_kernel<1, 3, false, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((bn_cls_bwd_kernel<1, 4, false, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((bn_cls_bwd_kernel<1, 5, false, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        default: hipLaunchKernelGGL((bn_cls_bwd_kernel<1, 6, false, true>), grid, dim3(64 * HF_WAVES), 0, st, a); break;
+        }
+        SEGF_CHECK_LAUNCH();
+        colreduce_finalize_launch(cwpart, nblk, (int64_t)K * C, dwcls, st);
+    } else {
+        HF_LAUNCH(1);
+    }
     SEGF_CHECK_LAUNCH();
     colreduce_finalize_launch(ws, nblk, 2 * (int64_t)C, sums, st);
     SEGF_CHECK_LAUNCH();

@@ -588,14 +588,23 @@ class BnActLinearFn(Function):
         else:
             dyp = hip.zeros((M, Np), x.dtype, x.device)
             hip.cast2d(_rowmajor(dy), dyp[:, :N])
-        dw = hip.gemm_pro(2, dyp, x, Np, K, M, scale, shift, rps, act, split_k=_splitk(Np, K, M))[:N].view(wshape)
         db = hip.colsum(dyp)[:N] if has_bias else None
+        dw = None
         if hip.bn_cls_bwd_supported(x.dtype, M, K, Np, rps):
             # da = dyp W is recomputed inside both BatchNorm passes (K = #classes terms per element) instead of being written
             # once and read twice: 19.8 -> 10.9 GB at cfg2, batch 128 (head_fused.hip)
             slot = ctx.fold_slot
             x1 = slot.get('x1') if slot is not None else None
-            if x1 is not None and x1.shape[0] == M and hip.bn_cls_bwd_dw_supported(x.dtype, M, K, Np, rps, x1.shape[1]):
+            ride_dg = x1 is not None and x1.shape[0] == M and hip.bn_cls_bwd_dw_supported(x.dtype, M, K, Np, rps, x1.shape[1])
+            if act in (0, 1) and not os.environ.get('SEGFAC_NO_HEAD_FUSED_CW'):
+                # ... and the classifier's own weight gradient rides on the first pass (it has the x and dy tiles on chip), as the
+                # stage-1 weight gradient of the folded head rides on the second: no separate pass over x for either
+                dx, dg, dbeta, dG, dwc = hip.bn_cls_bwd_full(dyp, w, x, mean, rstd, g, b, act, chan_scale, rps, eval_mode,
+                                                             x1=x1 if ride_dg else None)
+                dw = dwc[:N].view(wshape)
+                if ride_dg:
+                    slot['dG'] = dG
+            elif ride_dg:
                 # x is the folded SegFormerHead's stride-4 map: the weight-gradient product of its stage-1 term (dx^T x1 and the
                 # column sums of dx) rides on the second BatchNorm pass, which has the dx tile on chip (one 3.2 GB pass less)
                 dx, dg, dbeta, slot['dG'] = hip.bn_cls_bwd_dw(dyp, w, x, mean, rstd, g, b, act, chan_scale, rps, eval_mode, x1)
@@ -604,6 +613,8 @@ class BnActLinearFn(Function):
         else:
             da = hip.gemm(1, dyp, w, M, K, Np)               # gradient w.r.t. the (never materialised) normalised tensor
             dx, dg, dbeta = hip.bn_bwd(x, da, mean, rstd, g, b, act, chan_scale, rps, eval_mode)
+        if dw is None:
+            dw = hip.gemm_pro(2, dyp, x, Np, K, M, scale, shift, rps, act, split_k=_splitk(Np, K, M))[:N].view(wshape)
         return dx, dg, dbeta, None, None, None, None, None, None, None, None, dw, db, None, None, None
 
 

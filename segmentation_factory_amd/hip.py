@@ -47,6 +47,8 @@ _PROTOS = {
     'segf_bn_cls_bwd_dw_supported': (_i, [_i, _l, _i, _i, _l, _i]),
     'segf_bn_cls_bwd_dw_ws': (_l, [_l, _i, _l]),
     'segf_bn_cls_bwd_dw': (_i, [_i, _l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
+    'segf_bn_cls_bwd_full_ws': (_l, [_l, _i, _i, _l]),
+    'segf_bn_cls_bwd_full': (_i, [_i, _l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p]),
     'segf_grn_ws': (_l, [_i, _l, _i, _i]),
     'segf_grn_fwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_grn_bwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -517,6 +519,32 @@ def bn_cls_bwd_dw(dy, w, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_s
                                   _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(x1), x1.stride(0), C1, _ptr(dG), _stream()),
          'segf_bn_cls_bwd_dw')
     return dx, dgamma, dbeta, dG
+
+
+def bn_cls_bwd_full(dy, w, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode, x1=None, want_dwcls=True):
+    """bn_cls_bwd with everything that can ride along: dG (when x1 is given, as bn_cls_bwd_dw) and dwcls fp32 [K, C] = the
+    classifier's weight gradient dy^T (act(bn(x)) * drop) (act 0 / 1 only).  -> (dx, dgamma, dbeta, dG | None, dwcls | None)."""
+    _need_cuda(dy, w, x)
+    M, Cc = x.shape
+    K = w.shape[0]
+    assert dy.shape[0] == M and dy.stride(1) == 1 and dy.stride(0) >= K and w.shape[1] == Cc and w.is_contiguous() and x.is_contiguous()
+    assert act in (0, 1) or not want_dwcls
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    dG, C1 = None, 0
+    if x1 is not None:
+        assert x1.shape[0] == M and x1.stride(1) == 1 and x1.dtype == torch.bfloat16
+        C1 = x1.shape[1]
+        dG = torch.empty((Cc, C1 + 8), dtype=torch.float32, device=x.device)
+    dwcls = torch.empty((K, Cc), dtype=torch.float32, device=x.device) if want_dwcls else None
+    ws = _f32(lib().segf_bn_cls_bwd_full_ws(M, Cc, K, rows_per_sample), x.device)
+    _chk(lib().segf_bn_cls_bwd_full(BF16, M, Cc, K, _ptr(dy), dy.stride(0), _ptr(w), w.stride(0), _ptr(x), _ptr(mean), _ptr(rstd),
+                                    _ptr(gamma), _ptr(beta), act, _ptr(chan_scale), rows_per_sample, int(eval_mode), _ptr(dx),
+                                    _ptr(dgamma), _ptr(dbeta), _ptr(ws), _ptr(x1) if x1 is not None else None,
+                                    x1.stride(0) if x1 is not None else 0, C1, _ptr(dG) if dG is not None else None,
+                                    _ptr(dwcls) if dwcls is not None else None, _stream()), 'segf_bn_cls_bwd_full')
+    return dx, dgamma, dbeta, dG, dwcls
 
 
 def grn_fwd(x, gamma, beta, B, rps):
