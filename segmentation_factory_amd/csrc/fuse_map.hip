@@ -304,3 +304,147 @@ extern "C" int segf_fuse_map_248(int B, int H, int W, int C, int C1, const void*
     }
     return 0;
 }
+
+// =====================================================================================================================================
+// The transposed map: the three transposed bilinear resizes of the folded head's backward (gradient of the stride-4 map -> gradients
+// of the 1/2, 1/4, 1/8 maps; heads/segformer.py:44-50 backward) on the matrix pipe, for INTERIOR blocks.
+//   dT_i[src][c] = sum_pix W_i[pix][src] dy[pix][c]
+// A workgroup owns a run of 8 x 8 pixel blocks along x (one block row, one 128-channel slice).  A block OWNS the sources whose
+// support it centres: 4 x 4 pixels of the 1/2 map, 2 x 2 of the 1/4 map, 1 of the 1/8 map (21 sources); every gradient pixel that
+// touches them lies in the 16 x 16 window around the block, so  dT^T [channels x sources] = dy^T [channels x 256 window pixels] .
+// W [256 x 21]  is one MFMA product with K = 256 (8 steps of two window rows; the 1/2-map tile skips the two outer steps).  The
+// weights depend only on the position inside the window: per-wave constants in registers (B operand).  The window lives in LDS as it
+// lies in memory ([pixel][channel]) and is read through ds_read_b64_tr_b16; consecutive blocks of a run share half of their window,
+// so only the 8 new columns are staged per block (the two column halves swap roles: lane group g reads the physical half g ^ phase).
+// Every gradient element therefore passes the vector memory path twice (the VALU kernel: four times, and 2.26 TB/s of algorithmic
+// bytes = 0.28 of the HBM roofline).  Blocks on the image border (clamped source indices fold the weights of virtual sources into
+// the edge sources) keep the VALU kernel: bilinear_bwd_248_kernel<ring only> in resize.hip.
+struct FuseMapBwdArgs {
+    const bf16_t* dy; int64_t ldo;
+    bf16_t *d2, *d4, *d8;
+    int B, H, W, C;
+    int nslice, rows_in;                  // interior block rows = H / 8 - 2
+};
+
+__device__ __forceinline__ float fmb_tri(float d) { d = fabsf(d); return d < 1.f ? 1.f - d : 0.f; }
+// weight of window pixel (wy, wx) for owned source n of source tile nt (see the kernel)
+__device__ __forceinline__ float fmb_weight(int nt, int n, int wy, int wx) {
+    if (nt == 0) {                         // 1/2 map: source (sy, sx) = (n >> 2, n & 3) relative to (4 ty, 4 tx)
+        return fmb_tri(wy * 0.5f - 2.25f - (float)(n >> 2)) * fmb_tri(wx * 0.5f - 2.25f - (float)(n & 3));
+    }
+    if (n < 4) return fmb_tri(wy * 0.25f - 1.375f - (float)(n >> 1)) * fmb_tri(wx * 0.25f - 1.375f - (float)(n & 1));   // 1/4 map
+    if (n == 4) return fmb_tri(wy * 0.125f - 0.9375f) * fmb_tri(wx * 0.125f - 0.9375f);                                 // 1/8 map
+    return 0.f;
+}
+
+__global__ void __launch_bounds__(256, 2) fuse_map_bwd_kernel(FuseMapBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char win[4 * 64 * 256];          // 4 tiles of [64 k rows][128 channels]
+    __shared__ __attribute__((aligned(16))) unsigned char ost[2][16 * FM_SROW];       // [source tile][source][channel]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mi = lane & 15, g = lane >> 4;
+    const unsigned L = xcd_block();
+    const int slice = (int)(L % (unsigned)a.nslice);
+    const unsigned run = L / (unsigned)a.nslice;
+    const int ty = 1 + (int)(run % (unsigned)a.rows_in), b = (int)(run / (unsigned)a.rows_in);
+    const int c0 = slice * FM_SLICE;
+    const int w8 = a.W >> 3, nblk = w8 - 2;
+    const int h2 = a.H >> 1, w2 = a.W >> 1, h4 = a.H >> 2, w4 = a.W >> 2, h8 = a.H >> 3;
+
+    // weights: B operand, lane (source n = mi, k group g), K step s: window pixels k = 32 s + 8 g + j = (row 2 s + (g >> 1), column 8 (g & 1) + j)
+    bf16x8 wb0[6], wb1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        s16x8 v0, v1;
+        const int wy = 2 * s + (g >> 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int wx = 8 * (g & 1) + j;
+            v0[j] = (short)f2bf(fmb_weight(0, mi, wy, wx));
+            v1[j] = (short)f2bf(fmb_weight(1, mi, wy, wx));
+        }
+        if (s >= 1 && s <= 6) wb0[s - 1] = __builtin_bit_cast(bf16x8, v0);
+        wb1[s] = __builtin_bit_cast(bf16x8, v1);
+    }
+    // staging: 8 columns x 16 rows of 256-byte pixel rows = 2048 chunks of 16 bytes, 8 per thread: pixel p = tid / 16 + 16 i, chunk tid % 16
+    const int ck = threadIdx.x & 15, p0 = threadIdx.x >> 4;
+    const bf16_t* rowbase = a.dy + ((int64_t)b * a.H + 8 * ty - 4) * a.W * a.ldo + c0 + 8 * ck;
+    auto load_half = [&](int col0, u32x4 (&reg)[8]) {                  // window columns col0 .. col0 + 7 (global x), all 16 rows
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = p0 + 16 * i, wy = p >> 3, wxh = p & 7;
+            reg[i] = *reinterpret_cast<const u32x4*>(rowbase + ((int64_t)wy * a.W + col0 + wxh) * a.ldo);
+        }
+    };
+    auto store_half = [&](int phys, const u32x4 (&reg)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = p0 + 16 * i, wy = p >> 3, wxh = p & 7;
+            const int krow = 32 * ((wy & 3) >> 1) + 16 * (wy & 1) + 8 * phys + wxh;
+            *reinterpret_cast<u32x4*>(win + (wy >> 2) * 16384 + krow * 256 + ((ck ^ fm_swz(krow)) << 4)) = reg[i];
+        }
+    };
+    u32x4 sreg[8];
+    load_half(8 * 1 - 4, sreg);
+    store_half(0, sreg);
+    load_half(8 * 1 + 4, sreg);
+    store_half(1, sreg);
+    __syncthreads();
+    for (int j = 0; j < nblk; ++j) {
+        const int tx = 1 + j, phase = j & 1;
+        {   // the next block's new columns (the last block re-reads its own: unconditional loads)
+            const int txn = j + 1 < nblk ? tx + 1 : tx;
+            load_half(8 * txn + 4, sreg);
+            SEGF_LOADS_ISSUED();
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int cb = 16 * (2 * wave + ct);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                // A operand: dy^T, lane (channel cb + mi, k group g) -> physical k group g ^ phase (the column halves alternate)
+                const unsigned char* tile = win + (s >> 1) * 16384;
+                const int gp = g ^ phase, q = mi >> 2, pp = mi & 3;
+                const int u = (cb >> 2) + pp, chunk = u >> 1, half = u & 1;
+                const int kr0 = 32 * (s & 1) + 8 * gp + q, kr1 = kr0 + 4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(tile + kr0 * 256 + ((chunk ^ fm_swz(kr0)) << 4) + half * 8));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(tile + kr1 * 256 + ((chunk ^ fm_swz(kr1)) << 4) + half * 8));
+                const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                if (s >= 1 && s <= 6) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wb0[s - 1], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wb1[s], acc1, 0, 0, 0);
+            }
+            // acc[r] = dT^T[channel cb + 4 g + r][source mi]
+            *reinterpret_cast<uint2*>(ost[0] + mi * FM_SROW + (cb + 4 * g) * 2) = make_uint2(pack2bf(acc0[0], acc0[1]), pack2bf(acc0[2], acc0[3]));
+            *reinterpret_cast<uint2*>(ost[1] + mi * FM_SROW + (cb + 4 * g) * 2) = make_uint2(pack2bf(acc1[0], acc1[1]), pack2bf(acc1[2], acc1[3]));
+        }
+        __syncthreads();                                   // window reads done, output tiles complete
+        store_half(phase, sreg);                           // the new right half replaces this block's left half
+        {
+            const int src = threadIdx.x >> 4;              // 16 sources of the 1/2 map x 16 chunks
+            const uint4 o = *reinterpret_cast<const uint4*>(ost[0] + src * FM_SROW + 16 * ck);
+            *reinterpret_cast<uint4*>(a.d2 + (((int64_t)b * h2 + 4 * ty + (src >> 2)) * w2 + 4 * tx + (src & 3)) * a.C + c0 + 8 * ck) = o;
+            if (threadIdx.x < 80) {                        // 4 sources of the 1/4 map, 1 of the 1/8 map
+                const uint4 o1 = *reinterpret_cast<const uint4*>(ost[1] + src * FM_SROW + 16 * ck);
+                bf16_t* dst = src < 4 ? a.d4 + (((int64_t)b * h4 + 2 * ty + (src >> 1)) * w4 + 2 * tx + (src & 1)) * a.C
+                                      : a.d8 + (((int64_t)b * h8 + ty) * w8 + tx) * a.C;
+                *reinterpret_cast<uint4*>(dst + c0 + 8 * ck) = o1;
+            }
+        }
+        __syncthreads();                                   // window complete for the next block, output tiles free
+    }
+}
+
+int fuse_map_bwd_supported(int dt, int B, int H, int W, int C) {
+    return dt == SEGF_BF16 && B > 0 && H % 8 == 0 && W % 8 == 0 && H >= 24 && W >= 24 && C % FM_SLICE == 0 && !getenv("SEGFAC_NO_BWD248_MFMA");
+}
+// interior blocks only: the caller runs the border ring with the VALU kernel (segf_bilinear_bwd_248 does both)
+int fuse_map_bwd_interior_launch(int B, int H, int W, int C, const void* dy, int64_t ldo, void* d2, void* d4, void* d8, hipStream_t st) {
+    FuseMapBwdArgs a{(const bf16_t*)dy, ldo, (bf16_t*)d2, (bf16_t*)d4, (bf16_t*)d8, B, H, W, C, C / FM_SLICE, H / 8 - 2};
+    const int64_t wgs = (int64_t)B * a.rows_in * a.nslice;
+    if (wgs <= 0 || wgs >= (1ll << 31)) return SEGF_ERR_SHAPE;
+    hipLaunchKernelGGL(fuse_map_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}

@@ -4,6 +4,10 @@
 // reference it -- no atomics, deterministic).  Outputs may be channel slices of a wider concat buffer (ld*).
 #include "colreduce.h"
 
+// fuse_map.hip: the transposed 1/2-1/4-1/8 resizes of the interior 8 x 8 blocks on the matrix pipe
+int fuse_map_bwd_supported(int dt, int B, int H, int W, int C);
+int fuse_map_bwd_interior_launch(int B, int H, int W, int C, const void* dy, int64_t ldo, void* d2, void* d4, void* d8, hipStream_t st);
+
 template <typename T>
 __global__ void bilinear_fwd_kernel(const T* __restrict__ in, int64_t ldi, T* __restrict__ out, int64_t ldo, int B, int h, int w,
                                     int C, int H, int W, int ac, bool vec) {
@@ -624,12 +628,17 @@ template <typename T> __device__ __forceinline__ void store4v(T* p, const f32x2_
 }
 template <typename T>
 __global__ void __launch_bounds__(256, 2) bilinear_bwd_248_kernel(const T* __restrict__ dy, int64_t ldo, T* __restrict__ d2, T* __restrict__ d4,
-                                                                T* __restrict__ d8, int B, int H, int W, int C, int getenv_noflip) {
+                                                                T* __restrict__ d8, int B, int H, int W, int C, int getenv_noflip,
+                                                                int ring_only) {
     constexpr int CW = 4;
     const int h8 = H / 8, w8 = W / 8, h4 = H / 4, w4 = W / 4, h2 = H / 2, w2 = W / 2;
     const int nch = C / CW;
     const int G = nch % 16 == 0 ? 16 : (nch % 8 == 0 ? 8 : 2), ngrp = nch / G;    // 128-byte channel groups (see bilinear_bwd_int_kernel)
-    const int64_t total = (int64_t)B * h8 * w8 * nch;
+    // ring_only: the x8 pixels (= 8 x 8 blocks of the gradient) on the image border only -- the interior is done on the matrix pipe
+    // (fuse_map.hip: fuse_map_bwd_kernel), the border keeps this kernel's clamped-index weight tables.  Ring position r of an
+    // image: r < w8: (0, r); r < 2 w8: (h8 - 1, r - w8); then pairs (1 + q / 2, q odd ? w8 - 1 : 0).
+    const int nring = 2 * w8 + 2 * (h8 - 2);
+    const int64_t total = ring_only ? (int64_t)B * nring * nch : (int64_t)B * h8 * w8 * nch;
     // Weight tables for the four border variants of an x8 pixel along one axis (first, interior, last, the only one): the weights
     // of all interior pixels coincide (translation invariance), so 4 small tables per axis cover every thread of the launch and
     // the 48 column weights need no registers.
@@ -663,8 +672,16 @@ __global__ void __launch_bounds__(256, 2) bilinear_bwd_248_kernel(const T* __res
     for (int64_t idx = (int64_t)xcd_block() * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int chl = (int)(idx % G);
         int64_t t = idx / G;
-        const int x8 = (int)(t % w8); t /= w8;
-        const int y8 = (int)(t % h8); t /= h8;
+        int x8, y8;
+        if (ring_only) {
+            const int r = (int)(t % nring); t /= nring;
+            if (r < w8) { y8 = 0; x8 = r; }
+            else if (r < 2 * w8) { y8 = h8 - 1; x8 = r - w8; }
+            else { const int q = r - 2 * w8; y8 = 1 + (q >> 1); x8 = (q & 1) ? w8 - 1 : 0; }
+        } else {
+            x8 = (int)(t % w8); t /= w8;
+            y8 = (int)(t % h8); t /= h8;
+        }
         const int grp = (int)(t % ngrp);
         const int64_t b = t / ngrp;
         const int c0 = (grp * G + chl) * CW;
@@ -773,11 +790,17 @@ extern "C" int segf_bilinear_bwd_248(int dt, int B, int H, int W, int C, const v
     if (H % 8 || W % 8 || C % 8 || ldo < C || (ldo % 8)) return SEGF_ERR_SHAPE;
     if (((uintptr_t)dout | (uintptr_t)d2 | (uintptr_t)d4 | (uintptr_t)d8) % 16) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)B * (H / 8) * (W / 8) * (C / 4);
+    // interior 8 x 8 blocks on the matrix pipe (fuse_map.hip), the border ring (clamped source indices) with the VALU kernel
+    const int ring = fuse_map_bwd_supported(dt, B, H, W, C);
+    if (ring) {
+        const int rc = fuse_map_bwd_interior_launch(B, H, W, C, dout, ldo, d2, d4, d8, st);
+        if (rc) return rc;
+    }
+    const int64_t total = ring ? (int64_t)B * (2 * (W / 8) + 2 * (H / 8 - 2)) * (C / 4) : (int64_t)B * (H / 8) * (W / 8) * (C / 4);
     const int blocks = (int)imin64(cdiv64(total, 256), 32768);
     SEGF_DISPATCH_DT(dt, T, {
         hipLaunchKernelGGL((bilinear_bwd_248_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)dout, ldo, (T*)d2, (T*)d4, (T*)d8, B, H, W, C,
-                           getenv("SEGFAC_BWD248_NO_FLIP") ? 1 : 0);
+                           getenv("SEGFAC_BWD248_NO_FLIP") ? 1 : 0, ring);
     })
     SEGF_CHECK_LAUNCH();
     return 0;

@@ -1206,11 +1206,13 @@ def test_fuse_map_248_one_pass(hipmod, geom):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('geom', [(2, 16, 24, 16), (1, 8, 8, 40), (1, 32, 16, 8), (2, 128, 128, 64)])
+@pytest.mark.parametrize('geom', [(2, 16, 24, 16), (1, 8, 8, 40), (1, 32, 16, 8), (2, 128, 128, 64), (2, 32, 40, 128), (1, 24, 24, 256),
+                                  (2, 128, 128, 128), (1, 24, 64, 768)])
 def test_bilinear_bwd_248_equals_three_transposed_resizes(hipmod, dtype, geom):
     """segf_bilinear_bwd_248 (one pass over the gradient, nested windows) against the three segf_bilinear_bwd launches it
     replaces and against autograd through F.interpolate on the CPU; includes the clamped borders (8-wide maps: every output
-    pixel is a border pixel)."""
+    pixel is a border pixel).  bf16 with C % 128 == 0 and H, W >= 24: the interior 8 x 8 blocks run on the matrix pipe
+    (fuse_map.hip: fuse_map_bwd_kernel), the border ring on the VALU kernel -- (24, 24) has exactly one interior block."""
     B, H, W, C = geom
     g = torch.Generator().manual_seed(33)
     dy = torch.randn(B * H * W, C, generator=g)
@@ -1291,6 +1293,28 @@ def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
         assert float(dG[:, C1 + 1:].abs().max()) == 0.0
         dG2 = hip.bn_cls_bwd_dw(*args, x1d)[3]
         assert torch.equal(dG, dG2)
+    # segf_bn_cls_bwd_full: the classifier's weight gradient dW = dy^T a rides on pass 1 (a = act(bn(x)) * drop rounded to bf16 on
+    # chip): dx must not change by a bit (other workgroup chunking: dgamma / dbeta to fp32 round-off), dW against fp32 autograd
+    # (Wq's gradient above) within the bf16 rounding of a, and two runs bitwise equal
+    if act in (0, 1):
+        x1f = None
+        if hip.bn_cls_bwd_dw_supported(torch.bfloat16, M, C, K, h * w, C1):
+            x1f = x1d
+        dxf_, dgf, dbf, dGf, dwc = hip.bn_cls_bwd_full(*args, x1=x1f)
+        assert torch.equal(dxf_, dx)
+        assert (dgf - dg).abs().max().item() <= 1e-5 * dg.abs().max().item() + 1e-9
+        assert (dbf - db).abs().max().item() <= 1e-5 * db.abs().max().item() + 1e-9
+        if x1f is not None:
+            assert (dGf - dG).abs().max().item() <= 1e-5 * dG.abs().max().item() + 1e-9
+        assert dwc.shape == (K, C) and dwc.dtype == torch.float32
+        # reference: the layout-2 operand-prologue GEMM it replaces is dy^T bf16(a); here against exact fp32 a
+        a32 = a.detach()
+        want_w = dyq.double().t() @ a32.double()
+        bound = 2 ** -8 * (dyq.double().abs().t() @ a32.double().abs()).max().item()
+        assert (dwc.cpu().double() - want_w).abs().max().item() <= bound, ((dwc.cpu().double() - want_w).abs().max().item(), bound)
+        assert float(dwc[nc:].abs().max()) == 0.0 if nc < K else True
+        dwc2 = hip.bn_cls_bwd_full(*args, x1=x1f)[4]
+        assert torch.equal(dwc, dwc2)
 
 
 @pytest.mark.parametrize('shape', [(300, 256, 128), (1000, 768, 3072), (4096, 1536, 384), (129, 40, 256)])
