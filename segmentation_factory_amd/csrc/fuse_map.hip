@@ -307,34 +307,42 @@ extern "C" int segf_fuse_map_248(int B, int H, int W, int C, int C1, const void*
 
 // =====================================================================================================================================
 // The transposed map: the three transposed bilinear resizes of the folded head's backward (gradient of the stride-4 map -> gradients
-// of the 1/2, 1/4, 1/8 maps; heads/segformer.py:44-50 backward) on the matrix pipe, for INTERIOR blocks.
+// of the 1/2, 1/4, 1/8 maps; heads/segformer.py:44-50 backward) on the matrix pipe.
 //   dT_i[src][c] = sum_pix W_i[pix][src] dy[pix][c]
 // A workgroup owns a run of 8 x 8 pixel blocks along x (one block row, one 128-channel slice).  A block OWNS the sources whose
 // support it centres: 4 x 4 pixels of the 1/2 map, 2 x 2 of the 1/4 map, 1 of the 1/8 map (21 sources); every gradient pixel that
 // touches them lies in the 16 x 16 window around the block, so  dT^T [channels x sources] = dy^T [channels x 256 window pixels] .
-// W [256 x 21]  is one MFMA product with K = 256 (8 steps of two window rows; the 1/2-map tile skips the two outer steps).  The
-// weights depend only on the position inside the window: per-wave constants in registers (B operand).  The window lives in LDS as it
-// lies in memory ([pixel][channel]) and is read through ds_read_b64_tr_b16; consecutive blocks of a run share half of their window,
-// so only the 8 new columns are staged per block (the two column halves swap roles: lane group g reads the physical half g ^ phase).
-// Every gradient element therefore passes the vector memory path twice (the VALU kernel: four times, and 2.26 TB/s of algorithmic
-// bytes = 0.28 of the HBM roofline).  Blocks on the image border (clamped source indices fold the weights of virtual sources into
-// the edge sources) keep the VALU kernel: bilinear_bwd_248_kernel<ring only> in resize.hip.
+// W [256 x 21]  is one MFMA product with K = 256 (8 steps of two window rows; the 1/2-map tile skips the two outer steps).
+// W is separable, W[(wy, wx)][src] = wy[src_y][wy] * wx[src_x][wx], so a lane builds its B-operand fragments as the outer product of
+// two 8-vectors (exact in bf16: every factor is a multiple of 1/16).  Image borders: ATen clamps the source index, i.e. an edge
+// source also receives the weight of the virtual source beyond it, and window pixels outside the image do not exist -- both are
+// properties of the 1-D factors (fmb_w1d), so border blocks run the same code with their own factors (rebuilt for the first,
+// second and last block of a run; the window loads of outside pixels read clamped addresses and meet weight 0).
+// The window lives in LDS as it lies in memory ([pixel][channel]) and is read through ds_read_b64_tr_b16; consecutive blocks of a
+// run share half of their window, so only the 8 new columns are staged per block (the two column halves swap roles: lane group g
+// reads the physical half g ^ phase).  Every gradient element passes the vector memory path twice (the VALU kernel it replaces,
+// bilinear_bwd_248_kernel: four times, at 2.26 TB/s of algorithmic bytes = 0.28 of the HBM roofline).
 struct FuseMapBwdArgs {
     const bf16_t* dy; int64_t ldo;
     bf16_t *d2, *d4, *d8;
     int B, H, W, C;
-    int nslice, rows_in;                  // interior block rows = H / 8 - 2
+    int nslice;
 };
 
 __device__ __forceinline__ float fmb_tri(float d) { d = fabsf(d); return d < 1.f ? 1.f - d : 0.f; }
-// weight of window pixel (wy, wx) for owned source n of source tile nt (see the kernel)
-__device__ __forceinline__ float fmb_weight(int nt, int n, int wy, int wx) {
-    if (nt == 0) {                         // 1/2 map: source (sy, sx) = (n >> 2, n & 3) relative to (4 ty, 4 tx)
-        return fmb_tri(wy * 0.5f - 2.25f - (float)(n >> 2)) * fmb_tri(wx * 0.5f - 2.25f - (float)(n & 3));
-    }
-    if (n < 4) return fmb_tri(wy * 0.25f - 1.375f - (float)(n >> 1)) * fmb_tri(wx * 0.25f - 1.375f - (float)(n & 1));   // 1/4 map
-    if (n == 4) return fmb_tri(wy * 0.125f - 0.9375f) * fmb_tri(wx * 0.125f - 0.9375f);                                 // 1/8 map
-    return 0.f;
+// 1-D factor: weight of window position wpos (0..15; pixel 8 t - 4 + wpos of nb * 8 pixels) for the owned source `own` (0 .. 8 / R - 1)
+// of block t at ratio R = 2 << lvl, with ATen's index clamping folded in and pixels outside the image weighted 0
+__device__ __forceinline__ float fmb_w1d(int lvl, int own, int wpos, int t, int nb) {
+    const int P = 8 * t - 4 + wpos;
+    if (P < 0 || P >= 8 * nb) return 0.f;
+    const float R = (float)(2 << lvl);
+    const int per = 4 >> lvl;                               // owned sources per block and axis
+    const int S = per * t + own, smax = per * nb - 1;
+    const float rel = ((float)P + 0.5f) / R - 0.5f;
+    float w = fmb_tri(rel - (float)S);
+    if (S == 0) w += fmb_tri(rel + 1.f);
+    if (S == smax) w += fmb_tri(rel - (float)(smax + 1));
+    return w;
 }
 
 __global__ void __launch_bounds__(256, 2) fuse_map_bwd_kernel(FuseMapBwdArgs a) {
@@ -345,35 +353,62 @@ __global__ void __launch_bounds__(256, 2) fuse_map_bwd_kernel(FuseMapBwdArgs a) 
     const unsigned L = xcd_block();
     const int slice = (int)(L % (unsigned)a.nslice);
     const unsigned run = L / (unsigned)a.nslice;
-    const int ty = 1 + (int)(run % (unsigned)a.rows_in), b = (int)(run / (unsigned)a.rows_in);
+    const int h8 = a.H >> 3, w8 = a.W >> 3;
+    const int ty = (int)(run % (unsigned)h8), b = (int)(run / (unsigned)h8);
     const int c0 = slice * FM_SLICE;
-    const int w8 = a.W >> 3, nblk = w8 - 2;
-    const int h2 = a.H >> 1, w2 = a.W >> 1, h4 = a.H >> 2, w4 = a.W >> 2, h8 = a.H >> 3;
+    const int h2 = a.H >> 1, w2 = a.W >> 1, h4 = a.H >> 2, w4 = a.W >> 2;
 
-    // weights: B operand, lane (source n = mi, k group g), K step s: window pixels k = 32 s + 8 g + j = (row 2 s + (g >> 1), column 8 (g & 1) + j)
-    bf16x8 wb0[6], wb1[8];
+    // this lane's owned source in each source tile: tile 0 = the 4 x 4 sources of the 1/2 map; tile 1 = 2 x 2 of the 1/4 map
+    // (n = 0..3), the 1/8 source (n = 4), nothing (n >= 5)
+    const int l1 = mi < 4 ? 1 : 2, oy1 = mi < 4 ? (mi >> 1) : 0, ox1 = mi < 4 ? (mi & 1) : 0;
+    const bool live1 = mi < 5;
+    // y factors of the run: K step s, this lane's row 2 s + (g >> 1)
+    float wy0[6], wy1[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        s16x8 v0, v1;
         const int wy = 2 * s + (g >> 1);
+        if (s >= 1 && s <= 6) wy0[s - 1] = fmb_w1d(0, mi >> 2, wy, ty, h8);
+        wy1[s] = live1 ? fmb_w1d(l1, oy1, wy, ty, h8) : 0.f;
+    }
+    // B operand, lane (source n = mi, k group g), K step s: window pixels k = 32 s + 8 g + j = (row 2 s + (g >> 1), column 8 (g & 1) + j)
+    bf16x8 wb0[6], wb1[8];
+    auto build_weights = [&](int tx) {
+        float wx0[8], wx1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int wx = 8 * (g & 1) + j;
-            v0[j] = (short)f2bf(fmb_weight(0, mi, wy, wx));
-            v1[j] = (short)f2bf(fmb_weight(1, mi, wy, wx));
+            wx0[j] = fmb_w1d(0, mi & 3, wx, tx, w8);
+            wx1[j] = live1 ? fmb_w1d(l1, ox1, wx, tx, w8) : 0.f;
         }
-        if (s >= 1 && s <= 6) wb0[s - 1] = __builtin_bit_cast(bf16x8, v0);
-        wb1[s] = __builtin_bit_cast(bf16x8, v1);
-    }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s >= 1 && s <= 6) {
+                union { uint32_t u[4]; bf16x8 v; } f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f.u[j] = pack2bf(wy0[s - 1] * wx0[2 * j], wy0[s - 1] * wx0[2 * j + 1]);
+                wb0[s - 1] = f.v;
+            }
+            union { uint32_t u[4]; bf16x8 v; } f1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f1.u[j] = pack2bf(wy1[s] * wx1[2 * j], wy1[s] * wx1[2 * j + 1]);
+            wb1[s] = f1.v;
+        }
+    };
     // staging: 8 columns x 16 rows of 256-byte pixel rows = 2048 chunks of 16 bytes, 8 per thread: pixel p = tid / 16 + 16 i, chunk tid % 16
     const int ck = threadIdx.x & 15, p0 = threadIdx.x >> 4;
-    const bf16_t* rowbase = a.dy + ((int64_t)b * a.H + 8 * ty - 4) * a.W * a.ldo + c0 + 8 * ck;
-    auto load_half = [&](int col0, u32x4 (&reg)[8]) {                  // window columns col0 .. col0 + 7 (global x), all 16 rows
+    const bf16_t* imgbase = a.dy + (int64_t)b * a.H * a.W * a.ldo + c0 + 8 * ck;
+    int yoff[8];                                                   // clamped window rows of this thread's eight pixels (x W)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = p0 + 16 * i, wy = p >> 3, wxh = p & 7;
-            reg[i] = *reinterpret_cast<const u32x4*>(rowbase + ((int64_t)wy * a.W + col0 + wxh) * a.ldo);
-        }
+    for (int i = 0; i < 8; ++i) {
+        int y = 8 * ty - 4 + ((p0 + 16 * i) >> 3);
+        y = y < 0 ? 0 : (y > a.H - 1 ? a.H - 1 : y);
+        yoff[i] = y * a.W;
+    }
+    auto load_half = [&](int col0, u32x4 (&reg)[8]) {                  // window columns col0 .. col0 + 7 (global x, clamped), all 16 rows
+        int x = col0 + (p0 & 7);
+        x = x < 0 ? 0 : (x > a.W - 1 ? a.W - 1 : x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) reg[i] = *reinterpret_cast<const u32x4*>(imgbase + (int64_t)(yoff[i] + x) * a.ldo);
     };
     auto store_half = [&](int phys, const u32x4 (&reg)[8]) {
 #pragma unroll
@@ -384,18 +419,19 @@ __global__ void __launch_bounds__(256, 2) fuse_map_bwd_kernel(FuseMapBwdArgs a) 
         }
     };
     u32x4 sreg[8];
-    load_half(8 * 1 - 4, sreg);
+    load_half(-4, sreg);
     store_half(0, sreg);
-    load_half(8 * 1 + 4, sreg);
+    load_half(4, sreg);
     store_half(1, sreg);
     __syncthreads();
-    for (int j = 0; j < nblk; ++j) {
-        const int tx = 1 + j, phase = j & 1;
+    for (int tx = 0; tx < w8; ++tx) {
+        const int phase = tx & 1;
         {   // the next block's new columns (the last block re-reads its own: unconditional loads)
-            const int txn = j + 1 < nblk ? tx + 1 : tx;
+            const int txn = tx + 1 < w8 ? tx + 1 : tx;
             load_half(8 * txn + 4, sreg);
             SEGF_LOADS_ISSUED();
         }
+        if (tx <= 1 || tx == w8 - 1) build_weights(tx);    // x factors change at the two image borders only (wave-uniform)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             const int cb = 16 * (2 * wave + ct);
@@ -437,12 +473,12 @@ __global__ void __launch_bounds__(256, 2) fuse_map_bwd_kernel(FuseMapBwdArgs a) 
 }
 
 int fuse_map_bwd_supported(int dt, int B, int H, int W, int C) {
-    return dt == SEGF_BF16 && B > 0 && H % 8 == 0 && W % 8 == 0 && H >= 24 && W >= 24 && C % FM_SLICE == 0 && !getenv("SEGFAC_NO_BWD248_MFMA");
+    return dt == SEGF_BF16 && B > 0 && H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8 && C % FM_SLICE == 0 &&
+           (int64_t)H * W < (1ll << 30) && !getenv("SEGFAC_NO_BWD248_MFMA");
 }
-// interior blocks only: the caller runs the border ring with the VALU kernel (segf_bilinear_bwd_248 does both)
-int fuse_map_bwd_interior_launch(int B, int H, int W, int C, const void* dy, int64_t ldo, void* d2, void* d4, void* d8, hipStream_t st) {
-    FuseMapBwdArgs a{(const bf16_t*)dy, ldo, (bf16_t*)d2, (bf16_t*)d4, (bf16_t*)d8, B, H, W, C, C / FM_SLICE, H / 8 - 2};
-    const int64_t wgs = (int64_t)B * a.rows_in * a.nslice;
+int fuse_map_bwd_launch(int B, int H, int W, int C, const void* dy, int64_t ldo, void* d2, void* d4, void* d8, hipStream_t st) {
+    FuseMapBwdArgs a{(const bf16_t*)dy, ldo, (bf16_t*)d2, (bf16_t*)d4, (bf16_t*)d8, B, H, W, C, C / FM_SLICE};
+    const int64_t wgs = (int64_t)B * (H / 8) * a.nslice;
     if (wgs <= 0 || wgs >= (1ll << 31)) return SEGF_ERR_SHAPE;
     hipLaunchKernelGGL(fuse_map_bwd_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a);
     SEGF_CHECK_LAUNCH();

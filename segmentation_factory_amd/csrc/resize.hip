@@ -4,9 +4,9 @@
 // reference it -- no atomics, deterministic).  Outputs may be channel slices of a wider concat buffer (ld*).
 #include "colreduce.h"
 
-// fuse_map.hip: the transposed 1/2-1/4-1/8 resizes of the interior 8 x 8 blocks on the matrix pipe
+// fuse_map.hip: the transposed 1/2-1/4-1/8 resizes on the matrix pipe (bf16, C % 128 == 0)
 int fuse_map_bwd_supported(int dt, int B, int H, int W, int C);
-int fuse_map_bwd_interior_launch(int B, int H, int W, int C, const void* dy, int64_t ldo, void* d2, void* d4, void* d8, hipStream_t st);
+int fuse_map_bwd_launch(int B, int H, int W, int C, const void* dy, int64_t ldo, void* d2, void* d4, void* d8, hipStream_t st);
 
 template <typename T>
 __global__ void bilinear_fwd_kernel(const T* __restrict__ in, int64_t ldi, T* __restrict__ out, int64_t ldo, int B, int h, int w,
@@ -790,12 +790,14 @@ extern "C" int segf_bilinear_bwd_248(int dt, int B, int H, int W, int C, const v
     if (H % 8 || W % 8 || C % 8 || ldo < C || (ldo % 8)) return SEGF_ERR_SHAPE;
     if (((uintptr_t)dout | (uintptr_t)d2 | (uintptr_t)d4 | (uintptr_t)d8) % 16) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    // interior 8 x 8 blocks on the matrix pipe (fuse_map.hip), the border ring (clamped source indices) with the VALU kernel
-    const int ring = fuse_map_bwd_supported(dt, B, H, W, C);
-    if (ring) {
-        const int rc = fuse_map_bwd_interior_launch(B, H, W, C, dout, ldo, d2, d4, d8, st);
-        if (rc) return rc;
+    // bf16, C % 128 == 0: on the matrix pipe (fuse_map.hip); SEGFAC_BWD248_RING=1 keeps the border ring on the VALU kernel below
+    // (the two must agree there: tests)
+    const int mfma = fuse_map_bwd_supported(dt, B, H, W, C);
+    if (mfma) {
+        const int rc = fuse_map_bwd_launch(B, H, W, C, dout, ldo, d2, d4, d8, st);
+        if (rc || !getenv("SEGFAC_BWD248_RING") || H < 24 || W < 24) return rc;
     }
+    const int ring = mfma;
     const int64_t total = ring ? (int64_t)B * (2 * (W / 8) + 2 * (H / 8 - 2)) * (C / 4) : (int64_t)B * (H / 8) * (W / 8) * (C / 4);
     const int blocks = (int)imin64(cdiv64(total, 256), 32768);
     SEGF_DISPATCH_DT(dt, T, {

@@ -1207,12 +1207,13 @@ def test_fuse_map_248_one_pass(hipmod, geom):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('geom', [(2, 16, 24, 16), (1, 8, 8, 40), (1, 32, 16, 8), (2, 128, 128, 64), (2, 32, 40, 128), (1, 24, 24, 256),
-                                  (2, 128, 128, 128), (1, 24, 64, 768)])
+                                  (2, 128, 128, 128), (1, 24, 64, 768), (1, 8, 8, 128), (2, 8, 16, 128), (1, 16, 16, 256)])
 def test_bilinear_bwd_248_equals_three_transposed_resizes(hipmod, dtype, geom):
     """segf_bilinear_bwd_248 (one pass over the gradient, nested windows) against the three segf_bilinear_bwd launches it
     replaces and against autograd through F.interpolate on the CPU; includes the clamped borders (8-wide maps: every output
-    pixel is a border pixel).  bf16 with C % 128 == 0 and H, W >= 24: the interior 8 x 8 blocks run on the matrix pipe
-    (fuse_map.hip: fuse_map_bwd_kernel), the border ring on the VALU kernel -- (24, 24) has exactly one interior block."""
+    pixel is a border pixel).  bf16 with C % 128 == 0 runs on the matrix pipe (fuse_map.hip: fuse_map_bwd_kernel, ATen's index
+    clamping folded into the 1-D weight factors of the border blocks): 8 x 8 = one block that is first and last on both axes,
+    (8, 16) / (16, 16) = border blocks only, (24, 24) = exactly one interior block."""
     B, H, W, C = geom
     g = torch.Generator().manual_seed(33)
     dy = torch.randn(B * H * W, C, generator=g)
