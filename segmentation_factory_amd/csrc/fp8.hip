@@ -67,6 +67,79 @@ extern "C" int segf_quant_rows_fp8(int dt, int64_t rows, int K, const void* x, i
     return 0;
 }
 
+// ---- tensor-wise quantisation: one scale for a whole [rows][cols] activation / gradient tensor (the implicit-GEMM 3x3 convolution
+// gathers its K axis from nine neighbouring pixels, so per-token scales do not factor out of the sum).
+//   amax pass: amax_bits = max over the tensor of |x| (as the unsigned bits of a non-negative float: atomicMax is exact and
+//              order-independent); the caller zeroes amax_bits first.
+//   quantise : scale = amax / FMAX (1 if the tensor is all zero), q = cvt(x / scale), FMAX = 448 (e4m3fn) or 57344 (e5m2).
+template <typename T>
+__global__ void __launch_bounds__(256) amax_tensor_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int nch, unsigned* __restrict__ amax_bits) {
+    float mx = 0.f;
+    const int64_t total = rows * nch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nch;
+        const int c = (int)(i - r * nch);
+        float v[8];
+        load8<T>(x + r * ldx + 8 * c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(v[j]));
+    }
+    mx = wave_max_all(mx);
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax_bits, __float_as_uint(mx));
+}
+template <typename T, bool E5M2>
+__global__ void __launch_bounds__(256) quant_tensor_fp8_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int nch,
+                                                               const unsigned* __restrict__ amax_bits, uint8_t* __restrict__ q, int64_t ldq,
+                                                               float* __restrict__ scale_out) {
+    const float amax = __uint_as_float(amax_bits[0]);
+    const float s = amax > 0.f ? amax * (1.f / (E5M2 ? 57344.f : F8_MAX)) : 1.f;
+    const float inv = 1.f / s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+    const int64_t total = rows * nch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nch;
+        const int c = (int)(i - r * nch);
+        float v[8];
+        load8<T>(x + r * ldx + 8 * c, v);
+        int lo = 0, hi = 0;
+        if (E5M2) {
+            lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[0] * inv, v[1] * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_bf8_f32(v[2] * inv, v[3] * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[4] * inv, v[5] * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_bf8_f32(v[6] * inv, v[7] * inv, hi, true);
+        } else {
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+        }
+        *reinterpret_cast<int2*>(q + r * ldq + 8 * c) = make_int2(lo, hi);
+    }
+}
+// fmt 0 = e4m3fn, 1 = e5m2.  amax_ws: one uint32 of scratch (zeroed here with a kernel node: graph-safe).  scale: one float out.
+__global__ void fp8_zero_word_kernel(unsigned* p) { p[0] = 0u; }
+extern "C" int segf_quant_tensor_fp8(int dt, int fmt, int64_t rows, int cols, const void* x, int64_t ldx, void* q, int64_t ldq,
+                                     float* scale, void* amax_ws, void* stream) {
+    if (rows <= 0) return 0;
+    if (cols <= 0 || cols % 8 || ldx < cols || ldq < cols || (ldq % 8) || ((uintptr_t)x % 16) || ((uintptr_t)q % 8) || !scale || !amax_ws ||
+        fmt < 0 || fmt > 1)
+        return SEGF_ERR_SHAPE;
+    if ((ldx * (dt == SEGF_BF16 ? 2 : 4)) % 16) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = cols / 8;
+    const int blocks = (int)imin64(cdiv64(rows * nch, 256 * 4), 4096);
+    hipLaunchKernelGGL(fp8_zero_word_kernel, dim3(1), dim3(1), 0, st, (unsigned*)amax_ws);
+    SEGF_DISPATCH_DT(dt, T, {
+        hipLaunchKernelGGL((amax_tensor_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)x, ldx, rows, nch, (unsigned*)amax_ws);
+        if (fmt == 0) hipLaunchKernelGGL((quant_tensor_fp8_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, ldx, rows, nch,
+                                         (const unsigned*)amax_ws, (uint8_t*)q, ldq, scale);
+        else hipLaunchKernelGGL((quant_tensor_fp8_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x, ldx, rows, nch,
+                                (const unsigned*)amax_ws, (uint8_t*)q, ldq, scale);
+    })
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- GEMM ---------------------------------------------------------------------------------------------------------------
 struct Fp8Args {
     const uint8_t* A; int64_t lda;       // [M][K] e4m3 (activations)

@@ -38,6 +38,10 @@ struct GemmArgs {
     // act(x * pro_scale[g][f] + pro_shift[g][f]), g = token / pro_rpg, f = feature -- BatchNorm(+ReLU)(+Dropout2d scale) of
     // the producer applied on the way into LDS, so the normalised tensor is never materialised
     const float* pro_scale; const float* pro_shift; int64_t pro_rpg; int64_t pro_ld; int pro_act;
+    // fp8 operands (256-tile kernel, layout 0, template FP8): A / B hold OCP fp8 bytes and every K-axis quantity of this struct (K,
+    // lda, ldb, kchunk, cC) counts 2-BYTE UNITS -- the loaders and LDS images move bytes and never look inside -- C[m][n] =
+    // acc * f8_sa[0] * f8_sb[n]: one dequantisation scale for the activation tensor, one per weight row
+    const float* f8_sa; const float* f8_sb;
 };
 
 #define GB_BM 128
@@ -581,8 +585,12 @@ __device__ __forceinline__ void pro_apply(uint4& r, const float (&sc)[8], const 
 // DEEP (layout 0, full 64-deep K steps, vector-aligned operands): TWO K steps of operand tiles are in flight in registers while one
 // is multiplied (register sets alternate; every load unconditional so that the compiler can wait for one set and leave the other
 // in flight).  With one workgroup per CU and one 52 KB step in flight the classifier product was latency-bound at 2.9 TB/s.
-template <int LAYOUT, typename OutT, bool CONV, bool PRO = false, int SHAPE = 0, bool DEEP = false>
+// FP8 (layout 0 only): 1 = both operands e4m3, 2 = the token-side operand (A: a gradient) e5m2, the weight side e4m3.  A 16-byte
+// fragment then holds 16 values and feeds two v_mfma_f32_16x16x32_fp8 instructions (one per 8-byte half; both operands split the
+// same way, so the k pairing is consistent): the same bytes per K step and the same instruction count as bf16, twice the K.
+template <int LAYOUT, typename OutT, bool CONV, bool PRO = false, int SHAPE = 0, bool DEEP = false, int FP8 = 0>
 __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
+    static_assert(FP8 == 0 || (LAYOUT == 0 && !PRO && !DEEP && SHAPE == 0 && sizeof(OutT) == 2), "fp8: forward-type products, bf16 out");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][GG_TILE_BYTES];
     // DEEP + PRO: the operand affine of this workgroup's sample, staged once (K <= 1024 features): read from global memory
     // inside the K loop, the table loads are younger than the tile loads in flight and waiting for them drains the queue
@@ -681,7 +689,23 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int t = 0; t < MG; ++t)
-                        acc[tn][hm * MG + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[t], acc[tn][hm * MG + t], 0, 0, 0);
+                    {
+                        if constexpr (FP8 == 0) {
+                            acc[tn][hm * MG + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[t], acc[tn][hm * MG + t], 0, 0, 0);
+                        } else {
+                            typedef long f8x2 __attribute__((ext_vector_type(2)));
+                            const f8x2 wb = __builtin_bit_cast(f8x2, fb[tn]), xa = __builtin_bit_cast(f8x2, fa[t]);
+                            f32x4 c = acc[tn][hm * MG + t];
+                            if constexpr (FP8 == 1) {
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[0], xa[0], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[1], xa[1], c, 0, 0, 0);
+                            } else {
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(wb[0], xa[0], c, 0, 0, 0);
+                                c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(wb[1], xa[1], c, 0, 0, 0);
+                            }
+                            acc[tn][hm * MG + t] = c;
+                        }
+                    }
             }
         }
     };
@@ -753,9 +777,14 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
         float* stg = reinterpret_cast<float*>(&smem[0][0][0]);     // [64][GG_STG_LD] floats = 66.5 KB
         const int tchunk = threadIdx.x & 31, trow = threadIdx.x >> 5;
         const int64_t ncol = n0 + tchunk * 8;
-        float bs[8];
+        float bs[8], f8s[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) bs[j] = (a.bias && ncol + j < a.N) ? a.bias[ncol + j] : 0.f;
+        if (FP8) {
+            const float sa = a.f8_sa[0];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f8s[j] = ncol + j < a.N ? sa * a.f8_sb[ncol + j] : 0.f;
+        }
         const bool full = ncol + 8 <= a.N;
         for (int pass = 0; pass < 4; ++pass) {              // 64 rows per pass
             if (pass) __syncthreads();
@@ -776,8 +805,13 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
                 float v[8];
                 const float4 lo = *reinterpret_cast<const float4*>(stg + r * GG_STG_LD + tchunk * 8);
                 const float4 hi = *reinterpret_cast<const float4*>(stg + r * GG_STG_LD + tchunk * 8 + 4);
+                if (FP8) {
+                    v[0] = fmaf(lo.x, f8s[0], bs[0]); v[1] = fmaf(lo.y, f8s[1], bs[1]); v[2] = fmaf(lo.z, f8s[2], bs[2]); v[3] = fmaf(lo.w, f8s[3], bs[3]);
+                    v[4] = fmaf(hi.x, f8s[4], bs[4]); v[5] = fmaf(hi.y, f8s[5], bs[5]); v[6] = fmaf(hi.z, f8s[6], bs[6]); v[7] = fmaf(hi.w, f8s[7], bs[7]);
+                } else {
                 v[0] = lo.x + bs[0]; v[1] = lo.y + bs[1]; v[2] = lo.z + bs[2]; v[3] = lo.w + bs[3];
                 v[4] = hi.x + bs[4]; v[5] = hi.y + bs[5]; v[6] = hi.z + bs[6]; v[7] = hi.w + bs[7];
+                }
                 if (a.residual) {
                     const float sc = a.rscale ? a.rscale[m / a.rpg] : 1.f;
                     const bf16_t* rp = reinterpret_cast<const bf16_t*>(a.residual) + m * a.ldr + ncol;
@@ -1634,6 +1668,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     a.colsum_ws = (colsum && split_k > 1) ? ws + (int64_t)split_k * M * N : nullptr;
     a.pro_scale = pro ? pro->scale : nullptr; a.pro_shift = pro ? pro->shift : nullptr;
     a.pro_rpg = pro ? pro->rpg : 1; a.pro_ld = pro ? pro->ld : 0; a.pro_act = pro ? pro->act : 0;
+    a.f8_sa = nullptr; a.f8_sb = nullptr;
     {   // debugging switch: SEGFAC_GEMM_NO_TR=1 reads transposed fragments with scalar LDS loads instead of ds_read_b64_tr_b16
         const char* e = getenv("SEGFAC_GEMM_NO_TR");
         a.use_tr = (e && e[0] == '1') ? 0 : 1;
@@ -1775,6 +1810,7 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     a.a_vec = 1; a.b_vec = 1; a.r_vec = 0; a.use_tr = 1;
     a.cH = H; a.cW = W; a.csign = mode == 1 ? -1 : 1;
     a.colsum = nullptr; a.colsum_ws = nullptr; a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_rpg = 1; a.pro_ld = 0; a.pro_act = 0;
+    a.f8_sa = nullptr; a.f8_sb = nullptr;
     int layout;
     if (mode == 0) { layout = 0; a.M = P; a.N = Cout; a.K = 9 * (int64_t)Cin; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cin; }
     else if (mode == 1) { layout = 0; a.M = P; a.N = Cin; a.K = 9 * (int64_t)Cout; a.A = x; a.lda = ldx; a.B = w; a.ldb = ldw; a.cC = Cout; }
@@ -1824,5 +1860,45 @@ reduce3:
         else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (bf16_t*)y, ldy, blocks, (const float*)nullptr, (float*)nullptr, (int64_t)0);
         SEGF_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+
+// ---- 3x3 convolution with fp8 operands (BASELINE cfg5 "fp8 MFMA weights": the UPerHead / PPM 3x3 convs are ~700 of its 2,050
+// GFLOP per image; heads/upernet.py:26-31, modules/ppm.py:19).  Not a reference feature -- an option of this build.
+//   mode 0  y[pix][co]  = sx * sw[co] * sum_{tap,ci} xq[pix+off(tap)][ci] wq[co][tap*Cin+ci]       xq e4m3 (one scale sx for the tensor),
+//                                                                                                    wq e4m3 (one scale per row)
+//   mode 1  dx[pix][ci] = sg * sw[ci] * sum_{tap,co} gq[pix-off(tap)][co] wtq[ci][tap*Cout+co]      gq e5m2 (gradient), wtq e4m3
+// Same kernel, loaders and LDS images as the bf16 path (gemm_bf16_big_kernel<0, bf16, CONV, .., FP8>): the operands are addressed in
+// 2-byte units, a K step of 64 units = 128 fp8 values.  Channel counts must be multiples of 16, rows 16-byte aligned.  Output bf16.
+extern "C" int segf_conv3x3_fp8_supported(int mode, int B, int H, int W, int Cin, int Cout) {
+    if (getenv("SEGFAC_NO_FP8_CONV") || mode < 0 || mode > 1 || B <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % 16) return 0;
+    const int64_t P = (int64_t)B * H * W, N = mode == 0 ? Cout : Cin, K = 9 * (int64_t)(mode == 0 ? Cin : Cout) / 2;
+    return gemm_use_big(0, P, N, K) ? 1 : 0;
+}
+extern "C" int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout, const void* xq, int64_t ldx, const float* sx,
+                                const void* wq, int64_t ldw, const float* sw, void* y, int64_t ldy, void* stream) {
+    if (!segf_conv3x3_fp8_supported(mode, B, H, W, Cin, Cout)) return SEGF_ERR_SHAPE;
+    if (!xq || !wq || !sx || !sw || !y) return SEGF_ERR_SHAPE;
+    if (((uintptr_t)xq % 16) || ((uintptr_t)wq % 16) || (ldx % 16) || (ldw % 16) || ((uintptr_t)y % 16) || ((ldy * 2) % 16)) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = (int64_t)B * H * W;
+    const int Kc = mode == 0 ? Cin : Cout;                      // channels of the gathered operand
+    GemmArgs a;
+    a.bias = nullptr; a.residual = nullptr; a.rscale = nullptr; a.ldr = 0; a.rpg = 1;
+    a.a_vec = 1; a.b_vec = 1; a.r_vec = 0; a.use_tr = 1; a.fast = 0;
+    a.cH = H; a.cW = W; a.csign = mode == 1 ? -1 : 1;
+    a.colsum = nullptr; a.colsum_ws = nullptr; a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_rpg = 1; a.pro_ld = 0; a.pro_act = 0;
+    a.f8_sa = sx; a.f8_sb = sw;
+    a.M = P; a.N = mode == 0 ? Cout : Cin; a.K = 9 * (int64_t)Kc / 2;          // 2-byte units
+    a.A = xq; a.lda = ldx / 2; a.B = wq; a.ldb = ldw / 2; a.cC = Kc / 2;
+    a.C = y; a.ldc = ldy;
+    a.kchunk = cdiv64(a.K, GB_BK) * GB_BK; a.ws = nullptr;
+    a.c_vec = 1; a.c_vec16 = 1;
+    dim3 gridb((unsigned)cdiv64(a.N, GG_B), (unsigned)cdiv64(a.M, GG_B), 1);
+    if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
+    if (mode == 0) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, true, false, 0, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, true, false, 0, false, 2>), gridb, dim3(GG_THREADS), 0, st, a);
+    SEGF_CHECK_LAUNCH();
     return 0;
 }
