@@ -73,6 +73,20 @@ int segf_gemm_fp8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, c
                   const float* scale_b, const float* bias, const void* residual, int64_t ldr, const float* rscale,
                   int64_t rows_per_group, void* C, int64_t ldc, void* stream);
 
+/* fp8 3x3 convolutions (the UPerHead / PPM ConvModules, heads/upernet.py:26-31, modules/ppm.py:19: ~700 of cfg5's 2,050 GFLOP per
+ * image).  segf_quant_tensor_fp8: ONE scale for a whole [rows][cols] tensor (the implicit-GEMM K axis gathers nine pixels, so
+ * per-token scales do not factor out): q = cvt(x / scale), scale = amax |x| / FMAX; fmt 0 = e4m3fn (activations, FMAX 448),
+ * 1 = e5m2 (gradients, FMAX 57344); amax_ws = 4 bytes of scratch; all on the stream, no host read (graph-safe).
+ * segf_conv3x3_fp8: mode 0  y[pix][co] = sx * sw[co] * sum_{tap,ci} xq[pix+off(tap)][ci] wq[co][tap*Cin+ci]   (xq e4m3, wq e4m3 rows)
+ *                   mode 1  dx[pix][ci] = sx * sw[ci] * sum_{tap,co} gq[pix-off(tap)][co] wq[ci][tap*Cout+co]  (gq e5m2, wq e4m3 rows)
+ * bf16 output; Cin, Cout multiples of 16; ldx / ldw in bytes = elements, multiples of 16.  The weight gradient stays bf16
+ * (segf_conv3x3 mode 2). */
+int segf_quant_tensor_fp8(int dt, int fmt, int64_t rows, int cols, const void* x, int64_t ldx, void* q, int64_t ldq, float* scale,
+                          void* amax_ws, void* stream);
+int segf_conv3x3_fp8_supported(int mode, int B, int H, int W, int Cin, int Cout);
+int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout, const void* xq, int64_t ldx, const float* sx,
+                     const void* wq, int64_t ldw, const float* sw, void* y, int64_t ldy, void* stream);
+
 /* ---- stream ordering for the data-parallel exchange (train_gpu.py:233-236: DistributedDataParallel overlaps the gradient
  * all-reduce with backward through per-bucket hooks).  segf_event_record(.., external=1) during a stream capture adds an
  * EVENT-RECORD NODE to the hipGraph (hipEventRecordExternal); at each replay a stream outside the graph can

@@ -80,16 +80,23 @@ class SegmentationModel(BaseSegModel):
         return self
 
     def set_fp8(self, enabled: bool = True):
-        """BASELINE cfg5 ("fp8 MFMA weights"): run the forward products of the ConvNeXt / ConvNeXtV2 pointwise linears
-        (convnextv2.py:90-95) in OCP e4m3 on the block-scaled fp8 matrix instruction (csrc/fp8.hip): weights quantised per output
-        channel, activations per token, fp32 accumulate; backward stays bf16.  Not a reference feature: tolerance in the tests."""
+        """BASELINE cfg5 ("fp8 MFMA weights"): (a) the forward products of the ConvNeXt / ConvNeXtV2 pointwise linears
+        (convnextv2.py:90-95) in OCP e4m3 on the block-scaled fp8 matrix instruction (csrc/fp8.hip: weights quantised per output
+        channel, activations per token); (b) forward and data gradient of UPerHead's / PPM's 3x3 convolutions (heads/upernet.py:26-31,
+        modules/ppm.py:19) on fp8 operands (activations e4m3 / gradients e5m2 with one dynamic scale per tensor, weights e4m3 per
+        row; 256-tile implicit GEMM of csrc/gemm.hip).  fp32 accumulate everywhere; weight gradients and everything else stay
+        bf16.  Not a reference feature: tolerance stated in the tests."""
         n = 0
         for m in self.backbone.modules():
             if hasattr(m, 'fp8') and hasattr(m, 'pwconv1'):
                 m.fp8 = bool(enabled)
                 n += 1
+        if hasattr(self.decode_head, 'fp8'):
+            self.decode_head.fp8 = bool(enabled)
+            n += 1
         if enabled and n == 0:
-            raise ValueError(f'set_fp8: backbone {self.backbone_name!r} has no fp8-capable layers (ConvNeXt / ConvNeXtV2 blocks)')
+            raise ValueError(f'set_fp8: model {self.backbone_name!r} + {self.head_name!r} has no fp8-capable layers '
+                             '(ConvNeXt / ConvNeXtV2 blocks, UPerHead 3x3 convolutions)')
         return self
 
     def _features(self, x):

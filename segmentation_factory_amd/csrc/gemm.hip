@@ -1555,7 +1555,18 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     const int64_t tiles = big ? cdiv64(M, GG_B) * cdiv64(N, GG_B) : cdiv64(M, GB_BM) * cdiv64(N, GB_BN);
     // one wave of workgroups: 256 CUs x (1 big-tile | 2 small-tile) resident workgroups.  Rounded DOWN: 3 tiles x 86 slices =
     // 258 workgroups would run as two rounds (256 + 2) and take twice as long as 3 x 85
-    int64_t s = getenv("SEGFAC_SPLITK_CEIL") ? cdiv64(big ? 256 : 512, tiles) : (big ? 256 : 512) / tiles;
+    const int64_t res = big ? 256 : 512;                          // resident workgroups
+    int64_t s = getenv("SEGFAC_SPLITK_CEIL") ? cdiv64(res, tiles) : res / tiles;
+    if (tiles > res && !getenv("SEGFAC_SPLITK_NO_TAIL")) {
+        // more tiles than one round of workgroups (UPerHead's 3072 -> 768 3x3 conv: 3 x 108 = 324 tiles of 256^2 run as 256 + 68,
+        // 63 % of the machine on average: 565 vs 787 TFLOP/s measured against the forward of the same shape): the smallest slice
+        // count whose last round is >= 93 % full (324 x 3 = 972 workgroups = 3.8 rounds; the extra reduce pass is ~0.1 ms of 39)
+        s = 1;
+        for (int64_t c = 1; c <= 8; ++c) {
+            const int64_t wg = tiles * c;
+            if ((double)wg / (double)(cdiv64(wg, res) * res) >= 0.93) { s = c; break; }
+        }
+    }
     const int64_t maxs = K / (4 * GB_BK);
     if (s > maxs) s = maxs;
     if (s > 512) s = 512;

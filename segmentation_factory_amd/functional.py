@@ -840,34 +840,48 @@ class Conv3x3Fn(Function):
     heads/upernet.py:26,28, modules/ppm.py:19, heads/fpn.py:19).  x may be a column slice of a wider concat buffer."""
 
     @staticmethod
-    def forward(ctx, x, weight, B, H, W):
+    def forward(ctx, x, weight, B, H, W, fp8=False):
         x = _rowmajor(x)
         O, I = weight.shape[0], weight.shape[1]
         wm = hip.permute021(weight.detach().reshape(O, I, 9), O, I, 9, x.dtype).view(O, 9 * I)          # [O][(ky,kx)][ci]
-        y = hip.conv3x3(0, x, wm, B, H, W, I, O)
+        use8 = bool(fp8) and x.dtype == torch.bfloat16 and hip.conv3x3_fp8_supported(0, B, H, W, I, O)
+        if use8:
+            # fp8 forward (BASELINE cfg5): activations e4m3 with one dynamic scale for the tensor, weights e4m3 per output channel
+            xq, sx = hip.quant_tensor_fp8(x)
+            wq, sw = hip.quant_rows_fp8(wm)
+            y = hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, I, O)
+        else:
+            y = hip.conv3x3(0, x, wm, B, H, W, I, O)
         ctx.save_for_backward(x, weight.detach())
-        ctx.meta = (B, H, W, I, O, weight.shape)
+        ctx.meta = (B, H, W, I, O, weight.shape, bool(fp8))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        B, H, W, I, O, wshape = ctx.meta
+        B, H, W, I, O, wshape, fp8 = ctx.meta
         dy = _rowmajor(dy)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wt = hip.permute021(w.reshape(1, O, I * 9), 1, O, I * 9, dy.dtype).view(I, 9 * O)             # [ci][(ky,kx)][co]
-            dx = hip.conv3x3(1, dy, wt, B, H, W, I, O)
+            if fp8 and dy.dtype == torch.bfloat16 and hip.conv3x3_fp8_supported(1, B, H, W, I, O):
+                # data gradient in fp8: the gradient e5m2 (one dynamic scale), the transposed weights e4m3 per input channel
+                gq, sg = hip.quant_tensor_fp8(dy, e5m2=True)
+                wq, sw = hip.quant_rows_fp8(wt)
+                dx = hip.conv3x3_fp8(1, gq, sg, wq, sw, B, H, W, I, O)
+            else:
+                dx = hip.conv3x3(1, dy, wt, B, H, W, I, O)
         if ctx.needs_input_grad[1]:
             dwm = hip.conv3x3(2, x, dy, B, H, W, I, O, split_k=_splitk(O, 9 * I, B * H * W))               # [O][(ky,kx)][ci] fp32
             dw = hip.permute021(dwm.view(O, 9, I), O, 9, I, torch.float32).view(wshape)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def conv3x3(x, weight, B, H, W):
-    """bf16: implicit GEMM; fp32 parity mode: im2col + exact-fp32 GEMM (ConvPatchFn)."""
+def conv3x3(x, weight, B, H, W, fp8=False):
+    """bf16: implicit GEMM (fp8=True: forward and data gradient on fp8 operands where the shape takes the 256-tile kernel); fp32
+    parity mode: im2col + exact-fp32 GEMM (ConvPatchFn)."""
     if x.dtype == torch.bfloat16 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0:
-        return Conv3x3Fn.apply(x, weight, B, H, W)
+        return Conv3x3Fn.apply(x, weight, B, H, W, fp8)
     return ConvPatchFn.apply(x, weight, None, (B, H, W, weight.shape[1], 3, 1, 1), False, x.dtype)
 
 

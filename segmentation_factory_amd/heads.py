@@ -125,7 +125,7 @@ class PPM(nn.Module):
         gs = [(H, W)] + geoms[::-1]
         cat = Fh.resize_concat(feats, gs, [False] + [True] * len(outs), (B, H, W))     # align_corners=True (ppm.py:23)
         conv, bn = self.bottleneck[0], self.bottleneck[1]
-        return _bn_relu(Fh.conv3x3(cat, conv.weight, B, H, W), bn, training)
+        return _bn_relu(Fh.conv3x3(cat, conv.weight, B, H, W, fp8=getattr(self, 'fp8', False)), bn, training)
 
 
 class UPerHead(nn.Module):
@@ -146,11 +146,13 @@ class UPerHead(nn.Module):
         self.embed_dim, self.num_classes = channel, num_classes
         self.compute_dtype = torch.bfloat16
         self.stochastic_override = None               # tests: {'dropout2d': keep[B, channel]}
+        self.fp8 = False      # SegmentationModel.set_fp8: forward + data gradient of the 3x3 convs on fp8 operands (BASELINE cfg5)
 
     def forward_tokens(self, feats):
         tr = self.training
         B = feats[0].B
         ch, nc = self.embed_dim, self.num_classes
+        self.ppm.fp8 = self.fp8
         fa, fb = Fh.fork(self.ppm.tokens(feats[-1], tr), 2)               # PPM output: a pyramid level AND the top-down input
         f = TokenMap(fb, B, feats[-1].H, feats[-1].W)
         fpn = [TokenMap(fa, B, feats[-1].H, feats[-1].W)]
@@ -163,13 +165,13 @@ class UPerHead(nn.Module):
                 fsum, fnext = Fh.fork(fsum, 2)                              # feeds its 3x3 output conv and the next finer level
                 f = TokenMap(fnext, B, fi.H, fi.W)
             oc, obn = self.fpn_out[i][0], self.fpn_out[i][1]
-            fpn.append(TokenMap(_bn_relu(Fh.conv3x3(fsum, oc.weight, B, fi.H, fi.W), obn, tr), B, fi.H, fi.W))
+            fpn.append(TokenMap(_bn_relu(Fh.conv3x3(fsum, oc.weight, B, fi.H, fi.W, fp8=self.fp8), obn, tr), B, fi.H, fi.W))
         fpn.reverse()
         H1, W1 = fpn[0].H, fpn[0].W
         cat = Fh.resize_concat([t.data for t in fpn], [(t.H, t.W) for t in fpn], [False] * len(fpn), (B, H1, W1))
         conv, bn = self.bottleneck[0], self.bottleneck[1]
         drop = dropout2d_scale(tr and self.dropout.p > 0, B, ch, cat.device, self.stochastic_override, self.dropout)
-        x = _bn_relu(Fh.conv3x3(cat, conv.weight, B, H1, W1), bn, tr, chan_scale=drop, rows_per_sample=H1 * W1)
+        x = _bn_relu(Fh.conv3x3(cat, conv.weight, B, H1, W1, fp8=self.fp8), bn, tr, chan_scale=drop, rows_per_sample=H1 * W1)
         logits = Fh.linear(x, self.conv_seg.weight, self.conv_seg.bias, pad_to=(nc + 7) // 8 * 8)
         return TokenMap(logits, B, H1, W1)
 

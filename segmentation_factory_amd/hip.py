@@ -96,6 +96,9 @@ _PROTOS = {
     'segf_layernorm_bwd_fused': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_quant_rows_fp8': (_i, [_i, _l, _i, _p, _l, _p, _l, _p, _p]),
     'segf_gemm_fp8_supported': (_i, [_l, _l, _l]),
+    'segf_quant_tensor_fp8': (_i, [_i, _i, _l, _i, _p, _l, _p, _l, _p, _p, _p]),
+    'segf_conv3x3_fp8_supported': (_i, [_i, _i, _i, _i, _i, _i]),
+    'segf_conv3x3_fp8': (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _l, _p, _p, _l, _p]),
     'segf_gemm_fp8': (_i, [_l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p, _l, _p]),
     'segf_input_train': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     'segf_input_val_ws': (_l, [_i, _i, _i, _i]),
@@ -308,6 +311,36 @@ def quant_rows_fp8(x):
     scale = torch.empty(rows, dtype=torch.float32, device=x.device)
     _chk(lib().segf_quant_rows_fp8(dt_of(x), rows, K, _ptr(x), x.stride(0), _ptr(q), K, _ptr(scale), _stream()), 'segf_quant_rows_fp8')
     return q, scale
+
+
+def quant_tensor_fp8(x, e5m2=False):
+    """(q uint8 [rows, cols], scale fp32 [1]): one dynamic scale for the whole tensor, x = q * scale; e4m3fn or e5m2 bytes."""
+    _need_cuda(x)
+    assert x.ndim == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1, dtype=torch.int32, device=x.device)
+    _chk(lib().segf_quant_tensor_fp8(dt_of(x), int(e5m2), rows, cols, _ptr(x), x.stride(0), _ptr(q), cols, _ptr(scale), _ptr(ws),
+                                     _stream()), 'segf_quant_tensor_fp8')
+    return q, scale
+
+
+def conv3x3_fp8_supported(mode, B, H, W, Cin, Cout):
+    return bool(lib().segf_conv3x3_fp8_supported(mode, B, H, W, Cin, Cout))
+
+
+def conv3x3_fp8(mode, xq, sx, wq, sw, B, H, W, Cin, Cout):
+    """mode 0: y [P, Cout] bf16 from xq [P, Cin] e4m3 and wq [Cout, 9 Cin] e4m3; mode 1: dx [P, Cin] from gq [P, Cout] e5m2 and
+    wq [Cin, 9 Cout] e4m3.  sx: tensor scale [1]; sw: one scale per weight row."""
+    _need_cuda(xq, wq)
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.stride(-1) == 1 and wq.stride(-1) == 1
+    P = B * H * W
+    out = torch.empty((P, Cout if mode == 0 else Cin), dtype=torch.bfloat16, device=xq.device)
+    key = ('conv3x3_fp8', mode, P, Cin, Cout)
+    _chk(_timed(key, lambda: lib().segf_conv3x3_fp8(mode, B, H, W, Cin, Cout, _ptr(xq), xq.stride(0), _ptr(sx), _ptr(wq), wq.stride(0),
+                                                    _ptr(sw), _ptr(out), out.stride(0), _stream())), 'segf_conv3x3_fp8')
+    return out
 
 
 def gemm_fp8_supported(M, N, K):

@@ -1318,6 +1318,50 @@ def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
         assert torch.equal(dwc, dwc2)
 
 
+@pytest.mark.parametrize('geom', [(2, 128, 128, 512, 512), (1, 160, 160, 272, 384), (4, 96, 128, 144, 768)])
+def test_fp8_conv3x3_forward_and_data_gradient(hipmod, geom):
+    """segf_conv3x3_fp8 (BASELINE cfg5's UPerHead / PPM 3x3 convolutions on fp8 operands: the 256-tile implicit GEMM of gemm.hip
+    with 2-byte-unit addressing, two v_mfma_f32_16x16x32_fp8 per 16-byte fragment) and segf_quant_tensor_fp8, against
+    torch.conv2d on the DEQUANTISED operands in float64 -- fp8 x fp8 products are exact in fp32, so only accumulation order and the
+    bf16 output rounding remain -- for the forward (e4m3 x e4m3) and the data gradient (e5m2 x e4m3, transposed weights)."""
+    hip = hipmod
+    B, H, W, Cin, Cout = geom
+    g = torch.Generator().manual_seed(7)
+    P = B * H * W
+    x = (torch.randn(P, Cin, generator=g) * 2).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5)
+    dy = (torch.randn(P, Cout, generator=g) * 1e-3).to(torch.bfloat16)
+    assert hip.conv3x3_fp8_supported(0, B, H, W, Cin, Cout) and hip.conv3x3_fp8_supported(1, B, H, W, Cin, Cout)
+    # quantisation: tensor scale = amax / 448 (e4m3) or / 57344 (e5m2); bytes decode with torch's own fp8 dtypes
+    xq, sx = hip.quant_tensor_fp8(x.cuda())
+    assert abs(sx.item() - x.float().abs().max().item() / 448.0) <= 1e-6 * sx.item()
+    xd = xq.cpu().view(torch.float8_e4m3fn).double() * sx.item()
+    assert (xd - x.double()).abs().max().item() <= 2 ** -3 * x.float().abs().max().item() / 1.75        # half an e4m3 step at the top binade
+    gq, sg = hip.quant_tensor_fp8(dy.cuda(), e5m2=True)
+    gd = gq.cpu().view(torch.float8_e5m2).double() * sg.item()
+    assert (gd - dy.double()).abs().max().item() <= 2 ** -2 * dy.float().abs().max().item() / 1.5
+    # forward
+    wm = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(torch.bfloat16)                    # [O][(ky,kx)][ci]
+    wq, sw = hip.quant_rows_fp8(wm.cuda())
+    wd = (wq.cpu().view(torch.float8_e4m3fn).double() * sw.cpu().double()[:, None]).view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    y = hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout)
+    ref = F.conv2d(xd.view(B, H, W, Cin).permute(0, 3, 1, 2), wd, padding=1).permute(0, 2, 3, 1).reshape(P, Cout)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 2 ** -8 * ref.abs().max().item() + 1e-9, (err, ref.abs().max().item())
+    # ... and the fp8 result is a sensible approximation of the bf16 convolution it stands in for
+    yb = hip.conv3x3(0, x.cuda(), wm.cuda(), B, H, W, Cin, Cout)
+    assert (y.float() - yb.float()).abs().max().item() <= 0.12 * yb.float().abs().max().item()
+    # data gradient: dx = conv_transpose(dy, w): gq e5m2 x transposed weights e4m3 (rows = input channels)
+    wt = w.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous().to(torch.bfloat16)                    # [ci][(ky,kx)][co]
+    wtq, swt = hip.quant_rows_fp8(wt.cuda())
+    wtd = (wtq.cpu().view(torch.float8_e4m3fn).double() * swt.cpu().double()[:, None]).view(Cin, 3, 3, Cout)   # [ci][ky][kx][co]
+    dx = hip.conv3x3_fp8(1, gq, sg, wtq, swt, B, H, W, Cin, Cout)
+    wfull = wtd.permute(3, 0, 1, 2)                                                                           # [co][ci][ky][kx]
+    refdx = F.conv_transpose2d(gd.view(B, H, W, Cout).permute(0, 3, 1, 2), wfull, padding=1).permute(0, 2, 3, 1).reshape(P, Cin)
+    err = (dx.double().cpu() - refdx).abs().max().item()
+    assert err <= 2 ** -8 * refdx.abs().max().item() + 1e-12, (err, refdx.abs().max().item())
+
+
 @pytest.mark.parametrize('shape', [(300, 256, 128), (1000, 768, 3072), (4096, 1536, 384), (129, 40, 256)])
 def test_fp8_quantise_and_gemm(hipmod, shape):
     """csrc/fp8.hip: row-wise e4m3fn quantisation (decode with torch.float8_e4m3fn) and the block-scaled fp8 MFMA product against
