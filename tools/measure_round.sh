@@ -31,6 +31,8 @@ python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline > $O/${TAG}_bench_cf
 python3 bench.py --config cfg4 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_cfg4_b16.json 2>> $O/bench.err
 python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline > $O/${TAG}_bench_cfg5_b8.json 2>> $O/bench.err
 python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline --fp8 > $O/${TAG}_bench_cfg5_b8_fp8.json 2>> $O/bench.err
+python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline --fp8 > $O/${TAG}_bench_cfg3_b32_fp8.json 2>> $O/bench.err
+python3 tools/probe/fp8_conv_probe.py > $O/${TAG}_conv3x3_bf16_vs_fp8.txt 2>> $O/bench.err
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 # kernel statistics + counter traffic of the other BASELINE configs (the TFLOP/s and GB/s claims of DESIGN section 5 / 9)
 for cb in cfg3:32 cfg4:16 cfg5:8; do
