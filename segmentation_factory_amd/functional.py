@@ -50,49 +50,6 @@ def _w(param, dtype):
     return hip.cast(p, dtype) if dtype != torch.float32 else p
 
 
-# Weight gradients on a side stream (small per-GPU batches): the dW / db products of the Linear layers are off the critical path of
-# backward (nothing downstream reads them before the optimizer), and at batch <= 16 every kernel of the step occupies a fraction of
-# the 256 CUs (the 128-tile GEMMs of stages 3 / 4 run ~16 us each on a handful of workgroups).  Inside `side_stream_scope` they are
-# enqueued on a second stream -- a parallel branch of the captured hipGraph -- ordered after everything issued so far on the main
-# stream; the scope's exit joins the branch.  At batch 128 the step saturates the chip and the branch measured -0.6 %,
-# so graph.GraphedTrainStep only opens the scope for small batches.
-_SIDE = None
-
-
-class side_stream_scope:
-    def __init__(self, stream):
-        self.state = {'stream': stream, 'used': False} if stream is not None else None
-
-    def __enter__(self):
-        global _SIDE
-        self.prev, _SIDE = _SIDE, self.state
-        return self
-
-    def __exit__(self, *exc):
-        global _SIDE
-        _SIDE = self.prev
-        if self.state is not None and self.state['used']:
-            torch.cuda.current_stream().wait_stream(self.state['stream'])
-        return False
-
-
-def _on_side(fn, *operands):
-    """Run fn() on the side stream (when a scope is open), after everything enqueued so far on the current stream; `operands` are
-    the tensors it reads (their memory must not be recycled by the main stream's allocator before the side stream is done)."""
-    st = _SIDE
-    if st is None:
-        return fn()
-    main, side = torch.cuda.current_stream(), st['stream']
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        out = fn()
-    for t in operands:
-        if t is not None:
-            t.record_stream(side)
-    st['used'] = True
-    return out
-
-
 def _splitk(n_out, k_in, tokens):
     return hip.pick_splitk(n_out, k_in, tokens)
 
@@ -235,21 +192,14 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = hip.gemm(1, dys, wv, M, K, N)
         gw, gb = gslot(ctx, 1, (N, K)), gslot(ctx, 2)       # flat-gradient views (direct placement) or None
-        need_w, need_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
-
-        def param_grads():
-            dw_, db_ = None, None
-            if need_w and need_b:
-                dw_, db_ = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)   # one pass over dy for both
-                dw_ = dw_.view(wshape)
-            else:
-                if need_w:
-                    dw_ = hip.gemm(2, dys, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
-                if need_b:
-                    db_ = hip.colsum(dys, out=gb)
-            return dw_, db_
-        # (side stream only with direct placement: the results land in the optimizer's flat buffer, nothing is handed to autograd)
-        dw, db = _on_side(param_grads, dys, x) if (gw is not None and (gb is not None or not need_b)) else param_grads()
+        if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
+            dw, db = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)   # one pass over dy for both
+            dw = dw.view(wshape)
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = hip.gemm(2, dys, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dys, out=gb)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None
 
@@ -280,20 +230,14 @@ class LinearForkFn(Function):
         if ctx.needs_input_grad[0]:
             dx = hip.gemm(1, dy, w, M, K, N, residual=_rowmajor(dx2) if dx2 is not None else None)
         gw, gb = gslot(ctx, 1, (N, K)), gslot(ctx, 2)
-        need_w, need_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2]
-
-        def param_grads():
-            dw_, db_ = None, None
-            if need_w and need_b:
-                dw_, db_ = hip.gemm_dw_db(dy, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)
-                dw_ = dw_.view(wshape)
-            else:
-                if need_w:
-                    dw_ = hip.gemm(2, dy, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
-                if need_b:
-                    db_ = hip.colsum(dy, out=gb)
-            return dw_, db_
-        dw, db = _on_side(param_grads, dy, x) if (gw is not None and (gb is not None or not need_b)) else param_grads()
+        if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
+            dw, db = hip.gemm_dw_db(dy, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)
+            dw = dw.view(wshape)
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = hip.gemm(2, dy, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dy, out=gb)
         return dx, dw, db
 
 

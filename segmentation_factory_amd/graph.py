@@ -156,14 +156,6 @@ class GraphedTrainStep:
             self._shadow_map = {}
             for p, o in zip(self.opt._params, self.opt._offsets):
                 self._shadow_map[p.data_ptr()] = self._shadow[o:o + p.numel()]
-        # weight gradients of the Linear layers as a parallel branch of the graph (functional.side_stream_scope): pays when the
-        # kernels of the step do not fill the chip, i.e. for small per-GPU batches (the reference's default is 4, train_gpu.py:71);
-        # measured on the MI355X at cfg2: see DESIGN 5.  Not combined with the bucketed exchange (its events are recorded on the
-        # main stream).  SEGFAC_SIDE_DW=0 / 1 overrides.
-        pixels = sum(int(t.numel()) for t in self.static_inputs[:1]) // max(int(self.static_inputs[0].shape[1]), 1)
-        env_side = os.environ.get('SEGFAC_SIDE_DW')
-        use_side = (pixels <= 32 * 512 * 512) if env_side is None else env_side == '1'
-        self._side = torch.cuda.Stream() if (use_side and not self.exchanging) else None
         self.opt.enable_direct_grads(self._on_grad_written if (self.exchanging and overlap) else None)
         self._seed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.static_inputs[0].device)
         s = torch.cuda.Stream()
@@ -210,8 +202,7 @@ class GraphedTrainStep:
         with scope:
             loss = self.loss_fn(self.model, *self.static_inputs)
             # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
-            with Fh.side_stream_scope(self._side):
-                loss.backward(gradient=self._seed if self.exchanging else None)
+            loss.backward(gradient=self._seed if self.exchanging else None)
         return loss
 
     def _reset_pending(self):
