@@ -171,11 +171,20 @@ __global__ void __launch_bounds__(256, FM_OCC) fuse_map_kernel(FuseMapArgs a) {
         for (int h = 0; h < 2; ++h) { p1[nt][h] = f32x2_t{0.f, 0.f}; p2[nt][h] = f32x2_t{0.f, 0.f}; }
 
     u32x4 sreg[4], xa[KS1], xb[KS1];
-    int64_t t = stream;
-    const int64_t tstep = a.nstream;
-    if (t < a.ntiles) { load_sources(t, sreg); load_x1(t, xa); }
+    // Block order: stream-strided (concurrently running workgroups cover a contiguous band of the image).  FM_CHUNKED = 1 lets a
+    // stream walk a contiguous range in raster order instead (the block below comes up w/8 iterations later in the same workgroup,
+    // same XCD): measured no better on the MI355X (1.143 vs 1.116 ms stand-alone at cfg2 / batch 128; FETCH_SIZE reads 2.5 GB
+    // against 1.2 GB algorithmic either way -- the halo re-fetches are Infinity-Cache hits, the launch is bound by its 3.2 GB of writes).
+#ifndef FM_CHUNKED
+#define FM_CHUNKED 0
+#endif
+    const int64_t chunk = (a.ntiles + a.nstream - 1) / a.nstream;
+    int64_t t = FM_CHUNKED ? stream * chunk : stream;
+    const int64_t tstep = FM_CHUNKED ? 1 : a.nstream;
+    const int64_t tend = FM_CHUNKED ? (t + chunk < a.ntiles ? t + chunk : a.ntiles) : a.ntiles;
+    if (t < tend) { load_sources(t, sreg); load_x1(t, xa); }
     unsigned char* ost = ostage[wave];
-    for (; t < a.ntiles; t += tstep) {
+    for (; t < tend; t += tstep) {
         __syncthreads();                                              // every wave is done with the previous block's source image
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -184,7 +193,7 @@ __global__ void __launch_bounds__(256, FM_OCC) fuse_map_kernel(FuseMapArgs a) {
         }
         __syncthreads();
         {   // next block's operands on their way while this one is multiplied (the last iteration re-reads its own)
-            const int64_t tn = t + tstep < a.ntiles ? t + tstep : t;
+            const int64_t tn = t + tstep < tend ? t + tstep : t;
             load_sources(tn, sreg);
             load_x1(tn, xb);
             SEGF_LOADS_ISSUED();
