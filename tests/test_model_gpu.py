@@ -330,10 +330,16 @@ def test_full_size_fp32_and_bf16_vs_oracle(cfg):
             del model, lo, loss
             torch.cuda.empty_cache()
             continue
-        # cfg3: PPM's scale-1 branch feeds a BatchNorm with B samples per channel (quirk Q16), whose Jacobian is
-        # ill-conditioned; its neighbours' fp32 gradients move at the 1e-2 level with the summation order
-        # measured on the MI355X (fp32 / bf16): cfg2 2.0e-3 / 3.1e-2, cfg3 1.4e-2 / 1.4e-1, cfg4 4.4e-4 / 7.5e-3, cfg5 6.8e-3 / 2.6e-1; ~2x margin
-        assert worst <= {'cfg2': (5e-3, 8e-2), 'cfg3': (3e-2, 0.3), 'cfg4': (2e-3, 3e-2), 'cfg5': (1.5e-2, 0.5)}[cfg][0 if fp32 else 1], (wname, worst)
+        # Bars = the worst tensor of tools/grad_parity_fullsize.py on the MI355X (profiles/r03b_grad_parity_fullsize.txt) x ~1.5, named:
+        #   fp32: cfg2 2.0e-3; cfg3 1.4e-2 = decode_head.ppm.bottleneck.0.weight (PPM's scale-1 branch feeds a BatchNorm with B samples
+        #         per channel, quirk Q16, whose Jacobian is ill-conditioned: its neighbours move at the 1e-2 level with the summation
+        #         order; the next tensor is at 2.7e-3); cfg4 4.4e-4; cfg5 6.8e-3 = the same tensor
+        #   bf16: cfg2 3.1e-2; cfg3 0.135 = decode_head.ppm.stages.1.1.0.weight (the 2 x 2 pooled branch: BatchNorm over 16 values
+        #         per channel), then 0.134 backbone.downsample_layers.1.0.weight, median tensor 0.048 (ppm.stages.0.* = 0.29 is the
+        #         skipped scale-1 branch); cfg4 7.5e-3; cfg5 0.275 = backbone.stages.3.1.grn.gamma (a [1,1,1,6144] GRN scale whose
+        #         gradient is a sum of 400 products of bf16 activations), then 0.25 = the pwconv weights of stages 1 / 2, median 0.065
+        #         (ppm.stages.0.* = 0.51 skipped)
+        assert worst <= {'cfg2': (5e-3, 6e-2), 'cfg3': (3e-2, 0.2), 'cfg4': (2e-3, 2e-2), 'cfg5': (1.5e-2, 0.4)}[cfg][0 if fp32 else 1], (wname, worst)
         del model, lo, loss
         torch.cuda.empty_cache()
 
