@@ -1575,6 +1575,10 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
 }
 
 struct GemmPro { const float* scale; const float* shift; int64_t rpg; int64_t ld; int act; };
+// gemm8.hip: the eight-phase 256 x 256 tile (LDS-DMA staging, counted waits) for forward-type products / implicit 3x3 convolutions
+int gemm8_supported(int conv, int64_t M, int64_t N, int64_t K, int cC);
+int gemm8_launch(int conv, int fp8, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                 int64_t ldc, int cH, int cW, int cC, int csign, const float* f8_sa, const float* f8_sb, const float* bias, hipStream_t st);
 static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                      int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
                      const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream,
@@ -1839,6 +1843,8 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     a.c_vec = ((uintptr_t)y % (4 * csz) == 0) && ((ldy * csz) % (4 * csz) == 0);
     a.c_vec16 = ((uintptr_t)y % 16 == 0) && ((ldy * csz) % 16 == 0);
     const bool f32out = y_dt == SEGF_F32 || a.ws;
+    if (layout == 0 && !f32out && gemm8_supported(1, a.M, a.N, a.K, a.cC))
+        return gemm8_launch(1, 0, a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, nullptr, nullptr, bias, st);
     if (gemm_use_big(layout, a.M, a.N, a.K)) {
         dim3 gridb((unsigned)cdiv64(a.N, GG_B), (unsigned)cdiv64(a.M, GG_B), (unsigned)split_k);
         if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
@@ -1906,6 +1912,8 @@ extern "C" int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout
     a.C = y; a.ldc = ldy;
     a.kchunk = cdiv64(a.K, GB_BK) * GB_BK; a.ws = nullptr;
     a.c_vec = 1; a.c_vec16 = 1;
+    if (gemm8_supported(1, a.M, a.N, a.K, a.cC))
+        return gemm8_launch(1, mode == 0 ? 1 : 2, a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, sx, sw, nullptr, st);
     dim3 gridb((unsigned)cdiv64(a.N, GG_B), (unsigned)cdiv64(a.M, GG_B), 1);
     if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
     if (mode == 0) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, true, false, 0, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);
