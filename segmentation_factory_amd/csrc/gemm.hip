@@ -1579,6 +1579,9 @@ struct GemmPro { const float* scale; const float* shift; int64_t rpg; int64_t ld
 int gemm8_supported(int conv, int64_t M, int64_t N, int64_t K, int cC);
 int gemm8_launch(int conv, int fp8, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                  int64_t ldc, int cH, int cW, int cC, int csign, const float* f8_sa, const float* f8_sb, const float* bias, hipStream_t st);
+int gemm8t_supported(int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC);
+int gemm8t_launch(int64_t M, int64_t N, int64_t K, int64_t kchunk, int split_k, const void* dy, int64_t lda, const void* x, int64_t ldb,
+                  float* C, int64_t ldc, float* ws, int cH, int cW, int cC, hipStream_t st);
 static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                      int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
                      const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream,
@@ -1845,6 +1848,11 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     const bool f32out = y_dt == SEGF_F32 || a.ws;
     if (layout == 0 && !f32out && gemm8_supported(1, a.M, a.N, a.K, a.cC))
         return gemm8_launch(1, 0, a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, nullptr, nullptr, bias, st);
+    if (layout == 2 && y_dt == SEGF_F32 && gemm_use_big(2, a.M, a.N, a.K) && gemm8t_supported(a.M, a.N, a.K, a.kchunk, a.cC)) {
+        const int rc8 = gemm8t_launch(a.M, a.N, a.K, a.kchunk, split_k, a.A, a.lda, a.B, a.ldb, (float*)y, ldy, a.ws, H, W, a.cC, st);
+        if (rc8) return rc8;
+        goto reduce3;
+    }
     if (gemm_use_big(layout, a.M, a.N, a.K)) {
         dim3 gridb((unsigned)cdiv64(a.N, GG_B), (unsigned)cdiv64(a.M, GG_B), (unsigned)split_k);
         if (gridb.y > 65535u) return SEGF_ERR_SHAPE;

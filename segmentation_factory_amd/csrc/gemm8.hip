@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     // half: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  K tile index clamped to the last one (dummy loads keep the counted waits uniform)
     auto stage = [&](int kt, int half) {
         const int ktc = kt < nk ? kt : nk - 1;
-        unsigned char* dst = lds_half(ktc & 1, half) + (16 * wave) * 128;
+        unsigned char* dst = lds_half(kt & 1, half) + (16 * wave) * 128;     // (kt, not ktc: a dummy load lands where its tile WOULD go, never on live data)
         if (half >= 2) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         __builtin_amdgcn_s_setprio(0);
     };
 #define G8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define G8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define G8_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
     // ---- prologue: K tiles 0 and 1 in the steady-state issue order A0, B1, B0, A1 | A0, B1 (B0[1], A1[1] follow in phases 1, 2)
     stage(0, 0); stage(0, 3); stage(0, 2); stage(0, 1); stage(1, 0); stage(1, 3);
@@ -233,6 +233,191 @@ int gemm8_launch(int conv, int fp8, int64_t M, int64_t N, int64_t K, const void*
     if (conv) { if (fp8 == 0) G8_GO(true, 0); else if (fp8 == 1) G8_GO(true, 1); else G8_GO(true, 2); }
     else { if (fp8 == 0) G8_GO(false, 0); else if (fp8 == 1) G8_GO(false, 1); else G8_GO(false, 2); }
 #undef G8_GO
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
+// =====================================================================================================================================
+// The same eight-phase schedule for the WEIGHT GRADIENT of the 3x3 convolution (both operands reduction-major):
+//   dW[co][tap * Cin + ci] = sum_pix dy[pix][co] * x[pix + off(tap)][ci]        (K = pixels; split over grid.z, fp32 partials)
+// Half-tiles are [64 pixels][128 columns] (256-byte rows): A0 / A1 = dy columns co, B0 / B1 = x columns (tap, ci) -- Cin % 128 == 0,
+// so a half-tile lies inside ONE tap and the gather is a workgroup-constant pixel offset plus a per-row border test.  One LDS-DMA
+// instruction moves 4 rows x 256 B; the reduction-major XOR swizzle of gemm.hip (rm_swz) goes on the source address; fragments
+// come out of the image through ds_read_b64_tr_b16 (tokens become the contiguous k of the MFMA operands).
+__device__ __forceinline__ int g8_rm_swz(int krow) { return 2 * ((krow & 3) + 4 * ((krow >> 3) & 1)); }
+// Inline asm, not the builtin: hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every __builtin_amdgcn_ds_read_tr16_b64 while an
+// LDS-DMA is in flight (it cannot tell that the read does not alias the pending LDS writes; plain ds_read_b128 loads are
+// disambiguated), which drains the three half-tiles the schedule keeps in flight.  The consumer side is ordered by hand:
+// s_waitcnt lgkmcnt(0) + sched_barrier(0) before the MFMAs (G8_LGKM0).
+__device__ __forceinline__ g8_bf16x8 g8_frag_tr(const unsigned char* tile, int cb, int s, int lane) {
+    typedef __attribute__((ext_vector_type(4))) short g8_s16x4;
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int u = (cb >> 2) + p;
+    const int chunk = u >> 1, half = u & 1;
+    const int k0 = 32 * s + 8 * g + q, k1 = k0 + 4;
+    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + k0 * 256 + ((chunk ^ g8_rm_swz(k0)) << 4) + half * 8);
+    const uint32_t a1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + k1 * 256 + ((chunk ^ g8_rm_swz(k1)) << 4) + half * 8);
+    g8_s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+    return __builtin_bit_cast(g8_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+struct Gemm8TArgs {
+    const bf16_t* A; const bf16_t* B; float* C;      // A = dy [P][lda], B = x [P][ldb], C = dW fp32 [M][ldc] or split-K slabs
+    int64_t M, N, K, lda, ldb, ldc, kchunk;
+    int cH, cW, cC;
+    float* ws;                                        // [z][M][N] when gridDim.z > 1
+};
+__global__ void __launch_bounds__(512) gemm8t_kernel(Gemm8TArgs a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G8_BUF];       // [buf][A0, A1, B0, B1][64 k rows][256 B]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int64_t m0 = (int64_t)blockIdx.y * 256, n0 = (int64_t)blockIdx.x * 256;
+    const int64_t kbeg = (int64_t)blockIdx.z * a.kchunk;
+    const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const int nk = (int)((kend - kbeg) / 64);
+    // staging: rows 8 wave + 4 i + (lane >> 4) of every half-tile, physical chunk lane & 15 = logical chunk ^ rm_swz(row)
+    const int srow = 8 * wave + (lane >> 4);
+    int lch[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lch[i] = (lane & 15) ^ g8_rm_swz(srow + 4 * i);
+    // x gather: tap of each B half (workgroup constant), pixel coordinates of this lane's two rows at the current K tile
+    int tdy[2], tdx[2], tci[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t n = n0 + 128 * h;
+        const int tap = (int)(n / a.cC);
+        tdy[h] = tap / 3 - 1; tdx[h] = tap % 3 - 1; tci[h] = (int)(n - (int64_t)tap * a.cC);
+    }
+    auto lds_half = [&](int buf, int half) -> unsigned char* { return smem + buf * G8_BUF + half * G8_HALF; };
+    // Pixel coordinates of this lane's two rows for the NEXT K tile of each B half (the tiles of a half are staged in increasing order:
+    // 0, 1, 2, ...), advanced by 64 pixels per tile without a division
+    int py[2][2], px[2][2];
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t t = kbeg + srow + 4 * i;
+            const int x = (int)(t % a.cW), y = (int)((t / a.cW) % a.cH);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { py[h][i] = y; px[h][i] = x; }
+        }
+    }
+    const int adv_q = 64 / a.cW, adv_r = 64 % a.cW;
+    auto stage = [&](int kt, int half) {
+        const int ktc = kt < nk ? kt : nk - 1;
+        unsigned char* dst = lds_half(kt & 1, half) + (8 * wave) * 256;       // (kt, not ktc: a dummy load must not land on the last tile's live data)
+        const int64_t t0 = kbeg + (int64_t)ktc * 64 + srow;
+        if (half < 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.A + (t0 + 4 * i) * a.lda + m0 + 128 * half + 8 * lch[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        } else {
+            const int h = half - 2;
+            const bool real = kt < nk;                                  // wave-uniform: past the end only a dummy load (zero page) is issued
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = py[h][i] + tdy[h], xx = px[h][i] + tdx[h];
+                const bool ok = real && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
+                const bf16_t* p = a.B + (t0 + 4 * i + (int64_t)tdy[h] * a.cW + tdx[h]) * a.ldb + tci[h] + 8 * lch[i];
+                const void* src = ok ? (const void*)p : (const void*)g8_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+                // advance to the next K tile of this half
+                int nx = px[h][i] + adv_r, ny = py[h][i] + adv_q;
+                if (nx >= a.cW) { nx -= a.cW; ++ny; }
+                while (ny >= a.cH) ny -= a.cH;
+                px[h][i] = nx; py[h][i] = ny;
+            }
+        }
+    };
+    g8_f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = g8_f32x4{0.f, 0.f, 0.f, 0.f};
+    g8_bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto load_a = [&](int buf, int mq) {
+        const unsigned char* h = lds_half(buf, mq);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fa[t][s] = g8_frag_tr(h, 64 * wm + 16 * t, s, lane);
+    };
+    auto load_b = [&](int buf, int nq, g8_bf16x8 (&fb)[2][2]) {
+        const unsigned char* h = lds_half(buf, 2 + nq);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) fb[u][s] = g8_frag_tr(h, 32 * wn + 16 * u, s, lane);
+    };
+    auto mma = [&](int mq, int nq, const g8_bf16x8 (&fb)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[2 * nq + u][4 * mq + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u][s], fa[t][s], acc[2 * nq + u][4 * mq + t], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    stage(0, 0); stage(0, 3); stage(0, 2); stage(0, 1); stage(1, 0); stage(1, 3);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    G8_BAR();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int b = kt & 1;
+        load_a(b, 0); load_b(b, 0, fb0);
+        stage(kt + 1, 2);
+        G8_BAR(); G8_LGKM0();
+        mma(0, 0, fb0);
+        G8_BAR();
+        load_b(b, 1, fb1);
+        stage(kt + 1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        G8_BAR(); G8_LGKM0();
+        mma(0, 1, fb1);
+        G8_BAR();
+        load_a(b, 1);
+        stage(kt + 2, 0);
+        G8_BAR(); G8_LGKM0();
+        mma(1, 1, fb1);
+        G8_BAR();
+        stage(kt + 2, 3);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        G8_BAR();
+        mma(1, 0, fb0);
+        G8_BAR();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int fi = lane & 15, fg = lane >> 4;
+    float* out = a.ws ? a.ws + (int64_t)blockIdx.z * a.M * a.N : a.C;
+    const int64_t ldo = a.ws ? a.N : a.ldc;
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t n = n0 + 128 * nq + 32 * wn + 16 * u + 4 * fg;
+#pragma unroll
+            for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int64_t m = m0 + 128 * mq + 64 * wm + 16 * t + fi;
+                    *reinterpret_cast<g8_f32x4*>(out + m * ldo + n) = acc[2 * nq + u][4 * mq + t];
+                }
+        }
+}
+
+int gemm8t_supported(int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC) {
+    if (getenv("SEGFAC_NO_GEMM8") || getenv("SEGFAC_NO_GEMM8T")) return 0;
+    if (M % 256 || N % 256 || K % 64 || kchunk % 64 || kchunk < 256 || cC % 128) return 0;
+    return 1;
+}
+int gemm8t_launch(int64_t M, int64_t N, int64_t K, int64_t kchunk, int split_k, const void* dy, int64_t lda, const void* x, int64_t ldb,
+                  float* C, int64_t ldc, float* ws, int cH, int cW, int cC, hipStream_t st) {
+    if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)C) % 16 || (lda * 2) % 16 || (ldb * 2) % 16 || ldc % 4) return SEGF_ERR_SHAPE;
+    Gemm8TArgs a{(const bf16_t*)dy, (const bf16_t*)x, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, split_k > 1 ? ws : nullptr};
+    hipLaunchKernelGGL(gemm8t_kernel, dim3((unsigned)(N / 256), (unsigned)(M / 256), (unsigned)split_k), dim3(512), 0, st, a);
     SEGF_CHECK_LAUNCH();
     return 0;
 }

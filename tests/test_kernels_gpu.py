@@ -666,7 +666,8 @@ def test_dwconv7x7(dtype, geom):
 @pytest.mark.parametrize('cfg', [(2, 8, 8, 16, 24), (1, 5, 7, 64, 8), (2, 16, 12, 128, 136), (1, 1, 1, 8, 8),
                                  (3, 128, 128, 136, 264),       # runs on the 256x256 tile kernel in all three modes
                                  (4, 96, 128, 256, 512),        # forward and data gradient on the eight-phase kernel (gemm8.hip): whole
-                                 (2, 128, 128, 512, 256)])      # 256^2 tiles, channels % 128 == 0; borders on all four sides of every image
+                                 (2, 128, 128, 512, 256),       # 256^2 tiles, channels % 128 == 0; borders on all four sides of every image
+                                 (8, 96, 128, 256, 256)])       # >= 65536 pixels: the weight gradient on the eight-phase kernel too (28 K slices)
 def test_conv3x3_implicit_gemm(cfg):
     """bf16 implicit-GEMM 3x3 conv (forward, data gradient, weight gradient) vs F.conv2d on bf16-rounded inputs; the input
     is a column slice of a wider buffer as in the UPerNet concat."""
