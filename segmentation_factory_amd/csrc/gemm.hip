@@ -1575,13 +1575,12 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
 }
 
 struct GemmPro { const float* scale; const float* shift; int64_t rpg; int64_t ld; int act; };
-// gemm8.hip: the eight-phase 256 x 256 tile (LDS-DMA staging, counted waits) for forward-type products / implicit 3x3 convolutions
-int gemm8_supported(int conv, int64_t M, int64_t N, int64_t K, int cC);
-int gemm8_launch(int conv, int fp8, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
-                 int64_t ldc, int cH, int cW, int cC, int csign, const float* f8_sa, const float* f8_sb, const float* bias, hipStream_t st);
-int gemm8t_supported(int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC);
-int gemm8t_launch(int64_t M, int64_t N, int64_t K, int64_t kchunk, int split_k, const void* dy, int64_t lda, const void* x, int64_t ldb,
-                  float* C, int64_t ldc, float* ws, int cH, int cW, int cC, hipStream_t st);
+// gemm8.hip: the eight-phase 256 x 256 tile (LDS-DMA staging, counted waits).  kind 0 / 1 / 2 = layout 0 / 1 / 2; conv = implicit 3x3
+int gemm8_supported(int kind, int conv, int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC);
+int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, int64_t kchunk, int split_k, const void* A, int64_t lda,
+                 const void* B, int64_t ldb, void* C, int64_t ldc, int cH, int cW, int cC, int csign, const float* f8_sa,
+                 const float* f8_sb, const float* bias, const void* residual, int64_t ldr, const float* rscale, int64_t rpg, float* ws,
+                 hipStream_t st);
 static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                      int64_t ldb, void* C, int c_dt, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
                      const float* rscale, int64_t rows_per_group, int split_k, float* ws, float* colsum, void* stream,
@@ -1734,6 +1733,23 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                 if (ok) { SEGF_CHECK_LAUNCH(); goto reduce; }
             }
         }
+        // the eight-phase tile (gemm8.hip) for whole 256 x 256 tiles with plain epilogues -- OPT-IN (SEGFAC_GEMM8_LINEAR=1): correct
+        // (tests), but on the nn.Linear shapes of the BASELINE models (K = 6 .. 48 tiles of 64) its 12-load prologue, the drain
+        // at the end and the direct 8-byte stores of its epilogue eat what the schedule gains: cfg3 247 -> 242, cfg4 114.2 -> 113.5,
+        // cfg5 76.5 -> 76.1 img/s with it; the convolutions (K = 108 .. 648 tiles) are where it pays
+        if (!pro && a.use_tr && !colsum && (a.a_vec & 1) && (a.b_vec & 1) && gemm_use_big(layout, M, N, K) && getenv("SEGFAC_GEMM8_LINEAR")) {
+            const bool f32o8 = c_dt == SEGF_F32 || a.ws;
+            if (layout != 2 && !f32o8 && split_k == 1 && gemm8_supported(layout, 0, M, N, K, a.kchunk, 0) && (!residual || a.r_vec)) {
+                const int rc8 = gemm8_launch(layout, 0, 0, M, N, K, a.kchunk, 1, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, nullptr, nullptr, bias, residual,
+                                             ldr, rscale, a.rpg, nullptr, st);
+                if (rc8 != SEGF_ERR_SHAPE) return rc8;
+            }
+            if (layout == 2 && c_dt == SEGF_F32 && !bias && !residual && gemm8_supported(2, 0, M, N, K, a.kchunk, 0)) {
+                const int rc8 = gemm8_launch(2, 0, 0, M, N, K, a.kchunk, split_k, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, nullptr, nullptr, nullptr,
+                                             nullptr, 0, nullptr, 1, a.ws, st);
+                if (rc8 != SEGF_ERR_SHAPE) { if (rc8) return rc8; goto reduce; }
+            }
+        }
         if ((gemm_use_big(layout, M, N, K) || pro) && a.use_tr) {
             dim3 gridb((unsigned)cdiv64(N, GG_B), (unsigned)cdiv64(M, GG_B), (unsigned)split_k);
             if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
@@ -1846,10 +1862,12 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     a.c_vec = ((uintptr_t)y % (4 * csz) == 0) && ((ldy * csz) % (4 * csz) == 0);
     a.c_vec16 = ((uintptr_t)y % 16 == 0) && ((ldy * csz) % 16 == 0);
     const bool f32out = y_dt == SEGF_F32 || a.ws;
-    if (layout == 0 && !f32out && gemm8_supported(1, a.M, a.N, a.K, a.cC))
-        return gemm8_launch(1, 0, a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, nullptr, nullptr, bias, st);
-    if (layout == 2 && y_dt == SEGF_F32 && gemm_use_big(2, a.M, a.N, a.K) && gemm8t_supported(a.M, a.N, a.K, a.kchunk, a.cC)) {
-        const int rc8 = gemm8t_launch(a.M, a.N, a.K, a.kchunk, split_k, a.A, a.lda, a.B, a.ldb, (float*)y, ldy, a.ws, H, W, a.cC, st);
+    if (layout == 0 && !f32out && gemm8_supported(0, 1, a.M, a.N, a.K, a.kchunk, a.cC))
+        return gemm8_launch(0, 1, 0, a.M, a.N, a.K, a.kchunk, 1, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, nullptr, nullptr, bias,
+                            nullptr, 0, nullptr, 1, nullptr, st);
+    if (layout == 2 && y_dt == SEGF_F32 && gemm_use_big(2, a.M, a.N, a.K) && gemm8_supported(2, 1, a.M, a.N, a.K, a.kchunk, a.cC)) {
+        const int rc8 = gemm8_launch(2, 1, 0, a.M, a.N, a.K, a.kchunk, split_k, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, 1, nullptr, nullptr,
+                                     nullptr, nullptr, 0, nullptr, 1, a.ws, st);
         if (rc8) return rc8;
         goto reduce3;
     }
@@ -1920,8 +1938,9 @@ extern "C" int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout
     a.C = y; a.ldc = ldy;
     a.kchunk = cdiv64(a.K, GB_BK) * GB_BK; a.ws = nullptr;
     a.c_vec = 1; a.c_vec16 = 1;
-    if (gemm8_supported(1, a.M, a.N, a.K, a.cC))
-        return gemm8_launch(1, mode == 0 ? 1 : 2, a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, sx, sw, nullptr, st);
+    if (gemm8_supported(0, 1, a.M, a.N, a.K, a.kchunk, a.cC))
+        return gemm8_launch(0, 1, mode == 0 ? 1 : 2, a.M, a.N, a.K, a.kchunk, 1, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, sx, sw,
+                            nullptr, nullptr, 0, nullptr, 1, nullptr, st);
     dim3 gridb((unsigned)cdiv64(a.N, GG_B), (unsigned)cdiv64(a.M, GG_B), 1);
     if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
     if (mode == 0) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, true, false, 0, false, 1>), gridb, dim3(GG_THREADS), 0, st, a);

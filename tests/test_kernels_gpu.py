@@ -811,6 +811,50 @@ def test_gemm_big_tile_variant(hipmod, layout):
         assert err <= 1.2e-2 * full.abs().max().item()       # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize('layout', [0, 1, 2])
+def test_gemm_eight_phase_tile(hipmod, layout):
+    """gemm8.hip (256 x 256 tile in eight phases: LDS-DMA staging, counted waits) on whole-tile shapes of the ConvNeXt / MiT linears:
+    layout 0 with bias + residual + per-sample DropPath scale, layout 1 with a residual, layout 2 with split-K, against a float64
+    product of the bf16-rounded operands and against the two-phase 256-tile kernel (the default for plain products)."""
+    g = torch.Generator().manual_seed(90 + layout)
+    if layout == 2:
+        M, N, K = 768, 3072, 65536 + 64 * 5
+        sk = hipmod.pick_splitk(M, N, K)
+    else:
+        M, N, K, sk = 256 * 50, 256 * 4, 64 * 6 if layout == 0 else 64 * 12, 1
+    a = torch.randn((K, M) if layout == 2 else (M, K), generator=g)
+    b = torch.randn((N, K) if layout == 0 else (K, N), generator=g)
+    aq, bq = a.bfloat16().double(), b.bfloat16().double()
+    A = aq.t() if layout == 2 else aq
+    Bm = bq.t() if layout == 0 else bq
+    ref = A @ Bm
+    ad, bd = a.bfloat16().cuda(), b.bfloat16().cuda()
+
+    def run():
+        if layout == 2:
+            return hipmod.gemm(2, ad, bd, M, N, K, out_dtype=torch.float32, split_k=sk)
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda() if layout == 0 else None
+        res = torch.randn(M, N, generator=torch.Generator().manual_seed(6)).bfloat16().cuda()
+        rs = (torch.rand(50, generator=torch.Generator().manual_seed(7)) + 0.5).cuda() if layout == 0 else None
+        return hipmod.gemm(layout, ad, bd, M, N, K, bias=bias, residual=res, rscale=rs, rows_per_group=256 if layout == 0 else 1)
+    os.environ['SEGFAC_GEMM8_LINEAR'] = '1'              # opt-in for plain products (the convolutions take the kernel by default)
+    try:
+        out = run()
+    finally:
+        os.environ.pop('SEGFAC_GEMM8_LINEAR', None)
+    old = run()
+    if layout == 2:
+        assert (out.double().cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+        assert (out - old).abs().max().item() <= 1e-3 * old.abs().max().item()
+    else:
+        bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).double() if layout == 0 else 0.0
+        res = torch.randn(M, N, generator=torch.Generator().manual_seed(6)).bfloat16().double()
+        rs = (torch.rand(50, generator=torch.Generator().manual_seed(7)) + 0.5).double().repeat_interleave(256)[:, None] if layout == 0 else 1.0
+        full = res + rs * (ref + bias)
+        assert (out.double().cpu() - full).abs().max().item() <= 1.2e-2 * full.abs().max().item()
+        assert (out.float() - old.float()).abs().max().item() <= 2 ** -7 * old.float().abs().max().item()
+
+
 def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
     """[M x 32] -> 768 with M >= 65536 (the folded head's stage-1 projection): the whole-row form (weights in LDS, a wave writes
     complete 1536-byte rows) against fp64 and against the column-chunk form (switch): identical products, identical rounding."""
