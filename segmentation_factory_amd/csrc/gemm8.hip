@@ -23,7 +23,9 @@
 //     == 0: one wave-uniform pixel offset per K tile plus a per-lane border test); the weight gradient gathers the RM operand B (a
 //     half-tile of 128 columns lies inside one tap, channels % 128 == 0; the pixel coordinates of a lane's rows advance by 64 per K
 //     tile without a division).  Taps outside the image read a ZERO PAGE (LDS-DMA cannot write zeros itself);
-//   * fp8 operands (KC x KC only) as in gemm.hip's FP8 mode: 2-byte units along K, two v_mfma_f32_16x16x32_fp8 per 16-byte fragment.
+//   * fp8 operands (KC x KC only): 2-byte units along K as in gemm.hip's FP8 mode (the loaders and LDS images move bytes), but the two
+//     16-byte fragments of a row feed ONE v_mfma_scale_f32_16x16x128_f8f6f4 (block scales 2^0): the non-scaled fp8 MFMA runs at the
+//     bf16 rate, the block-scaled one at twice that.
 // Measured on the MI355X (3072 -> 768 3x3 @ 128^2, batch 32 = 22.3 TFLOP per direction): forward 28.3 -> 20.4 ms (787 -> 1094
 // TFLOP/s), data gradient 28.6 -> 21.2, weight gradient 25.8 -> 23.3 (957 TFLOP/s); fp8 forward 18.0 -> 14.5 ms (1534 TFLOP/s).
 #include <stdlib.h>
@@ -209,28 +211,35 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     };
     auto mma = [&](int mq, int nq, const g8_bf16x8 (&fb)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (FP8 == 0) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[2 * nq + u][4 * mq + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u][s], fa[t][s], acc[2 * nq + u][4 * mq + t], 0, 0, 0);
+        } else {
+            // fp8: the two 16-byte fragments of a row (K sub-steps 0 and 1 = 32 of its 128 values per lane group) are ONE operand of the
+            // block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with all block scales 2^0 (twice the bf16 rate at 4x the K; the non-scaled
+            // v_mfma_f32_16x16x32_fp8 runs at the bf16 rate).  A and B split their rows the same way, so the k pairing is consistent.
+            // Format codes: 0 = e4m3, 1 = e5m2; the "swapped" product puts the weight side first.
+            typedef int g8_i32x8 __attribute__((ext_vector_type(8)));
+            typedef int g8_i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const g8_i32x4 w0 = __builtin_bit_cast(g8_i32x4, fb[u][0]), w1 = __builtin_bit_cast(g8_i32x4, fb[u][1]);
+                const g8_i32x8 wv = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    g8_f32x4 c = acc[2 * nq + u][4 * mq + t];
-                    if constexpr (FP8 == 0) {
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u][s], fa[t][s], c, 0, 0, 0);
-                    } else {
-                        typedef long g8_l2 __attribute__((ext_vector_type(2)));
-                        const g8_l2 wb = __builtin_bit_cast(g8_l2, fb[u][s]), xa = __builtin_bit_cast(g8_l2, fa[t][s]);
-                        if constexpr (FP8 == 1) {
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[0], xa[0], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wb[1], xa[1], c, 0, 0, 0);
-                        } else {
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(wb[0], xa[0], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(wb[1], xa[1], c, 0, 0, 0);
-                        }
-                    }
-                    acc[2 * nq + u][4 * mq + t] = c;
+                    const g8_i32x4 x0 = __builtin_bit_cast(g8_i32x4, fa[t][0]), x1 = __builtin_bit_cast(g8_i32x4, fa[t][1]);
+                    const g8_i32x8 xv = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    acc[2 * nq + u][4 * mq + t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        wv, xv, acc[2 * nq + u][4 * mq + t], 0 /* weights: e4m3 */, FP8 == 2 ? 1 : 0 /* tokens: e5m2 gradient or e4m3 */,
+                        0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
                 }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
