@@ -79,13 +79,18 @@ int segf_gemm_fp8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, c
  * 1 = e5m2 (gradients, FMAX 57344); amax_ws = 4 bytes of scratch; all on the stream, no host read (graph-safe).
  * segf_conv3x3_fp8: mode 0  y[pix][co] = sx * sw[co] * sum_{tap,ci} xq[pix+off(tap)][ci] wq[co][tap*Cin+ci]   (xq e4m3, wq e4m3 rows)
  *                   mode 1  dx[pix][ci] = sx * sw[ci] * sum_{tap,co} gq[pix-off(tap)][co] wq[ci][tap*Cout+co]  (gq e5m2, wq e4m3 rows)
- * bf16 output; Cin, Cout multiples of 16; ldx / ldw in bytes = elements, multiples of 16.  The weight gradient stays bf16
- * (segf_conv3x3 mode 2). */
+ * bf16 output; Cin, Cout multiples of 16; ldx / ldw in bytes = elements, multiples of 16. */
 int segf_quant_tensor_fp8(int dt, int fmt, int64_t rows, int cols, const void* x, int64_t ldx, void* q, int64_t ldq, float* scale,
                           void* amax_ws, void* stream);
 int segf_conv3x3_fp8_supported(int mode, int B, int H, int W, int Cin, int Cout);
 int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout, const void* xq, int64_t ldx, const float* sx,
                      const void* wq, int64_t ldw, const float* sw, void* y, int64_t ldy, void* stream);
+/* ... and the weight gradient on the SAME quantised tensors: dW[co][tap*Cin+ci] = sg * sx * sum_pix gq[pix][co] xq[pix+off(tap)][ci]
+ * (gq: the e5m2 gradient of the data-gradient call, xq: the e4m3 input of the forward call; strides in bytes), fp32 [Cout][9*Cin];
+ * split_k > 1 needs ws >= split_k * Cout * 9 * Cin floats.  Cin % 128 == 0, Cout % 256 == 0, B*H*W >= 65536. */
+int segf_conv3x3_fp8_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+int segf_conv3x3_fp8_wgrad(int B, int H, int W, int Cin, int Cout, const void* xq, int64_t ldx, const float* sx, const void* gq,
+                           int64_t ldg, const float* sg, float* dw, int64_t lddw, int split_k, float* ws, void* stream);
 
 /* ---- stream ordering for the data-parallel exchange (train_gpu.py:233-236: DistributedDataParallel overlaps the gradient
  * all-reduce with backward through per-bucket hooks).  segf_event_record(.., external=1) during a stream capture adds an

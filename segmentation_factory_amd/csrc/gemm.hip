@@ -1948,3 +1948,34 @@ extern "C" int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+
+// mode 2 on fp8 operands: dW[co][tap*Cin+ci] = sg * sx * sum_pix gq[pix][co] xq[pix+off(tap)][ci]   (gq e5m2, xq e4m3: the tensors the
+// forward and the data gradient already quantised; one byte per element, row strides in bytes).  fp32 out [Cout][9*Cin]; split over K
+// (pixels) into fp32 slabs: ws >= split_k * Cout * 9 * Cin floats when split_k > 1 (segf_gemm_pick_splitk(Cout, 9 * Cin, B*H*W)).
+extern "C" int segf_conv3x3_fp8_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
+    if (getenv("SEGFAC_NO_FP8_CONV") || getenv("SEGFAC_NO_FP8_WGRAD") || B <= 0 || H <= 0 || W <= 0) return 0;
+    const int64_t P = (int64_t)B * H * W, M = Cout, N = 9 * (int64_t)Cin;
+    if (!gemm_use_big(2, M, N, P)) return 0;
+    return gemm8_supported(3, 1, M, N, P, 512, Cin);
+}
+extern "C" int segf_conv3x3_fp8_wgrad(int B, int H, int W, int Cin, int Cout, const void* xq, int64_t ldx, const float* sx, const void* gq,
+                                      int64_t ldg, const float* sg, float* dw, int64_t lddw, int split_k, float* ws, void* stream) {
+    if (!segf_conv3x3_fp8_wgrad_supported(B, H, W, Cin, Cout) || !xq || !gq || !sx || !sg || !dw) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t P = (int64_t)B * H * W, M = Cout, N = 9 * (int64_t)Cin;
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && !ws) return SEGF_ERR_WORKSPACE;
+    int64_t kchunk = cdiv64(cdiv64(P, split_k), 128) * 128;
+    split_k = (int)cdiv64(P, kchunk);
+    if (!gemm8_supported(3, 1, M, N, P, kchunk, Cin)) return SEGF_ERR_SHAPE;
+    const int rc = gemm8_launch(3, 1, 2, M, N, P, kchunk, split_k, gq, ldg, xq, ldx, dw, lddw, H, W, Cin, 1, sg, sx, nullptr, nullptr, 0, nullptr,
+                                1, ws, st);
+    if (rc) return rc;
+    if (split_k > 1) {
+        const unsigned blocks = (unsigned)cdiv64(M * N, 16);
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, dw, lddw, blocks, (const float*)nullptr,
+                           (float*)nullptr, (int64_t)0);
+        SEGF_CHECK_LAUNCH();
+    }
+    return 0;
+}

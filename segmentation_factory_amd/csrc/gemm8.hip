@@ -76,12 +76,34 @@ __device__ __forceinline__ g8_bf16x8 g8_frag_tr(const unsigned char* tile, int c
     return __builtin_bit_cast(g8_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// ALAY / BLAY: 0 = KC, 1 = RM.  CONV gathers A when ALAY == 0 (forward / data gradient), B when both are RM (weight gradient).
+// fp8 RM half-tile [128 k][128 B] (one byte per element): lane (i, g) of the 16-column block at cb receives T[k = 32 g + 16 s + j][cb + i],
+// j = 0..15, as two ds_read_b64_tr_b8 (probed on the MI355X, tools/probe/tr8_probe.hip: lane 2 q + p of a 16-lane group supplies the
+// address of row q, bytes 8 p .. 8 p + 7 of an 8-row x 16-byte block; lane i receives column i of the 8 rows, row q in byte q).
+// Swizzle: 16-byte chunk c of row r sits at chunk c ^ f(r), f(r) = ((r >> 1) & 3) | (((r >> 5) & 1) << 2): the 8 rows of a read and
+// the two 16-lane groups of a 32-lane half land on 16 different 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int g8_rm8_swz(int r) { return ((r >> 1) & 3) | (((r >> 5) & 1) << 2); }
+__device__ __forceinline__ g8_bf16x8 g8_frag_tr8(const unsigned char* tile, int cb, int s, int lane) {
+    typedef int g8_v2i __attribute__((ext_vector_type(2)));
+    typedef int g8_v4i __attribute__((ext_vector_type(4)));
+    const int g = lane >> 4, q = (lane & 15) >> 1, p = lane & 1, c = cb >> 4;
+    const int r0 = 32 * g + 16 * s + q, r1 = r0 + 8;
+    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + r0 * 128 + ((c ^ g8_rm8_swz(r0)) << 4) + 8 * p);
+    const uint32_t a1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + r1 * 128 + ((c ^ g8_rm8_swz(r1)) << 4) + 8 * p);
+    g8_v2i lo, hi;
+    asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(hi) : "v"(a1));
+    return __builtin_bit_cast(g8_bf16x8, g8_v4i{lo[0], lo[1], hi[0], hi[1]});
+}
+
+// ALAY / BLAY: 0 = KC, 1 = RM (bf16), 2 = RM fp8 (K tile = 128 rows).  CONV gathers A when ALAY == 0 (forward / data gradient), B when
+// both are RM (weight gradient).
 template <int ALAY, int BLAY, bool CONV, int FP8, typename OutT>
 __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
-    static_assert(FP8 == 0 || (ALAY == 0 && BLAY == 0), "fp8: K-contiguous operands");
-    static_assert(!CONV || ALAY == 0 || (ALAY == 1 && BLAY == 1), "gather: A (KC) or B (RM x RM)");
-    constexpr bool CONV_A = CONV && ALAY == 0, CONV_B = CONV && ALAY == 1;
+    static_assert(FP8 == 0 || (ALAY == 0 && BLAY == 0) || (ALAY == 2 && BLAY == 2), "fp8: both operands K-contiguous or both fp8 reduction-major");
+    static_assert((ALAY == 2) == (BLAY == 2) && (ALAY != 2 || FP8 != 0), "fp8 reduction-major: both operands");
+    static_assert(!CONV || ALAY == 0 || (ALAY >= 1 && BLAY == ALAY), "gather: A (KC) or B (RM x RM)");
+    constexpr bool CONV_A = CONV && ALAY == 0, CONV_B = CONV && ALAY >= 1;
+    constexpr int KT = ALAY == 2 ? 128 : 64;                  // rows / units of K per tile
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * G8_BUF];       // [buf][A0, A1, B0, B1][16 KB]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave & 1, wn = wave >> 1;
@@ -94,15 +116,17 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
     const int64_t kbeg = (int64_t)blockIdx.z * a.kchunk;
     const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
-    const int nk = (int)((kend - kbeg) / 64);
+    const int nk = (int)((kend - kbeg) / KT);
 
     // ---- staging geometry.  KC: this wave stages rows 16 wave + 8 i + (lane >> 3) of a half-tile, physical chunk lane & 7 holds the
     // logical chunk (lane & 7) ^ (row & 7).  RM: rows 8 wave + 4 i + (lane >> 4), physical chunk lane & 15 = logical ^ rm_swz(row).
     const int kc_row = 16 * wave + (lane >> 3), kc_chunk = (lane & 7) ^ (lane >> 3);
-    const int rm_row = 8 * wave + (lane >> 4);
+    const int rm_row = ALAY == 2 ? kc_row : 8 * wave + (lane >> 4);          // fp8 RM: 8 rows x 128 B per instruction, like KC
+    constexpr int RM_STEP = ALAY == 2 ? 8 : 4;                               // rows between a lane's two instructions
     int rm_chunk[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rm_chunk[i] = (lane & 15) ^ g8_rm_swz(rm_row + 4 * i);
+    for (int i = 0; i < 2; ++i)
+        rm_chunk[i] = ALAY == 2 ? ((lane & 7) ^ g8_rm8_swz(rm_row + 8 * i)) : ((lane & 15) ^ g8_rm_swz(rm_row + 4 * i));
     // KC operands: one base pointer per (half, i) at k = kbeg
     const unsigned char* gA[2][2];
     const unsigned char* gB[2][2];
@@ -131,12 +155,12 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int64_t t = kbeg + rm_row + 4 * i;
+            const int64_t t = kbeg + rm_row + RM_STEP * i;
             const int x = (int)(t % a.cW), y = (int)((t / a.cW) % a.cH);
 #pragma unroll
             for (int h = 0; h < 2; ++h) { py[h][i] = y; px[h][i] = x; }
         }
-        adv_q = 64 / a.cW; adv_r = 64 % a.cW;
+        adv_q = KT / a.cW; adv_r = KT % a.cW;
     }
     auto lds_half = [&](int buf, int half) -> unsigned char* { return smem + buf * G8_BUF + half * G8_HALF; };
     // half: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  The address uses the K tile clamped to the last one, the destination the tile's own buffer
@@ -162,21 +186,23 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                 for (int i = 0; i < 2; ++i) G8_GLDS((isA ? gA[h][i] : gB[h][i]) + (int64_t)ktc * 128, dst + i * 1024);
             }
         } else {
-            unsigned char* dst = lds_half(kt & 1, half) + (8 * wave) * 256;
-            const int64_t t0 = kbeg + (int64_t)ktc * 64 + rm_row;
+            // RM: bf16 = 4 rows x 256 B per instruction, fp8 = 8 rows x 128 B; element size EB bytes
+            constexpr int EB = ALAY == 2 ? 1 : 2;
+            unsigned char* dst = lds_half(kt & 1, half) + (ALAY == 2 ? 16 * wave * 128 : 8 * wave * 256);
+            const int64_t t0 = kbeg + (int64_t)ktc * KT + rm_row;
             if (isA || !CONV_B) {
-                const bf16_t* base = reinterpret_cast<const bf16_t*>(isA ? a.A : a.B);
+                const unsigned char* base = isA ? a.A : a.B;
                 const int64_t ld = isA ? a.lda : a.ldb, c0 = (isA ? m0 : n0) + 128 * h;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) G8_GLDS(base + (t0 + 4 * i) * ld + c0 + 8 * rm_chunk[i], dst + i * 1024);
+                for (int i = 0; i < 2; ++i)
+                    G8_GLDS(base + ((t0 + RM_STEP * i) * ld + c0) * EB + 16 * rm_chunk[i], dst + i * 1024);
             } else {
                 const bool real = kt < nk;                              // wave-uniform: past the end only a dummy load (zero page)
-                const bf16_t* base = reinterpret_cast<const bf16_t*>(a.B);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int yy = py[h][i] + tdy[h], xx = px[h][i] + tdx[h];
                     const bool ok = real && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
-                    const bf16_t* p = base + (t0 + 4 * i + (int64_t)tdy[h] * a.cW + tdx[h]) * a.ldb + tci[h] + 8 * rm_chunk[i];
+                    const unsigned char* p = a.B + ((t0 + RM_STEP * i + (int64_t)tdy[h] * a.cW + tdx[h]) * a.ldb + tci[h]) * EB + 16 * rm_chunk[i];
                     const void* src = ok ? (const void*)p : (const void*)g8_zero_page;
                     G8_GLDS(src, dst + i * 1024);
                     int nx = px[h][i] + adv_r, ny = py[h][i] + adv_q;
@@ -199,7 +225,8 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                fa[t][s] = ALAY == 0 ? g8_frag_kc(h, 64 * wm + 16 * t, s, lane) : g8_frag_tr(h, 64 * wm + 16 * t, s, lane);
+                fa[t][s] = ALAY == 0 ? g8_frag_kc(h, 64 * wm + 16 * t, s, lane)
+                         : (ALAY == 1 ? g8_frag_tr(h, 64 * wm + 16 * t, s, lane) : g8_frag_tr8(h, 64 * wm + 16 * t, s, lane));
     };
     auto load_b = [&](int buf, int nq, g8_bf16x8 (&fb)[2][2]) {
         const unsigned char* h = lds_half(buf, 2 + nq);
@@ -207,7 +234,8 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                fb[u][s] = BLAY == 0 ? g8_frag_kc(h, 32 * wn + 16 * u, s, lane) : g8_frag_tr(h, 32 * wn + 16 * u, s, lane);
+                fb[u][s] = BLAY == 0 ? g8_frag_kc(h, 32 * wn + 16 * u, s, lane)
+                         : (BLAY == 1 ? g8_frag_tr(h, 32 * wn + 16 * u, s, lane) : g8_frag_tr8(h, 32 * wn + 16 * u, s, lane));
     };
     auto mma = [&](int mq, int nq, const g8_bf16x8 (&fb)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
@@ -281,6 +309,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     if constexpr (sizeof(OutT) == 4) {
         float* out = a.ws ? a.ws + (int64_t)blockIdx.z * a.M * a.N : reinterpret_cast<float*>(a.C);
         const int64_t ldo = a.ws ? a.N : a.ldc;
+        const float sc8 = FP8 ? a.f8_sa[0] * a.f8_sb[0] : 1.f;           // fp8 weight gradient: both operands carry one tensor scale
 #pragma unroll
         for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
@@ -291,7 +320,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int64_t m = m0 + 128 * mq + 64 * wm + 16 * t + fi;
-                        *reinterpret_cast<g8_f32x4*>(out + m * ldo + n) = acc[2 * nq + u][4 * mq + t];
+                        *reinterpret_cast<g8_f32x4*>(out + m * ldo + n) = FP8 ? acc[2 * nq + u][4 * mq + t] * sc8 : acc[2 * nq + u][4 * mq + t];
                     }
             }
     } else {
@@ -331,9 +360,11 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 // kind 0: C[m][n] = sum_k A[m][k] B[n][k]   (layout 0; conv = forward / data gradient gather on A)           bf16 out
 // kind 1: C[m][n] = sum_k A[m][k] B[k][n]   (layout 1: data gradient of nn.Linear)                           bf16 out
 // kind 2: C[m][n] = sum_k A[k][m] B[k][n]   (layout 2; conv = weight-gradient gather on B), split-K          fp32 out
+// kind 3: the same on fp8 operands (A e5m2, B e4m3, one byte per element, K tiles of 128 rows), scaled by f8_sa[0] * f8_sb[0]
 int gemm8_supported(int kind, int conv, int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC) {
     if (getenv("SEGFAC_NO_GEMM8")) return 0;
     if (M % 256 || N % 256 || K % 64 || kchunk % 64 || kchunk < 256 || M / 256 > 65535) return 0;
+    if (kind == 3) return (K % 128 || kchunk % 128 || kchunk < 512 || !conv || cC % 128 || getenv("SEGFAC_NO_GEMM8T")) ? 0 : 1;      // fp8 weight gradient
     if (conv && (cC % (kind == 2 ? 128 : 64))) return 0;
     if (kind == 2) return getenv("SEGFAC_NO_GEMM8T") ? 0 : 1;
     return (M / 256) * (N / 256) >= 192;
@@ -342,9 +373,9 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
                  const void* B, int64_t ldb, void* C, int64_t ldc, int cH, int cW, int cC, int csign, const float* f8_sa,
                  const float* f8_sb, const float* bias, const void* residual, int64_t ldr, const float* rscale, int64_t rpg, float* ws,
                  hipStream_t st) {
-    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 || (lda * 2) % 16 || (ldb * 2) % 16 || ldc % 4) return SEGF_ERR_SHAPE;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 || (lda * (kind == 3 ? 1 : 2)) % 16 || (ldb * (kind == 3 ? 1 : 2)) % 16 || ldc % 4) return SEGF_ERR_SHAPE;
     if (residual && (((uintptr_t)residual % 8) || ldr % 4)) return SEGF_ERR_SHAPE;
-    if (kind != 2 && split_k != 1) return SEGF_ERR_SHAPE;
+    if (kind < 2 && split_k != 1) return SEGF_ERR_SHAPE;
     Gemm8Args a{(const unsigned char*)A, (const unsigned char*)B, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, csign, f8_sa, f8_sb, bias,
                 (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr};
     const dim3 grid((unsigned)(N / 256), (unsigned)(M / 256), (unsigned)split_k);
@@ -355,9 +386,12 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     } else if (kind == 1) {
         if (conv || fp8) return SEGF_ERR_SHAPE;
         G8_GO(0, 1, false, 0, bf16_t);
-    } else {
+    } else if (kind == 2) {
         if (fp8) return SEGF_ERR_SHAPE;
         if (conv) G8_GO(1, 1, true, 0, float); else G8_GO(1, 1, false, 0, float);
+    } else {                                   // kind 3: conv weight gradient on fp8 operands (A = dy e5m2 [P][M], B = x e4m3 [P][Cin]; strides in bytes)
+        if (!conv || !f8_sa || !f8_sb) return SEGF_ERR_SHAPE;
+        G8_GO(2, 2, true, 2, float);
     }
 #undef G8_GO
     SEGF_CHECK_LAUNCH();

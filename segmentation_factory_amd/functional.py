@@ -845,6 +845,7 @@ class Conv3x3Fn(Function):
         O, I = weight.shape[0], weight.shape[1]
         wm = hip.permute021(weight.detach().reshape(O, I, 9), O, I, 9, x.dtype).view(O, 9 * I)          # [O][(ky,kx)][ci]
         use8 = bool(fp8) and x.dtype == torch.bfloat16 and hip.conv3x3_fp8_supported(0, B, H, W, I, O)
+        xq = sx = None
         if use8:
             # fp8 forward (BASELINE cfg5): activations e4m3 with one dynamic scale for the tensor, weights e4m3 per output channel
             xq, sx = hip.quant_tensor_fp8(x)
@@ -852,27 +853,33 @@ class Conv3x3Fn(Function):
             y = hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, I, O)
         else:
             y = hip.conv3x3(0, x, wm, B, H, W, I, O)
-        ctx.save_for_backward(x, weight.detach())
+        # the quantised input is kept for the fp8 weight gradient (one byte per element next to the bf16 tensor autograd keeps anyway)
+        keep8 = use8 and hip.conv3x3_fp8_wgrad_supported(B, H, W, I, O)
+        ctx.save_for_backward(x, weight.detach(), xq if keep8 else None, sx if keep8 else None)
         ctx.meta = (B, H, W, I, O, weight.shape, bool(fp8))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, xq, sx = ctx.saved_tensors
         B, H, W, I, O, wshape, fp8 = ctx.meta
         dy = _rowmajor(dy)
         dx = dw = None
+        gq = sg = None
+        if fp8 and dy.dtype == torch.bfloat16 and (xq is not None or (ctx.needs_input_grad[0] and hip.conv3x3_fp8_supported(1, B, H, W, I, O))):
+            gq, sg = hip.quant_tensor_fp8(dy, e5m2=True)          # the gradient in e5m2, one dynamic scale: data and weight gradient share it
         if ctx.needs_input_grad[0]:
             wt = hip.permute021(w.reshape(1, O, I * 9), 1, O, I * 9, dy.dtype).view(I, 9 * O)             # [ci][(ky,kx)][co]
-            if fp8 and dy.dtype == torch.bfloat16 and hip.conv3x3_fp8_supported(1, B, H, W, I, O):
-                # data gradient in fp8: the gradient e5m2 (one dynamic scale), the transposed weights e4m3 per input channel
-                gq, sg = hip.quant_tensor_fp8(dy, e5m2=True)
-                wq, sw = hip.quant_rows_fp8(wt)
+            if gq is not None and hip.conv3x3_fp8_supported(1, B, H, W, I, O):
+                wq, sw = hip.quant_rows_fp8(wt)                   # transposed weights e4m3 per input channel
                 dx = hip.conv3x3_fp8(1, gq, sg, wq, sw, B, H, W, I, O)
             else:
                 dx = hip.conv3x3(1, dy, wt, B, H, W, I, O)
         if ctx.needs_input_grad[1]:
-            dwm = hip.conv3x3(2, x, dy, B, H, W, I, O, split_k=_splitk(O, 9 * I, B * H * W))               # [O][(ky,kx)][ci] fp32
+            if gq is not None and xq is not None:
+                dwm = hip.conv3x3_fp8_wgrad(xq, sx, gq, sg, B, H, W, I, O)
+            else:
+                dwm = hip.conv3x3(2, x, dy, B, H, W, I, O, split_k=_splitk(O, 9 * I, B * H * W))           # [O][(ky,kx)][ci] fp32
             dw = hip.permute021(dwm.view(O, 9, I), O, 9, I, torch.float32).view(wshape)
         return dx, dw, None, None, None, None
 

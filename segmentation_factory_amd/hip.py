@@ -99,6 +99,8 @@ _PROTOS = {
     'segf_quant_tensor_fp8': (_i, [_i, _i, _l, _i, _p, _l, _p, _l, _p, _p, _p]),
     'segf_conv3x3_fp8_supported': (_i, [_i, _i, _i, _i, _i, _i]),
     'segf_conv3x3_fp8': (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _p, _p, _l, _p, _p, _l, _p]),
+    'segf_conv3x3_fp8_wgrad_supported': (_i, [_i, _i, _i, _i, _i]),
+    'segf_conv3x3_fp8_wgrad': (_i, [_i, _i, _i, _i, _i, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _p]),
     'segf_gemm_fp8': (_i, [_l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p, _l, _p]),
     'segf_input_train': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     'segf_input_val_ws': (_l, [_i, _i, _i, _i]),
@@ -340,6 +342,26 @@ def conv3x3_fp8(mode, xq, sx, wq, sw, B, H, W, Cin, Cout):
     key = ('conv3x3_fp8', mode, P, Cin, Cout)
     _chk(_timed(key, lambda: lib().segf_conv3x3_fp8(mode, B, H, W, Cin, Cout, _ptr(xq), xq.stride(0), _ptr(sx), _ptr(wq), wq.stride(0),
                                                     _ptr(sw), _ptr(out), out.stride(0), _stream())), 'segf_conv3x3_fp8')
+    return out
+
+
+def conv3x3_fp8_wgrad_supported(B, H, W, Cin, Cout):
+    return bool(lib().segf_conv3x3_fp8_wgrad_supported(B, H, W, Cin, Cout))
+
+
+def conv3x3_fp8_wgrad(xq, sx, gq, sg, B, H, W, Cin, Cout):
+    """dW fp32 [Cout, 9 Cin] of the 3x3 convolution from the quantised input xq [P, Cin] (e4m3, scale sx) and the quantised output
+    gradient gq [P, Cout] (e5m2, scale sg)."""
+    _need_cuda(xq, gq)
+    assert xq.dtype == torch.uint8 and gq.dtype == torch.uint8 and xq.stride(-1) == 1 and gq.stride(-1) == 1
+    P = B * H * W
+    out = torch.empty((Cout, 9 * Cin), dtype=torch.float32, device=xq.device)
+    sk = pick_splitk(Cout, 9 * Cin, P)
+    ws = _f32(sk * Cout * 9 * Cin, xq.device) if sk > 1 else None
+    key = ('conv3x3_fp8_wgrad', P, Cin, Cout)
+    _chk(_timed(key, lambda: lib().segf_conv3x3_fp8_wgrad(B, H, W, Cin, Cout, _ptr(xq), xq.stride(0), _ptr(sx), _ptr(gq), gq.stride(0), _ptr(sg),
+                                                          _ptr(out), out.stride(0), sk, _ptr(ws) if ws is not None else None, _stream())),
+         'segf_conv3x3_fp8_wgrad')
     return out
 
 

@@ -1409,6 +1409,33 @@ def test_fp8_conv3x3_forward_and_data_gradient(hipmod, geom):
     assert err <= 2 ** -8 * refdx.abs().max().item() + 1e-12, (err, refdx.abs().max().item())
 
 
+def test_fp8_conv3x3_weight_gradient(hipmod):
+    """segf_conv3x3_fp8_wgrad: the conv weight gradient on the quantised tensors the forward / data-gradient calls already made (x e4m3,
+    dy e5m2, one scale per tensor) -- reduction-major fp8 operands through ds_read_b64_tr_b8, block-scaled K = 128 MFMA, split-K --
+    against autograd of F.conv2d on the DEQUANTISED tensors (fp8 x fp8 products are exact in fp32: only the summation order differs)."""
+    hip = hipmod
+    B, H, W, Cin, Cout = 8, 96, 128, 256, 256
+    P = B * H * W
+    g = torch.Generator().manual_seed(17)
+    x = (torch.randn(P, Cin, generator=g) * 2).to(torch.bfloat16)
+    dy = (torch.randn(P, Cout, generator=g) * 1e-3).to(torch.bfloat16)
+    assert hip.conv3x3_fp8_wgrad_supported(B, H, W, Cin, Cout)
+    xq, sx = hip.quant_tensor_fp8(x.cuda())
+    gq, sg = hip.quant_tensor_fp8(dy.cuda(), e5m2=True)
+    dw = hip.conv3x3_fp8_wgrad(xq, sx, gq, sg, B, H, W, Cin, Cout)
+    xd = (xq.cpu().view(torch.float8_e4m3fn).float() * sx.item()).view(B, H, W, Cin).permute(0, 3, 1, 2)
+    gd = (gq.cpu().view(torch.float8_e5m2).float() * sg.item()).view(B, H, W, Cout).permute(0, 3, 1, 2)
+    w0 = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(xd, w0, padding=1).backward(gd)
+    ref = w0.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)                           # [co][(ky,kx)][ci]
+    err = (dw.cpu() - ref).abs().max().item()
+    assert err <= 2e-4 * ref.abs().max().item(), (err, ref.abs().max().item())
+    assert torch.equal(dw, hip.conv3x3_fp8_wgrad(xq, sx, gq, sg, B, H, W, Cin, Cout))       # deterministic
+    # and it approximates the bf16 weight gradient it stands in for
+    dwb = hip.conv3x3(2, x.cuda(), dy.cuda(), B, H, W, Cin, Cout, split_k=hip.pick_splitk(Cout, 9 * Cin, P))
+    assert (dw - dwb).abs().max().item() <= 0.1 * dwb.abs().max().item()
+
+
 @pytest.mark.parametrize('shape', [(300, 256, 128), (1000, 768, 3072), (4096, 1536, 384), (129, 40, 256)])
 def test_fp8_quantise_and_gemm(hipmod, shape):
     """csrc/fp8.hip: row-wise e4m3fn quantisation (decode with torch.float8_e4m3fn) and the block-scaled fp8 MFMA product against

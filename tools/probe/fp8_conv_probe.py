@@ -30,7 +30,8 @@ for (B, H, W, Cin, Cout) in [(8, 160, 160, 3072, 768), (8, 160, 160, 768, 768), 
     gq, sg = hip.quant_tensor_fp8(dy, e5m2=True); wtq, swt = hip.quant_rows_fp8(wt)
     f0 = timed(lambda: hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout))
     f1 = timed(lambda: hip.conv3x3_fp8(1, gq, sg, wtq, swt, B, H, W, Cin, Cout))
+    f2 = timed(lambda: hip.conv3x3_fp8_wgrad(xq, sx, gq, sg, B, H, W, Cin, Cout)) if hip.conv3x3_fp8_wgrad_supported(B, H, W, Cin, Cout) else float('nan')
     q0 = timed(lambda: hip.quant_tensor_fp8(x))
     q1 = timed(lambda: hip.quant_rows_fp8(wm))
     print(f'[{B}x{H}x{W} {Cin}->{Cout}] {fl:.2f} TFLOP | bf16 fwd {t0:.2f} ms ({fl / t0 * 1e3:.0f} TF/s) dgrad {t1:.2f} ({fl / t1 * 1e3:.0f}) wgrad {t2:.2f} ({fl / t2 * 1e3:.0f}) | '
-          f'fp8 fwd {f0:.2f} ({fl / f0 * 1e3:.0f}) dgrad {f1:.2f} ({fl / f1 * 1e3:.0f}) | quant x {q0:.2f} ms, quant w {q1:.3f} ms')
+          f'fp8 fwd {f0:.2f} ({fl / f0 * 1e3:.0f}) dgrad {f1:.2f} ({fl / f1 * 1e3:.0f}) wgrad {f2:.2f} ({fl / f2 * 1e3:.0f}) | quant x {q0:.2f} ms, quant w {q1:.3f} ms')
