@@ -131,7 +131,7 @@ class GraphedTrainStep:
         self.buckets, self.events, self._pending = [], [], {}
         self._capturing = False
         if self.exchanging:
-            numels = [p.numel() for p in self.opt._params]
+            numels = list(self.opt._spans)          # aligned extents of the parameters in the flat buffers
             total = sum(numels)
             plan = plan_buckets(numels, int(bucket_mb * (1 << 20) / 4)) if overlap else [(0, total, 0, len(numels) - 1)]
             for k, (lo, hi, p0, p1) in enumerate(plan):

@@ -12,6 +12,7 @@ from . import hip
 
 class FusedAGCAdamW(torch.optim.Optimizer):
     FLAT_SLACK = 1024        # elements of zero padding behind the flat buffers (collective ranges round up to world x 16, graph.py)
+    PARAM_ALIGN = 8          # every parameter starts at a multiple of this many elements in the flat buffers (_build)
 
     """AdamW whose step (optionally preceded by unit-wise adaptive gradient clipping) runs as a single
     multi-tensor kernel (segf_agc_adamw).  Parameters are re-homed into one flat fp32 buffer (each
@@ -38,12 +39,16 @@ class FusedAGCAdamW(torch.optim.Optimizer):
             rank = {id(p): i for i, p in enumerate(order)}
             ps.sort(key=lambda p: rank.get(id(p), len(rank)))
         dev = ps[0].device
-        total = sum(p.numel() for p in ps)
+        # every parameter starts on a PARAM_ALIGN-element boundary of the flat buffers (32 bytes in fp32, 16 bytes in the bf16 weight
+        # shadow), whatever the sizes before it (a 19- or 171-class bias): the vector loads of the kernels that read weights in
+        # place rely on it.  The gap elements stay zero in all four buffers and belong to no optimizer unit.
+        self._spans = [-(-p.numel() // self.PARAM_ALIGN) * self.PARAM_ALIGN for p in ps]
+        total = sum(self._spans)
         store = torch.zeros(total + self.FLAT_SLACK, dtype=torch.float32, device=dev)
         flat = store[:total]
         offs, lens, flags = [], [], []
         o = 0
-        for p in ps:
+        for p, span in zip(ps, self._spans):
             d = decay[id(p)]
             n = p.numel()
             flat[o:o + n].copy_(p.data.reshape(-1))
@@ -54,16 +59,16 @@ class FusedAGCAdamW(torch.optim.Optimizer):
                 offs.append(o + r * cols)
                 lens.append(cols)
                 flags.append(1 if d else 0)
-            o += n
+            o += span
         self._params = ps
         self._flat = flat
         self._grad_store = torch.zeros(total + self.FLAT_SLACK, dtype=torch.float32, device=dev)
         self._grad = self._grad_store[:total]
         self._grad_views, self._offsets, o = [], [], 0
-        for p in ps:
+        for p, span in zip(ps, self._spans):
             self._grad_views.append(self._grad[o:o + p.numel()].view(p.shape))
             self._offsets.append(o)
-            o += p.numel()
+            o += span
         self._m = torch.zeros_like(flat)
         self._v = torch.zeros_like(flat)
         self._off = torch.tensor(offs, dtype=torch.int64, device=dev)
@@ -225,16 +230,15 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         sd = super().state_dict()
         if self._flat is not None and self._step > 0:
             ids = self._packed_ids()
-            state, o = {}, 0
+            state = {}
             usteps = self._ustep.cpu().tolist()
             for i, p in enumerate(self._params):
-                n = p.numel()
+                n, o = p.numel(), self._offsets[i]
                 t = usteps[self._unit_range[i][0]]
                 if t > 0:                       # torch lists state only for parameters that have been stepped
                     state[ids[id(p)]] = {'step': torch.tensor(float(t)),
                                          'exp_avg': self._m[o:o + n].view(p.shape).detach().cpu().clone(),
                                          'exp_avg_sq': self._v[o:o + n].view(p.shape).detach().cpu().clone()}
-                o += n
             sd['state'] = state
         return sd
 
@@ -258,11 +262,10 @@ class FusedAGCAdamW(torch.optim.Optimizer):
         for g in self.param_groups:
             for p in g['params']:
                 by_index[len(by_index)] = p
-        offs, o, pos = {}, 0, {}
+        offs, pos = {}, {}
         for i, p in enumerate(self._params):
-            offs[id(p)] = o
+            offs[id(p)] = self._offsets[i]
             pos[id(p)] = i
-            o += p.numel()
         for idx, st in state.items():
             p = by_index[int(idx)]
             if id(p) not in offs:

@@ -279,7 +279,8 @@ def test_fused_optimizer_state_dict_is_torch_adamw_layout():
     fused.load_state_dict(sd)
     assert fused.param_groups[0]['lr'] == 2e-4 and fused.param_groups[0]['weight_decay'] == 0.025 and fused._step == 3
     assert torch.equal(fused._m[:12].view(4, 3), sd['state'][0]['exp_avg'])
-    assert torch.equal(fused._v[12:].view(2, 2, 3), sd['state'][2]['exp_avg_sq'])
+    assert fused._offsets == [0, 16] and fused._m.numel() == 32        # every parameter starts on a PARAM_ALIGN (8) boundary
+    assert torch.equal(fused._v[16:28].view(2, 2, 3), sd['state'][2]['exp_avg_sq']) and not fused._v[12:16].any()
     out = fused.state_dict()
     assert set(out['state']) == {0, 2} and float(out['state'][2]['step']) == 3.0
     back = torch.optim.AdamW(ps, lr=1.0)
