@@ -222,7 +222,7 @@ def main():
     # region (launches inside a graph replay cannot be bracketed by events; the rocprofv3 summary of this command under
     # profiles/ gives the in-graph durations of the same launches)
     lo_ = torch.randn(M, ld, device=dev).to(dtype)[:, :NC]
-    loss_, stats_ = hip.ce_dice_fwd(lo_, args.batch, NC, hq, wq, H, W, y, 255, None, True)
+    loss_, stats_, lse_ = hip.ce_dice_fwd(lo_, args.batch, NC, hq, wq, H, W, y, 255, None, True, want_lse=True)   # as the step runs it
     go_ = torch.ones(1, device=dev)
     A_ = torch.randn(M, K, device=dev).to(dtype)
     W_ = torch.zeros(ld, K, device=dev, dtype=dtype)
@@ -235,7 +235,7 @@ def main():
     sh_ = torch.zeros(args.batch, K, device=dev)
     with hip.KernelTimer(lambda k: k in (loss_key, gemm_key)) as kt:
         for _ in range(max(args.steps, 5)):
-            hip.ce_dice_bwd(lo_, args.batch, NC, hq, wq, H, W, y, 255, None, True, stats_, go_)
+            hip.ce_dice_bwd(lo_, args.batch, NC, hq, wq, H, W, y, 255, None, True, stats_, go_, lse=lse_)
             if use_pro:
                 hip.gemm_pro(0, A_, W_, M, ld, K, sc_, sh_, rps_, 1, bias=b_)
             else:
@@ -329,8 +329,9 @@ def main():
                          "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note,
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
                          "padded_row_bytes_per_launch": loss_bytes_padded,
-                         "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~6 other VALU "
-                                 "instructions (ISA count: 248 VALU + 41 transcendental + 20 MFMA per 16-pixel cell); interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
+                         "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~3.6 other VALU "
+                                 "instructions (ISA count: 149 VALU + 41 transcendental + 20 MFMA per 16-pixel cell; the softmax normalisation arrives as the "
+                                 "forward's per-pixel log-sum, +64 B per cell, not counted in the algorithmic bytes); interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
             "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true, SHAPE=1, DEEP=true> (segf_gemm_pro, the in-graph variant; narrow 64x80 wave tiles, two K steps in flight): classifier 1x1 conv "
                                         f"[B*{hq}*{wq},768]x[768,{ld}] with BatchNorm + ReLU + Dropout2d applied on the operand load" if use_pro else

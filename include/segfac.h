@@ -322,18 +322,23 @@ int segf_bilinear_to_nchw_f32(int dt, int B, int h, int w, int C, const void* in
  * target: int64 [B][H][W]; stats (opaque to the caller, segf_ce_dice_stats_floats(B, C) floats): per image
  * {I[C], P[C], T[C], ce_sum, w_sum, n_valid, bad_label_flag}, then the batch totals [4], then block partials;
  * loss: fp32 [3] {total, ce, dice_loss}.  class_weight nullable ([C]).  dice=0 -> CE only.  C <= 192.
- * When H/h == W/w is a power of two the upsample is fused in both directions (no full-resolution tensor).  */
+ * When H/h == W/w is a power of two the upsample is fused in both directions (no full-resolution tensor).
+ * pix_lse (nullable; segf_ce_dice_lse_floats(...) floats, 0 = this configuration has none): scratch that carries the
+ * per-pixel log-sum-exp from the forward to the backward of the SAME logits, so the backward does not recompute the softmax
+ * normalisation (bf16, ratio-4 fused path only).  Pass the same buffer to both calls, or NULL to both.     */
 int64_t segf_ce_dice_stats_floats(int B, int C);
+int64_t segf_ce_dice_lse_floats(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl);
 int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
                      const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
-                     float* stats, float* loss, void* stream);
+                     float* stats, float* loss, float* pix_lse, void* stream);
 /* dlogits: NHWC [B][h][w][ldd] of dtype dt = grad_out[0] * d loss / d logits (the LOW-resolution head output; the
  * transposed bilinear resize is applied inside; columns [C, ldd) are zeroed).  ws: segf_ce_dice_bwd_ws floats
  * (0 on the fused power-of-two path; the generic path stages the full-resolution gradient there).        */
 int64_t segf_ce_dice_bwd_ws(int dt, int B, int C, int h, int w, int H, int W);
 int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
                      const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
-                     const float* stats, const float* grad_out, void* dlogits, int64_t ldd, float* ws, void* stream);
+                     const float* stats, const float* grad_out, void* dlogits, int64_t ldd, float* ws,
+                     const float* pix_lse, void* stream);
 
 /* test hook: out[16] = column sums of in[64][16] through the loss kernels' transposing wave reduction */
 int segf_debug_wave_reduce16(const float* in, float* out, void* stream);

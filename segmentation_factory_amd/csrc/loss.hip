@@ -1158,10 +1158,10 @@ static bool loss_use_mfma(int sc) { return sc == 4 && !getenv("SEGFAC_LOSS_NO_MF
 
 template <typename T>
 static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
-                       int64_t ignore_index, const float* cw, float* partial, int* retry) {
+                       int64_t ignore_index, const float* cw, float* partial, int* retry, float* lse) {
     bool band = false;
     if constexpr (sizeof(T) == 2) {
-        if (loss_use_mfma(sc)) band = loss_band_fwd_launch((const bf16_t*)logits, g, target, ignore_index, cw, partial, retry, st);
+        if (loss_use_mfma(sc)) band = loss_band_fwd_launch((const bf16_t*)logits, g, target, ignore_index, cw, partial, retry, lse, st);
     }
     if (band) {}
     else if (loss_use_mfma(sc)) {
@@ -1193,12 +1193,13 @@ static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logit
 template <typename T>
 static void bwd_cells_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                              int64_t ignore_index, const float* cw, int dice, const float* stats, const float* grad_out,
-                             T* dlow, int64_t ldd, int* retry) {
-    if (sc >= 2) hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, 4);
+                             T* dlow, int64_t ldd, int* retry, const float* lse) {
+    // with the forward's per-pixel log-sums in use, retry[1] (= "they are not usable", set by the forward) must survive
+    if (sc >= 2) hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, lse ? 1 : 4);
     bool band = false;
     if constexpr (sizeof(T) == 2) {
         if (loss_use_mfma(sc))
-            band = loss_band_bwd_launch((const bf16_t*)logits, g, target, ignore_index, cw, dice, stats, grad_out, (bf16_t*)dlow, ldd, retry, st);
+            band = loss_band_bwd_launch((const bf16_t*)logits, g, target, ignore_index, cw, dice, stats, grad_out, (bf16_t*)dlow, ldd, retry, lse, st);
     }
     if (band) {}
     else if (loss_use_mfma(sc)) {
@@ -1232,12 +1233,22 @@ static void bwd_generic_launch(int ns, dim3 grid, hipStream_t st, const T* logit
 #undef CALL
 }
 
+// floats of the per-pixel log-sum buffer the forward can leave for the backward (0: this configuration does not produce one)
+extern "C" int64_t segf_ce_dice_lse_floats(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl) {
+    if (dt != SEGF_BF16 || B <= 0 || C <= 0 || h <= 0 || w <= 0 || getenv("SEGFAC_LOSS_NO_LSE")) return 0;
+    if (!loss_use_mfma(pow2_scale(h, w, H, W))) return 0;
+    LossGeom g{B, C, h, w, H, W, ldl};
+    if (!loss_band_fwd_covers((const bf16_t*)logits, g)) return 0;
+    return (int64_t)B * (h + 1) * (w + 1) * 16;
+}
+
 extern "C" int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
                                 const int64_t* target, int64_t ignore_index, const float* class_weight, int dice, float* stats,
-                                float* loss, void* stream) {
+                                float* loss, float* pix_lse, void* stream) {
     if (B <= 0 || C <= 0 || C > 192 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || ldl < C || B > 65535) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     LossGeom g{B, C, h, w, H, W, ldl};
+    if (pix_lse && !segf_ce_dice_lse_floats(dt, B, C, h, w, H, W, logits, ldl)) return SEGF_ERR_SHAPE;
     float* partial = stats + (int64_t)B * (3 * C + 4) + 4;
     const int ns = (C + 63) / 64;
     const int sc = pow2_scale(h, w, H, W);
@@ -1247,7 +1258,7 @@ extern "C" int segf_ce_dice_fwd(int dt, int B, int C, int h, int w, int H, int W
         hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(64), 0, st, retry, 4);
         SEGF_CHECK_LAUNCH();
     }
-    SEGF_DISPATCH_DT(dt, T, { fwd_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, partial, retry); })
+    SEGF_DISPATCH_DT(dt, T, { fwd_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, partial, retry, pix_lse); })
     SEGF_CHECK_LAUNCH();
     colreduce_finalize_launch(partial, LS_NBLK, (int64_t)B * (3 * C + 4), stats, st);
     SEGF_CHECK_LAUNCH();
@@ -1269,8 +1280,10 @@ extern "C" int segf_bilinear_bwd(int dt, int B, int h, int w, int C, void* din, 
 
 extern "C" int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl,
                                 const int64_t* target, int64_t ignore_index, const float* class_weight, int dice,
-                                const float* stats, const float* grad_out, void* dlogits, int64_t ldd, float* ws, void* stream) {
+                                const float* stats, const float* grad_out, void* dlogits, int64_t ldd, float* ws,
+                                const float* pix_lse, void* stream) {
     if (B <= 0 || C <= 0 || C > 192 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || ldl < C || ldd < C || B > 65535) return SEGF_ERR_SHAPE;
+    if (pix_lse && !segf_ce_dice_lse_floats(dt, B, C, h, w, H, W, logits, ldl)) return SEGF_ERR_SHAPE;
     if (ldd > 64 * ((C + 63) / 64)) return SEGF_ERR_SHAPE;     // pad columns are zero-filled by the class lanes
     hipStream_t st = (hipStream_t)stream;
     LossGeom g{B, C, h, w, H, W, ldl};
@@ -1280,7 +1293,7 @@ extern "C" int segf_ce_dice_bwd(int dt, int B, int C, int h, int w, int H, int W
         const dim3 grid(((h + LS_TILE - 1) / LS_TILE) * ((w + LS_TILE - 1) / LS_TILE), B);
         // the retry word shares the forward's flag slot at the end of the stats buffer (the forward has long consumed it)
         int* retry = reinterpret_cast<int*>(const_cast<float*>(stats) + segf_ce_dice_stats_floats(B, C) - 4);
-        SEGF_DISPATCH_DT(dt, T, { bwd_cells_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)dlogits, ldd, retry); })
+        SEGF_DISPATCH_DT(dt, T, { bwd_cells_launch<T>(ns, sc, grid, st, (const T*)logits, g, target, ignore_index, class_weight, dice, stats, grad_out, (T*)dlogits, ldd, retry, pix_lse); })
         SEGF_CHECK_LAUNCH();
         return 0;
     }

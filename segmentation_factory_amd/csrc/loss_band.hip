@@ -18,6 +18,12 @@
 //   * the [class == label] terms go through float adds in the wave's own shared slab (one instruction = one cell, so the
 //     order of colliding adds is fixed) and are folded in when a tap row retires.
 // Bitwise reproducible: every sum has a fixed order.  Underflowing cells raise the retry flag (handled by the VALU kernel).
+//
+// LSE variant (the one the training step runs): the forward band kernel leaves, per (cell, pixel), nl = -log2(sum_c exp z) in
+// the exp2 domain (64 bytes per cell, + 9 % traffic).  The backward then takes nl as the C operand of the interpolation MFMA:
+// exp2 delivers the probabilities themselves, and the per-cell class maximum (9 max + a 6-step wave reduction), the per-pixel
+// sum of exponentials (one add per (pixel, class) + a 16-lane reduction), the reciprocal and the underflow test all disappear
+// from the VALU stream: 229 -> 150 vector instructions per 41 exp2.
 #include <stdlib.h>
 #include "loss_geom.h"
 
@@ -101,6 +107,8 @@ template <int NT>
 struct BandLoads {
     uint32_t raw[BandParts<NT>::NRAW];
     int64_t traw;
+    lossf4 nl4;         // LSE variant: -log2(sum exp) of the four pixels (row lane >> 4) of the cell, exp2 domain
+    float nl1;          //              and of this lane's label-path pixel
 };
 
 #ifndef BAND_SPLIT_D2
@@ -109,16 +117,24 @@ struct BandLoads {
 #ifndef BAND_OCC
 #define BAND_OCC 2
 #endif
+#ifndef BAND_AHEAD
+#define BAND_AHEAD 1
+#endif
+#if BAND_AHEAD
+#define BAND_AHEAD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BAND_AHEAD_FENCE() do {} while (0)
+#endif
 #define BAND_COLS 7         // tap columns owned by a wave; it evaluates BAND_COLS + 1 cells per cell row
 
-template <int NT, bool FULL0>
+template <int NT, bool FULL0, bool LSE>
 __global__ void __launch_bounds__(LS_THREADS, BAND_OCC) ce_dice_bwd_band_kernel(const bf16_t* __restrict__ logits, LossGeom g,
                                                                       const int64_t* __restrict__ target, int64_t ignore_index,
                                                                       const float* __restrict__ cw, int dice,
                                                                       const float* __restrict__ stats,
                                                                       const float* __restrict__ grad_out, bf16_t* __restrict__ dlow,
                                                                       int64_t ldd, int* __restrict__ retry, int nbands, int nseg,
-                                                                      int seg_rows) {
+                                                                      int seg_rows, const float* __restrict__ lse) {
     using BP = BandParts<NT>;
     constexpr int NCOL = NT * 16;
     __shared__ __attribute__((aligned(16))) float corr[4][4 * NCOL * 4];        // [wave][row group][tile][column][r]
@@ -129,6 +145,10 @@ __global__ void __launch_bounds__(LS_THREADS, BAND_OCC) ce_dice_bwd_band_kernel(
     const int c = lane & 15, gq = lane >> 4;
     const int task = blockIdx.x * 4 + wave;
     if (task >= g.B * nseg * nbands) return;            // no workgroup barrier below
+    if (LSE && retry[1]) {                               // the forward met an underflowing cell: its log-sums are not usable
+        if (lane == 0) atomicOr(retry, 1);
+        return;
+    }
     const int band = task % nbands, seg = (task / nbands) % nseg, b = task / (nbands * nseg);
     float* mycorr = corr[wave];
     for (int i = lane; i < 4 * NCOL; i += 64) reinterpret_cast<float4*>(mycorr)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -170,7 +190,8 @@ __global__ void __launch_bounds__(LS_THREADS, BAND_OCC) ce_dice_bwd_band_kernel(
 
     // Address arithmetic: per cell row the lane-dependent parts (tap row, label row) are formed once (RowCtx); per cell only the
     // column parts remain, from wave-uniform scalars.  All offsets are 32-bit byte offsets from wave-uniform base pointers.
-    struct RowCtx { uint32_t tap0, tap1, tap2, gat, lab; bool inY; };
+    struct RowCtx { uint32_t tap0, tap1, tap2, gat, lab, lrow; bool inY; };
+    const char* lseb = reinterpret_cast<const char*>(lse) + (LSE ? (int64_t)b * (g.h + 1) * (g.w + 1) * 64 : 0);
     const char* imgb = reinterpret_cast<const char*>(img);
     const char* tgb = reinterpret_cast<const char*>(tg);
     const uint32_t ldlb = 2u * ldl;
@@ -183,19 +204,26 @@ __global__ void __launch_bounds__(LS_THREADS, BAND_OCC) ce_dice_bwd_band_kernel(
         const int Y = 4 * cj + 2 + gq;
         R.inY = Y >= 0 && Y < g.H;
         R.lab = (uint32_t)((Y < 0 ? 0 : (Y >= g.H ? g.H - 1 : Y)) * g.W) * 8u;
+        R.lrow = (uint32_t)((cj + 1) * (g.w + 1)) * 64u;
         return R;
     };
     const int pc8 = 8 * pc;
     auto issue = [&](BandLoads<NT>& L, const RowCtx& R, int ck) {
         const int x0 = ck < 0 ? 0 : ck, x1 = ck + 1 > g.w - 1 ? g.w - 1 : ck + 1;
-        const uint32_t xo0 = (uint32_t)x0 * ldlb, xo1 = (uint32_t)x1 * ldlb;          // scalar multiplies
-        const uint32_t xo = (gq & 1) ? xo1 : xo0;
+        // (the compiler turns a select of two scalar products into a quarter-rate vector multiply of the select: ask for the
+        // full-rate 24-bit one -- tap indices and the row stride are far below 2^24 and the product below 2^31, host-checked)
+        const uint32_t xo = (uint32_t)__umul24((uint32_t)((gq & 1) ? x1 : x0), ldlb);
         band_load_part<BP::P0>(reinterpret_cast<const bf16_t*>(imgb + (R.tap0 + xo)), L.raw + BP::W0);
         if constexpr (BP::P1 > 0) band_load_part<BP::P1>(reinterpret_cast<const bf16_t*>(imgb + (R.tap1 + xo)), L.raw + BP::W1);
         if constexpr (BP::P2 > 0) band_load_part<BP::P2>(reinterpret_cast<const bf16_t*>(imgb + (R.tap2 + xo)), L.raw + BP::W2);
         int X8 = 8 * (4 * ck + 2) + pc8;
         X8 = X8 < 0 ? 0 : (X8 > 8 * (g.W - 1) ? 8 * (g.W - 1) : X8);
         L.traw = *reinterpret_cast<const int64_t*>(tgb + (R.lab + (uint32_t)X8));
+        if constexpr (LSE) {
+            const uint32_t co = R.lrow + (uint32_t)(ck + 1) * 64u + 16u * (uint32_t)gq;
+            L.nl4 = *reinterpret_cast<const lossf4*>(lseb + co);
+            L.nl1 = *reinterpret_cast<const float*>(lseb + (co + 4u * (uint32_t)pc));
+        }
     };
     const bool ign_in_range = ignore_index >= 0 && ignore_index < g.C;
 
@@ -207,9 +235,25 @@ __global__ void __launch_bounds__(LS_THREADS, BAND_OCC) ce_dice_bwd_band_kernel(
         Bp[t][0] = 0u; Bp[t][1] = 0u; Bp[t][2] = 0u; Bp[t][3] = 0u;
     }
     bool slow = false;
-    BandLoads<NT> nx;
+    // Loads run two cells ahead of the arithmetic.  Two register sets, nb[0] for the first cell of a pair and nb[1] for the
+    // second: a cell takes what it needs out of its set at the top and then refills the same set for the cell two ahead.  A
+    // cursor (pcj, pi) walks the cell sequence of the loops below with every cell row padded to an even number of cells (the
+    // phantom cell repeats the last real one), so the parity of a cell within its pair is also the parity of its position in
+    // the sequence; it stays on the last cell once it gets there, so every cell issues the same loads.
+    // (Measured at batch 128: one cell ahead 2.07 ms, two ahead 2.04 -- memory latency is not what this kernel waits for.  With
+    // the label-term LDS adds removed it runs 0.16 ms faster, without the scatter MFMAs 0.14, piecewise-constant labels cost the
+    // same as random ones: tools/probe/loss_probe.py.)
+    const int nrow = g.w - X0 + 1 < 8 ? g.w - X0 + 1 : 8;      // cells per cell row of this band (>= 2)
+    const int nrow2 = (nrow + 1) & ~1;
+    int pcj = y_lo - 1, pi = 0;
+    auto advance = [&]() {
+        if (pi + 1 < nrow2) ++pi;
+        else if (pcj + 1 < y_hi) { pi = 0; ++pcj; }
+    };
+    BandLoads<NT> nb[2];
     RowCtx Rn = make_row(y_lo - 1);
-    issue(nx, Rn, X0 - 1);
+    issue(nb[0], Rn, X0 - 1 + pi); advance();
+    issue(nb[1], Rn, X0 - 1 + pi); advance();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -225,76 +269,92 @@ __global__ void __launch_bounds__(LS_THREADS, BAND_OCC) ce_dice_bwd_band_kernel(
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int i = 2 * q + s, ck = X0 - 1 + i;
+                BandLoads<NT>& L = nb[s];
+                auto refill = [&]() {     // the cell two ahead in the walk: in this cell row or in the next one
+                    const bool nextrow = pcj > cj;
+                    RowCtx Rx;
+                    Rx.tap0 = nextrow ? Rn.tap0 : Rc.tap0; Rx.tap1 = nextrow ? Rn.tap1 : Rc.tap1; Rx.tap2 = nextrow ? Rn.tap2 : Rc.tap2;
+                    Rx.lab = nextrow ? Rn.lab : Rc.lab; Rx.lrow = nextrow ? Rn.lrow : Rc.lrow; Rx.inY = false; Rx.gat = 0;
+                    issue(L, Rx, X0 - 1 + (pi < nrow ? pi : nrow - 1));
+                    advance();
+                };
                 if (ck > g.w - 1) {                       // second cell of the pair past the image: its B half must be finite
 #pragma unroll
                     for (int t = 0; t < NT; ++t) { Bp[t][2 * s] = 0u; Bp[t][2 * s + 1] = 0u; }
+                    refill();
                     continue;
                 }
-                const BandLoads<NT> cur = nx;
-                // label-class gather first (waiting for the label must not drain the next cell's loads)
-                const int x0 = ck < 0 ? 0 : ck, x1 = ck + 1 > g.w - 1 ? g.w - 1 : ck + 1;
-                // pixels of the cell inside the image: all columns except at the two border cells (wave-uniform selection of a lane mask)
-                const bool inside = Rc.inY && (ck < 0 ? pc >= 2 : (ck >= g.w - 1 ? pc < 2 : true));
-                const bool valid0 = inside && (uint64_t)cur.traw < (uint64_t)g.C && !(ign_in_range && cur.traw == ignore_index);
-                const int tt = valid0 ? (int)cur.traw : 0;
-                // (as the aligned 32-bit word holding it: a 16-bit load is zero-extended at once, which would put the wait here)
-                const uint32_t gx0 = (uint32_t)x0 * ldlb, gx1 = (uint32_t)x1 * ldlb;
-                const uint32_t uloff = Rc.gat + ((kl & 1) ? gx1 : gx0) + 2u * (uint32_t)tt;
-                uint32_t ulbits = *reinterpret_cast<const uint32_t*>(imgb + (uloff & ~3u));
-                {   // next cell of the walk (after the last one: the same cell again, so that the loads stay unconditional
-                    // and the compiler can count them instead of draining the queue)
-                    const bool wrap = i == 7 || ck + 1 > g.w - 1;
-                    const bool last = wrap && cj + 1 >= y_hi;
-                    const int nck = last ? ck : (wrap ? X0 - 1 : ck + 1);
-                    RowCtx Rx;
-                    const bool nextrow = wrap && !last;
-                    Rx.tap0 = nextrow ? Rn.tap0 : Rc.tap0; Rx.tap1 = nextrow ? Rn.tap1 : Rc.tap1; Rx.tap2 = nextrow ? Rn.tap2 : Rc.tap2;
-                    Rx.lab = nextrow ? Rn.lab : Rc.lab; Rx.inY = false; Rx.gat = 0;
-                    issue(nx, Rx, nck);
-                }
-                // taps -> exp2-domain operands
+                // everything this cell needs from its register set, then the refill
+                const int64_t traw = L.traw;
+                const lossf4 nl4 = L.nl4;
+                const float nl1 = L.nl1;
                 float u[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int p = BP::part(t), k = t - BP::tbase(p);
-                    const uint32_t wd = cur.raw[BP::wbase(p) + (k >> 1)];
+                    const uint32_t wd = L.raw[BP::wbase(p) + (k >> 1)];
                     u[t] = __uint_as_float((k & 1) ? (wd & 0xffff0000u) : (wd << 16));
                     if (!(FULL0 && p == 0)) u[t] = cmask[t] ? u[t] : -1e30f;
                 }
-                float mx = u[0];
+                // label-class gather first (waiting for the label must not drain the next cells' loads)
+                const int x0 = ck < 0 ? 0 : ck, x1 = ck + 1 > g.w - 1 ? g.w - 1 : ck + 1;
+                // pixels of the cell inside the image: all columns except at the two border cells (wave-uniform selection of a lane mask)
+                const bool inside = Rc.inY && (ck < 0 ? pc >= 2 : (ck >= g.w - 1 ? pc < 2 : true));
+                const bool valid0 = inside && (uint64_t)traw < (uint64_t)g.C && !(ign_in_range && traw == ignore_index);
+                const int tt = valid0 ? (int)traw : 0;
+                // (as the aligned 32-bit word holding it: a 16-bit load is zero-extended at once, which would put the wait here)
+                const uint32_t uloff = Rc.gat + (uint32_t)__umul24((uint32_t)((kl & 1) ? x1 : x0), ldlb) + 2u * (uint32_t)tt;
+                uint32_t ulbits = *reinterpret_cast<const uint32_t*>(imgb + (uloff & ~3u));
+                const float2 gw = gIw[wave][tt];          // (read here: its LDS latency passes under the class tiles)
+                refill();
+                float mb = 0.f;
+                lossf4 cin;
+                if constexpr (LSE) cin = nl4;
+                else {
+                    float mx = u[0];
 #pragma unroll
-                for (int t = 1; t < NT; ++t) asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(u[t]));
-                const float mb = wave_max_all_fast(mx);
-                const float nmb = -mb * LS_LOG2E;
-                const lossf4 cin = {nmb, nmb, nmb, nmb};
+                    for (int t = 1; t < NT; ++t) asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(mx), "v"(u[t]));
+                    mb = wave_max_all_fast(mx);
+                    const float nmb = -mb * LS_LOG2E;
+                    cin = lossf4{nmb, nmb, nmb, nmb};
+                }
                 // scalar adds / fmas on purpose (and -fno-slp-vectorize for this file): beside MFMAs a packed f32 instruction
                 // costs far more than the two plain ones it replaces (MI355X_MICROARCH.md, per-instruction constants)
                 float s4[4] = {0.f, 0.f, 0.f, 0.f}, dp4[4] = {0.f, 0.f, 0.f, 0.f};
+                // the interpolation MFMA of tile t + 1 is issued before the exp2s of tile t (BAND_AHEAD): left to itself the
+                // scheduler issues MFMA t, waits out its 10 wait states, then runs the exp2s -- one stall per class tile
+                lossf4 zc = __builtin_amdgcn_mfma_f32_16x16x4f32(wAL, u[0], cin, 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const lossf4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(wAL, u[t], cin, 0, 0, 0);
+                    lossf4 zn = zc;
+                    if (t + 1 < NT) zn = __builtin_amdgcn_mfma_f32_16x16x4f32(wAL, u[t + 1], cin, 0, 0, 0);
+                    BAND_AHEAD_FENCE();
                     float e[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        e[r] = __builtin_amdgcn_exp2f(z[r]);
-                        s4[r] += e[r];
+                        e[r] = __builtin_amdgcn_exp2f(zc[r]);
+                        if constexpr (!LSE) s4[r] += e[r];
                         dp4[r] = fmaf(gP[t], e[r], dp4[r]);
                     }
                     Bp[t][2 * s] = pack2bf(e[0], e[1]); Bp[t][2 * s + 1] = pack2bf(e[2], e[3]);
+                    BAND_AHEAD_FENCE();
+                    zc = zn;
                 }
-                float tot = row_sum16_own(s4, lo8, even4);
-                const float dpm = row_sum16_own(dp4, lo8, even4);
+                float tot = 1.f;
+                if constexpr (!LSE) tot = row_sum16_own(s4, lo8, even4);
+                float dpm = row_sum16_own(dp4, lo8, even4);
                 // label path.  The empty asm ties the gathered label logit to a value that exists only now: without it the
                 // scheduler converts it right after the gather was issued and the wave waits out the load at the top of the cell
-                asm volatile("" : "+v"(ulbits), "+v"(tot));
+                if constexpr (LSE) asm volatile("" : "+v"(ulbits), "+v"(dpm));
+                else asm volatile("" : "+v"(ulbits), "+v"(tot));
                 const float ulraw = __uint_as_float((uloff & 2u) ? (ulbits & 0xffff0000u) : (ulbits << 16));
-                float zt = wL * ((ulraw - mb) * LS_LOG2E);
+                float zt = LSE ? wL * (ulraw * LS_LOG2E) : wL * ((ulraw - mb) * LS_LOG2E);
                 zt += dpp_mov<DPP_XOR1>(zt); zt += dpp_mov<DPP_XOR2>(zt);
-                const bool valid = valid0, under = valid && !(tot > 1e-30f);
+                if constexpr (LSE) zt += nl1;
+                const bool valid = valid0, under = LSE ? false : (valid && !(tot > 1e-30f));
                 slow |= under;
                 const float okf = (valid && !under) ? 1.f : 0.f;
-                const float inv = okf * __builtin_amdgcn_rcpf(fmaxf(tot, 1e-30f));
-                const float2 gw = gIw[wave][tt];
+                const float inv = LSE ? okf : okf * __builtin_amdgcn_rcpf(fmaxf(tot, 1e-30f));
                 const float wce = okf * gw.y * invW;
                 const float et = __builtin_amdgcn_exp2f(zt), git = gw.x;
                 const float c1 = go * inv;
@@ -393,7 +453,7 @@ template <int NT, bool FULL0>
 __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16_t* __restrict__ logits, LossGeom g,
                                                                       const int64_t* __restrict__ target, int64_t ignore_index,
                                                                       const float* __restrict__ cw, float* __restrict__ partial,
-                                                                      int* __restrict__ retry) {
+                                                                      int* __restrict__ retry, float* __restrict__ lse) {
     using BP = BandParts<NT>;
     constexpr int NCOL = NT * 16;
     __shared__ float hI[4][NCOL], hT[4][NCOL], redP[4][NCOL], redS[4][4];
@@ -423,6 +483,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
     for (int t = 0; t < NT; ++t) cmask[t] = band_class<NT>(c, t) < g.C;
     const int ncx = g.w + 1, ncell = (g.h + 1) * ncx;
     const int pc8 = 8 * pc;
+    float* lsei = lse ? lse + (int64_t)b * ncell * 16 : nullptr;
 
     struct CellGeo { int cj, ck; };
     auto geo = [&](int cell) { CellGeo G; G.cj = cell / ncx - 1; G.ck = cell - (G.cj + 1) * ncx - 1; return G; };
@@ -502,13 +563,18 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
             const float nmb = -mb * LS_LOG2E;
             const lossf4 cin = {nmb, nmb, nmb, nmb};
             float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            lossf4 zc = __builtin_amdgcn_mfma_f32_16x16x4f32(wAL, u[0], cin, 0, 0, 0);      // one tile ahead, as in the backward
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const lossf4 z = __builtin_amdgcn_mfma_f32_16x16x4f32(wAL, u[t], cin, 0, 0, 0);
+                lossf4 zn = zc;
+                if (t + 1 < NT) zn = __builtin_amdgcn_mfma_f32_16x16x4f32(wAL, u[t + 1], cin, 0, 0, 0);
+                BAND_AHEAD_FENCE();
                 float e[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(z[r]); s4[r] += e[r]; }
+                for (int r = 0; r < 4; ++r) { e[r] = __builtin_amdgcn_exp2f(zc[r]); s4[r] += e[r]; }
                 Bp[t][2 * s] = pack2bf(e[0], e[1]); Bp[t][2 * s + 1] = pack2bf(e[2], e[3]);
+                BAND_AHEAD_FENCE();
+                zc = zn;
             }
             float tot = row_sum16_own(s4, lo8, even4);
             asm volatile("" : "+v"(ulbits), "+v"(tot));
@@ -519,11 +585,19 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
             slow |= under;
             const bool ok = valid0 && !under;
             const float inv = ok ? __builtin_amdgcn_rcpf(fmaxf(tot, 1e-30f)) : 0.f;
+            const float lg = __builtin_amdgcn_logf(tot);
+            if (lse) {
+                // -log2(sum exp) of pixel (gq, pc) in the exp2 domain, for the backward (its interpolation MFMA adds it to the
+                // scaled logits, so exp2 yields the probability).  The four tap lanes of a pixel store the same word.  A pixel
+                // whose sum underflowed (label or not) makes the whole buffer unusable: retry[1]
+                slow |= lse != nullptr && !(tot > 1e-30f);
+                lsei[cidx * 16 + 4 * gq + pc] = nmb - lg;
+            }
             if (ok && kl == 0) {
                 const float wt = cw ? cw[tt] : 1.f;
                 atomicAdd(&hI[wave][tt], __builtin_amdgcn_exp2f(zt) * inv);
                 atomicAdd(&hT[wave][tt], 1.f);
-                cel = fmaf(wt, __builtin_amdgcn_logf(tot) - zt, cel);
+                cel = fmaf(wt, lg - zt, cel);
                 wsum += wt; nvalid += 1.f;
             }
             // A operand row 0 (lanes with c == 0): ok / S of pixels (gq, 0..3) = this lane and lanes c = 4, 8, 12 of the row group
@@ -540,7 +614,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
             D[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Av.v, Bv.v, D[t], 0, 0, 0);
         }
     }
-    if (__any(slow) && lane == 0) atomicOr(retry, 1);
+    if (__any(slow) && lane == 0) { atomicOr(retry, 1); if (lse) atomicOr(retry + 1, 1); }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (gq == 0) {
@@ -561,17 +635,22 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
     if (threadIdx.x < 4) dst[3 * g.C + threadIdx.x] = (redS[0][threadIdx.x] + redS[1][threadIdx.x]) + (redS[2][threadIdx.x] + redS[3][threadIdx.x]);
 }
 
-bool loss_band_fwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw,
-                          float* partial, int* retry, hipStream_t st) {
+bool loss_band_fwd_covers(const bf16_t* logits, LossGeom g) {
     if (getenv("SEGFAC_LOSS_NO_BAND") || getenv("SEGFAC_LOSS_NO_BAND_FWD")) return false;
     if (g.H != 4 * g.h || g.W != 4 * g.w || g.C > 192) return false;
-    const int nt = (g.C + 15) / 16;
-    const int NTb = nt <= 2 ? 2 : (nt <= 4 ? 4 : (nt <= 10 ? 10 : 12));
     if (g.ldl % 8 || g.ldl < g.C || ((uintptr_t)logits & 15)) return false;
     if ((int64_t)g.h * g.w * g.ldl >= (1ll << 30) || (int64_t)g.H * g.W >= (1ll << 28)) return false;
+    return true;
+}
+
+bool loss_band_fwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw,
+                          float* partial, int* retry, float* lse, hipStream_t st) {
+    if (!loss_band_fwd_covers(logits, g)) return false;
+    const int nt = (g.C + 15) / 16;
+    const int NTb = nt <= 2 ? 2 : (nt <= 4 ? 4 : (nt <= 10 ? 10 : 12));
     const dim3 grid(LS_NBLK, g.B);
 #define BAND_CALL(NT, FULL) hipLaunchKernelGGL((ce_dice_fwd_band_kernel<NT, FULL>), grid, dim3(LS_THREADS), 0, st, logits, g, target, \
-                                               ignore_index, cw, partial, retry)
+                                               ignore_index, cw, partial, retry, lse)
     if (NTb == 2) { if (g.C >= 32) BAND_CALL(2, true); else BAND_CALL(2, false); }
     else if (NTb == 4) { if (g.C >= 64) BAND_CALL(4, true); else BAND_CALL(4, false); }
     else if (NTb == 10) { if (g.C >= 128) BAND_CALL(10, true); else BAND_CALL(10, false); }
@@ -591,21 +670,26 @@ static int band_seg_rows(int B, int h, int nbands) {
 }
 
 bool loss_band_bwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw, int dice,
-                          const float* stats, const float* grad_out, bf16_t* dlow, int64_t ldd, int* retry, hipStream_t st) {
+                          const float* stats, const float* grad_out, bf16_t* dlow, int64_t ldd, int* retry, const float* lse,
+                          hipStream_t st) {
     if (getenv("SEGFAC_LOSS_NO_BAND")) return false;
+    if (lse && !loss_band_fwd_covers(logits, g)) return false;        // (the caller has checked this: the buffer was never written)
     if (g.H != 4 * g.h || g.W != 4 * g.w || g.C > 192) return false;
     const int nt = (g.C + 15) / 16;
     const int NTb = nt <= 2 ? 2 : (nt <= 4 ? 4 : (nt <= 10 ? 10 : 12));
     if (g.ldl % 8 || ldd % 8 || ldd > 16 * NTb || g.ldl < g.C || ldd < g.C) return false;
     if (((uintptr_t)logits | (uintptr_t)dlow) & 15) return false;
     if ((int64_t)g.h * g.w * g.ldl >= (1ll << 31) || (int64_t)g.H * g.W >= (1ll << 31)) return false;
+    if (g.ldl >= (1 << 22) || g.w >= (1 << 22)) return false;             // 24-bit multiplies in the tap addressing
     const int nbands = (g.w + BAND_COLS - 1) / BAND_COLS;
     const int seg_rows = band_seg_rows(g.B, g.h, nbands);
     const int nseg = (g.h + seg_rows - 1) / seg_rows;
     const int64_t tasks = (int64_t)g.B * nseg * nbands;
     const dim3 grid((unsigned)((tasks + 3) / 4));
-#define BAND_CALL(NT, FULL) hipLaunchKernelGGL((ce_dice_bwd_band_kernel<NT, FULL>), grid, dim3(LS_THREADS), 0, st, logits, g, target, \
-                                               ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry, nbands, nseg, seg_rows)
+#define BAND_CALL(NT, FULL) do { if (lse) hipLaunchKernelGGL((ce_dice_bwd_band_kernel<NT, FULL, true>), grid, dim3(LS_THREADS), 0, st, logits, g, target, \
+                                               ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry, nbands, nseg, seg_rows, lse);        \
+        else hipLaunchKernelGGL((ce_dice_bwd_band_kernel<NT, FULL, false>), grid, dim3(LS_THREADS), 0, st, logits, g, target, \
+                                               ignore_index, cw, dice, stats, grad_out, dlow, ldd, retry, nbands, nseg, seg_rows, lse); } while (0)
     if (NTb == 2) { if (g.C >= 32) BAND_CALL(2, true); else BAND_CALL(2, false); }
     else if (NTb == 4) { if (g.C >= 64) BAND_CALL(4, true); else BAND_CALL(4, false); }
     else if (NTb == 10) { if (g.C >= 128) BAND_CALL(10, true); else BAND_CALL(10, false); }

@@ -40,7 +40,10 @@ __device__ __forceinline__ void dice_coef_one(const float* __restrict__ stats, i
 }
 
 // loss_band.hip: band-sweep backward for ratio 4 / bf16; returns false when the configuration is not covered
+// lse (nullable): per (image, cell, pixel) -log2(sum exp), written by the forward and consumed by the backward (LSE variant)
+bool loss_band_fwd_covers(const bf16_t* logits, LossGeom g);
 bool loss_band_bwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw, int dice,
-                          const float* stats, const float* grad_out, bf16_t* dlow, int64_t ldd, int* retry, hipStream_t st);
+                          const float* stats, const float* grad_out, bf16_t* dlow, int64_t ldd, int* retry, const float* lse,
+                          hipStream_t st);
 bool loss_band_fwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw,
-                          float* partial, int* retry, hipStream_t st);
+                          float* partial, int* retry, float* lse, hipStream_t st);

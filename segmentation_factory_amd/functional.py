@@ -1145,18 +1145,20 @@ class UpsampleCEDiceFn(Function):
         if logits.shape[0] != B * h * w or logits.shape[1] < Cc:
             raise RuntimeError(f'criterion: logits {tuple(logits.shape)} do not match geometry {geom}')
         target = target.contiguous()
-        loss, stats = hip.ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice)
-        ctx.save_for_backward(logits, target, stats, class_weight)
+        # lse: the per-pixel log-sums the forward leaves for the backward (None where the configuration has no such path)
+        loss, stats, lse = hip.ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice,
+                                           want_lse=torch.is_grad_enabled() or logits.requires_grad)
+        ctx.save_for_backward(logits, target, stats, class_weight, lse)
         ctx.meta = (geom, ignore_index, dice)
         ctx.mark_non_differentiable(stats)
         return loss[0], loss.detach(), stats
 
     @staticmethod
     def backward(ctx, gloss, _gparts, _gstats):
-        logits, target, stats, cw = ctx.saved_tensors
+        logits, target, stats, cw, lse = ctx.saved_tensors
         (B, Cc, h, w, H, W), ignore_index, dice = ctx.meta
         go = gloss.reshape(1).to(torch.float32).contiguous()
-        dl = hip.ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, cw, dice, stats, go)[:, :Cc]
+        dl = hip.ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, cw, dice, stats, go, lse=lse)[:, :Cc]
         return dl, None, None, None, None, None
 
 

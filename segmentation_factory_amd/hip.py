@@ -81,9 +81,10 @@ _PROTOS = {
     'segf_bn_stats_from_sums': (_i, [_p, _l, _i, _p, _p, _p, _p, _f, _f, _p]),
     'segf_bilinear_to_nchw_f32': (_i, [_i, _i, _i, _i, _i, _p, _l, _i, _i, _p, _p]),
     'segf_ce_dice_stats_floats': (_l, [_i, _i]),
-    'segf_ce_dice_fwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p]),
+    'segf_ce_dice_lse_floats': (_l, [_i, _i, _i, _i, _i, _i, _i, _p, _l]),
+    'segf_ce_dice_fwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p, _p]),
     'segf_ce_dice_bwd_ws': (_l, [_i, _i, _i, _i, _i, _i, _i]),
-    'segf_ce_dice_bwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p, _l, _p, _p]),
+    'segf_ce_dice_bwd': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _i, _p, _p, _p, _l, _p, _p, _p]),
     'segf_debug_wave_reduce16': (_i, [_p, _p, _p]),
     'segf_argmax_confmat': (_i, [_i, _i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p]),
     'segf_confmat_pairs': (_i, [_p, _p, _l, _i, _l, _p, _p, _p, _p]),
@@ -897,17 +898,23 @@ def bilinear_to_nchw_f32(x, B, h, w, Cc, H, W):
 
 
 # ---- loss / metrics ------------------------------------------------------------------------------------
-def ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice):
+def ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice, want_lse=False):
+    """(loss[3], stats) or, with want_lse, (loss[3], stats, lse): lse = the per-pixel log-sum buffer for ce_dice_bwd of the
+    same logits (None when this configuration does not produce one)."""
     stats = _f32(lib().segf_ce_dice_stats_floats(B, Cc), logits.device)
     loss = torch.empty(3, dtype=torch.float32, device=logits.device)
+    lse = None
+    if want_lse:
+        n = lib().segf_ce_dice_lse_floats(dt_of(logits), B, Cc, h, w, H, W, _ptr(logits), logits.stride(0))
+        lse = torch.empty(n, dtype=torch.float32, device=logits.device) if n else None
     _chk(lib().segf_ce_dice_fwd(dt_of(logits), B, Cc, h, w, H, W, _ptr(logits), logits.stride(0), _ptr(target),
-                                int(ignore_index), _ptr(class_weight), int(dice), _ptr(stats), _ptr(loss), _stream()),
+                                int(ignore_index), _ptr(class_weight), int(dice), _ptr(stats), _ptr(loss), _ptr(lse), _stream()),
          'segf_ce_dice_fwd')
-    return loss, stats
+    return (loss, stats, lse) if want_lse else (loss, stats)
 
 
-def ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice, stats, grad_out):
-    """d loss / d (low-res logits), same row stride as `logits` (pad columns zeroed)."""
+def ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice, stats, grad_out, lse=None):
+    """d loss / d (low-res logits), same row stride as `logits` (pad columns zeroed).  lse: ce_dice_fwd(want_lse=True)'s."""
     ld = logits.stride(0)
     dlow = torch.empty((B * h * w, ld), dtype=logits.dtype, device=logits.device)
     dt = dt_of(logits)
@@ -915,7 +922,7 @@ def ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, d
     ws = _f32(nws, logits.device) if nws else None
     _chk(_timed(('ce_dice_bwd', B, Cc, h, w, H, W), lambda: lib().segf_ce_dice_bwd(
         dt, B, Cc, h, w, H, W, _ptr(logits), ld, _ptr(target), int(ignore_index), _ptr(class_weight), int(dice), _ptr(stats),
-        _ptr(grad_out), _ptr(dlow), ld, _ptr(ws), _stream())), 'segf_ce_dice_bwd')
+        _ptr(grad_out), _ptr(dlow), ld, _ptr(ws), _ptr(lse), _stream())), 'segf_ce_dice_bwd')
     return dlow
 
 

@@ -1,6 +1,7 @@
 """GPU parity tests of every HIP kernel (through the C ABI via segmentation_factory_amd.hip / functional)
 against a plain PyTorch fp32 CPU statement of the same op.  fp32 storage must match to ~1e-5; bf16 storage to
 bf16 rounding of inputs/outputs (fp32 accumulation inside)."""
+import math
 import os
 
 import numpy as np
@@ -413,6 +414,30 @@ def test_loss_backward_band_kernel_vs_tile_kernel_and_oracle(cfg, monkeypatch):
         assert err < 1e-2 * scale, (err, scale)                  # bf16 storage of the gradient: 2^-8 relative
     # the segment length only changes which wave computes a tap, never the arithmetic of a tap
     assert torch.equal(band, band3)
+    # the variant the training step runs: the forward leaves -log2(sum exp) per pixel, the backward's exp2 yields probabilities
+    # (no class maximum, no sum, no reciprocal).  Same forward statistics bit for bit, gradient within the same bar, reproducible,
+    # independent of the segment length, pad columns zero
+    monkeypatch.delenv('SEGFAC_LOSS_NO_BAND')
+    loss_l, stats_l, lse = hip.ce_dice_fwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, want_lse=True)
+    assert lse is not None and lse.numel() == B * (h + 1) * (w + 1) * 16
+    assert torch.equal(loss_l, loss) and torch.equal(stats_l[:n], stats[:n]) and stats_l[-4:].view(torch.int32)[1].item() == 0
+    # the buffer against the oracle's full-resolution logits: pixel (y, x) lives in cell ((y + 2) // 4, (x + 2) // 4)
+    ys, xs = torch.arange(H), torch.arange(W)
+    cell = ((ys + 2) // 4)[:, None] * (w + 1) + ((xs + 2) // 4)[None, :]
+    slot = (((ys + 2) % 4) * 4)[:, None] + ((xs + 2) % 4)[None, :]
+    got_lse = lse.view(B, (h + 1) * (w + 1), 16).cpu()[:, cell, slot]
+    want_lse = -torch.logsumexp(up.detach(), dim=1) / math.log(2.0)
+    assert (got_lse - want_lse).abs().max().item() < 1e-4 * max(1.0, want_lse.abs().max().item())
+    l1 = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats_l, go, lse=lse)
+    monkeypatch.setenv('SEGFAC_LOSS_BAND_ROWS', '8')
+    l2 = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats_l, go, lse=lse)
+    l3 = hip.ce_dice_bwd(tok, B, C, h, w, H, W, tg, 255, cwd, True, stats_l, go, lse=lse)
+    torch.cuda.synchronize()
+    assert stats_l[-4:].view(torch.int32)[0].item() == 0                        # no hand-over to the exact-maximum pass
+    assert torch.equal(l1, l2) and torch.equal(l2, l3) and not l1[:, C:].any()
+    err = (l1[:, :C].float().cpu() - want).abs().max().item()
+    assert err < 1e-2 * scale, (err, scale)
+    assert (l1.float() - band.float()).abs().max().item() <= 2.0 ** -7 * scale   # two bf16 roundings of the same value
 
 
 def test_loss_backward_band_kernel_hands_over_on_underflow():
@@ -435,6 +460,14 @@ def test_loss_backward_band_kernel_hands_over_on_underflow():
     assert stats[-4:].view(torch.int32)[0].item() != 0
     want = lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, C)
     assert (d[:, :C].float().cpu() - want).abs().max().item() < 1e-2 * want.abs().max().item()
+    # with the per-pixel log-sum hand-over: the forward marks its buffer unusable (retry[1]), the backward's band kernel steps
+    # aside without touching it and the exact-maximum pass delivers the same gradient
+    loss_l, stats_l, lse = hip.ce_dice_fwd(buf[:, :C], B, C, h, w, H, W, t.cuda(), 255, None, True, want_lse=True)
+    assert stats_l[-4:].view(torch.int32)[1].item() != 0 and torch.equal(loss_l, loss)
+    dl = hip.ce_dice_bwd(buf[:, :C], B, C, h, w, H, W, t.cuda(), 255, None, True, stats_l, torch.ones(1, device='cuda'), lse=lse)
+    torch.cuda.synchronize()
+    assert stats_l[-4:].view(torch.int32)[0].item() != 0
+    assert torch.equal(dl, d)
 
 
 def test_argmax_confmat_and_metrics_golden(golden_dir):
