@@ -954,6 +954,67 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Wide form for large outputs (the weight gradients of the wider models: 3072 x 768 fp32 x 8 slices is 75 MB of partials): one
+// thread per four consecutive outputs, the slices added in order z = 0, 1, ... with four 16-byte loads in flight -- every slab is
+// read as whole contiguous rows.  (The 16 x 16 form above reads 64-byte pieces and ran at ~1 TB/s on these; it stays for small
+// outputs with many slices, where this one would leave most of the chip idle.)  N % 4 == 0, ldc % 4 == 0, ws 16-byte aligned.
+template <typename OutT>
+__global__ void __launch_bounds__(256) splitk_reduce_wide_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                                  OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                                  const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
+    if (blockIdx.x >= main_blocks) {          // bias-gradient slices riding on the product: [split][cs_n] -> [cs_n], same order
+        const int64_t i = (int64_t)(blockIdx.x - main_blocks) * 256 + threadIdx.x;
+        if (i < cs_n) {
+            float t = 0.f;
+            for (int z = 0; z < split; ++z) t += cs_ws[(int64_t)z * cs_n + i];
+            cs_out[i] = t;
+        }
+        return;
+    }
+    const int64_t total = M * N;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const float* __restrict__ src = ws + i;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 4 <= split; z += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)z * total);
+        const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)(z + 1) * total);
+        const float4 c = *reinterpret_cast<const float4*>(src + (int64_t)(z + 2) * total);
+        const float4 d = *reinterpret_cast<const float4*>(src + (int64_t)(z + 3) * total);
+        acc.x = ((acc.x + a.x) + b.x) + c.x + d.x; acc.y = ((acc.y + a.y) + b.y) + c.y + d.y;
+        acc.z = ((acc.z + a.z) + b.z) + c.z + d.z; acc.w = ((acc.w + a.w) + b.w) + c.w + d.w;
+    }
+    for (; z < split; ++z) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)z * total);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    const int64_t m = i / N, n = i - m * N;
+    OutT* o = C + m * ldc + n;
+    if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float4*>(o) = acc;
+    else { uint2 u; u.x = pack2bf(acc.x, acc.y); u.y = pack2bf(acc.z, acc.w); *reinterpret_cast<uint2*>(o) = u; }
+}
+
+// one entry for every split-K product: picks the form by output size
+template <typename OutT>
+static void splitk_reduce_launch(hipStream_t st, const float* ws, int split, int64_t M, int64_t N, OutT* C, int64_t ldc,
+                                 const float* cs_ws, float* cs_out, int64_t cs_n) {
+    const int64_t total = M * N;
+    const bool wide = total >= 65536 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) &&
+                      !getenv("SEGFAC_NO_WIDE_REDUCE");
+    if (wide) {
+        const unsigned blocks = (unsigned)cdiv64(total, 1024);
+        const unsigned csb = cs_ws ? (unsigned)cdiv64(cs_n, 256) : 0u;
+        hipLaunchKernelGGL((splitk_reduce_wide_kernel<OutT>), dim3(blocks + csb), dim3(256), 0, st, ws, split, M, N, C, ldc, blocks,
+                           cs_ws, cs_out, cs_n);
+    } else {
+        const unsigned blocks = (unsigned)cdiv64(total, 16);
+        const unsigned csb = cs_ws ? (unsigned)cdiv64(cs_n, 16) : 0u;
+        hipLaunchKernelGGL((splitk_reduce_kernel<OutT>), dim3(blocks + csb), dim3(256), 0, st, ws, split, M, N, C, ldc, blocks,
+                           cs_ws, cs_out, cs_n);
+    }
+}
+
 // ---- streaming kernel for huge-M, small-K, small-N products (stage-1/2 linears, the head's stage-1 projection) ------------
 // y = x W^T with M ~ 10^6 tokens and K, N <= 128 is pure HBM streaming: one 64..256-byte row in, one out.  The tiled
 // kernels above stage both operands through LDS in 128-wide tiles and waste most of a tile on N = 32.  Here the weight
@@ -1810,15 +1871,9 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     SEGF_CHECK_LAUNCH();
 reduce:
     if (a.ws) {
-        const int64_t total = M * N;
-        const unsigned blocks = (unsigned)cdiv64(total, 16);
-        const unsigned csb = a.colsum_ws ? (unsigned)cdiv64(M, 16) : 0u;        // the bias gradient's slices: same launch
-        if (c_dt == SEGF_F32)
-            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks + csb), dim3(256), 0, st, ws, split_k, M, N, (float*)C, ldc,
-                               blocks, a.colsum_ws, a.colsum, M);
-        else
-            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks + csb), dim3(256), 0, st, ws, split_k, M, N, (bf16_t*)C, ldc,
-                               blocks, a.colsum_ws, a.colsum, M);
+        // (the bias gradient's slices ride in the same launch)
+        if (c_dt == SEGF_F32) splitk_reduce_launch<float>(st, ws, split_k, M, N, (float*)C, ldc, a.colsum_ws, a.colsum, M);
+        else splitk_reduce_launch<bf16_t>(st, ws, split_k, M, N, (bf16_t*)C, ldc, a.colsum_ws, a.colsum, M);
         SEGF_CHECK_LAUNCH();
     }
     return 0;
@@ -1898,9 +1953,8 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     }
 reduce3:
     if (a.ws) {
-        const unsigned blocks = (unsigned)cdiv64(a.M * a.N, 16);
-        if (y_dt == SEGF_F32) hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (float*)y, ldy, blocks, (const float*)nullptr, (float*)nullptr, (int64_t)0);
-        else hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, split_k, a.M, a.N, (bf16_t*)y, ldy, blocks, (const float*)nullptr, (float*)nullptr, (int64_t)0);
+        if (y_dt == SEGF_F32) splitk_reduce_launch<float>(st, ws, split_k, a.M, a.N, (float*)y, ldy, nullptr, nullptr, 0);
+        else splitk_reduce_launch<bf16_t>(st, ws, split_k, a.M, a.N, (bf16_t*)y, ldy, nullptr, nullptr, 0);
         SEGF_CHECK_LAUNCH();
     }
     return 0;
@@ -1972,9 +2026,7 @@ extern "C" int segf_conv3x3_fp8_wgrad(int B, int H, int W, int Cin, int Cout, co
                                 1, ws, st);
     if (rc) return rc;
     if (split_k > 1) {
-        const unsigned blocks = (unsigned)cdiv64(M * N, 16);
-        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, split_k, M, N, dw, lddw, blocks, (const float*)nullptr,
-                           (float*)nullptr, (int64_t)0);
+        splitk_reduce_launch<float>(st, ws, split_k, M, N, dw, lddw, nullptr, nullptr, 0);
         SEGF_CHECK_LAUNCH();
     }
     return 0;
