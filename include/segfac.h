@@ -92,6 +92,23 @@ int segf_conv3x3_fp8_wgrad_supported(int B, int H, int W, int Cin, int Cout);
 int segf_conv3x3_fp8_wgrad(int B, int H, int W, int Cin, int Cout, const void* xq, int64_t ldx, const float* sx, const void* gq,
                            int64_t ldg, const float* sg, float* dw, int64_t lddw, int split_k, float* ws, void* stream);
 
+/* nn.Linear products on fp8 operands with one scale per activation / gradient TENSOR and one per weight row (the ConvNeXt block MLPs,
+ * convnextv2.py:83-113), on the 256 x 256 tile kernel:
+ *   mode 0  y[m][n] = sa * sb[n] * sum_k Aq[m][k] Bq[n][k] (+ bias[n]); with residual: y = residual + rscale[m / rows_per_group] * (..)
+ *           Aq e4m3 [M][K] (segf_quant_tensor_fp8, fmt 0), Bq e4m3 [N][K] (segf_quant_rows_fp8 of the weight), bf16 out
+ *   mode 1  the same with Aq in e5m2: the data gradient dx = dy W (Aq = the quantised gradient [M][N_out], Bq = W^T quantised per row)
+ *   segf_linear_fp8_wgrad: dW[n][k] = sg * sx * sum_t gq[t][n] xq[t][k], gq e5m2 [T][N], xq e4m3 [T][K] -- the tensors mode 1 / mode 0
+ *           were called with -- fp32 out; split_k > 1 needs ws >= split_k * N * K floats.
+ * M (T), N multiples of 256, K of 128; strides in bytes = elements, multiples of 16.  segf_linear_fp8_supported(mode, M, N, K) with
+ * mode 2 = the weight gradient (M = T tokens, N x K the weight). */
+int segf_linear_fp8_supported(int mode, int64_t M, int64_t N, int64_t K);
+int segf_linear_fp8(int mode, int64_t M, int64_t N, int64_t K, const void* Aq, int64_t lda, const float* sa, const void* Bq,
+                    int64_t ldb, const float* sb, void* C, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
+                    const float* rscale, int64_t rows_per_group, void* stream);
+int segf_linear_fp8_wgrad_splitk(int64_t N, int64_t K, int64_t T);      /* slices over the tokens (sizes ws) */
+int segf_linear_fp8_wgrad(int64_t N, int64_t K, int64_t T, const void* gq, int64_t ldg, const float* sg, const void* xq,
+                          int64_t ldx, const float* sx, float* dw, int64_t lddw, int split_k, float* ws, void* stream);
+
 /* ---- stream ordering for the data-parallel exchange (train_gpu.py:233-236: DistributedDataParallel overlaps the gradient
  * all-reduce with backward through per-bucket hooks).  segf_event_record(.., external=1) during a stream capture adds an
  * EVENT-RECORD NODE to the hipGraph (hipEventRecordExternal); at each replay a stream outside the graph can

@@ -2031,3 +2031,57 @@ extern "C" int segf_conv3x3_fp8_wgrad(int B, int H, int W, int Cin, int Cout, co
     }
     return 0;
 }
+
+// ---- nn.Linear products on fp8 operands, one dynamic scale per activation / gradient TENSOR (segf_quant_tensor_fp8) and one per weight
+// row (segf_quant_rows_fp8): the ConvNeXt block MLPs of BASELINE cfg5 (convnextv2.py:83-113: pwconv1 / pwconv2), all three products on
+// the 256 x 256 eight-wave tile kernel (gemm8.hip) with the block-scaled K = 128 fp8 matrix instruction.
+//   mode 0  y[m][n]  = sa * sb[n] * sum_k Aq[m][k] Bq[n][k] (+ bias[n]) (+ residual: y = residual + rscale[m / rpg] * (..))   A e4m3
+//   mode 1  the same with A in e5m2 (the data gradient dx = dy W: Aq = the quantised gradient, Bq = W^T quantised per row)
+//   mode 2  dW[n][k] = sg * sx * sum_t gq[t][n] xq[t][k]       gq e5m2 [T][N], xq e4m3 [T][K] (the tensors the forward / data gradient
+//           already hold), fp32 out, split over the tokens: ws >= split_k * N * K floats (segf_gemm_pick_splitk(N, K, T))
+// Row strides in bytes (= elements).  Not a reference feature -- an option of this build (SegmentationModel.set_fp8).
+extern "C" int segf_linear_fp8_supported(int mode, int64_t M, int64_t N, int64_t K) {
+    if (getenv("SEGFAC_NO_FP8_LINEAR") || M <= 0 || N <= 0 || K <= 0) return 0;
+    if (mode == 2) {                     // M = tokens (the reduction), N x K = the weight
+        if (N % 256 || K % 256 || (N / 256) * (K / 256) * (M / 1024) < 128) return 0;       // enough 256 x 256 x >= 1024-token pieces
+        return gemm8_supported(3, 0, N, K, M, 512, 0);
+    }
+    if (mode != 0 && mode != 1) return 0;
+    if (K % 128 || M % 256 || N % 256 || (M / 256) * (N / 256) < 128) return 0;      // K in 2-byte units: a multiple of 64
+    return gemm8_supported(2, 0, M, N, K / 2, K / 2, 0);                              // (kind 2 = the shape rules without the tile-count bar)
+}
+extern "C" int segf_linear_fp8(int mode, int64_t M, int64_t N, int64_t K, const void* Aq, int64_t lda, const float* sa, const void* Bq,
+                               int64_t ldb, const float* sb, void* C, int64_t ldc, const float* bias, const void* residual, int64_t ldr,
+                               const float* rscale, int64_t rows_per_group, void* stream) {
+    if (!segf_linear_fp8_supported(mode, M, N, K) || mode == 2) return SEGF_ERR_SHAPE;
+    if (!Aq || !Bq || !sa || !sb || !C || (lda % 16) || (ldb % 16) || lda < K || ldb < K || ldc < N) return SEGF_ERR_SHAPE;
+    return gemm8_launch(0, 0, mode == 0 ? 1 : 2, M, N, K / 2, K / 2, 1, Aq, lda / 2, Bq, ldb / 2, C, ldc, 0, 0, 0, 1, sa, sb, bias, residual,
+                        ldr, rscale, rows_per_group, nullptr, (hipStream_t)stream);
+}
+// slices over the tokens for segf_linear_fp8_wgrad: one 256 x 256 tile per compute unit and slice, slices of >= 1024 tokens
+extern "C" int segf_linear_fp8_wgrad_splitk(int64_t N, int64_t K, int64_t T) {
+    const int64_t tiles = cdiv64(N, 256) * cdiv64(K, 256);
+    int64_t s = (256 + tiles / 2) / tiles;
+    if (s > T / 1024) s = T / 1024;
+    if (s > 16) s = 16;
+    return (int)(s < 1 ? 1 : s);
+}
+extern "C" int segf_linear_fp8_wgrad(int64_t N, int64_t K, int64_t T, const void* gq, int64_t ldg, const float* sg, const void* xq,
+                                     int64_t ldx, const float* sx, float* dw, int64_t lddw, int split_k, float* ws, void* stream) {
+    if (!segf_linear_fp8_supported(2, T, N, K)) return SEGF_ERR_SHAPE;
+    if (!gq || !xq || !sg || !sx || !dw || ldg < N || ldx < K || lddw < K) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (split_k < 1) split_k = 1;
+    if (split_k > 1 && !ws) return SEGF_ERR_WORKSPACE;
+    int64_t kchunk = cdiv64(cdiv64(T, split_k), 128) * 128;
+    split_k = (int)cdiv64(T, kchunk);
+    if (!gemm8_supported(3, 0, N, K, T, kchunk, 0)) return SEGF_ERR_SHAPE;
+    const int rc = gemm8_launch(3, 0, 2, N, K, T, kchunk, split_k, gq, ldg, xq, ldx, dw, lddw, 0, 0, 0, 1, sg, sx, nullptr, nullptr, 0, nullptr,
+                                1, ws, st);
+    if (rc) return rc;
+    if (split_k > 1) {
+        splitk_reduce_launch<float>(st, ws, split_k, N, K, dw, lddw, nullptr, nullptr, 0);
+        SEGF_CHECK_LAUNCH();
+    }
+    return 0;
+}

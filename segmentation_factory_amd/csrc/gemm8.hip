@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 int gemm8_supported(int kind, int conv, int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC) {
     if (getenv("SEGFAC_NO_GEMM8")) return 0;
     if (M % 256 || N % 256 || K % 64 || kchunk % 64 || kchunk < 256 || M / 256 > 65535) return 0;
-    if (kind == 3) return (K % 128 || kchunk % 128 || kchunk < 512 || !conv || cC % 128 || getenv("SEGFAC_NO_GEMM8T")) ? 0 : 1;      // fp8 weight gradient
+    if (kind == 3) return (K % 128 || kchunk % 128 || kchunk < 512 || (conv && cC % 128) || getenv("SEGFAC_NO_GEMM8T")) ? 0 : 1;     // fp8 weight gradient
     if (conv && (cC % (kind == 2 ? 128 : 64))) return 0;
     if (kind == 2) return getenv("SEGFAC_NO_GEMM8T") ? 0 : 1;
     return (M / 256) * (N / 256) >= 192;
@@ -389,9 +389,9 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     } else if (kind == 2) {
         if (fp8) return SEGF_ERR_SHAPE;
         if (conv) G8_GO(1, 1, true, 0, float); else G8_GO(1, 1, false, 0, float);
-    } else {                                   // kind 3: conv weight gradient on fp8 operands (A = dy e5m2 [P][M], B = x e4m3 [P][Cin]; strides in bytes)
-        if (!conv || !f8_sa || !f8_sb) return SEGF_ERR_SHAPE;
-        G8_GO(2, 2, true, 2, float);
+    } else {                                   // kind 3: weight gradient on fp8 operands (A = dy e5m2 [P][M], B = x e4m3 [P][Cin]; strides in bytes)
+        if (!f8_sa || !f8_sb) return SEGF_ERR_SHAPE;
+        if (conv) G8_GO(2, 2, true, 2, float); else G8_GO(2, 2, false, 2, float);
     }
 #undef G8_GO
     SEGF_CHECK_LAUNCH();

@@ -135,6 +135,20 @@ class LinearFn(Function):
         M, K = x.shape
         N = weight.shape[0]
         Np = pad_to if (pad_to and pad_to > N) else N
+        if fp8 and Np == N and x.dtype == torch.bfloat16 and hip.linear_fp8_supported(0, M, N, K):
+            # FP8 on the 256 x 256 tile kernel (BASELINE cfg5): the activation tensor quantised to e4m3 with ONE dynamic scale, the
+            # weight rows with one each.  The quantised input is kept for the weight gradient (instead of the bf16 tensor, when that
+            # product has an fp8 form too); the backward quantises the gradient once (e5m2) for its two products.
+            w = _w(weight.reshape(N, -1), x.dtype)
+            xq, sx = hip.quant_tensor_fp8(x)
+            wq, sw = hip.quant_rows_fp8(weight.detach().reshape(N, -1))
+            y = hip.linear_fp8(0, xq, sx, wq, sw, bias=bias.detach() if bias is not None else None, residual=residual, rscale=rscale,
+                               rows_per_group=rows_per_group or 1)
+            keep8 = hip.linear_fp8_supported(2, M, N, K)
+            ctx.save_for_backward(None if keep8 else x, w, rscale, xq if keep8 else None, sx if keep8 else None)
+            ctx.meta = (M, N, K, bias is not None, residual is not None, rows_per_group or 1, weight.shape, Np)
+            ctx.fp8t = True
+            return y
         if fp8 and Np == N and x.dtype == torch.bfloat16 and hip.gemm_fp8_supported(M, N, K):
             # FP8 forward (BASELINE cfg5): token rows and output-channel rows quantised to e4m3 with dynamic amax scales, product
             # on the block-scaled fp8 matrix instruction; the backward products below stay bf16 on the saved operands
@@ -168,6 +182,8 @@ class LinearFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if getattr(ctx, 'fp8t', False):
+            return LinearFn._backward_fp8(ctx, dy)
         x, w, rscale = ctx.saved_tensors
         M, N, K, has_bias, has_res, rpg, wshape, Np = ctx.meta
         dy = _rowmajor(dy)
@@ -202,6 +218,41 @@ class LinearFn(Function):
                 db = hip.colsum(dys, out=gb)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None, None
+
+
+def _linear_backward_fp8(ctx, dy):
+    """Backward of the tensor-scaled fp8 Linear: dx = dy W and dW = dy^T x on fp8 operands where the shapes have the tile kernel
+    (the gradient quantised once, e5m2, one scale), bf16 otherwise; the bias gradient is a column sum of the bf16 gradient."""
+    x, w, rscale, xq, sx = ctx.saved_tensors
+    M, N, K, has_bias, has_res, rpg, wshape, Np = ctx.meta
+    dy = _rowmajor(dy)
+    dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
+    dx8 = ctx.needs_input_grad[0] and hip.linear_fp8_supported(1, M, K, N)
+    dw8 = ctx.needs_input_grad[1] and xq is not None
+    gq = sg = None
+    if dx8 or dw8:
+        gq, sg = hip.quant_tensor_fp8(dys, e5m2=True)
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        if dx8:
+            wt = hip.permute021(w.reshape(1, N, K), 1, N, K, w.dtype).view(K, N)       # W^T, rows = input features
+            wtq, swt = hip.quant_rows_fp8(wt)
+            dx = hip.linear_fp8(1, gq, sg, wtq, swt)
+        else:
+            dx = hip.gemm(1, dys, w, M, K, N)
+    gw, gb = gslot(ctx, 1, (N, K)), gslot(ctx, 2)
+    if ctx.needs_input_grad[1]:
+        if dw8:
+            dw = hip.linear_fp8_wgrad(gq, sg, xq, sx, out=gw).view(wshape)
+        else:
+            dw = hip.gemm(2, dys, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
+    if has_bias and ctx.needs_input_grad[2]:
+        db = hip.colsum(dys, out=gb)
+    dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+    return dx, dw, db, dres, None, None, None, None
+
+
+LinearFn._backward_fp8 = staticmethod(_linear_backward_fp8)
 
 
 @direct_grads(1, 2)

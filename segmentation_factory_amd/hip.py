@@ -103,6 +103,10 @@ _PROTOS = {
     'segf_conv3x3_fp8_wgrad_supported': (_i, [_i, _i, _i, _i, _i]),
     'segf_conv3x3_fp8_wgrad': (_i, [_i, _i, _i, _i, _i, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _p]),
     'segf_gemm_fp8': (_i, [_l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _p, _l, _p, _l, _p, _l, _p]),
+    'segf_linear_fp8_supported': (_i, [_i, _l, _l, _l]),
+    'segf_linear_fp8': (_i, [_i, _l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _l, _p, _p, _l, _p, _l, _p]),
+    'segf_linear_fp8_wgrad_splitk': (_i, [_l, _l, _l]),
+    'segf_linear_fp8_wgrad': (_i, [_l, _l, _l, _p, _l, _p, _p, _l, _p, _p, _l, _i, _p, _p]),
     'segf_input_train': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     'segf_input_val_ws': (_l, [_i, _i, _i, _i]),
     'segf_input_val': (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
@@ -363,6 +367,43 @@ def conv3x3_fp8_wgrad(xq, sx, gq, sg, B, H, W, Cin, Cout):
     _chk(_timed(key, lambda: lib().segf_conv3x3_fp8_wgrad(B, H, W, Cin, Cout, _ptr(xq), xq.stride(0), _ptr(sx), _ptr(gq), gq.stride(0), _ptr(sg),
                                                           _ptr(out), out.stride(0), sk, _ptr(ws) if ws is not None else None, _stream())),
          'segf_conv3x3_fp8_wgrad')
+    return out
+
+
+def linear_fp8_supported(mode, M, N, K):
+    """mode 0 / 1: y [M, N] from [M, K] x [N, K]; mode 2: the weight gradient [N, K] over M tokens."""
+    return bool(lib().segf_linear_fp8_supported(mode, M, N, K))
+
+
+def linear_fp8(mode, aq, sa, bq, sb, bias=None, residual=None, rscale=None, rows_per_group=1):
+    """bf16 [M, N] = sa * sb[None, :] * (aq . bq^T) (+ bias) (residual + rscale * .): aq [M, K] e4m3 (mode 0) or e5m2 (mode 1) with ONE
+    scale sa [1], bq [N, K] e4m3 with a scale per row."""
+    _need_cuda(aq, bq)
+    assert aq.dtype == torch.uint8 and bq.dtype == torch.uint8 and aq.stride(-1) == 1 and bq.stride(-1) == 1
+    M, K = aq.shape
+    N = bq.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=aq.device)
+    key = ('linear_fp8', mode, M, N, K)
+    _chk(_timed(key, lambda: lib().segf_linear_fp8(mode, M, N, K, _ptr(aq), aq.stride(0), _ptr(sa), _ptr(bq), bq.stride(0), _ptr(sb),
+                                                   _ptr(out), N, _ptr(bias), _ptr(residual),
+                                                   residual.stride(0) if residual is not None else 0, _ptr(rscale), rows_per_group,
+                                                   _stream())), 'segf_linear_fp8')
+    return out
+
+
+def linear_fp8_wgrad(gq, sg, xq, sx, out=None):
+    """dW fp32 [N, K] = sg * sx * gq^T xq from the e5m2 gradient gq [T, N] and the e4m3 input xq [T, K] (tensor scales)."""
+    _need_cuda(gq, xq)
+    assert gq.dtype == torch.uint8 and xq.dtype == torch.uint8 and gq.stride(-1) == 1 and xq.stride(-1) == 1
+    T, N = gq.shape
+    K = xq.shape[1]
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float32, device=gq.device)
+    sk = lib().segf_linear_fp8_wgrad_splitk(N, K, T)
+    ws = _f32(sk * N * K, gq.device) if sk > 1 else None
+    key = ('linear_fp8_wgrad', T, N, K)
+    _chk(_timed(key, lambda: lib().segf_linear_fp8_wgrad(N, K, T, _ptr(gq), gq.stride(0), _ptr(sg), _ptr(xq), xq.stride(0), _ptr(sx),
+                                                         _ptr(out), out.stride(0), sk, _ptr(ws), _stream())), 'segf_linear_fp8_wgrad')
     return out
 
 

@@ -1469,6 +1469,62 @@ def test_fp8_conv3x3_weight_gradient(hipmod):
     assert (dw - dwb).abs().max().item() <= 0.1 * dwb.abs().max().item()
 
 
+@pytest.mark.parametrize('shape', [(8192, 1024, 512), (12800, 3072, 768), (12800, 768, 3072)])
+def test_fp8_linear_tensor_scaled_products(hipmod, shape):
+    """segf_linear_fp8 / segf_linear_fp8_wgrad (the ConvNeXt block MLPs with set_fp8, convnextv2.py:83-113): y = x W^T + b with the
+    residual / per-sample scale epilogue, dx = dy W, dW = dy^T x on fp8 operands with ONE scale per activation / gradient tensor and one
+    per weight row, against fp32 matmuls of the DEQUANTISED operands (fp8 x fp8 products are exact in fp32: only the summation order and
+    the bf16 output rounding remain); deterministic; and close to the bf16 products they stand in for."""
+    hip = hipmod
+    M, N, K = shape
+    g = torch.Generator().manual_seed(67)
+    x = (torch.randn(M, K, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    rpg = M // 8
+    rs = (torch.rand(8, generator=g) + 0.5).cuda()
+    dy = (torch.randn(M, N, generator=g) * 1e-3).to(torch.bfloat16).cuda()
+    assert hip.linear_fp8_supported(0, M, N, K)
+    xq, sx = hip.quant_tensor_fp8(x)
+    wq, sw = hip.quant_rows_fp8(w)
+    xd = xq.view(torch.float8_e4m3fn).float() * sx
+    wd = wq.view(torch.float8_e4m3fn).float() * sw[:, None]
+    y = hip.linear_fp8(0, xq, sx, wq, sw, bias=bias, residual=res, rscale=rs, rows_per_group=rpg)
+    lin = xd @ wd.t() + bias
+    ref = res.float() + rs.repeat_interleave(rpg)[:, None] * lin
+    assert (y.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6
+    y0 = hip.linear_fp8(0, xq, sx, wq, sw)
+    assert (y0.float() - xd @ wd.t()).abs().max().item() <= 2 ** -8 * lin.abs().max().item() + 1e-6
+    assert torch.equal(y0, hip.linear_fp8(0, xq, sx, wq, sw))
+    yb = hip.gemm(0, x, w.to(torch.bfloat16), M, N, K)
+    assert (y0.float() - yb.float()).abs().max().item() <= 0.06 * yb.float().abs().max().item()
+    # data gradient: dy e5m2 (one scale), W^T e4m3 per row
+    gq, sg = hip.quant_tensor_fp8(dy, e5m2=True)
+    gd = gq.view(torch.float8_e5m2).float() * sg
+    if hip.linear_fp8_supported(1, M, K, N):
+        wt = w.t().contiguous()
+        wtq, swt = hip.quant_rows_fp8(wt)
+        wtd = wtq.view(torch.float8_e4m3fn).float() * swt[:, None]
+        dx = hip.linear_fp8(1, gq, sg, wtq, swt)
+        refdx = gd @ wtd.t()
+        assert (dx.float() - refdx).abs().max().item() <= 2 ** -8 * refdx.abs().max().item() + 1e-12
+        dxb = dy.float() @ w
+        assert (dx.float() - dxb).abs().max().item() <= 0.1 * dxb.abs().max().item()
+    else:
+        assert (M // 256) * (K // 256) < 128
+    # weight gradient on the same quantised tensors
+    if hip.linear_fp8_supported(2, M, N, K):
+        dw = hip.linear_fp8_wgrad(gq, sg, xq, sx)
+        refdw = gd.t() @ xd
+        assert (dw - refdw).abs().max().item() <= 2e-4 * refdw.abs().max().item()
+        assert torch.equal(dw, hip.linear_fp8_wgrad(gq, sg, xq, sx))
+        dwb = dy.float().t() @ x.float()
+        assert (dw - dwb).abs().max().item() <= 0.1 * dwb.abs().max().item()
+    else:
+        assert (N // 256) * (K // 256) * (M // 1024) < 128
+
+
 @pytest.mark.parametrize('shape', [(300, 256, 128), (1000, 768, 3072), (4096, 1536, 384), (129, 40, 256)])
 def test_fp8_quantise_and_gemm(hipmod, shape):
     """csrc/fp8.hip: row-wise e4m3fn quantisation (decode with torch.float8_e4m3fn) and the block-scaled fp8 MFMA product against
