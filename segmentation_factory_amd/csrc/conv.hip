@@ -813,8 +813,7 @@ extern "C" int segf_dwconv7x7_bwd(int dt, int B, int H, int W, int C, const void
                            H, W, C, p.ch, p.rl, p.units_per_blk);
     })
     SEGF_CHECK_LAUNCH();
-    for (int ky = 0; ky < 7; ++ky)
-        colreduce_finalize_launch(ws + (int64_t)ky * p.nblk * 8 * C, p.nblk, 8 * (int64_t)C, sums + (int64_t)ky * 8 * C, st);
+    colreduce_finalize_launch(ws, p.nblk, 8 * (int64_t)C, sums, st, 7);          // the seven kernel rows as one batched launch
     SEGF_CHECK_LAUNCH();
     hipLaunchKernelGGL(dw7_scatter_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dw, db);
     SEGF_CHECK_LAUNCH();
