@@ -773,7 +773,12 @@ __global__ void dw7_scatter_kernel(const float* __restrict__ sums, int C, float*
 }
 
 static inline int dw7_blocks(int B, int H, int W, int C) {
-    return colfixed_blocks((int64_t)B * H * ((W + DW7_PIX - 1) / DW7_PIX), C / 8, 4, 16384);
+    // strips per thread: 4 on large maps, fewer while that would leave under ~8 workgroups per CU -- a strip is a serial chain of
+    // 7 x 3 load round trips and 2744 packed multiply-adds (~10 us): [8, 40, 40, 768] ran 150 workgroups x 4 strips = 45 us
+    const int64_t units = (int64_t)B * H * ((W + DW7_PIX - 1) / DW7_PIX);
+    int upt = (int)(units * (C / 8) / 256 / 2048);
+    upt = upt < 1 ? 1 : (upt > 4 ? 4 : upt);
+    return colfixed_blocks(units, C / 8, upt, 16384);
 }
 static inline int dw7_check(int B, int H, int W, int C, const void* a, const void* b) {
     if (C <= 0 || C % 8 != 0 || ((uintptr_t)a % 16) || ((uintptr_t)b % 16)) return SEGF_ERR_SHAPE;
