@@ -221,12 +221,15 @@ int segf_bn_cls_bwd_full(int dt, int64_t M, int C, int K, const void* dy, int64_
                          float* ws, const void* x1, int64_t ldx1, int C1, float* dG, float* dwcls, void* stream);
 
 /* ---- Global Response Normalization (ConvNeXtV2 GRN, convnextv2.py:68-80) on NHWC rows, B images of rows_per_sample rows:
- * y = gamma * (x * Nx) + beta + x, Nx = ||x||_2(H,W) / (mean_c ||x||_2 + 1e-6).  sumsq_out [B][C] is saved for the backward. */
+ * y = gamma * (x * Nx) + beta + x, Nx = ||x||_2(H,W) / (mean_c ||x||_2 + 1e-6).  sumsq_out [B][C] is saved for the backward.
+ * pre_gelu != 0: the input of the normalisation is gelu(x) of the stored tensor (nn.GELU between pwconv1 and grn, convnextv2.py:92-94):
+ * the activation is applied on the way in and the backward returns the gradient of the PRE-activation, dx = dGRN * gelu'(x) -- gelu(x)
+ * is never written or read. */
 int64_t segf_grn_ws(int B, int64_t rows_per_sample, int C, int bwd);
 int segf_grn_fwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const float* gamma, const float* beta, void* y,
-                 float* a_scratch, float* sumsq_out, float* ws, void* stream);
+                 float* a_scratch, float* sumsq_out, float* ws, int pre_gelu, void* stream);
 int segf_grn_bwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const void* dy, const float* gamma,
-                 const float* sumsq_saved, void* dx, float* dgamma, float* dbeta, float* ws, void* stream);
+                 const float* sumsq_saved, void* dx, float* dgamma, float* dbeta, float* ws, int pre_gelu, void* stream);
 
 /* ---- MiT spatial-reduction attention core (mit.py:52-57): O = softmax(Q K^T * scale) V -----------
  * q: [B*N][ldq] with head h at columns h*hd; k, v likewise over B*Nkv rows; o: [B*N][ldo]; lse: [B][heads][N] */

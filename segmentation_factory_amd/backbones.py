@@ -5,6 +5,8 @@ Internally every activation is a token-major ``[B*H*W, C]`` tensor in the comput
 a HIP kernel (segmentation_factory_amd.functional).  The NCHW maps handed to the head are zero-copy
 permuted views of those token buffers.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -262,10 +264,15 @@ class ConvNeXtBlock(nn.Module):
         x, xc = Fh.fork(x, 2)                        # residual + depthwise conv both read x
         h = Fh.dwconv7x7(xc, self.dwconv.weight, self.dwconv.bias, B, H, W)
         h = Fh.layer_norm(h, self.norm.weight, self.norm.bias, self.norm.eps)
-        h = Fh.gelu(Fh.linear(h, self.pwconv1.weight, self.pwconv1.bias, fp8=self.fp8))
+        h = Fh.linear(h, self.pwconv1.weight, self.pwconv1.bias, fp8=self.fp8)
         if self.v2:
-            h = Fh.grn(h, self.grn.gamma, self.grn.beta, B, H * W)
+            # act -> grn (convnextv2.py:92-94) as one op: the GELU is applied inside the GRN kernels, gelu(h) is never written
+            if os.environ.get('SEGFAC_NO_GELU_GRN'):
+                h = Fh.grn(Fh.gelu(h), self.grn.gamma, self.grn.beta, B, H * W)
+            else:
+                h = Fh.grn(h, self.grn.gamma, self.grn.beta, B, H * W, pre_gelu=True)
             return Fh.linear(h, self.pwconv2.weight, self.pwconv2.bias, residual=x, rscale=scale, rows_per_group=H * W, fp8=self.fp8)
+        h = Fh.gelu(h)
         if hasattr(self, 'gamma'):
             return Fh.linear_layer_scale(h, self.pwconv2.weight, self.pwconv2.bias, self.gamma, residual=x, rscale=scale,
                                          rows_per_group=H * W)

@@ -286,6 +286,39 @@ __device__ __forceinline__ void gelu_erf8(f32x2_t (&a)[4], const f32x2_t* __rest
         else { const f32x2_t h = a[i] * 0.5f; a[i] = h * er + h; }
     }
 }
+// gelu(a) and gelu'(a) together (the fused GELU + GRN backward needs both): g <- gelu(a), a <- gelu'(a)
+__device__ __forceinline__ void gelu_erf8_both(f32x2_t (&a)[4], f32x2_t (&g)[4]) {
+    f32x2_t e[4], t[4], p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t q = a[i] * a[i] * -0.72134752044448170368f;
+        const f32x2_t d = __builtin_elementwise_abs(a[i]) * (0.3275911f * 0.70710678118654752440f) + 1.f;
+        e[i] = f32x2_t{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+        t[i] = f32x2_t{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        p[i] = t[i] * 1.061405429f + -1.453152027f;
+        p[i] = p[i] * t[i] + 1.421413741f;
+        p[i] = p[i] * t[i] + -0.284496736f;
+        p[i] = p[i] * t[i] + 0.254829592f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t y = 1.f - p[i] * t[i] * e[i];
+        const f32x2_t er = {copysignf(y.x, a[i].x), copysignf(y.y, a[i].y)};
+        const f32x2_t h = a[i] * 0.5f;
+        g[i] = h * er + h;
+        a[i] = a[i] * e[i] * 0.39894228040143267794f + (er * 0.5f + 0.5f);
+    }
+}
+// the same on eight floats in place (column-reduction functors)
+__device__ __forceinline__ void gelu_erf8_floats(float (&v)[8]) {
+    f32x2_t a[4] = {f32x2_t{v[0], v[1]}, f32x2_t{v[2], v[3]}, f32x2_t{v[4], v[5]}, f32x2_t{v[6], v[7]}};
+    gelu_erf8<false>(a, nullptr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = a[i].x; v[2 * i + 1] = a[i].y; }
+}
 // 8 consecutive elements as 4 channel pairs
 template <typename T> __device__ __forceinline__ void unpack8v(const Raw8<T>& r, f32x2_t (&v)[4]);
 template <> __device__ __forceinline__ void unpack8v<float>(const Raw8<float>& r, f32x2_t (&v)[4]) {

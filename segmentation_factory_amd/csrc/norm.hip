@@ -537,17 +537,20 @@ extern "C" int segf_bn_bwd(int dt, int64_t rows, int C, const void* x, const voi
 // backward: batched column reduction (sum dy*x, sum dy) -> coefficient kernel -> dx = a * dy + K * x, with
 //           K[b][c] = dL/dGx / Gx,  dL/dGx[c] = A[c]/(m+eps) - (1/C) sum_c' A[c'] Gx[c'] / (m+eps)^2,  A = gamma * sum_p dy*x
 #define GRN_EPS 1e-6f
-template <typename T> struct GrnSqF {
+// ACT: the GRN input is gelu(x) of what is stored (ConvNeXtV2: pwconv1 -> GELU -> GRN, convnextv2.py:92-94): the activation is
+// applied on the way in, in fp32, and gelu(x) is never written -- the pre-activation is what the GELU backward needs anyway.
+template <typename T, bool ACT = false> struct GrnSqF {
     const T* x; int C; bool vec;
     struct Col {};
     __device__ void init(int, int, Col&) const {}
     __device__ void operator()(const Col&, int64_t r, int c0, int nv, float (&v)[1][8]) const {
         load8_guard<T>(x + r * C + c0, nv, vec, v[0]);
+        if (ACT) gelu_erf8_floats(v[0]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[0][j] *= v[0][j];
     }
 };
-template <typename T> struct GrnBwdF {
+template <typename T, bool ACT = false> struct GrnBwdF {
     const T* x; const T* dy; int C; bool vec;
     struct Col {};
     __device__ void init(int, int, Col&) const {}
@@ -555,6 +558,7 @@ template <typename T> struct GrnBwdF {
         float xv[8];
         load8_guard<T>(x + r * C + c0, nv, vec, xv);
         load8_guard<T>(dy + r * C + c0, nv, vec, v[1]);
+        if (ACT) gelu_erf8_floats(xv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[0][j] = v[1][j] * xv[j];
     }
@@ -595,7 +599,8 @@ __global__ void __launch_bounds__(256) grn_coef_kernel(const float* __restrict__
     }
 }
 // y = a[b][c] * x + (k ? k[b][c] * x2 : beta[c])     fwd: (x, a, beta);  bwd: dx = a * dy + K * x  (x := dy, x2 := x)
-template <typename T>
+// ACT (see GrnSqF): fwd y = a * gelu(x) + beta;  bwd (x := dy, x2 := the stored pre-activation u): du = (a * dy + K * gelu(u)) * gelu'(u)
+template <typename T, bool ACT = false>
 __global__ void __launch_bounds__(256) grn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ a,
                                                          const float* __restrict__ k, const float* __restrict__ beta, T* __restrict__ y,
                                                          int64_t rows, FastDivU32 rps, int C) {
@@ -615,9 +620,20 @@ __global__ void __launch_bounds__(256) grn_apply_kernel(const T* __restrict__ x,
             float w[8], kv[8];
             load8<T>(x2 + r * C + c0, w);
             load8f(k + b * C + c0, kv);
+            if (ACT) {
+                f32x2_t u2[4] = {f32x2_t{w[0], w[1]}, f32x2_t{w[2], w[3]}, f32x2_t{w[4], w[5]}, f32x2_t{w[6], w[7]}}, g2[4];
+                gelu_erf8_both(u2, g2);                       // g2 = gelu(u), u2 = gelu'(u)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(av[j], v[j], kv[j] * w[j]);
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] = fmaf(av[2 * i], v[2 * i], kv[2 * i] * g2[i].x) * u2[i].x;
+                    v[2 * i + 1] = fmaf(av[2 * i + 1], v[2 * i + 1], kv[2 * i + 1] * g2[i].y) * u2[i].y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(av[j], v[j], kv[j] * w[j]);
+            }
         } else {
+            if (ACT) gelu_erf8_floats(v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = fmaf(av[j], v[j], bt[j]);
         }
@@ -640,7 +656,7 @@ extern "C" int64_t segf_grn_ws(int B, int64_t rows_per_sample, int C, int bwd) {
 }
 // y = gamma * (x * Nx) + beta + x;  a_out [B][C] (scratch) and g_out [B][C] (sum_p x^2, saved for the backward)
 extern "C" int segf_grn_fwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const float* gamma, const float* beta,
-                            void* y, float* a_out, float* g_out, float* ws, void* stream) {
+                            void* y, float* a_out, float* g_out, float* ws, int pre_gelu, void* stream) {
     if (B <= 0 || rows_per_sample <= 0) return 0;
     if (C <= 0 || C % 8 || ((uintptr_t)x % 16) || ((uintptr_t)y % 16)) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
@@ -648,19 +664,23 @@ extern "C" int segf_grn_fwd(int dt, int B, int64_t rows_per_sample, int C, const
     float* sumsq = ws + (int64_t)B * cr_ws_floats(rows_per_sample, C, 1);
     const int64_t rows = (int64_t)B * rows_per_sample;
     SEGF_DISPATCH_DT(dt, T, {
-        GrnSqF<T> f{(const T*)x, C, true};
-        const int rc = colreduce_launch_batched<1>(f, rows_per_sample, B, C, ws, sumsq, st);
+        int rc;
+        if (pre_gelu) { GrnSqF<T, true> f{(const T*)x, C, true}; rc = colreduce_launch_batched<1>(f, rows_per_sample, B, C, ws, sumsq, st); }
+        else { GrnSqF<T, false> f{(const T*)x, C, true}; rc = colreduce_launch_batched<1>(f, rows_per_sample, B, C, ws, sumsq, st); }
         if (rc) return rc;
         hipLaunchKernelGGL(grn_coef_kernel, dim3(B), dim3(256), 0, st, sumsq, gamma, C, a_out, g_out, (const float*)nullptr,
                            (float*)nullptr, (float*)nullptr);
-        hipLaunchKernelGGL((grn_apply_kernel<T>), dim3(colfixed_blocks(rows, C / 8, 4, 8192)), dim3(256), 0, st, (const T*)x,
+        const dim3 grid(colfixed_blocks(rows, C / 8, 4, 8192));
+        if (pre_gelu) hipLaunchKernelGGL((grn_apply_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x,
+                           (const T*)nullptr, a_out, (const float*)nullptr, beta, (T*)y, rows, fastdiv_make((uint32_t)rows_per_sample), C);
+        else hipLaunchKernelGGL((grn_apply_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x,
                            (const T*)nullptr, a_out, (const float*)nullptr, beta, (T*)y, rows, fastdiv_make((uint32_t)rows_per_sample), C);
     })
     SEGF_CHECK_LAUNCH();
     return 0;
 }
 extern "C" int segf_grn_bwd(int dt, int B, int64_t rows_per_sample, int C, const void* x, const void* dy, const float* gamma,
-                            const float* g_saved, void* dx, float* dgamma, float* dbeta, float* ws, void* stream) {
+                            const float* g_saved, void* dx, float* dgamma, float* dbeta, float* ws, int pre_gelu, void* stream) {
     if (B <= 0 || rows_per_sample <= 0) return 0;
     if (C <= 0 || C % 8 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)dx % 16)) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
@@ -670,12 +690,16 @@ extern "C" int segf_grn_bwd(int dt, int B, int64_t rows_per_sample, int C, const
     float* K = a + (int64_t)B * C;
     const int64_t rows = (int64_t)B * rows_per_sample;
     SEGF_DISPATCH_DT(dt, T, {
-        GrnBwdF<T> f{(const T*)x, (const T*)dy, C, true};
-        const int rc = colreduce_launch_batched<2>(f, rows_per_sample, B, C, ws, S, st);
+        int rc;
+        if (pre_gelu) { GrnBwdF<T, true> f{(const T*)x, (const T*)dy, C, true}; rc = colreduce_launch_batched<2>(f, rows_per_sample, B, C, ws, S, st); }
+        else { GrnBwdF<T, false> f{(const T*)x, (const T*)dy, C, true}; rc = colreduce_launch_batched<2>(f, rows_per_sample, B, C, ws, S, st); }
         if (rc) return rc;
         // dg_part reuses the front of the (now consumed) partial workspace
         hipLaunchKernelGGL(grn_coef_kernel, dim3(B), dim3(256), 0, st, g_saved, gamma, C, a, (float*)nullptr, S, K, ws);
-        hipLaunchKernelGGL((grn_apply_kernel<T>), dim3(colfixed_blocks(rows, C / 8, 4, 8192)), dim3(256), 0, st, (const T*)dy,
+        const dim3 grid(colfixed_blocks(rows, C / 8, 4, 8192));
+        if (pre_gelu) hipLaunchKernelGGL((grn_apply_kernel<T, true>), grid, dim3(256), 0, st, (const T*)dy,
+                           (const T*)x, a, K, (const float*)nullptr, (T*)dx, rows, fastdiv_make((uint32_t)rows_per_sample), C);
+        else hipLaunchKernelGGL((grn_apply_kernel<T, false>), grid, dim3(256), 0, st, (const T*)dy,
                            (const T*)x, a, K, (const float*)nullptr, (T*)dx, rows, fastdiv_make((uint32_t)rows_per_sample), C);
     })
     SEGF_CHECK_LAUNCH();

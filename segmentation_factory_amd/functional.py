@@ -1002,28 +1002,30 @@ def linear_layer_scale(x, weight, bias, gamma, residual=None, rscale=None, rows_
 
 @direct_grads(1, 2)
 class GRNFn(Function):
-    """Global Response Normalization of ConvNeXtV2 (convnextv2.py:68-80) on NHWC tokens; gamma / beta are [1,1,1,C]."""
+    """Global Response Normalization of ConvNeXtV2 (convnextv2.py:68-80) on NHWC tokens; gamma / beta are [1,1,1,C].
+    pre_gelu: GRN(gelu(x)) with the activation applied inside the GRN kernels (convnextv2.py:92-94: act then grn) -- gelu(x) is
+    never materialised and the backward returns the gradient of the pre-activation."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, B, rows_per_sample):
+    def forward(ctx, x, gamma, beta, B, rows_per_sample, pre_gelu=False):
         x = x if x.is_contiguous() else x.contiguous()
         g = gamma.detach().reshape(-1).contiguous()
         b = beta.detach().reshape(-1).contiguous()
-        y, sq = hip.grn_fwd(x, g, b, B, rows_per_sample)
+        y, sq = hip.grn_fwd(x, g, b, B, rows_per_sample, pre_gelu)
         ctx.save_for_backward(x, g, sq)
-        ctx.meta = (B, rows_per_sample, gamma.shape)
+        ctx.meta = (B, rows_per_sample, gamma.shape, bool(pre_gelu))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, sq = ctx.saved_tensors
-        B, rps, pshape = ctx.meta
-        dx, dg, db = hip.grn_bwd(x, dy if dy.is_contiguous() else dy.contiguous(), g, sq, B, rps)
-        return dx, dg.view(pshape), db.view(pshape), None, None
+        B, rps, pshape, pre_gelu = ctx.meta
+        dx, dg, db = hip.grn_bwd(x, dy if dy.is_contiguous() else dy.contiguous(), g, sq, B, rps, pre_gelu)
+        return dx, dg.view(pshape), db.view(pshape), None, None, None
 
 
-def grn(x, gamma, beta, B, rows_per_sample):
-    return GRNFn.apply(x, gamma, beta, B, rows_per_sample)
+def grn(x, gamma, beta, B, rows_per_sample, pre_gelu=False):
+    return GRNFn.apply(x, gamma, beta, B, rows_per_sample, pre_gelu)
 
 
 class AdaptiveAvgPoolFn(Function):

@@ -50,8 +50,8 @@ _PROTOS = {
     'segf_bn_cls_bwd_full_ws': (_l, [_l, _i, _i, _l]),
     'segf_bn_cls_bwd_full': (_i, [_i, _l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p]),
     'segf_grn_ws': (_l, [_i, _l, _i, _i]),
-    'segf_grn_fwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
-    'segf_grn_bwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_grn_fwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    'segf_grn_bwd': (_i, [_i, _i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'segf_attention_fwd': (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _l, _f, _p, _l, _p, _p]),
     'segf_attention_bwd_ws': (_l, [_i, _i, _i, _i, _i]),
     'segf_attention_bwd': (_i, [_i, _i, _i, _i, _i, _i, _p, _l, _p, _l, _p, _l, _f, _p, _l, _p, _l, _p,
@@ -644,24 +644,24 @@ def bn_cls_bwd_full(dy, w, x, mean, rstd, gamma, beta, act, chan_scale, rows_per
     return dx, dgamma, dbeta, dG, dwcls
 
 
-def grn_fwd(x, gamma, beta, B, rps):
+def grn_fwd(x, gamma, beta, B, rps, pre_gelu=False):
     Cc = x.shape[1]
     y = torch.empty_like(x)
     a = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
     sq = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
     ws = _f32(lib().segf_grn_ws(B, rps, Cc, 0), x.device)
     _chk(lib().segf_grn_fwd(dt_of(x), B, rps, Cc, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(a), _ptr(sq), _ptr(ws),
-                            _stream()), 'segf_grn_fwd')
+                            int(pre_gelu), _stream()), 'segf_grn_fwd')
     return y, sq
 
 
-def grn_bwd(x, dy, gamma, sq, B, rps):
+def grn_bwd(x, dy, gamma, sq, B, rps, pre_gelu=False):
     Cc = x.shape[1]
     dx = torch.empty_like(x)
     dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     ws = _f32(lib().segf_grn_ws(B, rps, Cc, 1), x.device)
     _chk(lib().segf_grn_bwd(dt_of(x), B, rps, Cc, _ptr(x), _ptr(dy), _ptr(gamma), _ptr(sq), _ptr(dx), dgb[0].data_ptr(),
-                            dgb[1].data_ptr(), _ptr(ws), _stream()), 'segf_grn_bwd')
+                            dgb[1].data_ptr(), _ptr(ws), int(pre_gelu), _stream()), 'segf_grn_bwd')
     return dx, dgb[0], dgb[1]
 
 

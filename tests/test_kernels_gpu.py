@@ -805,6 +805,42 @@ def test_grn(dtype):
     _close(bd.grad, br.grad, dtype, fac=4)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_grn_with_gelu_applied_inside(dtype):
+    """act -> grn of the ConvNeXtV2 block (convnextv2.py:92-94) as ONE op: Fh.grn(u, ..., pre_gelu=True) = GRN(gelu(u)) with the
+    GELU applied inside the GRN kernels (gelu(u) never materialised) against torch's nn.GELU + the GRN formula, forward and all
+    three gradients (the gradient of the PRE-activation u); and against the two-op path of this library."""
+    from segmentation_factory_amd import functional as Fh
+    g = torch.Generator().manual_seed(14)
+    B, H, W, C = 3, 6, 5, 64
+    u = torch.randn(B, H, W, C, generator=g) * 1.5
+    u[..., 7] = 0
+    gam = torch.randn(1, 1, 1, C, generator=g) * 0.5
+    bet = torch.randn(1, 1, 1, C, generator=g) * 0.1
+    dy = torch.randn(B, H, W, C, generator=g)
+    ur = _q(u, dtype).requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    a = F.gelu(ur)
+    Gx = torch.norm(a, p=2, dim=(1, 2), keepdim=True)
+    Nx = Gx / (Gx.mean(dim=-1, keepdim=True) + 1e-6)
+    ref = gr * (a * Nx) + br + a
+    ref.backward(_q(dy, dtype))
+    outs = []
+    for fused in (True, False):
+        ud = _dev(u.reshape(-1, C), dtype).requires_grad_(True)
+        gd, bd = _dev(gam).requires_grad_(True), _dev(bet).requires_grad_(True)
+        y = Fh.grn(ud, gd, bd, B, H * W, pre_gelu=True) if fused else Fh.grn(Fh.gelu(ud), gd, bd, B, H * W)
+        y.backward(_dev(dy.reshape(-1, C), dtype))
+        _close(y, ref.reshape(-1, C), dtype, fac=2)
+        _close(ud.grad, ur.grad.reshape(-1, C), dtype, fac=3)
+        _close(gd.grad, gr.grad, dtype, fac=4)
+        _close(bd.grad, br.grad, dtype, fac=4)
+        outs.append((y.detach().float(), ud.grad.float()))
+    if dtype == torch.float32:       # same arithmetic, other rounding points: the two paths of this library agree to fp32 round-off
+        assert (outs[0][0] - outs[1][0]).abs().max().item() <= 1e-5 * outs[1][0].abs().max().item()
+        assert (outs[0][1] - outs[1][1]).abs().max().item() <= 1e-5 * outs[1][1].abs().max().item()
+
+
 def test_wave_reduce16_transposing_reduction(hipmod):
     """The permlane32/16-swap + DPP reduction the loss kernels use for 16 pixels at a time (exact integer data)."""
     x = torch.randint(-50, 50, (64, 16)).float()
