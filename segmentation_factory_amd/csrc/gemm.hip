@@ -129,6 +129,46 @@ __device__ __forceinline__ void swrite_rm(unsigned char* tile, const uint4 (&reg
     }
 }
 
+// ---- branch-free loaders for the deep-prefetch loop (gemm_bf16_kernel<.., DEEP>): every thread issues exactly four 16-byte loads per
+// operand and K step, whatever the step -- the compiler can then COUNT the loads of the younger step when it waits for the older
+// one.  Rows / columns past the operand are clamped (they only feed outputs that are never stored); a chunk or row past the end
+// of K re-reads a valid one of the same row / the last valid row (same cache lines as the valid lanes: no extra HBM traffic) and
+// is zeroed when the registers go to LDS (`ok` bit i = load i is real).  Returns the ok bits.
+__device__ __forceinline__ unsigned gload_kc_nb(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t rmax,
+                                                int64_t k0, int64_t kend, uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const int64_t k = k0 + c * 8;
+    const bool ok = k < kend;
+    const int64_t kc = ok ? k : kend - 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t row = row0 + r + 32 * i;
+        reg[i] = *reinterpret_cast<const uint4*>(base + (row < rmax ? row : rmax - 1) * ld + kc);
+    }
+    return ok ? 0xfu : 0u;
+}
+__device__ __forceinline__ unsigned gload_rm_nb(const bf16_t* __restrict__ base, int64_t ld, int64_t col0, int64_t cmax,
+                                                int64_t k0, int64_t kend, uint4 (&reg)[4]) {
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int64_t col = col0 + c * 8;
+    const bf16_t* p = base + (col < cmax ? col : 0);
+    unsigned ok = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + r + 16 * i;
+        ok |= (k < kend ? 1u : 0u) << i;
+        reg[i] = *reinterpret_cast<const uint4*>(p + (k < kend ? k : kend - 1) * ld);
+    }
+    return ok;
+}
+__device__ __forceinline__ void zero_unless_ok(uint4 (&reg)[4], unsigned ok) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m = (ok >> i) & 1u ? 0xffffffffu : 0u;
+        reg[i].x &= m; reg[i].y &= m; reg[i].z &= m; reg[i].w &= m;
+    }
+}
+
 // implicit-im2col variants: the tile rows are output pixels, k = tap * C + channel.  All index arithmetic that does not change
 // from one K step to the next lives in a per-thread ConvState set up once per workgroup (the tap / channel split and the pixel
 // coordinates are integer divisions -- 64-bit ones cost ~80 instructions each, and the loaders used to redo up to nine of them
@@ -284,8 +324,12 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int
 // NBUF = 2: double-buffered K loop (64 KB LDS, 2 workgroups per CU).  NBUF = 1: launches whose K fits one 64-deep step
 // (the stage-1 MiT linears and the folded head products, K = 32 / 64) need no second buffer; 34 KB of LDS lets 4 workgroups
 // share a CU, which is what hides the load -> MFMA -> store latency chain of these purely HBM-bound launches.
-template <int LAYOUT, typename OutT, bool TR, bool CONV = false, int NBUF = 2>
+// DEEP (layouts 0 / 1, no gather): TWO K steps of operand loads in flight (two register sets, branch-free loaders) -- with K = 160 ...
+// 1024 a tile is a chain of 3 ... 16 load -> LDS -> MFMA round trips whose arithmetic is a few hundred cycles each; the MiT
+// stage-3 / 4 products ([131072 x 160] x [160 x 160]: 51 us against 14 us of HBM time) are bound by that chain, not by bytes.
+template <int LAYOUT, typename OutT, bool TR, bool CONV = false, int NBUF = 2, bool DEEP = false>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
+    static_assert(!DEEP || (!CONV && NBUF == 2), "deep prefetch: no gather, double-buffered LDS");
     constexpr int SMEM_BYTES = NBUF == 2 ? 4 * GB_TILE_BYTES : (64 * GB_STG_LD * 4 > 2 * GB_TILE_BYTES ? 64 * GB_STG_LD * 4 : 2 * GB_TILE_BYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
     unsigned char (*smem)[2][GB_TILE_BYTES] = reinterpret_cast<unsigned char (*)[2][GB_TILE_BYTES]>(smem_raw);
@@ -361,6 +405,103 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
     };
 
     const int nk = (int)((kend - kbeg + GB_BK - 1) / GB_BK);
+    auto compute = [&](int buf) {
+        const unsigned char* ta = smem[buf][0];
+        const unsigned char* tb = smem[buf][1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int mb = wm * 64 + t * 16, nb = wn * 64 + t * 16;
+                if (LAYOUT == 2) fa[t] = TR ? frag_rm_tr(ta, mb, s, lane) : frag_rm_scalar(ta, mb, s, lane);
+                else fa[t] = frag_kc(ta, mb, s, lane);
+                if (LAYOUT == 0) fb[t] = frag_kc(tb, nb, s, lane);
+                else fb[t] = TR ? frag_rm_tr(tb, nb, s, lane) : frag_rm_scalar(tb, nb, s, lane);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+            if (LAYOUT == 2 && !CONV && cs_mfma) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) accs[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fones, fa[tm], accs[tm], 0, 0, 0);
+            }
+        }
+    };
+    if constexpr (DEEP) {
+        uint4 ra1[4], rb1[4];                                  // second register set (the first is ra / rb)
+        unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;           // ok bits of the sets
+        auto gl = [&](int kt, uint4 (&xa)[4], uint4 (&xb)[4], unsigned& ma, unsigned& mb) {
+            const int64_t k0 = kbeg + (int64_t)kt * GB_BK;
+            ma = LAYOUT == 2 ? gload_rm_nb(A, a.lda, m0, a.M, k0, kend, xa) : gload_kc_nb(A, a.lda, m0, a.M, k0, kend, xa);
+            mb = LAYOUT == 0 ? gload_kc_nb(B, a.ldb, n0, a.N, k0, kend, xb) : gload_rm_nb(B, a.ldb, n0, a.N, k0, kend, xb);
+        };
+        auto sw = [&](int buf, uint4 (&xa)[4], uint4 (&xb)[4], unsigned ma, unsigned mb) {
+            zero_unless_ok(xa, ma); zero_unless_ok(xb, mb);
+            if (LAYOUT == 2 && csn >= 0 && (int)(threadIdx.x & 15) == (csn >> 3)) {      // the all-ones column of the bias gradient
+                const uint32_t sh = 16u * (csn & 1), one = 0x3f80u << sh, keep = ~(0xffffu << sh);
+                const int wsel = (csn & 7) >> 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((ma >> i) & 1u) {                  // row k of this load lies inside the K range (A and B share the k rows)
+                        if (wsel == 0) xb[i].x = (xb[i].x & keep) | one;
+                        else if (wsel == 1) xb[i].y = (xb[i].y & keep) | one;
+                        else if (wsel == 2) xb[i].z = (xb[i].z & keep) | one;
+                        else xb[i].w = (xb[i].w & keep) | one;
+                    }
+                }
+            }
+            if (LAYOUT == 2) swrite_rm(smem[buf][0], xa); else swrite_kc(smem[buf][0], xa);
+            if (LAYOUT == 0) swrite_kc(smem[buf][1], xb); else swrite_rm(smem[buf][1], xb);
+        };
+        // invariant at the top of a step kt (even): buffer 0 holds step kt, set 1 holds step kt + 1 (in flight)
+        if (nk > 0) gl(0, ra, rb, ma0, mb0);
+        if (nk > 1) gl(1, ra1, rb1, ma1, mb1);
+        if (nk > 0) sw(0, ra, rb, ma0, mb0);
+        __syncthreads();
+        int kt = 0;
+        // (the scheduling fences keep the order loads | products | wait + LDS write: left alone, hipcc sinks the loads below the
+        // products and hoists the LDS writes above them, and every wait becomes vmcnt(0))
+#define DEEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+        for (; kt + 3 < nk; kt += 2) {                         // both steps of the pair have a step two ahead to fetch
+            gl(kt + 2, ra, rb, ma0, mb0);
+            DEEP_FENCE();
+            compute(0);
+            DEEP_FENCE();
+            sw(1, ra1, rb1, ma1, mb1);
+            __syncthreads();
+            gl(kt + 3, ra1, rb1, ma1, mb1);
+            DEEP_FENCE();
+            compute(1);
+            DEEP_FENCE();
+            sw(0, ra, rb, ma0, mb0);
+            __syncthreads();
+        }
+        if (kt + 2 < nk) {                                     // three steps left
+            gl(kt + 2, ra, rb, ma0, mb0);
+            DEEP_FENCE();
+            compute(0);
+            DEEP_FENCE();
+            sw(1, ra1, rb1, ma1, mb1);
+            __syncthreads();
+            compute(1);
+            sw(0, ra, rb, ma0, mb0);
+            __syncthreads();
+            compute(0);
+        } else if (kt + 1 < nk) {                              // two
+            compute(0);
+            sw(1, ra1, rb1, ma1, mb1);
+            __syncthreads();
+            compute(1);
+        } else if (kt < nk) {
+            compute(0);
+        }
+#undef DEEP_FENCE
+        __syncthreads();
+    } else
+    {
     if (nk > 0) {
         gload(kbeg);
         swrite(0);
@@ -394,6 +535,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
         }
         if (kt + 1 < nk) swrite(buf ^ 1);
         __syncthreads();
+    }
     }
     if (LAYOUT == 2 && !CONV && cs_mfma && (lane >> 4) == 0) {          // every product row holds the sums: row 0 = register 0 of lanes 0..15
         float* cdst = a.colsum_ws ? a.colsum_ws + (int64_t)bz * a.M : a.colsum;
@@ -1849,9 +1991,17 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
         dim3 grid((unsigned)cdiv64(N, GB_BN), (unsigned)cdiv64(M, GB_BM), (unsigned)split_k);
         if (grid.y > 65535u) return SEGF_ERR_SHAPE;
         const bool one_step = kchunk <= GB_BK && layout != 2;     // single K step: the 34 KB single-buffer variant
+        // two K steps in flight (branch-free loaders) whenever the operands are vectorisable and there are several steps.  Measured
+        // (same box, on / off): batch 4 836 / 814 img/s, 16: 2249 / 2211, 32: 3054 / 3014, 128: neutral; cfg5 86.0 / 84.2; the
+        // split-K weight gradients (layout 2) add +1 % at batch 4 and are neutral elsewhere
+        const bool vec_ab = a.a_vec && a.b_vec;
+        const bool deep128 = !one_step && a.use_tr && a.fast && vec_ab && !getenv("SEGFAC_GEMM_NO_DEEP128") &&
+                             (layout == 2 ? (M % 8 == 0 && N % 8 == 0 && !getenv("SEGFAC_GEMM_NO_DEEP128_L2"))
+                                          : (K % 8 == 0 && (layout == 0 || N % 8 == 0) && split_k == 1));
 #define LAUNCH_B(L, OT)                                                                                      \
     do {                                                                                                     \
         if (one_step && L != 2) hipLaunchKernelGGL((gemm_bf16_kernel<(L == 2 ? 0 : L), OT, true, false, 1>), grid, dim3(256), 0, st, a); \
+        else if (deep128) hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, true, false, 2, true>), grid, dim3(256), 0, st, a); \
         else if (L == 0 || a.use_tr) hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, true>), grid, dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((gemm_bf16_kernel<L, OT, false>), grid, dim3(256), 0, st, a);                 \
     } while (0)
