@@ -995,6 +995,10 @@ static inline bool gemm_use_big(int layout, int64_t M, int64_t N, int64_t K) {
     if (getenv("SEGFAC_GEMM_NO_BIG")) return false;
     if (M <= 128 || N <= 128 || K <= GB_BK) return false;
     const int64_t tiles = cdiv64(M, GG_B) * cdiv64(N, GG_B);
+    if (layout != 2) {
+        static const int smallk = getenv("SEGFAC_GEMM_SMALLK_128") ? atoi(getenv("SEGFAC_GEMM_SMALLK_128")) : 0;
+        if (smallk > 0 && K <= smallk && N > 160) return false;      // experiment: short reductions on the 128-tile kernel (two workgroups per CU)
+    }
     if (layout == 2) return K >= 65536;                       // token-count K: split-K supplies the parallelism (at K = 16384 the
                                                               // 128x128 tile with twice the slices measured 1.2-1.9x faster, at
                                                               // K = 32768 still 1.2-1.4x: [256x256] 53 vs 67 us, [1024x256] 78 vs 98)
