@@ -996,8 +996,12 @@ static inline bool gemm_use_big(int layout, int64_t M, int64_t N, int64_t K) {
     if (M <= 128 || N <= 128 || K <= GB_BK) return false;
     const int64_t tiles = cdiv64(M, GG_B) * cdiv64(N, GG_B);
     if (layout != 2) {
-        static const int smallk = getenv("SEGFAC_GEMM_SMALLK_128") ? atoi(getenv("SEGFAC_GEMM_SMALLK_128")) : 0;
-        if (smallk > 0 && K <= smallk && N > 160) return false;      // experiment: short reductions on the 128-tile kernel (two workgroups per CU)
+        // short reductions (K <= 704: the MiT stage-3 / 4 linears at 160 / 640 / 256) stay on the 128-tile kernel: with a handful of K
+        // steps the 256-tile kernel's operand reuse buys nothing (the product is bound by its output) and its one workgroup per CU
+        // exposes every load -> LDS -> MFMA round trip; two workgroups per CU with two K steps in flight: cfg2 +0.4 %, batch 16
+        // +0.7 %, cfg4 +0.2 % (same box).  The narrow shapes (N <= 160) keep their one-tile kernel.
+        static const int smallk = getenv("SEGFAC_GEMM_SMALLK_128") ? atoi(getenv("SEGFAC_GEMM_SMALLK_128")) : 704;
+        if (K <= smallk && N > 160) return false;
     }
     if (layout == 2) return K >= 65536;                       // token-count K: split-K supplies the parallelism (at K = 16384 the
                                                               // 128x128 tile with twice the slices measured 1.2-1.9x faster, at
