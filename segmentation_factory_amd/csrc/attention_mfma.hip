@@ -433,6 +433,225 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     }
 }
 
+// ---- backward in ONE kernel when a workgroup can own all keys of a head (Nkv <= 4 waves x 64 keys at head dim 32: the 512^2
+// inputs of BASELINE cfg1-3, 256 keys in every stage) ---------------------------------------------------------------------------
+// The key-side kernel above already holds S and dS of a 32-query tile for all keys; the query side needs dQ = dS K, a contraction
+// over KEYS, i.e. dS with the keys along the MFMA k index -- the transpose of how the accumulators hold it.  Each wave writes its
+// dS (bf16, four consecutive queries per 8-byte store) into a private [key][query] slab and reads it back through
+// ds_read_b64_tr_b16 as the B operand of dQ^T [d][q] += K^T [d][key] dS^T [key][q] (K^T fragments: the wave's own 64 keys, read
+// once the same way); the four waves' partial dQ^T tiles meet in LDS (double-buffered: summed -- in fixed wave order -- and stored
+// at the START of the next tile, behind the barrier that tile needs anyway).  D = rowsum(dO o O) is formed by the threads that
+// stage the dO tile.  Five matrix products per (query tile, key tile) instead of the seven of the two-kernel form, Q / dO / lse
+// read once instead of twice, no D round trip through memory; dK / dV partial slabs as before.
+template <int HD, int KW>
+__global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_fused_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+                                                                          const bf16_t* __restrict__ k, int64_t ldk,
+                                                                          const bf16_t* __restrict__ v, int64_t ldv,
+                                                                          const bf16_t* __restrict__ o, int64_t ldo,
+                                                                          const bf16_t* __restrict__ dO, int64_t lddo,
+                                                                          const float* __restrict__ lse, bf16_t* __restrict__ dq,
+                                                                          int64_t lddq, float* __restrict__ slab, int heads, int N,
+                                                                          int Nkv, int B, int qchunk, float scale) {
+    static_assert(HD == 32, "fused backward: head dim 32");
+    constexpr int KS = HD / 32, DT = HD / 16, WK = 16 * KW, DS_LD = 40;      // DS_LD: row stride (elements) of the dS^T slab
+    __shared__ __attribute__((aligned(16))) bf16_t Qs2[2][32 * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs2[2][32 * HD];
+    __shared__ float Ls2[2][32], Ds2[2][32];
+    __shared__ __attribute__((aligned(16))) bf16_t dSt[4][WK * DS_LD];       // per wave: dS^T [key][query]
+    __shared__ __attribute__((aligned(16))) bf16_t Kst[4][WK * HD];          // per wave: its K rows (read once, transposed)
+    __shared__ __attribute__((aligned(16))) float dQp[2][4][2 * DT][64 * 4];  // [buffer][wave][tile (dt, qt)][lane][4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int bh = blockIdx.z, b = bh / heads, h = bh - b * heads;
+    const int z = blockIdx.y;
+    const int key0 = wave * WK;
+    const int nwav = (Nkv + WK - 1) / WK;                                     // waves that own keys
+    const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
+    const bf16_t* Ob = o + (int64_t)b * N * ldo + h * HD;
+    const bf16_t* dOb = dO + (int64_t)b * N * lddo + h * HD;
+    const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
+    const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
+    const float* lb = lse + ((int64_t)b * heads + h) * N;
+    bf16_t* dQb = dq + (int64_t)b * N * lddq + h * HD;
+    bf16x8 Kf[KW][KS], Vf[KW][KS];
+#pragma unroll
+    for (int kt = 0; kt < KW; ++kt)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int key = key0 + 16 * kt + c;
+            Kf[kt][s] = ld_frag_global(Kb + (int64_t)key * ldk + 32 * s + 8 * g, key < Nkv);
+            Vf[kt][s] = ld_frag_global(Vb + (int64_t)key * ldv + 32 * s + 8 * g, key < Nkv);
+        }
+    // K^T fragments of this wave's keys: A operand [d][key], k-slot j of lane group g = key 32 kh + 4 g + j (j < 4) / 32 kh + 16 + 4 g + j - 4
+    bf16x8 KTf[DT][WK / 32];
+    {
+        constexpr int CPR = HD / 8;
+        for (int i = lane; i < WK * CPR; i += 64) {
+            const int r = i / CPR, cc = i - r * CPR;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (key0 + r < Nkv) u = *reinterpret_cast<const uint4*>(Kb + (int64_t)(key0 + r) * ldk + cc * 8);
+            *reinterpret_cast<uint4*>(Kst[wave] + r * HD + cc * 8) = u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kh = 0; kh < WK / 32; ++kh) KTf[dt][kh] = ld_frag_tr<HD>(Kst[wave], 32 * kh + 4 * g, 32 * kh + 16 + 4 * g, 16 * dt, lane);
+    }
+    f32x4 dK[DT][KW], dV[DT][KW];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int kt = 0; kt < KW; ++kt) { dK[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    const int qbeg = z * qchunk, qend = qbeg + qchunk < N ? qbeg + qchunk : N;
+    // staging: threads 0..127 take the Q tile (32 rows x 4 chunks), 128..255 the dO tile and, with the same chunk of O, D = rowsum(dO o O)
+    constexpr int CPR = HD / 8, NCH = 32 * CPR;
+    const int sid = threadIdx.x & (NCH - 1);
+    const int srow = sid / CPR, scol = (sid - srow * CPR) * 8;
+    const bool doQ = threadIdx.x < NCH, doO = !doQ;
+    uint4 rq = make_uint4(0, 0, 0, 0), ro = make_uint4(0, 0, 0, 0);
+    float rl = INFINITY, rd = 0.f;
+    auto fetch = [&](int qt0) {
+        const int row = qt0 + srow;
+        rq = make_uint4(0, 0, 0, 0); ro = make_uint4(0, 0, 0, 0);
+        uint4 oo = make_uint4(0, 0, 0, 0);
+        if (doQ && row < qend) rq = *reinterpret_cast<const uint4*>(Qb + (int64_t)row * ldq + scol);
+        if (doO && row < qend) {
+            ro = *reinterpret_cast<const uint4*>(dOb + (int64_t)row * lddo + scol);
+            oo = *reinterpret_cast<const uint4*>(Ob + (int64_t)row * ldo + scol);
+        }
+        const bf16x8 a = __builtin_bit_cast(bf16x8, ro), bq = __builtin_bit_cast(bf16x8, oo);
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)a[j] * (float)bq[j];
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);          // the four chunks of a row sit in adjacent lanes
+        rd = part;
+        if (threadIdx.x < 32) {
+            const int r2 = qt0 + threadIdx.x;
+            rl = r2 < qend ? lb[r2] : INFINITY;          // exp(s - inf) = 0: rows beyond the chunk contribute nothing
+        }
+    };
+    auto put = [&](int buf) {
+        if (doQ) *reinterpret_cast<uint4*>(Qs2[buf] + srow * HD + scol) = rq;
+        else {
+            *reinterpret_cast<uint4*>(dOs2[buf] + srow * HD + scol) = ro;
+            if ((sid & (CPR - 1)) == 0) Ds2[buf][srow] = rd;
+        }
+        if (threadIdx.x < 32) Ls2[buf][threadIdx.x] = rl;
+    };
+    // sum of the waves' partial dQ^T tiles of the PREVIOUS query tile (buffer pb), in wave order; wave w finishes tile w = (dt, qt)
+    auto finish_dq = [&](int pb, int qprev) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < nwav; ++w) acc += *reinterpret_cast<const f32x4*>(&dQp[pb][w][wave][lane * 4]);
+        const int dt = wave >> 1, qt = wave & 1;
+        const int row = qprev + 16 * qt + c;
+        if (row < qend) {
+            const uint2 u = make_uint2(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]));
+            *reinterpret_cast<uint2*>(dQb + (int64_t)row * lddq + 16 * dt + 4 * g) = u;
+        }
+    };
+    fetch(qbeg);
+    put(0);
+    __syncthreads();
+    int buf = 0;
+    for (int qt0 = qbeg; qt0 < qend; qt0 += 32, buf ^= 1) {
+        const bool more = qt0 + 32 < qend;
+        if (more) fetch(qt0 + 32);
+        if (qt0 > qbeg) finish_dq(buf ^ 1, qt0 - 32);          // the previous tile's partials were complete at the last barrier
+        const bf16_t* Qs = Qs2[buf];
+        const bf16_t* dOs = dOs2[buf];
+        const float* Ls = Ls2[buf];
+        const float* Ds = Ds2[buf];
+        if (key0 < Nkv) {
+            float P[2][KW][4], dS[2][KW][4];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                bf16x8 Qa[KS], dOa[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    Qa[s] = ld_frag_lds(Qs + (16 * qt + c) * HD + 32 * s + 8 * g);
+                    dOa[s] = ld_frag_lds(dOs + (16 * qt + c) * HD + 32 * s + 8 * g);
+                }
+                float lr[4], dr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { lr[r] = Ls[16 * qt + 4 * g + r]; dr[r] = Ds[16 * qt + 4 * g + r]; }
+#pragma unroll
+                for (int kt = 0; kt < KW; ++kt) {
+                    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qa[s], Kf[kt][s], S, 0, 0, 0);
+                        dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOa[s], Vf[kt][s], dP, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __expf(S[r] * scale - lr[r]);
+                        P[qt][kt][r] = p;
+                        dS[qt][kt][r] = p * (dP[r] - dr[r]) * scale;
+                    }
+                    // dS^T slab: key 16 kt + c, queries 16 qt + 4 g .. + 3
+                    *reinterpret_cast<uint2*>(dSt[wave] + (16 * kt + c) * DS_LD + 16 * qt + 4 * g) =
+                        make_uint2(pack2bf(dS[qt][kt][0], dS[qt][kt][1]), pack2bf(dS[qt][kt][2], dS[qt][kt][3]));
+                }
+            }
+            bf16x8 dOT[DT], QT[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                dOT[d] = ld_frag_tr<HD>(dOs, 4 * g, 16 + 4 * g, 16 * d, lane);
+                QT[d] = ld_frag_tr<HD>(Qs, 4 * g, 16 + 4 * g, 16 * d, lane);
+            }
+#pragma unroll
+            for (int kt = 0; kt < KW; ++kt) {
+                const bf16x8 Pf = pack_acc(P[0][kt], P[1][kt]);
+                const bf16x8 dSf = pack_acc(dS[0][kt], dS[1][kt]);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    dV[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dOT[d], Pf, dV[d][kt], 0, 0, 0);
+                    dK[d][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QT[d], dSf, dK[d][kt], 0, 0, 0);
+                }
+            }
+            // dQ^T [d][q] partial over this wave's keys
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                bf16x8 dSTf[WK / 32];
+#pragma unroll
+                for (int kh = 0; kh < WK / 32; ++kh)
+                    dSTf[kh] = ld_frag_tr<DS_LD>(dSt[wave], 32 * kh + 4 * g, 32 * kh + 16 + 4 * g, 16 * qt, lane);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kh = 0; kh < WK / 32; ++kh) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KTf[dt][kh], dSTf[kh], acc, 0, 0, 0);
+                    *reinterpret_cast<f32x4*>(&dQp[buf][wave][dt * 2 + qt][lane * 4]) = acc;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (more) put(buf ^ 1);          // the other buffer was last read before the barrier that ended the previous tile
+        __syncthreads();
+    }
+    if (qend > qbeg) finish_dq(buf ^ 1, qbeg + ((qend - qbeg - 1) / 32) * 32);
+    if (key0 >= Nkv) return;
+    const int C = heads * HD;
+    float* sb = slab + (int64_t)z * B * Nkv * 2 * C;
+#pragma unroll
+    for (int kt = 0; kt < KW; ++kt) {
+        const int key = key0 + 16 * kt + c;
+        if (key < Nkv) {
+            float* row = sb + ((int64_t)b * Nkv + key) * 2 * C + h * HD;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                *reinterpret_cast<float4*>(row + 16 * d + 4 * g) = make_float4(dK[d][kt][0], dK[d][kt][1], dK[d][kt][2], dK[d][kt][3]);
+                *reinterpret_cast<float4*>(row + C + 16 * d + 4 * g) = make_float4(dV[d][kt][0], dV[d][kt][1], dV[d][kt][2], dV[d][kt][3]);
+            }
+        }
+    }
+}
+
 int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64_t ldq, const void* k, int64_t ldk,
                   const void* v, int64_t ldv, float scale, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
                   const float* lse, void* dq, int64_t lddq, float* Dbuf, float* slab, int nchunk, int qchunk, hipStream_t st) {
@@ -441,7 +660,11 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
     dim3 g2((unsigned)cdiv64(Nkv, hd == 32 ? 256 : 128), nchunk, B * heads);      // keys per workgroup = 4 waves x 16 KW
     const bf16_t* Q = (const bf16_t*)q; const bf16_t* K = (const bf16_t*)k; const bf16_t* V = (const bf16_t*)v;
     const bf16_t* O = (const bf16_t*)o; const bf16_t* DO = (const bf16_t*)d_o;
-    if (hd == 32) {
+    if (hd == 32 && Nkv <= 256 && !getenv("SEGFAC_ATTN_NO_FUSED_BWD")) {      // one workgroup owns all keys: dQ, dK, dV in one kernel
+        dim3 g3(1, nchunk, B * heads);
+        hipLaunchKernelGGL((attn_mfma_bwd_fused_kernel<32, 4>), g3, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
+                           (bf16_t*)dq, lddq, slab, heads, N, Nkv, B, qchunk, scale);
+    } else if (hd == 32) {
         hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<32, QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo,
                            lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
         hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<32>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf,

@@ -203,6 +203,34 @@ def test_attention(dtype, shape):
     _close(kvd.grad, kvr.grad, dtype, fac=4)
 
 
+@pytest.mark.parametrize('shape', [(2, 1, 4096, 256, 32), (3, 2, 1000, 200, 32), (2, 5, 70, 64, 32), (1, 8, 256, 256, 32)])
+def test_attention_backward_one_kernel_form_equals_two_kernel_form(shape, monkeypatch):
+    """Head dim 32 with at most 256 keys (every stage of the 512^2 configs): the backward runs as ONE kernel (dQ through a transposed
+    pass of dS over the wave's LDS slab, the waves' partial dQ tiles summed in fixed order) -- against the two-kernel form of the same
+    library (env switch) and, through test_attention, the oracle.  dK / dV take the same arithmetic in both: bitwise equal; dQ differs
+    by the bf16 rounding of dS (it is the B operand of an MFMA in both forms, summed in another order): within bf16 of the gradient scale.
+    Two runs agree bitwise."""
+    from segmentation_factory_amd import functional as Fh
+    B, heads, N, Nkv, hd = shape
+    C = heads * hd
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(B * N, C, generator=g)
+    kv = torch.randn(B * Nkv, 2 * C, generator=g)
+    do = torch.randn(B * N, C, generator=g)
+    outs = []
+    for mode in ('fused', 'fused', 'split'):
+        if mode == 'split':
+            monkeypatch.setenv('SEGFAC_ATTN_NO_FUSED_BWD', '1')
+        qd, kvd = _dev(q, torch.bfloat16).requires_grad_(True), _dev(kv, torch.bfloat16).requires_grad_(True)
+        Fh.attention(qd, kvd, B, N, Nkv, heads).backward(_dev(do, torch.bfloat16))
+        torch.cuda.synchronize()
+        outs.append((qd.grad.clone(), kvd.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][1], outs[2][1])
+    sc = outs[2][0].float().abs().max().item()
+    assert (outs[0][0].float() - outs[2][0].float()).abs().max().item() <= 2.0 ** -7 * sc
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('geom', [(2, 9, 13, 32), (1, 16, 16, 128), (2, 5, 3, 8), (1, 1, 1, 64)])
 def test_dwconv3x3_gelu(dtype, geom):
