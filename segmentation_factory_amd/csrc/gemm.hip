@@ -995,14 +995,6 @@ static inline bool gemm_use_big(int layout, int64_t M, int64_t N, int64_t K) {
     if (getenv("SEGFAC_GEMM_NO_BIG")) return false;
     if (M <= 128 || N <= 128 || K <= GB_BK) return false;
     const int64_t tiles = cdiv64(M, GG_B) * cdiv64(N, GG_B);
-    if (layout != 2) {
-        // short reductions (K <= 704: the MiT stage-3 / 4 linears at 160 / 640 / 256) stay on the 128-tile kernel: with a handful of K
-        // steps the 256-tile kernel's operand reuse buys nothing (the product is bound by its output) and its one workgroup per CU
-        // exposes every load -> LDS -> MFMA round trip; two workgroups per CU with two K steps in flight: cfg2 +0.4 %, batch 16
-        // +0.7 %, cfg4 +0.2 % (same box).  The narrow shapes (N <= 160) keep their one-tile kernel.
-        static const int smallk = getenv("SEGFAC_GEMM_SMALLK_128") ? atoi(getenv("SEGFAC_GEMM_SMALLK_128")) : 704;
-        if (K <= smallk && N > 160) return false;
-    }
     if (layout == 2) return K >= 65536;                       // token-count K: split-K supplies the parallelism (at K = 16384 the
                                                               // 128x128 tile with twice the slices measured 1.2-1.9x faster, at
                                                               // K = 32768 still 1.2-1.4x: [256x256] 53 vs 67 us, [1024x256] 78 vs 98)
@@ -1961,7 +1953,14 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                 if (rc8 != SEGF_ERR_SHAPE) { if (rc8) return rc8; goto reduce; }
             }
         }
-        if ((gemm_use_big(layout, M, N, K) || pro) && a.use_tr) {
+        // short reductions (K <= 704: the MiT stage-3 / 4 linears at 160 / 640 / 256) stay on the 128-tile kernel: with a handful of K
+        // steps the 256-tile kernel's operand reuse buys nothing (the product is bound by its output) and its one workgroup per CU
+        // exposes every load -> LDS -> MFMA round trip; two workgroups per CU with two K steps in flight: cfg2 +0.4 %, batch 16
+        // +0.7 %, cfg4 +0.2 % (same box).  The narrow shapes (N <= 160) keep their one-tile kernel; the implicit-GEMM convolutions
+        // (other entry points) are not concerned.
+        static const int smallk = getenv("SEGFAC_GEMM_SMALLK_128") ? atoi(getenv("SEGFAC_GEMM_SMALLK_128")) : 704;
+        const bool short_k = layout != 2 && K <= smallk && N > 160 && !pro;
+        if (((gemm_use_big(layout, M, N, K) && !short_k) || pro) && a.use_tr) {
             dim3 gridb((unsigned)cdiv64(N, GG_B), (unsigned)cdiv64(M, GG_B), (unsigned)split_k);
             if (gridb.y > 65535u) return SEGF_ERR_SHAPE;
             const bool f32o = c_dt == SEGF_F32 || a.ws;
