@@ -58,6 +58,9 @@ int segf_colsum(int dt, const void* x, int64_t ldx, int64_t rows, int64_t cols, 
  * B * C entries; state = {seed, launch counter} (uint64[2], advanced by the kernel: graph replays draw fresh numbers). */
 int segf_zero(void* p, int64_t nbytes, void* stream);
 int segf_add_i64(int64_t* p, int64_t v, void* stream);
+/* Metrics.update's `self.hist += bincount(...)` (util/metrics.py:24-27): hist fp32 [n] += (float)counts int64 [n] (torch's promotion of
+ * float32 += int64: each count rounded to fp32, then added); clear != 0 also zeroes the counts for the next batch. */
+int segf_hist_accum(float* hist, int64_t* counts, int64_t n, int clear, void* stream);
 int segf_bernoulli_scale(uint64_t* state, const float* keep_prob, int64_t n, int64_t row_len, float* out, void* stream);
 
 /* ---- FP8 (OCP e4m3fn) forward GEMM: BASELINE cfg5 "ConvNeXtV2-L + UPerNet, fp8 MFMA weights" (the pointwise linears of

@@ -287,6 +287,22 @@ extern "C" int segf_zero(void* p, int64_t nbytes, void* stream) {
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+// Metrics.update (util/metrics.py:24-27): `self.hist += bincount(...)` with hist fp32 and the batch counts int64 -- each count is
+// converted to fp32 (round to nearest even, torch's type promotion of float32 += int64) and added; quirk Q5: exact below 2^24 per
+// cell.  The counts are cleared for the next batch in the same pass, so a captured evaluation step needs no separate fill.
+__global__ void hist_accum_kernel(float* __restrict__ hist, int64_t* __restrict__ counts, int64_t n, int clear) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    hist[i] += (float)counts[i];
+    if (clear) counts[i] = 0;
+}
+extern "C" int segf_hist_accum(float* hist, int64_t* counts, int64_t n, int clear, void* stream) {
+    if (n <= 0) return 0;
+    if (!hist || !counts) return SEGF_ERR_SHAPE;
+    hipLaunchKernelGGL(hist_accum_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, hist, counts, n, clear);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
 __global__ void add_i64_kernel(int64_t* p, int64_t v) { if (threadIdx.x == 0) *p += v; }
 extern "C" int segf_add_i64(int64_t* p, int64_t v, void* stream) {
     hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);

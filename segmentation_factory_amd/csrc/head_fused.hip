@@ -414,9 +414,13 @@ extern "C" int64_t segf_bn_cls_bwd_ws(int64_t M, int C, int64_t rows_per_sample)
 
 // everything that can ride: x1 / dG (pass 2, nullable pair) and dWcls fp32 [K][C] (pass 1, nullable)
 extern "C" int64_t segf_bn_cls_bwd_full_ws(int64_t M, int C, int K, int64_t rows_per_sample) {
+    // sized for the larger of the two workgroup budgets: with dwcls == NULL the launch uses the 3072-workgroup plan (up to 4x the chunks
+    // of the 768-workgroup plan that carries the classifier's weight gradient), and x1 / dG may still ride on pass 2
     const int B = (int)(M / rows_per_sample);
-    const int64_t nblk = (int64_t)B * hf_chunks(B, (int)(rows_per_sample / 16), C / (32 * HF_WAVES), true);
-    return nblk * 2 * C + 2 * C + nblk * C * DW_LD + nblk * (int64_t)K * C;
+    const int gps = (int)(rows_per_sample / 16), ny = C / (32 * HF_WAVES);
+    const int64_t nb_cw = (int64_t)B * hf_chunks(B, gps, ny, true), nb_plain = (int64_t)B * hf_chunks(B, gps, ny, false);
+    const int64_t nblk = nb_cw > nb_plain ? nb_cw : nb_plain;
+    return nblk * 2 * C + 2 * C + nblk * C * DW_LD + nb_cw * (int64_t)K * C;
 }
 
 extern "C" int segf_bn_cls_bwd_dw_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample, int C1) {
@@ -441,7 +445,7 @@ extern "C" int segf_bn_cls_bwd_full(int dt, int64_t M, int C, int K, const void*
                                     void* stream) {
     if (x1 && (!segf_bn_cls_bwd_dw_supported(dt, M, C, K, rows_per_sample, C1) || !dG || ldx1 < C1 || ldx1 % 8 || ((uintptr_t)x1 % 16)))
         return SEGF_ERR_SHAPE;
-    if (dwcls && K > 192) return SEGF_ERR_SHAPE;
+    if (dwcls && (K > 192 || act > 1)) return SEGF_ERR_SHAPE;      // the riding weight gradient rebuilds a = max(z, zlo): identity / ReLU only
     return bn_cls_bwd_impl(dt, M, C, K, dy, ldy, w, ldw, x, mean, rstd, gamma, beta, act, chan_scale, rows_per_sample, eval_mode, dx,
                            dgamma, dbeta, ws, x1, ldx1, x1 ? dG : nullptr, stream, dwcls);
 }

@@ -11,6 +11,7 @@ import sys
 import torch
 
 from . import functional as Fh
+from . import hip
 from . import utils
 from .backbones import TokenMap, tokens_from_nchw
 from .metrics import Metrics
@@ -47,6 +48,40 @@ def criterion(inputs, target, loss_weight=None, num_classes: int = 2, dice: bool
     return criterion_lowres(tm, target, (H, W), loss_weight, num_classes, dice, ignore_index)
 
 
+class _DeferredLosses:
+    """Device ring of the last steps' loss values (graph path of train_one_epoch): `push` is one 4-byte device copy behind the
+    replayed step, `drain` is the one host synchronisation of a logging interval."""
+
+    def __init__(self, device, capacity):
+        self.ring = torch.zeros(capacity, 1, dtype=torch.float32, device=device)
+        self.meta, self.n = [], 0
+
+    def full(self):
+        return self.n == self.ring.shape[0]
+
+    def push(self, loss, lr, it):
+        hip.cast2d(loss.detach().reshape(1, 1), self.ring[self.n:self.n + 1])
+        self.meta.append((lr, it))
+        self.n += 1
+
+    def drain(self):
+        vals = self.ring[:self.n, 0].cpu().tolist()          # the synchronisation point
+        out = [(v, lr, it) for v, (lr, it) in zip(vals, self.meta)]
+        self.meta, self.n = [], 0
+        return out
+
+
+def _flush_losses(pending, metric_logger, writer, print_freq, it0):
+    for loss_value, lr, it in pending.drain():
+        if not math.isfinite(loss_value):
+            print("Loss is {}, stopping training".format(loss_value))
+            sys.exit(1)
+        metric_logger.update(loss=loss_value, lr=lr)
+        if writer is not None and (it - it0) % print_freq == 0:
+            writer.add_scalar('train_loss', loss_value, it)
+            writer.add_scalar('train_lr', lr, it)
+
+
 def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, clip_grad, clip_mode, loss_scaler,
                     writer=None, args=None):
     model.train()
@@ -59,6 +94,7 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
     fused = hasattr(core, 'forward_lowres')
     use_graph = bool(getattr(args, 'hip_graph', False)) and fused
 
+    pending = None
     for idx, (img, lbl) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
         img = img.to(device, non_blocking=True)
         lbl = lbl.to(device, non_blocking=True)
@@ -79,16 +115,15 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
             if getattr(dataloader, 'bind_output', None) is not None and getattr(dataloader, 'out', None) is None:
                 dataloader.bind_output(gs.static_inputs)    # device-side input pipeline: later batches land in the step's buffers
             loss = gs.step(img, lbl)
-            loss_value = loss.item()
-            if not math.isfinite(loss_value):
-                print("Loss is {}, stopping training".format(loss_value))
-                sys.exit(1)
             lr = optimizer.param_groups[0]["lr"]
-            metric_logger.update(loss=loss_value, lr=lr)
-            if writer is not None and idx % print_freq == 0 and getattr(args, 'local_rank', 0) == 0:
-                it = epoch * num_steps + idx
-                writer.add_scalar('train_loss', loss_value, it)
-                writer.add_scalar('train_lr', lr, it)
+            # ONE host synchronisation per logging interval instead of one per step (the reference reads
+            # loss.item() and calls torch.cuda.synchronize() every step, engine.py:44,56): the step's loss is parked in a device
+            # ring, and the meters / the non-finite check / the TensorBoard scalars see every value, in order, when the line is due
+            if pending is None:
+                pending = _DeferredLosses(loss.device, max(1, min(int(print_freq), 256)))
+            pending.push(loss, lr, epoch * num_steps + idx)
+            if idx % print_freq == 0 or idx == num_steps - 1 or pending.full():
+                _flush_losses(pending, metric_logger, writer if getattr(args, 'local_rank', 0) == 0 else None, print_freq, epoch * num_steps)
             continue
         optimizer.zero_grad()
         if fused:
@@ -116,6 +151,8 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
             it = epoch * num_steps + idx
             writer.add_scalar('train_loss', loss, it)
             writer.add_scalar('train_lr', lr, it)
+    if pending is not None and pending.n:           # a loader that yielded fewer batches than len() promised
+        _flush_losses(pending, metric_logger, writer if getattr(args, 'local_rank', 0) == 0 else None, print_freq, epoch * num_steps)
     metric_logger.synchronize_between_processes()
     return metric_logger.meters["loss"].global_avg, lr
 

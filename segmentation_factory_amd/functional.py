@@ -1199,8 +1199,10 @@ class UpsampleCEDiceFn(Function):
             raise RuntimeError(f'criterion: logits {tuple(logits.shape)} do not match geometry {geom}')
         target = target.contiguous()
         # lse: the per-pixel log-sums the forward leaves for the backward (None where the configuration has no such path)
+        # (grad mode is always off inside Function.forward and _rowmajor may have copied: the autograd context knows whether a backward
+        # can follow)
         loss, stats, lse = hip.ce_dice_fwd(logits, B, Cc, h, w, H, W, target, ignore_index, class_weight, dice,
-                                           want_lse=torch.is_grad_enabled() or logits.requires_grad)
+                                           want_lse=bool(ctx.needs_input_grad[0]))
         ctx.save_for_backward(logits, target, stats, class_weight, lse)
         ctx.meta = (geom, ignore_index, dice)
         ctx.mark_non_differentiable(stats)

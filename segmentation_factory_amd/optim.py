@@ -187,6 +187,10 @@ class FusedAGCAdamW(torch.optim.Optimizer):
             torch._foreach_copy_(dst, src)
         if not self.direct:
             self._set_nograd(missing)          # torch.optim.AdamW: `if p.grad is None: continue`
+            if missing and getattr(self, 'clip_mode', 'agc') in ('norm', 'value'):
+                # clip_grad_norm_ / clip_grad_value_ ignore parameters without a gradient; the flat-buffer kernels see every slot, so a
+                # gradient left over from an earlier step must not enter the global norm
+                torch._foreach_zero_([self._grad_views[i] for i in missing])
 
     @torch.no_grad()
     def apply_flat(self):
@@ -252,8 +256,22 @@ class FusedAGCAdamW(torch.optim.Optimizer):
             self.ensure_built()
             self._step = int(fused['step'])
             self._ustep.fill_(self._step)
-            self._m.copy_(fused['exp_avg'])
-            self._v.copy_(fused['exp_avg_sq'])
+            # the round-1 layout was UNPADDED (parameters back to back); the flat buffers now align every parameter: scatter by offset
+            m_old, v_old = fused['exp_avg'].reshape(-1), fused['exp_avg_sq'].reshape(-1)
+            total = sum(p.numel() for p in self._params)
+            if m_old.numel() == self._m.numel():               # written by a build with the same (padded) layout
+                self._m.copy_(m_old)
+                self._v.copy_(v_old)
+            elif m_old.numel() == total:
+                pos = 0
+                for i, p in enumerate(self._params):
+                    n, o = p.numel(), self._offsets[i]
+                    self._m[o:o + n].copy_(m_old[pos:pos + n])
+                    self._v[o:o + n].copy_(v_old[pos:pos + n])
+                    pos += n
+            else:
+                raise ValueError(f"FusedAGCAdamW.load_state_dict: legacy 'fused' moments hold {m_old.numel()} values, the model has "
+                                 f'{total} parameters ({self._m.numel()} with alignment padding)')
             return
         if not state:
             return
