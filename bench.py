@@ -99,6 +99,45 @@ def cpu_baseline(sample_batch=2, timed_steps=3, loop_timed_steps=2):
             "os_cpu_count": os.cpu_count(), "torch_threads": torch.get_num_threads(), "cpu_model": cpu_model}
 
 
+def extra_legs(budget_s):
+    """What the headline line does not show, measured by THIS command so that the driver observes it: the other BASELINE.json configs
+    (cfg3 / cfg4 / cfg5, cfg5 with fp8, cfg2 at the reference's default batch 4 and at 16), the loop a user runs
+    (engine.train_one_epoch with --hip-graph over the device-side loader) against the replay-only rate, and engine.evaluate at the
+    reference's default --val_batch_size 1 and at 32 (/root/reference/train_gpu.py:71-72, engine.py:36-56,74-104).  One child process
+    per leg (tools/bench_legs.py), each under a timeout; a leg that fails is reported as such and never costs the headline line."""
+    import subprocess
+    legs = [('other_configs', ['config', 'cfg3']), ('other_configs', ['config', 'cfg3', '--fp8']), ('other_configs', ['config', 'cfg4']),
+            ('other_configs', ['config', 'cfg5']), ('other_configs', ['config', 'cfg5', '--fp8']),
+            ('other_configs', ['config', 'cfg2', '--batch', '4', '--steps', '40', '--warmup', '10']),
+            ('other_configs', ['config', 'cfg2', '--batch', '16', '--steps', '20', '--warmup', '5']),
+            ('train_loop', ['train_loop', '--batch', '128', '--steps', '10', '--epochs', '2']),
+            ('train_loop', ['train_loop', '--batch', '4', '--steps', '100', '--epochs', '2']),
+            ('eval', ['eval', '--batch', '1', '--steps', '100']), ('eval', ['eval', '--batch', '32', '--steps', '10'])]
+    res = {'other_configs': [], 'train_loop': [], 'eval': []}
+    t0 = time.time()
+    for key, argv in legs:
+        left = budget_s - (time.time() - t0)
+        tag = ' '.join(argv)
+        if left < 8:
+            res[key].append({'leg': tag, 'skipped': f'legs budget of {budget_s:.0f} s used up'})
+            continue
+        t1 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_legs.py')] + argv, capture_output=True, text=True,
+                               timeout=min(left, 90.0))
+            line = next((l for l in r.stdout.splitlines() if l.startswith('LEG_JSON ')), None)
+            if r.returncode == 0 and line:
+                d = json.loads(line[len('LEG_JSON '):])
+                d['leg_wall_s'] = round(time.time() - t1, 1)
+                res[key].append(d)
+            else:
+                res[key].append({'leg': tag, 'error': (r.stderr or r.stdout)[-400:]})
+        except subprocess.TimeoutExpired:
+            res[key].append({'leg': tag, 'error': 'timeout'})
+    res['extra_legs_wall_s'] = round(time.time() - t0, 1)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -113,7 +152,10 @@ def main():
     ap.add_argument('--eager', action='store_true', help='per-kernel launches + torch DDP instead of the hipGraph step')
     ap.add_argument('--copy-inputs', action='store_true', help='copy the batch into the captured step\'s input buffers every step '
                                                                  '(default: it already sits there, as the device input pipeline delivers it)')
-    ap.add_argument('--fp8', action='store_true', help='cfg3 / cfg5: forward products of the ConvNeXt pointwise linears in OCP e4m3 (set_fp8)')
+    ap.add_argument('--fp8', action='store_true', help='cfg3 / cfg5: the UPerHead 3x3 convolutions and the ConvNeXt block MLPs on fp8 operands in all three '
+                                                      'products (forward e4m3 x e4m3, gradients e5m2; set_fp8)')
+    ap.add_argument('--no-extra-legs', action='store_true', help='skip the secondary legs (other BASELINE configs, train loop, evaluate)')
+    ap.add_argument('--legs-budget-s', type=float, default=150.0, help='wall-clock budget for the secondary legs; legs that do not fit are listed as skipped')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -344,6 +386,11 @@ def main():
         }
         if inp is not None:
             out["input_pipeline"] = inp
+        if world == 1 and not args.no_extra_legs and args.config == 'cfg2' and not args.eager:
+            # free this process's share of the HBM first: the children build their own models and graphs
+            del gs
+            torch.cuda.empty_cache()
+            out.update(extra_legs(args.legs_budget_s))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

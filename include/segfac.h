@@ -61,6 +61,9 @@ int segf_add_i64(int64_t* p, int64_t v, void* stream);
 /* Metrics.update's `self.hist += bincount(...)` (util/metrics.py:24-27): hist fp32 [n] += (float)counts int64 [n] (torch's promotion of
  * float32 += int64: each count rounded to fp32, then added); clear != 0 also zeroes the counts for the next batch. */
 int segf_hist_accum(float* hist, int64_t* counts, int64_t n, int clear, void* stream);
+/* test hook: a single wave that occupies `stream` for `us` microseconds (<= 200000), e.g. to delay a gradient in the data-parallel
+ * ordering test (the event-ordered exchange of train_gpu.py:233-236's DDP replacement). */
+int segf_debug_spin(int64_t us, void* stream);
 int segf_bernoulli_scale(uint64_t* state, const float* keep_prob, int64_t n, int64_t row_len, float* out, void* stream);
 
 /* ---- FP8 (OCP e4m3fn) forward GEMM: BASELINE cfg5 "ConvNeXtV2-L + UPerNet, fp8 MFMA weights" (the pointwise linears of

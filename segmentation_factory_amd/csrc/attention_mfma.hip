@@ -13,7 +13,9 @@
 //   dq  : S^T form again, dS^T feeds dQ^T += K^T dS^T directly from the accumulators
 //   dkv : S form (rows = queries), each wave owns 64 keys whose K/V fragments stay in registers for the whole kernel;
 //         Q / dO tiles go through LDS; dV^T += dO^T P and dK^T += Q^T dS take P / dS from the accumulators.
+#include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "attention_mfma.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -23,6 +25,12 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 #define AM_KC_OF(HD) ((HD) == 64 ? 128 : 256)      // keys per LDS stage: 32 KB of K + V either way (3+ workgroups per CU)
 #define AM_THREADS 256
+// waves per SIMD the query-side kernels are compiled for: head dim 64 with swizzled tiles keeps six fragment addresses live and spilled
+// 150 - 250 bytes under the 128-register cap of four waves per SIMD; three waves (168 registers) hold everything
+#ifndef AM_QOCC64
+#define AM_QOCC64 3
+#endif
+#define AM_QOCC(HD) ((HD) == 64 ? AM_QOCC64 : 4)
 
 __device__ __forceinline__ bf16x8 ld_frag_global(const bf16_t* __restrict__ p, bool valid) {
     uint4 u = make_uint4(0, 0, 0, 0);
@@ -44,30 +52,79 @@ __device__ __forceinline__ bf16x8 ld_frag_tr(const bf16_t* tile, int r_lo, int r
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
+// LDS tiles at head dim 64 (128-byte rows) are XOR-SWIZZLED: 16-byte chunk ch of row r sits at chunk ch ^ (r & 7).  Unswizzled, the
+// 16 rows of a ds_read_b128 fragment read (same column, rows 128 bytes apart) fall on 2 of the 16 sixteen-byte slots of the 256-byte
+// bank row (8-way conflict) and the four same-parity rows of a transposed read on one (4-way): 33 % / 41 % / 49 % of the CU cycles of
+// the forward / query-side / key-side kernels at 2048 keys were LDS bank-conflict cycles (profiles/r04_mfma_kernels_pmc_before.txt).
+// With the swizzle both kinds of read are conflict-free (row-major reads: slot = (r & 1, ch ^ (r & 7)), distinct over a 16-lane group;
+// transposed reads: the four rows of one parity land on four different chunk pairs).  Head dim 32 keeps its dense 64-byte rows.
+template <int HD, bool SWZ = true>
+__device__ __forceinline__ int am_chunk(int ch, int row_low3) { return (HD == 64 && SWZ) ? (ch ^ row_low3) : ch; }
+// transposed fragment from a swizzled row-major [row][HD] tile; rows r_lo + q and r_hi + q with r_lo = r_hi = 4 g (mod 8),
+// 16-column block d: element j < 4 <- row r_lo + j, j >= 4 <- row r_hi + (j - 4), column 16 d + (lane & 15)
+template <int HD, bool SWZ = true>
+__device__ __forceinline__ bf16x8 ld_frag_trs(const bf16_t* tile, int r_lo, int r_hi, int d, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4;
+    const int col = (am_chunk<HD, SWZ>(2 * d + (p >> 1), (4 * g + q) & 7) << 3) + 4 * (p & 1);
+    const bf16_t* a = tile + (r_lo + q) * HD + col;
+    const bf16_t* b = tile + (r_hi + q) * HD + col;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b);
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// fragment times a power of two (exact in bf16): head dim 64 has scale = 2^-3, which then rides on an operand instead of on
+// every score (S (q s) = s S (q) bit for bit; the gradients are rescaled once at the end)
+__device__ __forceinline__ bf16x8 scale_frag_pow2(bf16x8 f, float s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)((float)f[j] * s);
+    return r;
+}
 // two accumulator tiles (rows 4g+r of the first / second 16-row tile) -> one bf16 operand fragment
 __device__ __forceinline__ bf16x8 pack_acc(const float (&a)[4], const float (&b)[4]) {
     uint4 u;
     u.x = pack2bf(a[0], a[1]); u.y = pack2bf(a[2], a[3]); u.z = pack2bf(b[0], b[1]); u.w = pack2bf(b[2], b[3]);
     return __builtin_bit_cast(bf16x8, u);
 }
-__device__ __forceinline__ float xgroup_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float xgroup_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+// reductions over the four 16-lane groups of a wave (lanes i, i + 16, i + 32, i + 48), result in all four: v_permlane16_swap /
+// v_permlane32_swap exchange whole 16- / 32-lane rows between two registers in the VALU -- with both operands holding v, one register
+// comes back as (row 0, row 0, row 2, row 2) and the other as (row 1, row 1, row 3, row 3) (resp. lower half twice / upper half twice).
+// __shfl_xor(v, 16 / 32) compiled to ds_bpermute_b32: two LDS round trips (~100 cycles each) in the middle of the online-softmax
+// dependency chain of every 32-key step.  Same values in the same association, bit for bit (max and + are commutative).
+// (inline asm: hipcc 7.2 miscompiles the two-result builtins when both results feed arithmetic, loss.hip; the s_nops are the
+// VALU-write -> permlane-read wait states)
+__device__ __forceinline__ void am_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void am_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float xgroup_max(float v) {
+    float a = v, b = v;
+    am_swap16(a, b); v = fmaxf(a, b);
+    a = v; b = v;
+    am_swap32(a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ float xgroup_sum(float v) {
+    float a = v, b = v;
+    am_swap16(a, b); v = a + b;
+    a = v; b = v;
+    am_swap32(a, b); return a + b;
+}
 
 // stage rows [r0, r0 + nrows) x HD of a [rows][ld] global matrix into a dense [nrows][HD] LDS tile (zero beyond rmax)
-template <int HD>
+template <int HD, bool SWZ = true>
 __device__ __forceinline__ void stage_rows(bf16_t* tile, const bf16_t* __restrict__ src, int64_t ld, int r0, int nrows, int rmax) {
     constexpr int CPR = HD / 8;                      // 16-byte chunks per row
     for (int i = threadIdx.x; i < nrows * CPR; i += AM_THREADS) {
         const int r = i / CPR, c = i - r * CPR;
         uint4 u = make_uint4(0, 0, 0, 0);
         if (r0 + r < rmax) u = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + r) * ld + c * 8);
-        *reinterpret_cast<uint4*>(tile + r * HD + c * 8) = u;
+        *reinterpret_cast<uint4*>(tile + r * HD + am_chunk<HD, SWZ>(c, r & 7) * 8) = u;
     }
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
-template <int HD, int QW>
-__global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+// P2S: `scale` is a power of two (head dim 64: 2^-3) and rides on the Q fragments (exact), so the scores leave the MFMA already scaled
+template <int HD, int QW, bool P2S, int OCC = 4, bool SWZ = true>
+__global__ void __launch_bounds__(AM_THREADS, OCC) attn_mfma_fwd_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                     const bf16_t* __restrict__ k, int64_t ldk,
                                                                     const bf16_t* __restrict__ v, int64_t ldv,
                                                                     bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse,
@@ -90,6 +147,7 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
         for (int s = 0; s < KS; ++s) {
             const int row = q0 + 16 * t + c;
             Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
+            if (P2S) Qf[t][s] = scale_frag_pow2(Qf[t][s], scale);
         }
     f32x4 O[DT][QW];
     float m[QW], l[QW];
@@ -103,8 +161,8 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
         const int nk = Nkv - kc0 < AM_KC ? Nkv - kc0 : AM_KC;
         const int nk32 = (nk + 31) & ~31;
         __syncthreads();
-        stage_rows<HD>(Ks, Kb, ldk, kc0, nk32, Nkv);
-        stage_rows<HD>(Vs, Vb, ldv, kc0, nk32, Nkv);
+        stage_rows<HD, SWZ>(Ks, Kb, ldk, kc0, nk32, Nkv);
+        stage_rows<HD, SWZ>(Vs, Vb, ldv, kc0, nk32, Nkv);
         __syncthreads();
         if (q0 >= N) continue;                       // wave-uniform; the wave still takes part in the barriers
         for (int kb = 0; kb < nk; kb += 32) {
@@ -112,42 +170,52 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int s = 0; s < KS; ++s) Kf[kt][s] = ld_frag_lds(Ks + (kb + 16 * kt + c) * HD + 32 * s + 8 * g);
+                for (int s = 0; s < KS; ++s) Kf[kt][s] = ld_frag_lds(Ks + (kb + 16 * kt + c) * HD + (am_chunk<HD, SWZ>(4 * s + g, c & 7) << 3));
 #pragma unroll
-            for (int d = 0; d < DT; ++d) Vf[d] = ld_frag_tr<HD>(Vs, kb + 4 * g, kb + 16 + 4 * g, 16 * d, lane);
+            for (int d = 0; d < DT; ++d) Vf[d] = ld_frag_trs<HD, SWZ>(Vs, kb + 4 * g, kb + 16 + 4 * g, d, lane);
+            // MASK: only the last 32-key step of a key count that is not a multiple of 32 has keys to hide (wave-uniform choice)
+            auto step = [&](auto maskc) {
+                constexpr bool MASK = decltype(maskc)::value;
 #pragma unroll
-            for (int t = 0; t < QW; ++t) {
-                float sv[2][4];
+                for (int t = 0; t < QW; ++t) {
+                    float sv[2][4];
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int kt = 0; kt < 2; ++kt) {
+                        f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
+                        for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kc0 + kb + 16 * kt + 4 * g + r;
-                        sv[kt][r] = key < Nkv ? S[r] * scale : -INFINITY;
+                        for (int r = 0; r < 4; ++r) {
+                            const float sc = P2S ? S[r] : S[r] * scale;
+                            if (MASK) {
+                                const int key = kc0 + kb + 16 * kt + 4 * g + r;
+                                sv[kt][r] = key < Nkv ? sc : -INFINITY;
+                            } else {
+                                sv[kt][r] = sc;
+                            }
+                        }
+                    }
+                    float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
+                                     fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
+                    mx = xgroup_max(mx);
+                    const float mnew = fmaxf(m[t], mx);
+                    const float alpha = __expf(m[t] - mnew);
+                    float ps = 0.f;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { sv[kt][r] = __expf(sv[kt][r] - mnew); ps += sv[kt][r]; }
+                    l[t] = l[t] * alpha + ps;
+                    m[t] = mnew;
+                    const bf16x8 Pf = pack_acc(sv[0], sv[1]);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        O[d][t] *= alpha;
+                        O[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[d], Pf, O[d][t], 0, 0, 0);
                     }
                 }
-                float mx = fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
-                                 fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])));
-                mx = xgroup_max(mx);
-                const float mnew = fmaxf(m[t], mx);
-                const float alpha = __expf(m[t] - mnew);
-                float ps = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { sv[kt][r] = __expf(sv[kt][r] - mnew); ps += sv[kt][r]; }
-                l[t] = l[t] * alpha + ps;
-                m[t] = mnew;
-                const bf16x8 Pf = pack_acc(sv[0], sv[1]);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    O[d][t] *= alpha;
-                    O[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[d], Pf, O[d][t], 0, 0, 0);
-                }
-            }
+            };
+            if (kc0 + kb + 32 <= Nkv) step(std::false_type{}); else step(std::true_type{});
         }
     }
     if (q0 >= N) return;
@@ -168,23 +236,348 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_fwd_kernel(const bf16
     }
 }
 
+// a power of two well inside the normal range: multiplying bf16 / fp32 values by it is exact
+// ---- head dim 64, long key sequences (MiT-B2 at 1024 x 2048: 2048 keys): K / V stages by LDS-DMA, double-buffered ------------------
+// The kernels above stage 128 keys, wait for them, compute, and stage again: two barriers and one exposed global-load latency per
+// stage, covered only by the other workgroups of the CU.  Here a stage is 64 keys (K 8 KB + V 8 KB); the NEXT stage's sixteen 1-KB
+// pieces are issued as global_load_lds_dwordx4 (four per wave) into the other buffer right after the one barrier per stage, and land
+// under the current stage's 32 matrix instructions per wave.  An LDS-DMA piece is lane-linear in LDS (wave-uniform base + 16 lane
+// bytes = 8 rows of 128 bytes), so the XOR swizzle of the tiles is applied to the per-lane SOURCE address: lane l of a piece fetches
+// logical chunk (l & 7) ^ (l >> 3) of row (l >> 3).  Rows beyond the last key are clamped (their scores are masked).
+// transposed fragment as ld_frag_trs<64, true>, but INLINE ASM: in front of the ds_read_tr builtin hipcc 7.2 waits vmcnt(0) while an
+// LDS-DMA is in flight (it cannot tell the DMA's LDS destination from the read's source), which would drain the prefetch at the first
+// read of every stage.  The compiler does not track these reads: the caller waits (AMP_LGKM0) before the first use.
+__device__ __forceinline__ bf16x8 amp_frag_trs(const bf16_t* tile, int r_lo, int r_hi, int d, int lane) {
+    const int i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4;
+    const int col = (((2 * d + (p >> 1)) ^ ((4 * g + q) & 7)) << 3) + 4 * (p & 1);
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + (r_lo + q) * 64 + col);
+    const uint32_t b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + (r_hi + q) * 64 + col);
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(b));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+#define AMP_LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define AMP_KC 64
+#define AMP_GLDS(SRC, DST) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC), \
+                                                             (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+__device__ __forceinline__ void amp_stage(bf16_t* Kt, bf16_t* Vt, const bf16_t* __restrict__ Kb, int64_t ldk, const bf16_t* __restrict__ Vb,
+                                          int64_t ldv, int kc0, int Nkv, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = 4 * i + wave;                                  // 8 rows x 128 bytes each
+        int row = kc0 + 8 * piece + (lane >> 3);
+        row = row < Nkv ? row : Nkv - 1;
+        const int col = ((lane & 7) ^ (lane >> 3)) * 8;
+        AMP_GLDS(Kb + (int64_t)row * ldk + col, Kt + piece * 512);
+        AMP_GLDS(Vb + (int64_t)row * ldv + col, Vt + piece * 512);
+    }
+}
+
+// raw single instructions: the library forms add a canonicalising v_max in front of every fmaxf on an MFMA result and range fix-ups
+// around exp2f -- the forward below is bound by VALU issue (85 % of the SIMD cycles, ~4.2 cycles per vector instruction), so every
+// instruction per (query, key) pair counts
+__device__ __forceinline__ float am_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float am_max2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define AMP_THR 6.0f        // lazy rescale: the running maximum is only raised when a score exceeds it by more than 2^6 (log2 units)
+
+// Forward at head dim 64, long key sequences.  The softmax runs in the exp2 domain with `scale` folded into the exponent's multiply-add:
+// p = exp2(s c - m), c = scale log2(e), m = the running maximum of s c -- one v_fma + one v_exp per (query, key) pair where the
+// form above spends a multiply (scale), a subtract, a multiply (log2 e) and the exponential.  The running maximum is raised LAZILY:
+// only when some score of the step exceeds it by more than AMP_THR does the wave rescale O and l (a wave-uniform branch); until then
+// p <= 2^AMP_THR, which the fp32 accumulators and the bf16 P operand (a floating-point format: its relative precision does not depend
+// on the magnitude) take without loss.  After the first few steps of a 2048-key row the branch is rarely taken, which removes the 16
+// accumulator multiplies per (query tile, step).  This changes the rounding order against the head-dim-32 kernels; head dim 64 only
+// occurs in MiT-B2 and up, whose parity is pinned against the fp32 oracle with the bf16 tolerance (tests: test_attention,
+// test_full_size_fp32_and_bf16_vs_oracle[cfg4]); the SegFormer-B0 fixtures never reach this kernel.
+template <int QW>
+__global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+                                                                    int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
+                                                                    bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse, int heads,
+                                                                    int N, int Nkv, float scale) {
+    constexpr int HD = 64, KS = 2, DT = 4;
+    __shared__ __attribute__((aligned(1024))) bf16_t KV[2][2][AMP_KC * HD];          // [buffer][K, V]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * (16 * QW);
+    const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
+    const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
+    const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
+    amp_stage(KV[0][0], KV[0][1], Kb, ldk, Vb, ldv, 0, Nkv, wave, lane);
+    const float cs = scale * 1.44269504088896340736f;              // scores -> log2 units
+    bf16x8 Qf[QW][KS];
+#pragma unroll
+    for (int t = 0; t < QW; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int row = q0 + 16 * t + c;
+            Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
+        }
+    f32x4 O[DT][QW];
+    float m[QW], l[QW];
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        m[t] = -INFINITY; l[t] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) O[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int nst = (Nkv + AMP_KC - 1) / AMP_KC;
+    for (int st = 0; st < nst; ++st) {
+        const int kc0 = st * AMP_KC;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage st have landed ...
+        __syncthreads();                                       // ... everyone's have, and nobody reads the other buffer any more
+        if (st + 1 < nst) amp_stage(KV[(st + 1) & 1][0], KV[(st + 1) & 1][1], Kb, ldk, Vb, ldv, kc0 + AMP_KC, Nkv, wave, lane);
+        if (q0 >= N) continue;                                 // wave-uniform; the wave still stages its pieces and joins the barriers
+        const bf16_t* Ks = KV[st & 1][0];
+        const bf16_t* Vs = KV[st & 1][1];
+#pragma unroll
+        for (int kb = 0; kb < AMP_KC; kb += 32) {
+            bf16x8 Kf[2][KS], Vf[DT];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) Kf[kt][s] = ld_frag_lds(Ks + (kb + 16 * kt + c) * HD + (((4 * s + g) ^ (c & 7)) << 3));
+#pragma unroll
+            for (int d = 0; d < DT; ++d) Vf[d] = amp_frag_trs(Vs, kb + 4 * g, kb + 16 + 4 * g, d, lane);
+            AMP_LGKM0();
+            float sv[QW][2][4], mx[QW];
+#pragma unroll
+            for (int t = 0; t < QW; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[t][kt][r] = S[r];
+                }
+            if (kc0 + kb + 32 > Nkv) {                          // last step of a key count that is not a multiple of 32 (wave-uniform)
+#pragma unroll
+                for (int t = 0; t < QW; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kc0 + kb + 16 * kt + 4 * g + r >= Nkv) sv[t][kt][r] = -INFINITY;
+            }
+#pragma unroll
+            for (int t = 0; t < QW; ++t)
+                mx[t] = am_max2(am_max3(sv[t][0][0], sv[t][0][1], sv[t][0][2]),
+                                am_max3(sv[t][1][0], sv[t][1][1], am_max3(sv[t][0][3], sv[t][1][2], sv[t][1][3])));
+            if constexpr (QW == 2) {
+                float a0 = mx[0], b0 = mx[0], a1 = mx[1], b1 = mx[1];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1\n\tv_permlane16_swap_b32_e32 %2, %3\n\ts_nop 1" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+                a0 = b0 = am_max2(a0, b0); a1 = b1 = am_max2(a1, b1);
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1\n\tv_permlane32_swap_b32_e32 %2, %3\n\ts_nop 1" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+                mx[0] = am_max2(a0, b0); mx[1] = am_max2(a1, b1);
+            } else {
+#pragma unroll
+                for (int t = 0; t < QW; ++t) mx[t] = xgroup_max(mx[t]);
+            }
+            bool grow = false;
+#pragma unroll
+            for (int t = 0; t < QW; ++t) { mx[t] *= cs; grow = grow || (mx[t] > m[t] + AMP_THR); }
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {       // rare after the first steps: raise the maxima, rescale O and l
+#pragma unroll
+                for (int t = 0; t < QW; ++t) {
+                    const float mnew = fmaxf(m[t], mx[t]);
+                    const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);          // exp2(-inf) = 0 on the first step
+                    m[t] = mnew;
+                    l[t] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) O[d][t] *= alpha;
+                }
+            }
+            bf16x8 Pf[QW];
+#pragma unroll
+            for (int t = 0; t < QW; ++t) {
+                const float nm = -m[t];
+                float ps = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sv[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sv[t][kt][r], cs, nm)); ps += sv[t][kt][r]; }
+                l[t] += ps;
+                Pf[t] = pack_acc(sv[t][0], sv[t][1]);
+            }
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int t = 0; t < QW; ++t) O[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[d], Pf[t], O[d][t], 0, 0, 0);
+        }
+    }
+    if (q0 >= N) return;
+    bf16_t* Ob = o + (int64_t)b * N * ldo + h * HD;
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        const float lt = xgroup_sum(l[t]);
+        const float inv = 1.f / lt;
+        const int row = q0 + 16 * t + c;
+        if (row < N) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const uint2 u = make_uint2(pack2bf(O[d][t][0] * inv, O[d][t][1] * inv), pack2bf(O[d][t][2] * inv, O[d][t][3] * inv));
+                *reinterpret_cast<uint2*>(Ob + (int64_t)row * ldo + 16 * d + 4 * g) = u;
+            }
+            // log-sum-exp in natural units, as the backward takes it: m is in log2 units
+            if (g == 0) lse[((int64_t)b * heads + h) * N + row] = m[t] * 0.69314718055994530942f + __logf(lt);
+        }
+    }
+}
+
+template <int QW, bool P2S>
+__global__ void __launch_bounds__(AM_THREADS, QW == 1 ? 4 : 3) attn_bwd_dq64p_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+                                                                       int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
+                                                                       const bf16_t* __restrict__ o, int64_t ldo,
+                                                                       const bf16_t* __restrict__ dO, int64_t lddo,
+                                                                       const float* __restrict__ lse, bf16_t* __restrict__ dq, int64_t lddq,
+                                                                       float* __restrict__ Dbuf, int heads, int N, int Nkv, float scale) {
+    constexpr int HD = 64, KS = 2, DT = 4;
+    __shared__ __attribute__((aligned(1024))) bf16_t KV[2][2][AMP_KC * HD];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * (16 * QW);
+    const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
+    const bf16_t* Ob = o + (int64_t)b * N * ldo + h * HD;
+    const bf16_t* dOb = dO + (int64_t)b * N * lddo + h * HD;
+    const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
+    const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
+    amp_stage(KV[0][0], KV[0][1], Kb, ldk, Vb, ldv, 0, Nkv, wave, lane);
+    bf16x8 Qf[QW][KS], dOf[QW][KS];
+    float Dq[QW], lq[QW];
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        const int row = q0 + 16 * t + c;
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
+            dOf[t][s] = ld_frag_global(dOb + (int64_t)row * lddo + 32 * s + 8 * g, row < N);
+            const bf16x8 of = ld_frag_global(Ob + (int64_t)row * ldo + 32 * s + 8 * g, row < N);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)dOf[t][s][j] * (float)of[j];
+        }
+        Dq[t] = xgroup_sum(part);
+        lq[t] = row < N ? lse[((int64_t)b * heads + h) * N + row] : INFINITY;
+        if (g == 0 && row < N) Dbuf[((int64_t)b * heads + h) * N + row] = Dq[t];
+        if (P2S) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) Qf[t][s] = scale_frag_pow2(Qf[t][s], scale);
+        }
+    }
+    f32x4 dQ[DT][QW];
+#pragma unroll
+    for (int t = 0; t < QW; ++t)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) dQ[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nst = (Nkv + AMP_KC - 1) / AMP_KC;
+    for (int st = 0; st < nst; ++st) {
+        const int kc0 = st * AMP_KC;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < nst) amp_stage(KV[(st + 1) & 1][0], KV[(st + 1) & 1][1], Kb, ldk, Vb, ldv, kc0 + AMP_KC, Nkv, wave, lane);
+        if (q0 >= N) continue;
+        const bf16_t* Ks = KV[st & 1][0];
+        const bf16_t* Vs = KV[st & 1][1];
+#pragma unroll
+        for (int kb = 0; kb < AMP_KC; kb += 32) {
+            bf16x8 Kf[2][KS], Vf[2][KS], KT[DT];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int off = (kb + 16 * kt + c) * HD + (((4 * s + g) ^ (c & 7)) << 3);
+                    Kf[kt][s] = ld_frag_lds(Ks + off);
+                    Vf[kt][s] = ld_frag_lds(Vs + off);
+                }
+#pragma unroll
+            for (int d = 0; d < DT; ++d) KT[d] = amp_frag_trs(Ks, kb + 4 * g, kb + 16 + 4 * g, d, lane);
+            AMP_LGKM0();
+            auto step = [&](auto maskc) {
+                constexpr bool MASK = decltype(maskc)::value;
+#pragma unroll
+                for (int t = 0; t < QW; ++t) {
+                    float ds[2][4];
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
+                            dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float p = __expf(P2S ? S[r] - lq[t] : S[r] * scale - lq[t]);
+                            if (MASK) {
+                                const int key = kc0 + kb + 16 * kt + 4 * g + r;
+                                p = key < Nkv ? p : 0.f;
+                            }
+                            ds[kt][r] = P2S ? p * (dP[r] - Dq[t]) : p * (dP[r] - Dq[t]) * scale;
+                        }
+                    }
+                    const bf16x8 dSf = pack_acc(ds[0], ds[1]);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf, dQ[d][t], 0, 0, 0);
+                }
+            };
+            if (kc0 + kb + 32 <= Nkv) step(std::false_type{}); else step(std::true_type{});
+        }
+    }
+    if (q0 >= N) return;
+    bf16_t* dQb = dq + (int64_t)b * N * lddq + h * HD;
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+        const int row = q0 + 16 * t + c;
+        if (row < N) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                if (P2S) dQ[d][t] *= scale;
+                const uint2 u = make_uint2(pack2bf(dQ[d][t][0], dQ[d][t][1]), pack2bf(dQ[d][t][2], dQ[d][t][3]));
+                *reinterpret_cast<uint2*>(dQb + (int64_t)row * lddq + 16 * d + 4 * g) = u;
+            }
+        }
+    }
+}
+
+// A/B switch (SEGFAC_ATTN_VARIANT) for the head-dim-64 kernels: bit 0 = compile for three waves per SIMD instead of four (query-side
+// kernels), bit 1 = dense (unswizzled) LDS tiles
+static int am_variant() {           // unset / negative: the shipped choice (pipelined LDS-DMA kernels where they apply)
+    const char* e = getenv("SEGFAC_ATTN_VARIANT");
+    return e ? (atoi(e) < 0 ? -1 : (atoi(e) & 3)) : -1;
+}
+static bool am_is_pow2(float s) {
+    int e;
+    return s > 0.f && frexpf(s, &e) == 0.5f && e > -60 && e < 60;
+}
+
 int attn_mfma_fwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64_t ldq, const void* k, int64_t ldk,
                   const void* v, int64_t ldv, float scale, void* o, int64_t ldo, float* lse, hipStream_t st) {
     constexpr int QW = 2;
     dim3 grid((unsigned)cdiv64(N, 4 * 16 * QW), heads, B);      // (one query tile per wave measured 2 % slower at head dim 64)
-    if (hd == 32)
-        hipLaunchKernelGGL((attn_mfma_fwd_kernel<32, QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+#define AM_FWD(HDv, P2, OCCv, SWv) hipLaunchKernelGGL((attn_mfma_fwd_kernel<HDv, QW, P2, OCCv, SWv>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, \
+        (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale)
+    const int var = am_variant();
+    if (hd == 32) AM_FWD(32, false, 4, false);
+    else if (var < 0 && Nkv >= 2 * AMP_KC) {
+        hipLaunchKernelGGL((attn_fwd64p_kernel<QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
                            (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
-    else
-        hipLaunchKernelGGL((attn_mfma_fwd_kernel<64, QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                           (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
+    }
+    else if (!am_is_pow2(scale)) AM_FWD(64, false, 4, true);
+    else if (var <= 0) AM_FWD(64, true, 4, true);
+    else if (var == 1) AM_FWD(64, true, 3, true);
+    else if (var == 2) AM_FWD(64, true, 4, false);
+    else AM_FWD(64, true, 3, false);
+#undef AM_FWD
     SEGF_CHECK_LAUNCH();
     return 0;
 }
 
 // ---- backward, query side: D = rowsum(dO * O), dQ = scale * (P o (dP - D)) K ---------------------------------------------
-template <int HD, int QW>
-__global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const bf16_t* __restrict__ q, int64_t ldq,
+template <int HD, int QW, bool P2S, int OCC = 4, bool SWZ = true>
+__global__ void __launch_bounds__(AM_THREADS, OCC) attn_mfma_bwd_dq_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                        const bf16_t* __restrict__ k, int64_t ldk,
                                                                        const bf16_t* __restrict__ v, int64_t ldv,
                                                                        const bf16_t* __restrict__ o, int64_t ldo,
@@ -222,6 +615,10 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
         Dq[t] = xgroup_sum(part);
         lq[t] = row < N ? lse[((int64_t)b * heads + h) * N + row] : INFINITY;
         if (g == 0 && row < N) Dbuf[((int64_t)b * heads + h) * N + row] = Dq[t];
+        if (P2S) {              // the scores come out of the MFMA scaled; dS stays unscaled and dQ is scaled once at the end (all exact)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) Qf[t][s] = scale_frag_pow2(Qf[t][s], scale);
+        }
     }
     f32x4 dQ[DT][QW];
 #pragma unroll
@@ -232,8 +629,8 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
         const int nk = Nkv - kc0 < AM_KC ? Nkv - kc0 : AM_KC;
         const int nk32 = (nk + 31) & ~31;
         __syncthreads();
-        stage_rows<HD>(Ks, Kb, ldk, kc0, nk32, Nkv);
-        stage_rows<HD>(Vs, Vb, ldv, kc0, nk32, Nkv);
+        stage_rows<HD, SWZ>(Ks, Kb, ldk, kc0, nk32, Nkv);
+        stage_rows<HD, SWZ>(Vs, Vb, ldv, kc0, nk32, Nkv);
         __syncthreads();
         if (q0 >= N) continue;
         for (int kb = 0; kb < nk; kb += 32) {
@@ -242,33 +639,41 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    Kf[kt][s] = ld_frag_lds(Ks + (kb + 16 * kt + c) * HD + 32 * s + 8 * g);
-                    Vf[kt][s] = ld_frag_lds(Vs + (kb + 16 * kt + c) * HD + 32 * s + 8 * g);
+                    const int off = (kb + 16 * kt + c) * HD + (am_chunk<HD, SWZ>(4 * s + g, c & 7) << 3);
+                    Kf[kt][s] = ld_frag_lds(Ks + off);
+                    Vf[kt][s] = ld_frag_lds(Vs + off);
                 }
 #pragma unroll
-            for (int d = 0; d < DT; ++d) KT[d] = ld_frag_tr<HD>(Ks, kb + 4 * g, kb + 16 + 4 * g, 16 * d, lane);
+            for (int d = 0; d < DT; ++d) KT[d] = ld_frag_trs<HD, SWZ>(Ks, kb + 4 * g, kb + 16 + 4 * g, d, lane);
+            auto step = [&](auto maskc) {
+                constexpr bool MASK = decltype(maskc)::value;
 #pragma unroll
-            for (int t = 0; t < QW; ++t) {
-                float ds[2][4];
+                for (int t = 0; t < QW; ++t) {
+                    float ds[2][4];
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int kt = 0; kt < 2; ++kt) {
+                        f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
-                        dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP, 0, 0, 0);
+                        for (int s = 0; s < KS; ++s) {
+                            S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
+                            dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float p = __expf(P2S ? S[r] - lq[t] : S[r] * scale - lq[t]);
+                            if (MASK) {
+                                const int key = kc0 + kb + 16 * kt + 4 * g + r;
+                                p = key < Nkv ? p : 0.f;
+                            }
+                            ds[kt][r] = P2S ? p * (dP[r] - Dq[t]) : p * (dP[r] - Dq[t]) * scale;
+                        }
                     }
+                    const bf16x8 dSf = pack_acc(ds[0], ds[1]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kc0 + kb + 16 * kt + 4 * g + r;
-                        const float p = key < Nkv ? __expf(S[r] * scale - lq[t]) : 0.f;
-                        ds[kt][r] = p * (dP[r] - Dq[t]) * scale;
-                    }
+                    for (int d = 0; d < DT; ++d) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf, dQ[d][t], 0, 0, 0);
                 }
-                const bf16x8 dSf = pack_acc(ds[0], ds[1]);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf, dQ[d][t], 0, 0, 0);
-            }
+            };
+            if (kc0 + kb + 32 <= Nkv) step(std::false_type{}); else step(std::true_type{});
         }
     }
     if (q0 >= N) return;
@@ -279,6 +684,7 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
         if (row < N) {
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
+                if (P2S) dQ[d][t] *= scale;
                 const uint2 u = make_uint2(pack2bf(dQ[d][t][0], dQ[d][t][1]), pack2bf(dQ[d][t][2], dQ[d][t][3]));
                 *reinterpret_cast<uint2*>(dQb + (int64_t)row * lddq + 16 * d + 4 * g) = u;
             }
@@ -291,7 +697,7 @@ __global__ void __launch_bounds__(AM_THREADS, 4) attn_mfma_bwd_dq_kernel(const b
 // stay in registers; Q / dO tiles of 32 queries pass through LDS.  Output: fp32 slab[z][b*Nkv + key][2C] partial sums.
 // KW = 16-key tiles per wave: 4 (64 keys) at head dim 32; 2 at head dim 64, where 64 keys per wave need ~300 registers (one
 // wave per SIMD, nothing to overlap the Q / dO staging with) and 32 keys fit two waves per SIMD
-template <int HD, int KW = (HD == 32 ? 4 : 2)>
+template <int HD, bool P2S, bool SWZ = true, int KW = (HD == 32 ? 4 : 2)>
 __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                         const bf16_t* __restrict__ k, int64_t ldk,
                                                                         const bf16_t* __restrict__ v, int64_t ldv,
@@ -325,6 +731,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             const int key = key0 + 16 * kt + c;
             Kf[kt][s] = ld_frag_global(Kb + (int64_t)key * ldk + 32 * s + 8 * g, key < Nkv);
             Vf[kt][s] = ld_frag_global(Vb + (int64_t)key * ldv + 32 * s + 8 * g, key < Nkv);
+            if (P2S) Kf[kt][s] = scale_frag_pow2(Kf[kt][s], scale);       // K only feeds the scores here; dK is scaled once at the end
         }
     f32x4 dK[DT][KW], dV[DT][KW];
 #pragma unroll
@@ -351,9 +758,10 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             rd = r2 < qend ? Db[r2] : 0.f;
         }
     };
+    const int sswz = srow * HD + (am_chunk<HD, SWZ>(scol >> 3, srow & 7) << 3);      // swizzled LDS position of this thread's chunk
     auto put = [&](int buf) {
-        if (doQ) *reinterpret_cast<uint4*>(Qs2[buf] + srow * HD + scol) = rq;
-        if (doO) *reinterpret_cast<uint4*>(dOs2[buf] + srow * HD + scol) = ro;
+        if (doQ) *reinterpret_cast<uint4*>(Qs2[buf] + sswz) = rq;
+        if (doO) *reinterpret_cast<uint4*>(dOs2[buf] + sswz) = ro;
         if (threadIdx.x < 32) { Ls2[buf][threadIdx.x] = rl; Ds2[buf][threadIdx.x] = rd; }
     };
     fetch(qbeg);
@@ -374,8 +782,9 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             bf16x8 Qa[KS], dOa[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                Qa[s] = ld_frag_lds(Qs + (16 * qt + c) * HD + 32 * s + 8 * g);
-                dOa[s] = ld_frag_lds(dOs + (16 * qt + c) * HD + 32 * s + 8 * g);
+                const int off = (16 * qt + c) * HD + (am_chunk<HD, SWZ>(4 * s + g, c & 7) << 3);
+                Qa[s] = ld_frag_lds(Qs + off);
+                dOa[s] = ld_frag_lds(dOs + off);
             }
             float lr[4], dr[4];
 #pragma unroll
@@ -390,17 +799,17 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(S[r] * scale - lr[r]);
+                    const float p = __expf(P2S ? S[r] - lr[r] : S[r] * scale - lr[r]);
                     P[qt][kt][r] = p;
-                    dS[qt][kt][r] = p * (dP[r] - dr[r]) * scale;
+                    dS[qt][kt][r] = P2S ? p * (dP[r] - dr[r]) : p * (dP[r] - dr[r]) * scale;
                 }
             }
         }
         bf16x8 dOT[DT], QT[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-            dOT[d] = ld_frag_tr<HD>(dOs, 4 * g, 16 + 4 * g, 16 * d, lane);
-            QT[d] = ld_frag_tr<HD>(Qs, 4 * g, 16 + 4 * g, 16 * d, lane);
+            dOT[d] = ld_frag_trs<HD, SWZ>(dOs, 4 * g, 16 + 4 * g, d, lane);
+            QT[d] = ld_frag_trs<HD, SWZ>(Qs, 4 * g, 16 + 4 * g, d, lane);
         }
 #pragma unroll
         for (int kt = 0; kt < KW; ++kt) {
@@ -426,6 +835,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             float* row = sb + ((int64_t)b * Nkv + key) * 2 * C + h * HD;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
+                if (P2S) dK[d][kt] *= scale;
                 *reinterpret_cast<float4*>(row + 16 * d + 4 * g) = make_float4(dK[d][kt][0], dK[d][kt][1], dK[d][kt][2], dK[d][kt][3]);
                 *reinterpret_cast<float4*>(row + C + 16 * d + 4 * g) = make_float4(dV[d][kt][0], dV[d][kt][1], dV[d][kt][2], dV[d][kt][3]);
             }
@@ -665,15 +1075,39 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
         hipLaunchKernelGGL((attn_mfma_bwd_fused_kernel<32, 4>), g3, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
                            (bf16_t*)dq, lddq, slab, heads, N, Nkv, B, qchunk, scale);
     } else if (hd == 32) {
-        hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<32, QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo,
+        hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<32, QW, false, 4, false>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo,
                            lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
-        hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<32>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf,
+        hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<32, false, false>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf,
                            slab, heads, N, Nkv, B, qchunk, scale);
     } else {
-        hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<64, QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo,
-                           lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
-        hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf,
-                           slab, heads, N, Nkv, B, qchunk, scale);
+#define AM_DQ(P2, OCCv, SWv) hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<64, QW, P2, OCCv, SWv>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, \
+        DO, lddo, lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale)
+#define AM_DKV(P2, SWv) hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64, P2, SWv>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf, \
+        slab, heads, N, Nkv, B, qchunk, scale)
+        const int var = am_variant();
+        if (var < 0 && Nkv >= 2 * AMP_KC) {
+            if (am_is_pow2(scale) && getenv("SEGFAC_ATTN_QW1")) {
+                dim3 g11((unsigned)cdiv64(N, 4 * 16), heads, B);
+                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<1, true>), g11, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
+                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+                AM_DKV(true, true);
+            } else if (am_is_pow2(scale)) {
+                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW, true>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
+                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+                AM_DKV(true, true);
+            } else {
+                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW, false>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
+                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+                AM_DKV(false, true);
+            }
+        }
+        else if (!am_is_pow2(scale)) { AM_DQ(false, 4, true); AM_DKV(false, true); }
+        else {
+            if (var <= 0) AM_DQ(true, 4, true); else if (var == 1) AM_DQ(true, 3, true); else if (var == 2) AM_DQ(true, 4, false); else AM_DQ(true, 3, false);
+            if (var & 2) AM_DKV(true, false); else AM_DKV(true, true);
+        }
+#undef AM_DQ
+#undef AM_DKV
     }
     SEGF_CHECK_LAUNCH();
     return 0;

@@ -303,6 +303,21 @@ extern "C" int segf_hist_accum(float* hist, int64_t* counts, int64_t n, int clea
     SEGF_CHECK_LAUNCH();
     return 0;
 }
+// TEST HOOK: one wave that holds its stream for `us` microseconds (s_memrealtime ticks at 100 MHz), capped at 200 ms so that every
+// launch ends (tests/test_model_gpu.py: the data-parallel ordering test delays a gradient behind it).
+__global__ void debug_spin_kernel(int64_t ticks) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (int guard = 0; guard < (1 << 24); ++guard) {
+        if ((int64_t)(__builtin_amdgcn_s_memrealtime() - t0) >= ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+extern "C" int segf_debug_spin(int64_t us, void* stream) {
+    if (us < 0 || us > 200000) return SEGF_ERR_SHAPE;
+    hipLaunchKernelGGL(debug_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, us * 100);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
 __global__ void add_i64_kernel(int64_t* p, int64_t v) { if (threadIdx.x == 0) *p += v; }
 extern "C" int segf_add_i64(int64_t* p, int64_t v, void* stream) {
     hipLaunchKernelGGL(add_i64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);

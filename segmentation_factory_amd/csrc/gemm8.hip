@@ -29,11 +29,13 @@
 // Measured on the MI355X (3072 -> 768 3x3 @ 128^2, batch 32 = 22.3 TFLOP per direction): forward 28.3 -> 20.4 ms (787 -> 1094
 // TFLOP/s), data gradient 28.6 -> 21.2, weight gradient 25.8 -> 23.3 (957 TFLOP/s); fp8 forward 18.0 -> 14.5 ms (1534 TFLOP/s).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 g8_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float g8_f32x4;
 typedef __attribute__((ext_vector_type(4))) short g8_s16x4;
+template <int N> using g8_ic = std::integral_constant<int, N>;
 
 struct Gemm8Args {
     const unsigned char* A; const unsigned char* B; void* C;
@@ -45,6 +47,9 @@ struct Gemm8Args {
     const float* bias;               // [N] (bf16 output only)
     const bf16_t* residual; int64_t ldr; const float* rscale; int64_t rpg;      // C = residual + rscale[m / rpg] * (...)
     float* ws;                       // [z][M][N] fp32 when gridDim.z > 1
+    int korder;                      // CONV gather on A: 1 = K walks (channel block, tap), 0 = (tap, channel block) as the weights store it
+    unsigned kmagic, kper;           // korder 0: K tiles per tap and floor(2^32 / kper) + 1 (tile / kper by multiply-high)
+    int tile_order;                  // CONV gather on B (weight gradient): 1 = the taps / row tiles of a channel block are launch neighbours
 };
 // the zero page of the CONV border taps: LDS-DMA cannot write zeros itself, so lanes whose tap lies outside the image load from here
 __device__ __attribute__((aligned(256))) unsigned char g8_zero_page[256];
@@ -62,17 +67,22 @@ __device__ __forceinline__ g8_bf16x8 g8_frag_kc(const unsigned char* half, int r
     const int row = row0 + (lane & 15);
     return *reinterpret_cast<const g8_bf16x8*>(half + row * 128 + (((4 * s + (lane >> 4)) ^ (row & 7)) << 4));
 }
-// RM half-tile [64 k][256 B]: lane (i, g) receives T[k = 32 s + 8 g + j][column cb + i], j = 0..7 (two transposed 4-row reads)
-__device__ __forceinline__ g8_bf16x8 g8_frag_tr(const unsigned char* tile, int cb, int s, int lane) {
+// RM half-tile [64 k][256 B]: lane (i, g) receives T[k = 32 s + 8 g + j][column cb + i], j = 0..7 (two transposed 4-row reads).
+// The per-lane byte offset inside a half-tile is split into a part that depends on the 16-column block (g8_tr_base: computed ONCE per
+// kernel, 4 + 2 registers) and compile-time immediates: k + 4 and k + 32 keep the swizzle ((k & 3) and bit 3 of k are unchanged), so the
+// second read of a fragment is +1024 bytes and K sub-step 1 is +8192 bytes; the half-tile's own offset joins the immediate where it fits.
+__device__ __forceinline__ uint32_t g8_tr_base(int cb, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int u = (cb >> 2) + p;
     const int chunk = u >> 1, half = u & 1;
-    const int k0 = 32 * s + 8 * g + q, k1 = k0 + 4;
-    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + k0 * 256 + ((chunk ^ g8_rm_swz(k0)) << 4) + half * 8);
-    const uint32_t a1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)(tile + k1 * 256 + ((chunk ^ g8_rm_swz(k1)) << 4) + half * 8);
+    const int k0 = 8 * g + q;
+    return (uint32_t)(k0 * 256 + ((chunk ^ g8_rm_swz(k0)) << 4) + half * 8);
+}
+template <int OFF>
+__device__ __forceinline__ g8_bf16x8 g8_frag_tr(uint32_t addr) {
     g8_s16x4 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(OFF + 1024));
     return __builtin_bit_cast(g8_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
@@ -112,7 +122,16 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     const unsigned orig = blockIdx.x + gx * blockIdx.y;
     const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);      // bijective XCD remap
-    const unsigned bx = wgid % gx, by = wgid / gx;
+    unsigned bx = wgid % gx, by = wgid / gx;
+    if (CONV_B && a.tile_order && a.cC % 256 == 0 && gx == 9u * (unsigned)(a.cC / 256)) {
+        // weight gradient: the 9 taps x gy row tiles of ONE 256-channel block are neighbours in the launch order (hence on one XCD, at
+        // the same time): they read the same pixels of x shifted by a row / a column and the same dy tiles, so x is fetched once per
+        // channel block instead of once per (tap, row tile) -- with the taps outermost FETCH_SIZE was 75 GB per launch for 4 GB of operands
+        const unsigned ncb = (unsigned)(a.cC / 256), grp = 9u * gy;
+        const unsigned chb = wgid / grp, rem = wgid - chb * grp;
+        by = rem / 9u;
+        bx = (rem - by * 9u) * ncb + chb;
+    }
     const int64_t m0 = (int64_t)by * 256, n0 = (int64_t)bx * 256;
     const int64_t kbeg = (int64_t)blockIdx.z * a.kchunk;
     const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
@@ -130,18 +149,44 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     // KC operands: one base pointer per (half, i) at k = kbeg
     const unsigned char* gA[2][2];
     const unsigned char* gB[2][2];
-    int ay[2][2], ax[2][2];                                   // CONV_A: pixel of each staged row
+    unsigned amask[2][2];                                     // CONV_A: bit t = tap t of this staged row lies inside the image
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (ALAY == 0) {
                 const int64_t m = m0 + 128 * h + kc_row + 8 * i;
-                if (CONV_A) { ax[h][i] = (int)(m % a.cW); ay[h][i] = (int)((m / a.cW) % a.cH); }
-                gA[h][i] = a.A + (m * a.lda + kbeg + 8 * kc_chunk) * 2;
+                if (CONV_A) {
+                    const int x = (int)(m % a.cW), y = (int)((m / a.cW) % a.cH);
+                    unsigned mk = 0;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int yy = y + a.csign * (t / 3 - 1), xx = x + a.csign * (t % 3 - 1);
+                        mk |= (unsigned)(yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW) << t;
+                    }
+                    amask[h][i] = mk;
+                    gA[h][i] = a.A + (m * a.lda + 8 * kc_chunk) * 2;           // the K position (tap, channel) joins per stage
+                } else {
+                    gA[h][i] = a.A + (m * a.lda + kbeg + 8 * kc_chunk) * 2;
+                }
             }
             if (BLAY == 0) gB[h][i] = a.B + ((n0 + 128 * h + kc_row + 8 * i) * a.ldb + kbeg + 8 * kc_chunk) * 2;
         }
+    // CONV_A walks K with the CHANNEL BLOCK outermost and the nine taps innermost: K tile T = (64-channel block T / 9, tap T % 9).  The
+    // nine taps of one channel block read the same pixels shifted by a row / a column, back to back in time, so the gathered operand
+    // comes out of the XCD's L2 eight times out of nine; with the tap outermost (the order in which the weights store K) a tap's
+    // re-read came a whole channel sweep -- 17 MB per XCD -- later and missed: FETCH_SIZE 39 GB per launch for a 3.2 GB operand.
+    // (The weight operand's K tile is then the 128-byte piece at (tap, channel block) of its row: a strided walk over the same bytes.)
+    const int64_t cv_row = CONV_A ? (int64_t)a.csign * a.lda * 2 : 0;          // bytes per pixel step, signed
+    // RM operands (bf16): per-lane fragment addresses inside a half-tile, one per 16-column block of this wave (g8_frag_tr)
+    uint32_t trA[4], trB[2];
+    if (ALAY == 1 || BLAY == 1) {
+        const uint32_t sb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) trA[t] = sb + g8_tr_base(64 * wm + 16 * t, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) trB[u] = sb + g8_tr_base(32 * wn + 16 * u, lane);
+    }
     // CONV_B: tap of each B half (workgroup constant) and the pixel coordinates of this lane's two rows at the NEXT K tile of each
     // half (the tiles of a half are staged in increasing order), advanced by 64 pixels per tile without a division
     int tdy[2], tdx[2], tci[2], py[2][2], px[2][2];
@@ -170,16 +215,23 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         const int h = half & 1;
         if ((isA ? ALAY : BLAY) == 0) {
             unsigned char* dst = lds_half(kt & 1, half) + (16 * wave) * 128;
-            if (isA && CONV_A) {
-                const int k0 = (int)kbeg + ktc * 64, tap = k0 / a.cC, ch0 = k0 - tap * a.cC;           // wave-uniform
-                const int dy = a.csign * (tap / 3 - 1), dx = a.csign * (tap % 3 - 1);
-                const int64_t off = (((int64_t)dy * a.cW + dx) * a.lda + ch0 - kbeg) * 2;
+            if (CONV_A) {
+                // wave-uniform (scalar): channel block and tap of K tile ktc; / 9 and / 3 by multiply-shift
+                unsigned chb, tap;
+                if (a.korder) { chb = __umulhi((unsigned)ktc, 0x38E38E39u) >> 1; tap = (unsigned)ktc - 9u * chb; }
+                else { tap = __umulhi((unsigned)ktc, a.kmagic); chb = (unsigned)ktc - tap * a.kper; }
+                if (isA) {
+                    const int t3 = (int)((tap * 11u) >> 5);                             // tap / 3 for tap < 9
+                    const int64_t off = (int64_t)((t3 - 1) * a.cW + ((int)tap - 3 * t3 - 1)) * cv_row + (int64_t)chb * 128;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int yy = ay[h][i] + dy, xx = ax[h][i] + dx;
-                    const bool ok = yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
-                    const unsigned char* p = ok ? gA[h][i] + off : g8_zero_page;
-                    G8_GLDS(p, dst + i * 1024);
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned char* p = ((amask[h][i] >> tap) & 1u) ? gA[h][i] + off : g8_zero_page;
+                        G8_GLDS(p, dst + i * 1024);
+                    }
+                } else {
+                    const int64_t off = ((int64_t)tap * a.cC + (int64_t)chb * 64) * 2;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) G8_GLDS(gB[h][i] + off, dst + i * 1024);
                 }
             } else {
 #pragma unroll
@@ -219,23 +271,43 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = g8_f32x4{0.f, 0.f, 0.f, 0.f};
     g8_bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
-    auto load_a = [&](int buf, int mq) {
-        const unsigned char* h = lds_half(buf, mq);
+    auto load_a = [&](int buf, auto mqc) {
+        constexpr int MQ = decltype(mqc)::value;
+        if constexpr (ALAY == 1) {
+            const uint32_t bo = (uint32_t)buf << 16;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t va = trA[t] + bo;
+                fa[t][0] = g8_frag_tr<MQ * G8_HALF>(va);
+                fa[t][1] = g8_frag_tr<MQ * G8_HALF + 8192>(va);
+            }
+        } else {
+            const unsigned char* h = lds_half(buf, MQ);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                fa[t][s] = ALAY == 0 ? g8_frag_kc(h, 64 * wm + 16 * t, s, lane)
-                         : (ALAY == 1 ? g8_frag_tr(h, 64 * wm + 16 * t, s, lane) : g8_frag_tr8(h, 64 * wm + 16 * t, s, lane));
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    fa[t][s] = ALAY == 0 ? g8_frag_kc(h, 64 * wm + 16 * t, s, lane) : g8_frag_tr8(h, 64 * wm + 16 * t, s, lane);
+        }
     };
-    auto load_b = [&](int buf, int nq, g8_bf16x8 (&fb)[2][2]) {
-        const unsigned char* h = lds_half(buf, 2 + nq);
+    auto load_b = [&](int buf, auto nqc, g8_bf16x8 (&fb)[2][2]) {
+        constexpr int NQ = decltype(nqc)::value;
+        if constexpr (BLAY == 1) {
+            const uint32_t bo = (uint32_t)buf << 16;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t va = trB[u] + bo;
+                fb[u][0] = g8_frag_tr<(2 + NQ) * G8_HALF>(va);
+                fb[u][1] = g8_frag_tr<(2 + NQ) * G8_HALF + 8192>(va);
+            }
+        } else {
+            const unsigned char* h = lds_half(buf, 2 + NQ);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                fb[u][s] = BLAY == 0 ? g8_frag_kc(h, 32 * wn + 16 * u, s, lane)
-                         : (BLAY == 1 ? g8_frag_tr(h, 32 * wn + 16 * u, s, lane) : g8_frag_tr8(h, 32 * wn + 16 * u, s, lane));
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    fb[u][s] = BLAY == 0 ? g8_frag_kc(h, 32 * wn + 16 * u, s, lane) : g8_frag_tr8(h, 32 * wn + 16 * u, s, lane);
+        }
     };
     auto mma = [&](int mq, int nq, const g8_bf16x8 (&fb)[2][2]) {
         __builtin_amdgcn_s_setprio(1);
@@ -275,23 +347,31 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     stage(0, 0); stage(0, 3); stage(0, 2); stage(0, 1); stage(1, 0); stage(1, 3);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 // all of K tile 0 has landed (this wave's share)
     G8_BAR();
+    // STAGGER: waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so that on every SIMD one wave is in its MFMA
+    // section while the other reads fragments and issues its DMA -- in lockstep all eight waves read together and then queue for the
+    // matrix pipe together, and the pipe idles through every read section (measured: 43 % MFMA-busy).  Every wait placement below
+    // keeps "wait before a phase's first barrier, read in the next phase": with the groups one barrier apart that is still at least
+    // one barrier between ANY wave's wait and ANY wave's read, and a half-tile is restaged two phases after its last read.
+    const bool late = wave >= 4;
+    if (late) G8_BAR();
+    constexpr g8_ic<0> I0{}; constexpr g8_ic<1> I1{};
     for (int kt = 0; kt < nk; ++kt) {
         const int b = kt & 1;
         // phase 1: quadrant (m0, n0)
-        load_a(b, 0); load_b(b, 0, fb0);
+        load_a(b, I0); load_b(b, I0, fb0);
         stage(kt + 1, 2);
         G8_BAR(); G8_LGKM0();
         mma(0, 0, fb0);
         G8_BAR();
         // phase 2: quadrant (m0, n1)
-        load_b(b, 1, fb1);
+        load_b(b, I1, fb1);
         stage(kt + 1, 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // A1[kt] (read in phase 3)
         G8_BAR(); G8_LGKM0();
         mma(0, 1, fb1);
         G8_BAR();
         // phase 3: quadrant (m1, n1)
-        load_a(b, 1);
+        load_a(b, I1);
         stage(kt + 2, 0);
         G8_BAR(); G8_LGKM0();
         mma(1, 1, fb1);
@@ -303,6 +383,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         mma(1, 0, fb0);
         G8_BAR();
     }
+    if (!late) G8_BAR();                                             // pairs with the late group's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- epilogue: acc[2 nq + u][4 mq + t][r] = C[m0 + 128 mq + 64 wm + 16 t + fi][n0 + 128 nq + 32 wn + 16 u + 4 fg + r]
     const int fi = lane & 15, fg = lane >> 4;
@@ -376,8 +457,12 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 || (lda * (kind == 3 ? 1 : 2)) % 16 || (ldb * (kind == 3 ? 1 : 2)) % 16 || ldc % 4) return SEGF_ERR_SHAPE;
     if (residual && (((uintptr_t)residual % 8) || ldr % 4)) return SEGF_ERR_SHAPE;
     if (kind < 2 && split_k != 1) return SEGF_ERR_SHAPE;
+    if (conv && kind < 2 && kchunk != K) return SEGF_ERR_SHAPE;      // the gathered forward / data gradient walks all of K (channel blocks x taps)
     Gemm8Args a{(const unsigned char*)A, (const unsigned char*)B, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, csign, f8_sa, f8_sb, bias,
-                (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr};
+                (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr, 1, 0u, 1u, 1};
+    if (const char* e = getenv("SEGFAC_G8_KORDER")) a.korder = atoi(e);
+    if (const char* e = getenv("SEGFAC_G8_TILE_ORDER")) a.tile_order = atoi(e);
+    if (conv && kind < 2 && cC > 0) { a.kper = (unsigned)(cC / 64); a.kmagic = (unsigned)(0x100000000ull / a.kper) + 1u; }
     const dim3 grid((unsigned)(N / 256), (unsigned)(M / 256), (unsigned)split_k);
 #define G8_GO(...) hipLaunchKernelGGL((gemm8_kernel<__VA_ARGS__>), grid, dim3(512), 0, st, a)
     if (kind == 0) {

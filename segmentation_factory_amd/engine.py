@@ -166,11 +166,22 @@ def evaluate(args, model, dataloader, device, print_freq, writer=None):
     header = 'Test:'
     core = model.module if hasattr(model, 'module') else model
     fused = hasattr(core, 'forward_lowres')
+    if utils.get_world_size() > 1:
+        # collective C2: the reference evaluates the DDP-wrapped model, whose forward first hands every rank rank 0's BatchNorm
+        # buffers (train_gpu.py:233-236, broadcast_buffers=True).  The forwards below call the core module directly (graph path: there
+        # is no wrapper at all), so the broadcast is issued here, once, in front of the forwards that read the running statistics
+        from .graph import broadcast_buffers_
+        broadcast_buffers_(core)
+    use_graph = bool(getattr(args, 'hip_graph', False)) and fused
     for idx, (images, labels) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
         images = images.to(device, non_blocking=True)
         labels = labels.to(device, non_blocking=True)
         if fused:
-            lo = core.forward_lowres(images)
+            if use_graph and images.is_cuda:
+                from .graph import graphed_eval_forward
+                lo = graphed_eval_forward(core, images)      # the eval forward as one replayed hipGraph per input shape
+            else:
+                lo = core.forward_lowres(images)
             metric.update_lowres(lo, labels, images.shape[2:], confmat=confmat)     # one pass feeds both matrices
         else:
             outputs = model(images)

@@ -47,6 +47,82 @@ def broadcast_flat_(flat: torch.Tensor, src: int = 0, group=None):
     return flat
 
 
+def broadcast_buffers_(module, src: int = 0, group=None):
+    """Collective C2: DistributedDataParallel(broadcast_buffers=True, the default at train_gpu.py:233-236) hands every rank
+    rank `src`'s buffers -- BatchNorm running_mean / running_var / num_batches_tracked -- before EVERY forward, training and
+    `evaluate` alike (engine.py:74-104 runs the wrapped model).  Training forwards never read the running statistics, and rank 0's own
+    sequence of momentum updates is not changed by receiving its own values back, so one broadcast in front of the forwards that DO read
+    them (evaluate) leaves exactly the state the reference's per-forward broadcasts leave.  One flat broadcast per dtype."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    by_dtype = {}
+    for b in module.buffers():
+        by_dtype.setdefault(b.dtype, []).append(b)
+    n = 0
+    with torch.no_grad():
+        for dtype in sorted(by_dtype, key=str):
+            bufs = by_dtype[dtype]
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+            n += len(bufs)
+    return n
+
+
+def _storage_signature(module):
+    """Changes when any parameter / buffer moves (the optimizer re-homing parameters into its flat buffer, .to(), load into new
+    tensors): captured graphs hold raw addresses."""
+    h = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        h = (h * 1000003 + t.data_ptr()) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+class GraphedEvalForward:
+    """`forward_lowres` of an eval-mode model as ONE replayed hipGraph (the forward of engine.evaluate, engine.py:86-88).  At the
+    reference's default --val_batch_size 1 (train_gpu.py:72) an eager forward is ~300 launches of a few microseconds each and
+    the host cannot enqueue them as fast as the GPU retires them.  The graph is a pure function of the static input buffer; the
+    fused upsample + argmax + confusion-matrix kernel consumes its (static) output outside the graph."""
+
+    def __init__(self, core, images, warmup: int = 1):
+        assert not core.training, 'GraphedEvalForward captures the eval-mode forward'
+        self.x = images.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                core.forward_lowres(self.x)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            self.out = core.forward_lowres(self.x)
+
+    def __call__(self, images):
+        if images.data_ptr() != self.x.data_ptr():
+            self.x.copy_(images, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
+def graphed_eval_forward(core, images, max_graphs: int = 8):
+    """The cached GraphedEvalForward of `core` for this input shape (validation images of a few sizes: a few graphs)."""
+    cache = core.__dict__.setdefault('_graphed_eval', {})
+    sig = _storage_signature(core)
+    if cache.get('sig') != sig:
+        cache.clear()
+        cache['sig'] = sig
+    key = (tuple(images.shape), images.dtype)
+    g = cache.get(key)
+    if g is None:
+        while len(cache) > max_graphs:                      # 'sig' + max_graphs entries: drop the oldest graph
+            cache.pop(next(k for k in cache if k != 'sig'))
+        g = cache[key] = GraphedEvalForward(core, images)
+    return g(images)
+
+
 def plan_buckets(numels, bucket_elems):
     """Cut the flat buffer (parameters in registration order, sizes `numels`) into contiguous buckets of >= bucket_elems
     elements, walking from the END (the gradients that backward finishes first).  Returns [(lo, hi, first_param, last_param)]
@@ -130,6 +206,7 @@ class GraphedTrainStep:
         # ---- buckets of the flat gradient buffer, in completion order -------------------------------------------------
         self.buckets, self.events, self._pending = [], [], {}
         self._capturing = False
+        self._spin_us = int(os.environ.get('SEGFAC_TEST_SPIN_US', '0'))
         if self.exchanging:
             numels = list(self.opt._spans)          # aligned extents of the parameters in the flat buffers
             total = sum(numels)
@@ -223,6 +300,10 @@ class GraphedTrainStep:
         if k is None:
             return
         self._left[k] -= 1
+        if self._left[k] == 1 and self._spin_us > 0:
+            # TEST HOOK (tests/test_model_gpu.py, ordering test): hold the stream in front of this bucket's LAST gradient, so that a
+            # communication stream that did not wait for THIS replay's event record would exchange the previous step's values
+            hip.debug_spin(self._spin_us)
         if self._left[k] == 0 and self.events[k] is not None:
             self.events[k].record_external()
 

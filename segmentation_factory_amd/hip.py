@@ -93,6 +93,8 @@ _PROTOS = {
     'segf_clip_grad': (_i, [_p, _l, _i, _f, _p, _p]),
     'segf_zero': (_i, [_p, _l, _p]),
     'segf_add_i64': (_i, [_p, _l, _p]),
+    'segf_hist_accum': (_i, [_p, _p, _l, _i, _p]),
+    'segf_debug_spin': (_i, [_l, _p]),
     'segf_bernoulli_scale': (_i, [_p, _p, _l, _l, _p, _p]),
     'segf_layernorm_bwd_fused': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_quant_rows_fp8': (_i, [_i, _l, _i, _p, _l, _p, _l, _p, _p]),
@@ -513,6 +515,20 @@ def add_i64_(t, v=1):
     assert t.dtype == torch.int64 and t.numel() == 1 and t.is_cuda
     _chk(lib().segf_add_i64(_ptr(t), int(v), _stream()), 'segf_add_i64')
     return t
+
+
+def debug_spin(us):
+    """Test hook: hold the current stream for `us` microseconds."""
+    _chk(lib().segf_debug_spin(int(us), _stream()), 'segf_debug_spin')
+
+
+def hist_accum_(hist, counts, clear=True):
+    """hist (fp32) += counts (int64) element by element, counts cleared: Metrics.update's `self.hist += bincount` (util/metrics.py:27)."""
+    _need_cuda(hist, counts)
+    assert hist.dtype == torch.float32 and counts.dtype == torch.int64 and hist.numel() == counts.numel()
+    assert hist.is_contiguous() and counts.is_contiguous()
+    _chk(lib().segf_hist_accum(_ptr(hist), _ptr(counts), hist.numel(), int(clear), _stream()), 'segf_hist_accum')
+    return hist
 
 
 def bernoulli_scale(state, keep_prob, n, row_len):

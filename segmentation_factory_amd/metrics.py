@@ -19,9 +19,16 @@ class Metrics:
         self.device = device
         self.bad_label_seen = None
 
-    def _accumulate(self, counts_i64, flag):
-        self.hist += counts_i64.to(torch.float32)
-        self.bad_label_seen = flag if self.bad_label_seen is None else (self.bad_label_seen | flag)
+    def _scratch(self, dev):
+        """Per-batch int64 counts + the bad-label flag: static buffers (zeroed once, the accumulate kernel clears the counts again), so
+        that an evaluation step can be captured as a hipGraph and launches no allocator-backed fills."""
+        if getattr(self, '_counts', None) is None or self._counts.device != dev:
+            n = self.num_classes
+            self._counts = hip.zeros((n, n), torch.int64, dev)
+            self.bad_label_seen = hip.zeros((1,), torch.int32, dev)
+            if self.hist.device != dev:
+                self.hist = self.hist.to(dev)
+        return self._counts, self.bad_label_seen
 
     def update(self, pred: torch.Tensor, target: torch.Tensor) -> None:
         """pred: [B, n, H, W] logits; target: flat (or [B,H,W]) int64 labels (util/metrics.py:24-27)."""
@@ -35,17 +42,18 @@ class Metrics:
         H, W = size
         n = self.num_classes
         dev = lowres.data.device
-        counts = torch.zeros((n, n), dtype=torch.int64, device=dev)
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        mat = None
+        counts, flag = self._scratch(dev)
         if confmat is not None:
             confmat._ensure(dev)
             mat = confmat.mat
         else:
-            mat = torch.zeros((n, n), dtype=torch.int64, device=dev)
-        hip.argmax_confmat(lowres.data, lowres.B, n, lowres.H, lowres.W, H, W, target.contiguous().to(torch.int64),
-                           self.ignore_label, mat, counts, flag)
-        self._accumulate(counts, flag)
+            if getattr(self, '_mat_unused', None) is None:
+                self._mat_unused = hip.zeros((n, n), torch.int64, dev)
+            mat = self._mat_unused
+        if target.dtype != torch.int64 or not target.is_contiguous():
+            target = target.contiguous().to(torch.int64)
+        hip.argmax_confmat(lowres.data, lowres.B, n, lowres.H, lowres.W, H, W, target, self.ignore_label, mat, counts, flag)
+        hip.hist_accum_(self.hist, counts)        # hist (fp32) += this batch's int64 counts, as the reference's `self.hist += bincount`
 
     def _finish(self, v):
         m = v[~v.isnan()].mean().item()

@@ -45,10 +45,27 @@ def main():
                           exchange=exchange, payload=payload, force_exchange=True)
     losses = [gs.step(x, y).item() for _ in range(steps)]
     torch.cuda.synchronize()
+    extra = {}
+    if os.environ.get('DP_MODE') == 'evalsync':
+        # collective C2 on the graph path: after training every rank holds its OWN BatchNorm statistics; engine.evaluate must hand
+        # everyone rank 0's before its forwards (train_gpu.py:233-236 broadcast_buffers=True), then C4 / C5 sum the matrices
+        from types import SimpleNamespace
+        from segmentation_factory_amd.engine import evaluate
+        mine = torch.cat([b.detach().float().reshape(-1) for b in model.buffers()])
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        extra['buffers_differed_before'] = bool((both[0] != both[-1]).any().item())
+        args = SimpleNamespace(nb_classes=nc, ignore_label=255, hip_graph=True)
+        confmat, metric = evaluate(args, model, [(x, y), (x.flip(3).contiguous(), y.flip(2).contiguous())], torch.device('cuda'), 1)
+        after = torch.cat([b.detach().float().reshape(-1) for b in model.buffers()])
+        both = [torch.empty_like(after) for _ in range(world)]
+        dist.all_gather(both, after)
+        extra.update(buffers_equal_after=bool(all(torch.equal(both[0], t) for t in both)), hist=metric.hist.cpu(), mat=confmat.mat.cpu(),
+                     eval_graphs=len(model.__dict__.get('_graphed_eval', {})) - 1)
     if rank == 0:
         torch.save({'losses': losses, 'state': {k: v.detach().cpu() for k, v in model.state_dict().items()},
                     'n_buckets': len(gs.buckets), 'events': sum(e is not None for e in gs.events), 'ranges': gs.ranges,
-                    'backend': dist.get_backend(), 'exchanging': gs.exchanging}, out_path)
+                    'backend': dist.get_backend(), 'exchanging': gs.exchanging, **extra}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -1619,3 +1619,36 @@ def test_fp8_quantise_and_gemm(hipmod, shape):
     # against the unquantised product: the fp8 error itself (about 2^-4 per operand element, averaged over K)
     full = x.float().cuda() @ w.cuda().t() + bias.cuda()
     assert (out.float() - full).abs().max().item() <= 8e-2 * full.abs().max().item()
+
+
+def test_direct_gradient_placement_refuses_a_second_delivery():
+    """with direct placement a parameter's slot in the flat gradient buffer is an ASSIGNMENT target.  A parameter
+    consumed by two Functions in one backward (tied weights, a module applied twice) would keep only the last contribution and
+    release its data-parallel bucket early: the optimizer's delivery bookkeeping must refuse instead (plain autograd, i.e. the
+    eager path, accumulates such gradients as torch does)."""
+    from segmentation_factory_amd import functional as Fh
+    from segmentation_factory_amd.optim import FusedAGCAdamW
+    lin = torch.nn.Linear(32, 32).cuda()
+    opt = FusedAGCAdamW([{'params': list(lin.parameters()), 'weight_decay': 0.0}], lr=1e-3)
+    opt.enable_direct_grads()
+    x = torch.randn(64, 32, device='cuda', requires_grad=True)
+    opt.begin_backward()
+    Fh.linear(x, lin.weight, lin.bias).sum().backward()              # one consumer: fine, and nothing lands in .grad
+    assert lin.weight.grad is None and opt.flat_grads.abs().sum().item() > 0
+    opt.begin_backward()
+    y = Fh.linear(Fh.linear(x, lin.weight, lin.bias), lin.weight, lin.bias)
+    with pytest.raises(RuntimeError, match='two gradients'):
+        y.sum().backward()
+
+
+def test_hist_accum_matches_torch_promotion():
+    """segf_hist_accum = Metrics.update's `self.hist += bincount(...)` (util/metrics.py:27): float32 += int64, counts cleared."""
+    from segmentation_factory_amd import hip
+    g = torch.Generator().manual_seed(3)
+    counts = torch.randint(0, 1 << 26, (19, 19), generator=g, dtype=torch.int64)      # beyond 2^24: the rounding of quirk Q5 shows
+    hist = torch.randint(0, 1 << 25, (19, 19), generator=g).float()
+    want = hist.clone()
+    want += counts
+    h, c = hist.cuda(), counts.cuda()
+    hip.hist_accum_(h, c)
+    assert torch.equal(h.cpu(), want) and c.abs().sum().item() == 0

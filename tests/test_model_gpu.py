@@ -743,6 +743,29 @@ def test_two_rank_eager_ddp_finetune_freeze(tmp_path):
     assert 'Epoch: [0]  [1/2]' in outs[0] and 'Val_mIOU' in outs[0]
 
 
+def test_two_rank_graph_mode_cli(tmp_path):
+    """`train_gpu.py --hip-graph` under two ranks (gloo, sharing this box's GPU): one epoch of the graphed step with the bucketed
+    exchange, then `evaluate` with the C2 buffer broadcast, the graphed eval forward and the C4 - C6 reductions
+    (train_gpu.py:211-236,322-336; util/utils.py:125-131; util/metrics.py:108-114).  Both ranks must print the same validation line."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ['--dataset', 'synthetic', '--data_len', '8', '--image_size', '64', '--nb_classes', '5', '--backbone', 'MiT-B0',
+            '--heads', 'SegFormerHead', '--batch-size', '2', '--val_batch_size', '2', '--epochs', '1', '--save_weights_dir', '',
+            '--writer_output', str(tmp_path), '--train_print_freq', '1', '--val_print_freq', '1', '--lr', '1e-3', '--hip-graph']
+    env = dict(os.environ, PYTHONPATH=root, MASTER_ADDR='127.0.0.1', MASTER_PORT='29579', WORLD_SIZE='2',
+               SEGFAC_DIST_BACKEND='gloo', SEGFAC_PRINT_ALL_RANKS='1')
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'train_gpu.py')] + args, cwd=str(tmp_path),
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-2000:]
+    assert 'Epoch: [0]  [1/2]' in outs[0] and 'Val_mIOU' in outs[0]
+    vals = [re.findall(r'Val_mIOU[^\n]*', o) for o in outs]
+    assert vals[0] and vals[0] == vals[1], vals                     # the reduced matrices (hence every printed figure) agree
+
+
 @pytest.mark.parametrize('exchange,payload', [('all_reduce', 'fp32'), ('rs_ag', 'fp32'), ('all_reduce', 'bf16')])
 def test_one_rank_rccl_exchange_leg(tmp_path, exchange, payload):
     """The RCCL leg of the data-parallel step on ONE GPU: a fresh child process with a 1-rank `nccl` process group and the
@@ -787,14 +810,22 @@ def test_one_rank_rccl_exchange_leg(tmp_path, exchange, payload):
         np.testing.assert_allclose(got['losses'], losses, rtol=1e-3)
 
 
-@pytest.mark.parametrize('bucket_mb,exchange', [(4.0, 'all_reduce'), (1000.0, 'all_reduce'), (4.0, 'rs_ag')])
-def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb, exchange):
+@pytest.mark.parametrize('bucket_mb,exchange,mode', [(4.0, 'all_reduce', ''), (1000.0, 'all_reduce', ''), (4.0, 'rs_ag', ''),
+                                                     (4.0, 'all_reduce', 'spin'), (4.0, 'all_reduce', 'evalsync')])
+def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb, exchange, mode):
     """D1 / collective C1 on the PRODUCT step: two ranks (fresh child processes, gloo, sharing this box's GPU) each drive
     GraphedTrainStep on their shard -- hipGraph replay, per-bucket external events, all-reduce on the communication stream,
     fused AGC/AdamW -- for three steps.  Expected values: data parallelism by hand in this process = per-shard forward /
     backward on the SAME weights (BatchNorm statistics per shard, as per rank: the reference uses plain BatchNorm2d), mean of
     the two gradients, one optimizer step (train_gpu.py:233-236 DistributedDataParallel semantics).  bucket_mb=4: six buckets
-    with in-graph events; 1000: a single bucket."""
+    with in-graph events; 1000: a single bucket.
+
+    mode 'spin' = the DETERMINISTIC ordering test: a 20 ms spin kernel is captured in front of the LAST gradient of every bucket
+    (SEGFAC_TEST_SPIN_US, graph.py), so a communication stream whose `ev.wait()` saw an older record of the bucket's event than THIS
+    replay's would start its collective 20 ms before that gradient exists and exchange the previous step's values -- the result must
+    still equal the manual average.  mode 'evalsync' = collective C2 on the graph path: after the three steps the ranks hold
+    different BatchNorm statistics; `engine.evaluate` (with its forward replayed as a hipGraph) must leave every rank with rank 0's
+    and return the matrices of rank 0's model over both shards."""
     import subprocess
     import sys
     from segmentation_factory_amd import criterion_lowres
@@ -803,6 +834,10 @@ def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb,
     steps, world, per_rank = 3, 2, 2
     out = tmp_path / 'rank0.pt'
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29583', WORLD_SIZE=str(world))
+    if mode == 'spin':
+        env['SEGFAC_TEST_SPIN_US'] = '20000'
+    elif mode:
+        env['DP_MODE'] = mode
     procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_worker.py'), str(out), str(steps), str(bucket_mb), 'gloo', exchange],
                               env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -846,6 +881,31 @@ def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb,
         else:
             assert torch.equal(v, r), k
     assert worst <= 2e-5, worst
+    if mode == 'evalsync':
+        from segmentation_factory_amd.metrics import Metrics
+        from segmentation_factory_amd.utils import ConfusionMatrix
+        assert got['buffers_differed_before'] and got['buffers_equal_after'] and got['eval_graphs'] == 1
+        # rank 0's model (weights AND BatchNorm statistics) over both ranks' validation batches
+        m0 = models[0].eval()
+        metric, confmat = Metrics(nc, 255, 'cuda'), ConfusionMatrix(nc)
+        with torch.inference_mode():
+            for r in range(world):
+                xs, ys = x[r * per_rank:(r + 1) * per_rank].cuda(), y[r * per_rank:(r + 1) * per_rank].cuda()
+                for xv, yv in ((xs, ys), (xs.flip(3).contiguous(), ys.flip(2).contiguous())):
+                    metric.update_lowres(m0.forward_lowres(xv), yv, (H, W), confmat=confmat)
+        total = metric.hist.sum().item()
+        assert got['hist'].sum().item() == total and got['mat'].sum().item() == confmat.mat.sum().item()
+        # weights agree to 2e-5, so a handful of near-tie pixels may fall the other way; rank-local statistics would move thousands
+        assert (got['hist'] - metric.hist.cpu()).abs().sum().item() <= 0.002 * total
+        m1 = models[1].eval()                      # control: rank 1's own statistics give a visibly different matrix
+        metric1 = Metrics(nc, 255, 'cuda')
+        with torch.inference_mode():
+            for r in range(world):
+                xs, ys = x[r * per_rank:(r + 1) * per_rank].cuda(), y[r * per_rank:(r + 1) * per_rank].cuda()
+                for xv, yv in ((xs, ys), (xs.flip(3).contiguous(), ys.flip(2).contiguous())):
+                    metric1.update_lowres(m1.forward_lowres(xv), yv, (H, W))
+        print('evalsync: |hist - rank0-stat hist| =', (got['hist'] - metric.hist.cpu()).abs().sum().item(),
+              ' |rank1-stat hist - rank0-stat hist| =', (metric1.hist - metric.hist).abs().sum().item())
 
 
 def test_fp8_forward_of_cfg5_model_within_stated_tolerance():

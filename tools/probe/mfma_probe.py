@@ -27,13 +27,18 @@ def conv(n):
     wm = (torch.randn(Cout, 9 * Cin, device='cuda') * 0.01).to(torch.bfloat16)
     wt = (torch.randn(Cin, 9 * Cout, device='cuda') * 0.01).to(torch.bfloat16)
     fl = 2.0 * P * 9 * Cin * Cout / 1e12
-    t0 = timed(lambda: hip.conv3x3(0, x, wm, B, H, W, Cin, Cout), n)
-    t1 = timed(lambda: hip.conv3x3(1, dy, wt, B, H, W, Cin, Cout), n)
-    t2 = timed(lambda: hip.conv3x3(2, x, dy, B, H, W, Cin, Cout, split_k=hip.pick_splitk(Cout, 9 * Cin, P)), n)
     xq, sx = hip.quant_tensor_fp8(x); wq, sw = hip.quant_rows_fp8(wm)
-    f0 = timed(lambda: hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout), n)
-    print(f'conv3x3 [{B}x{H}x{W} {Cin}->{Cout}] {fl:.2f} TFLOP | bf16 fwd {t0:.2f} ms ({fl / t0 * 1e3:.0f} TF/s) dgrad {t1:.2f} ({fl / t1 * 1e3:.0f}) '
-          f'wgrad {t2:.2f} ({fl / t2 * 1e3:.0f}) | fp8 fwd {f0:.2f} ({fl / f0 * 1e3:.0f})', flush=True)
+    orders = os.environ.get('PROBE_G8_ORDERS', '').split(',') if os.environ.get('PROBE_G8_ORDERS') else [None]
+    for rnd in range(2 if len(orders) > 1 else 1):
+        for od in orders:
+            if od is not None:
+                os.environ['SEGFAC_G8_KORDER'] = od; os.environ['SEGFAC_G8_TILE_ORDER'] = od
+            t0 = timed(lambda: hip.conv3x3(0, x, wm, B, H, W, Cin, Cout), n)
+            t1 = timed(lambda: hip.conv3x3(1, dy, wt, B, H, W, Cin, Cout), n)
+            t2 = timed(lambda: hip.conv3x3(2, x, dy, B, H, W, Cin, Cout, split_k=hip.pick_splitk(Cout, 9 * Cin, P)), n)
+            f0 = timed(lambda: hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout), n)
+            print(f'conv3x3 [{B}x{H}x{W} {Cin}->{Cout}] order {od} {fl:.2f} TFLOP | bf16 fwd {t0:.2f} ms ({fl / t0 * 1e3:.0f} TF/s) dgrad {t1:.2f} ({fl / t1 * 1e3:.0f}) '
+                  f'wgrad {t2:.2f} ({fl / t2 * 1e3:.0f}) | fp8 fwd {f0:.2f} ({fl / f0 * 1e3:.0f})', flush=True)
     # plain product of the same size class through the same kernel (no gather): [P x 3072] x [3072 -> 3072]^T
     M, N, K = 65536, 3072, 3072
     a = torch.randn(M, K, device='cuda').to(torch.bfloat16); w = (torch.randn(N, K, device='cuda') * 0.02).to(torch.bfloat16)
@@ -46,7 +51,7 @@ def conv(n):
 
 
 def attn(n):
-    B, heads, N, Nkv, hd = 2, 1, 131072, 2048, 64
+    B, heads, N, Nkv, hd = 8, 1, 131072, 2048, 64
     scale = hd ** -0.5
     q = torch.randn(B * N, heads * hd, device='cuda').to(torch.bfloat16)
     k = torch.randn(B * Nkv, heads * hd, device='cuda').to(torch.bfloat16)
@@ -55,10 +60,18 @@ def attn(n):
     o, lse = hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, scale)
     dk = torch.empty_like(k); dv = torch.empty_like(v)
     ff = 4.0 * B * heads * N * Nkv * hd / 1e12
-    t0 = timed(lambda: hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, scale), n)
-    t1 = timed(lambda: hip.attention_bwd(q, k, v, o, do, lse, B, heads, N, Nkv, hd, scale, dk, dv), n)
-    print(f'attention [{B} x {heads} x {N} x {Nkv} x {hd}] fwd {ff:.2f} TFLOP {t0:.2f} ms ({ff / t0 * 1e3:.0f} TF/s) | bwd {2.5 * ff:.2f} TFLOP {t1:.2f} ms '
-          f'({2.5 * ff / t1 * 1e3:.0f} TF/s)', flush=True)
+    variants = os.environ.get('PROBE_ATTN_VARIANTS', '').split(',') if os.environ.get('PROBE_ATTN_VARIANTS') else [None]
+    for rnd in range(3 if len(variants) > 1 else 1):              # interleaved rounds in one process (same device, same clocks)
+        for var in variants:
+            if var is not None:
+                if var == 'q1':
+                    os.environ['SEGFAC_ATTN_VARIANT'] = '-1'; os.environ['SEGFAC_ATTN_QW1'] = '1'
+                else:
+                    os.environ['SEGFAC_ATTN_VARIANT'] = var; os.environ.pop('SEGFAC_ATTN_QW1', None)
+            t0 = timed(lambda: hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, scale), n)
+            t1 = timed(lambda: hip.attention_bwd(q, k, v, o, do, lse, B, heads, N, Nkv, hd, scale, dk, dv), n)
+            print(f'attention [{B} x {heads} x {N} x {Nkv} x {hd}] variant {var} fwd {ff:.2f} TFLOP {t0:.3f} ms ({ff / t0 * 1e3:.0f} TF/s) | bwd {2.5 * ff:.2f} TFLOP '
+                  f'{t1:.3f} ms ({2.5 * ff / t1 * 1e3:.0f} TF/s)', flush=True)
 
 
 if __name__ == '__main__':

@@ -14,7 +14,7 @@ import csv,sys,collections,re
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k=r['Kernel_Name']
-    if 'gemm8_kernel' in k or 'attn_mfma' in k:
+    if 'gemm8_kernel' in k or 'attn_' in k:
         k=re.sub(r'\(.*','',k)[:70]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in acc.items():
