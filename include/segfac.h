@@ -64,6 +64,11 @@ int segf_hist_accum(float* hist, int64_t* counts, int64_t n, int clear, void* st
 /* test hook: a single wave that occupies `stream` for `us` microseconds (<= 200000), e.g. to delay a gradient in the data-parallel
  * ordering test (the event-ordered exchange of train_gpu.py:233-236's DDP replacement). */
 int segf_debug_spin(int64_t us, void* stream);
+/* Tuning switch of the eight-phase GEMM (gemm8.hip; the UPerHead / PPM 3x3 ConvModules of heads/upernet.py:26-31, modules/ppm.py:19 and
+ * the ConvNeXt block MLPs on fp8 operands): what = 0 selects whether the fp8 kernels run their two wave groups one barrier apart
+ * (value 1, default) or in lockstep (value 0); any other value only reads.  Returns the previous setting (or SEGF_ERR_SHAPE).  The host
+ * layer times both on the device at hand once per process: devices differ in the clock they hold under the denser schedule. */
+int segf_gemm8_option(int what, int value);
 int segf_bernoulli_scale(uint64_t* state, const float* keep_prob, int64_t n, int64_t row_len, float* out, void* stream);
 
 /* ---- FP8 (OCP e4m3fn) forward GEMM: BASELINE cfg5 "ConvNeXtV2-L + UPerNet, fp8 MFMA weights" (the pointwise linears of

@@ -80,12 +80,15 @@ class SegmentationModel(BaseSegModel):
         return self
 
     def set_fp8(self, enabled: bool = True):
-        """BASELINE cfg5 ("fp8 MFMA weights"): (a) the forward products of the ConvNeXt / ConvNeXtV2 pointwise linears
-        (convnextv2.py:90-95) in OCP e4m3 on the block-scaled fp8 matrix instruction (csrc/fp8.hip: weights quantised per output
-        channel, activations per token); (b) forward and data gradient of UPerHead's / PPM's 3x3 convolutions (heads/upernet.py:26-31,
-        modules/ppm.py:19) on fp8 operands (activations e4m3 / gradients e5m2 with one dynamic scale per tensor, weights e4m3 per
-        row; 256-tile implicit GEMM of csrc/gemm.hip).  fp32 accumulate everywhere; weight gradients and everything else stay
-        bf16.  Not a reference feature: tolerance stated in the tests."""
+        """BASELINE cfg5 ("fp8 MFMA weights"): all three products -- forward, data gradient, weight gradient -- of (a) the ConvNeXt /
+        ConvNeXtV2 block MLPs (convnextv2.py:90-95) where the shapes fill 256 x 256 tiles and (b) UPerHead's / PPM's 3x3 convolutions
+        (heads/upernet.py:26-31, modules/ppm.py:19) on OCP fp8 operands: activations and weights e4m3, gradients e5m2, one dynamic scale
+        per activation / gradient tensor and one per weight row, fp32 accumulate on the block-scaled fp8 matrix instruction (csrc/gemm8.hip,
+        csrc/fp8.hip); everything else stays bf16.  Not a reference feature: tolerances stated in the tests.  Enabling it times the two
+        schedules of the fp8 GEMM on this device once per process (hip.autotune_gemm8_fp8)."""
+        if enabled and torch.cuda.is_available():
+            from . import hip
+            hip.autotune_gemm8_fp8()
         n = 0
         for m in self.backbone.modules():
             if hasattr(m, 'fp8') and hasattr(m, 'pwconv1'):

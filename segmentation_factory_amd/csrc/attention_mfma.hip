@@ -426,8 +426,11 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
     }
 }
 
-template <int QW, bool P2S>
-__global__ void __launch_bounds__(AM_THREADS, QW == 1 ? 4 : 3) attn_bwd_dq64p_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+// Query-side backward at head dim 64, long key sequences: P = exp2(s c - lse log2(e)) (one v_fma + one v_exp per pair, the scale inside c),
+// dS = P (dP - D) unscaled (dQ is scaled once at the end), K^T fragments read only after the score products have consumed the
+// row-major K / V fragments (their registers are free by then: no spills under the three-waves-per-SIMD budget).
+template <int QW>
+__global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                        int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                                        const bf16_t* __restrict__ o, int64_t ldo,
                                                                        const bf16_t* __restrict__ dO, int64_t lddo,
@@ -445,8 +448,9 @@ __global__ void __launch_bounds__(AM_THREADS, QW == 1 ? 4 : 3) attn_bwd_dq64p_ke
     const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
     const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
     amp_stage(KV[0][0], KV[0][1], Kb, ldk, Vb, ldv, 0, Nkv, wave, lane);
+    const float cs = scale * 1.44269504088896340736f;
     bf16x8 Qf[QW][KS], dOf[QW][KS];
-    float Dq[QW], lq[QW];
+    float Dq[QW], nl2[QW];                  // nl2 = -lse in log2 units (+inf -> -inf for rows beyond N: their probabilities are 0)
 #pragma unroll
     for (int t = 0; t < QW; ++t) {
         const int row = q0 + 16 * t + c;
@@ -460,12 +464,8 @@ __global__ void __launch_bounds__(AM_THREADS, QW == 1 ? 4 : 3) attn_bwd_dq64p_ke
             for (int j = 0; j < 8; ++j) part += (float)dOf[t][s][j] * (float)of[j];
         }
         Dq[t] = xgroup_sum(part);
-        lq[t] = row < N ? lse[((int64_t)b * heads + h) * N + row] : INFINITY;
+        nl2[t] = row < N ? -lse[((int64_t)b * heads + h) * N + row] * 1.44269504088896340736f : -INFINITY;
         if (g == 0 && row < N) Dbuf[((int64_t)b * heads + h) * N + row] = Dq[t];
-        if (P2S) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) Qf[t][s] = scale_frag_pow2(Qf[t][s], scale);
-        }
     }
     f32x4 dQ[DT][QW];
 #pragma unroll
@@ -483,47 +483,60 @@ __global__ void __launch_bounds__(AM_THREADS, QW == 1 ? 4 : 3) attn_bwd_dq64p_ke
         const bf16_t* Vs = KV[st & 1][1];
 #pragma unroll
         for (int kb = 0; kb < AMP_KC; kb += 32) {
-            bf16x8 Kf[2][KS], Vf[2][KS], KT[DT];
+            float ds[QW][2][4];
+            {
+                bf16x8 Kf[2][KS], Vf[2][KS];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int off = (kb + 16 * kt + c) * HD + (((4 * s + g) ^ (c & 7)) << 3);
-                    Kf[kt][s] = ld_frag_lds(Ks + off);
-                    Vf[kt][s] = ld_frag_lds(Vs + off);
-                }
+                    for (int s = 0; s < KS; ++s) {
+                        const int off = (kb + 16 * kt + c) * HD + (((4 * s + g) ^ (c & 7)) << 3);
+                        Kf[kt][s] = ld_frag_lds(Ks + off);
+                        Vf[kt][s] = ld_frag_lds(Vs + off);
+                    }
+                f32x4 S[QW][2], dP[QW][2];
 #pragma unroll
-            for (int d = 0; d < DT; ++d) KT[d] = amp_frag_trs(Ks, kb + 4 * g, kb + 16 + 4 * g, d, lane);
-            AMP_LGKM0();
-            auto step = [&](auto maskc) {
-                constexpr bool MASK = decltype(maskc)::value;
-#pragma unroll
-                for (int t = 0; t < QW; ++t) {
-                    float ds[2][4];
+                for (int t = 0; t < QW; ++t)
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt) {
-                        f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        S[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dP[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int s = 0; s < KS; ++s) {
-                            S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
-                            dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float p = __expf(P2S ? S[r] - lq[t] : S[r] * scale - lq[t]);
-                            if (MASK) {
-                                const int key = kc0 + kb + 16 * kt + 4 * g + r;
-                                p = key < Nkv ? p : 0.f;
-                            }
-                            ds[kt][r] = P2S ? p * (dP[r] - Dq[t]) : p * (dP[r] - Dq[t]) * scale;
+                            S[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S[t][kt], 0, 0, 0);
+                            dP[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP[t][kt], 0, 0, 0);
                         }
                     }
-                    const bf16x8 dSf = pack_acc(ds[0], ds[1]);
 #pragma unroll
-                    for (int d = 0; d < DT; ++d) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf, dQ[d][t], 0, 0, 0);
-                }
-            };
-            if (kc0 + kb + 32 <= Nkv) step(std::false_type{}); else step(std::true_type{});
+                for (int t = 0; t < QW; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(fmaf(S[t][kt][r], cs, nl2[t]));
+                            ds[t][kt][r] = p * (dP[t][kt][r] - Dq[t]);
+                        }
+            }
+            if (kc0 + kb + 32 > Nkv) {                          // keys beyond the last one carry no gradient (wave-uniform tail)
+#pragma unroll
+                for (int t = 0; t < QW; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (kc0 + kb + 16 * kt + 4 * g + r >= Nkv) ds[t][kt][r] = 0.f;
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // the K^T reads stay behind the score products (register budget)
+            bf16x8 KT[DT];
+#pragma unroll
+            for (int d = 0; d < DT; ++d) KT[d] = amp_frag_trs(Ks, kb + 4 * g, kb + 16 + 4 * g, d, lane);
+            bf16x8 dSf[QW];
+#pragma unroll
+            for (int t = 0; t < QW; ++t) dSf[t] = pack_acc(ds[t][0], ds[t][1]);
+            AMP_LGKM0();
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int t = 0; t < QW; ++t) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf[t], dQ[d][t], 0, 0, 0);
         }
     }
     if (q0 >= N) return;
@@ -534,7 +547,7 @@ __global__ void __launch_bounds__(AM_THREADS, QW == 1 ? 4 : 3) attn_bwd_dq64p_ke
         if (row < N) {
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                if (P2S) dQ[d][t] *= scale;
+                dQ[d][t] *= scale;
                 const uint2 u = make_uint2(pack2bf(dQ[d][t][0], dQ[d][t][1]), pack2bf(dQ[d][t][2], dQ[d][t][3]));
                 *reinterpret_cast<uint2*>(dQb + (int64_t)row * lddq + 16 * d + 4 * g) = u;
             }
@@ -697,7 +710,9 @@ __global__ void __launch_bounds__(AM_THREADS, OCC) attn_mfma_bwd_dq_kernel(const
 // stay in registers; Q / dO tiles of 32 queries pass through LDS.  Output: fp32 slab[z][b*Nkv + key][2C] partial sums.
 // KW = 16-key tiles per wave: 4 (64 keys) at head dim 32; 2 at head dim 64, where 64 keys per wave need ~300 registers (one
 // wave per SIMD, nothing to overlap the Q / dO staging with) and 32 keys fit two waves per SIMD
-template <int HD, bool P2S, bool SWZ = true, int KW = (HD == 32 ? 4 : 2)>
+// EX2 (head dim 64): P = exp2(s c - lse log2(e)) with the scale inside c = scale log2(e) -- one v_fma + one v_exp per pair, the
+// log-sum-exp stored negated in log2 units when the tile is staged; dS unscaled, dK scaled once at the end (as P2S, for any scale)
+template <int HD, bool P2S, bool SWZ = true, bool EX2 = false, int KW = (HD == 32 ? 4 : 2)>
 __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                         const bf16_t* __restrict__ k, int64_t ldk,
                                                                         const bf16_t* __restrict__ v, int64_t ldv,
@@ -731,7 +746,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             const int key = key0 + 16 * kt + c;
             Kf[kt][s] = ld_frag_global(Kb + (int64_t)key * ldk + 32 * s + 8 * g, key < Nkv);
             Vf[kt][s] = ld_frag_global(Vb + (int64_t)key * ldv + 32 * s + 8 * g, key < Nkv);
-            if (P2S) Kf[kt][s] = scale_frag_pow2(Kf[kt][s], scale);       // K only feeds the scores here; dK is scaled once at the end
+            if (P2S && !EX2) Kf[kt][s] = scale_frag_pow2(Kf[kt][s], scale);       // K only feeds the scores here; dK is scaled once at the end
         }
     f32x4 dK[DT][KW], dV[DT][KW];
 #pragma unroll
@@ -739,6 +754,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
 #pragma unroll
         for (int kt = 0; kt < KW; ++kt) { dK[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dV[d][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const int qbeg = z * qchunk, qend = qbeg + qchunk < N ? qbeg + qchunk : N;
+    const float cs = scale * 1.44269504088896340736f;
     // staging map: 32 rows x HD / 8 sixteen-byte chunks per matrix = HD * 4 chunks; 256 threads: one chunk of Q and one of dO each at
     // head dim 64, at head dim 32 the lower half of the workgroup takes Q and the upper half dO
     constexpr int CPR = HD / 8, NCH = 32 * CPR;
@@ -755,6 +771,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
         if (threadIdx.x < 32) {
             const int r2 = qt0 + threadIdx.x;
             rl = r2 < qend ? lb[r2] : INFINITY;          // exp(s - inf) = 0: rows beyond the chunk contribute nothing
+            if (EX2) rl *= -1.44269504088896340736f;
             rd = r2 < qend ? Db[r2] : 0.f;
         }
     };
@@ -799,9 +816,9 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(P2S ? S[r] - lr[r] : S[r] * scale - lr[r]);
+                    const float p = EX2 ? __builtin_amdgcn_exp2f(fmaf(S[r], cs, lr[r])) : __expf(P2S ? S[r] - lr[r] : S[r] * scale - lr[r]);
                     P[qt][kt][r] = p;
-                    dS[qt][kt][r] = P2S ? p * (dP[r] - dr[r]) : p * (dP[r] - dr[r]) * scale;
+                    dS[qt][kt][r] = (P2S || EX2) ? p * (dP[r] - dr[r]) : p * (dP[r] - dr[r]) * scale;
                 }
             }
         }
@@ -835,7 +852,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             float* row = sb + ((int64_t)b * Nkv + key) * 2 * C + h * HD;
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                if (P2S) dK[d][kt] *= scale;
+                if (P2S || EX2) dK[d][kt] *= scale;
                 *reinterpret_cast<float4*>(row + 16 * d + 4 * g) = make_float4(dK[d][kt][0], dK[d][kt][1], dK[d][kt][2], dK[d][kt][3]);
                 *reinterpret_cast<float4*>(row + C + 16 * d + 4 * g) = make_float4(dV[d][kt][0], dV[d][kt][1], dV[d][kt][2], dV[d][kt][3]);
             }
@@ -1082,29 +1099,18 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
     } else {
 #define AM_DQ(P2, OCCv, SWv) hipLaunchKernelGGL((attn_mfma_bwd_dq_kernel<64, QW, P2, OCCv, SWv>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, \
         DO, lddo, lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale)
-#define AM_DKV(P2, SWv) hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64, P2, SWv>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf, \
+#define AM_DKV(P2, SWv, EXv) hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64, P2, SWv, EXv>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf, \
         slab, heads, N, Nkv, B, qchunk, scale)
         const int var = am_variant();
         if (var < 0 && Nkv >= 2 * AMP_KC) {
-            if (am_is_pow2(scale) && getenv("SEGFAC_ATTN_QW1")) {
-                dim3 g11((unsigned)cdiv64(N, 4 * 16), heads, B);
-                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<1, true>), g11, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
-                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
-                AM_DKV(true, true);
-            } else if (am_is_pow2(scale)) {
-                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW, true>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
-                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
-                AM_DKV(true, true);
-            } else {
-                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW, false>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
-                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
-                AM_DKV(false, true);
-            }
+            hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
+                               (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+            AM_DKV(false, true, true);
         }
-        else if (!am_is_pow2(scale)) { AM_DQ(false, 4, true); AM_DKV(false, true); }
+        else if (!am_is_pow2(scale)) { AM_DQ(false, 4, true); AM_DKV(false, true, false); }
         else {
             if (var <= 0) AM_DQ(true, 4, true); else if (var == 1) AM_DQ(true, 3, true); else if (var == 2) AM_DQ(true, 4, false); else AM_DQ(true, 3, false);
-            if (var & 2) AM_DKV(true, false); else AM_DKV(true, true);
+            if (var & 2) AM_DKV(true, false, false); else AM_DKV(true, true, false);
         }
 #undef AM_DQ
 #undef AM_DKV

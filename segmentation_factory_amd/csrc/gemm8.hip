@@ -50,6 +50,7 @@ struct Gemm8Args {
     int korder;                      // CONV gather on A: 1 = K walks (channel block, tap), 0 = (tap, channel block) as the weights store it
     unsigned kmagic, kper;           // korder 0: K tiles per tap and floor(2^32 / kper) + 1 (tile / kper by multiply-high)
     int tile_order;                  // CONV gather on B (weight gradient): 1 = the taps / row tiles of a channel block are launch neighbours
+    int stagger;                     // 1 = waves 4-7 run one barrier behind waves 0-3 (see the main loop)
 };
 // the zero page of the CONV border taps: LDS-DMA cannot write zeros itself, so lanes whose tap lies outside the image load from here
 __device__ __attribute__((aligned(256))) unsigned char g8_zero_page[256];
@@ -189,6 +190,14 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     }
     // CONV_B: tap of each B half (workgroup constant) and the pixel coordinates of this lane's two rows at the NEXT K tile of each
     // half (the tiles of a half are staged in increasing order), advanced by 64 pixels per tile without a division
+    // RM staging: a lane's byte offset inside the (wave-uniform) K tile of each operand -- the tile's own position is scalar arithmetic
+    constexpr int EBR = ALAY == 2 ? 1 : 2;                                   // bytes per element of the RM operands
+    uint32_t rmoffA[2] = {0u, 0u}, rmoffB[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (ALAY >= 1) rmoffA[i] = (uint32_t)((int64_t)(rm_row + RM_STEP * i) * a.lda * EBR + 16 * rm_chunk[i]);
+        if (BLAY >= 1) rmoffB[i] = (uint32_t)((int64_t)(rm_row + RM_STEP * i) * a.ldb * EBR + 16 * rm_chunk[i]);
+    }
     int tdy[2], tdx[2], tci[2], py[2][2], px[2][2];
     int adv_q = 0, adv_r = 0;
     if (CONV_B) {
@@ -205,7 +214,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) { py[h][i] = y; px[h][i] = x; }
         }
-        adv_q = KT / a.cW; adv_r = KT % a.cW;
+        adv_q = (KT / a.cW) % a.cH; adv_r = KT % a.cW;                      // y advances modulo the image height: one conditional wrap
     }
     auto lds_half = [&](int buf, int half) -> unsigned char* { return smem + buf * G8_BUF + half * G8_HALF; };
     // half: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  The address uses the K tile clamped to the last one, the destination the tile's own buffer
@@ -238,28 +247,27 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                 for (int i = 0; i < 2; ++i) G8_GLDS((isA ? gA[h][i] : gB[h][i]) + (int64_t)ktc * 128, dst + i * 1024);
             }
         } else {
-            // RM: bf16 = 4 rows x 256 B per instruction, fp8 = 8 rows x 128 B; element size EB bytes
+            // RM: bf16 = 4 rows x 256 B per instruction, fp8 = 8 rows x 128 B; element size EB bytes.  The K tile's position (and, for the
+            // gathered operand, its tap) is wave-uniform: a scalar base pointer per stage + the lane's constant offset (one 64-bit add)
             constexpr int EB = ALAY == 2 ? 1 : 2;
             unsigned char* dst = lds_half(kt & 1, half) + (ALAY == 2 ? 16 * wave * 128 : 8 * wave * 256);
-            const int64_t t0 = kbeg + (int64_t)ktc * KT + rm_row;
+            const int64_t t0 = kbeg + (int64_t)ktc * KT;
             if (isA || !CONV_B) {
-                const unsigned char* base = isA ? a.A : a.B;
-                const int64_t ld = isA ? a.lda : a.ldb, c0 = (isA ? m0 : n0) + 128 * h;
+                const unsigned char* base = (isA ? a.A + (t0 * a.lda + m0 + 128 * h) * EB : a.B + (t0 * a.ldb + n0 + 128 * h) * EB);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    G8_GLDS(base + ((t0 + RM_STEP * i) * ld + c0) * EB + 16 * rm_chunk[i], dst + i * 1024);
+                for (int i = 0; i < 2; ++i) G8_GLDS(base + (isA ? rmoffA[i] : rmoffB[i]), dst + i * 1024);
             } else {
                 const bool real = kt < nk;                              // wave-uniform: past the end only a dummy load (zero page)
+                const unsigned char* base = a.B + ((t0 + (int64_t)tdy[h] * a.cW + tdx[h]) * a.ldb + tci[h]) * EB;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int yy = py[h][i] + tdy[h], xx = px[h][i] + tdx[h];
-                    const bool ok = real && yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW;
-                    const unsigned char* p = a.B + ((t0 + RM_STEP * i + (int64_t)tdy[h] * a.cW + tdx[h]) * a.ldb + tci[h]) * EB + 16 * rm_chunk[i];
-                    const void* src = ok ? (const void*)p : (const void*)g8_zero_page;
+                    const bool ok = real && (unsigned)yy < (unsigned)a.cH && (unsigned)xx < (unsigned)a.cW;
+                    const void* src = ok ? (const void*)(base + rmoffB[i]) : (const void*)g8_zero_page;
                     G8_GLDS(src, dst + i * 1024);
                     int nx = px[h][i] + adv_r, ny = py[h][i] + adv_q;
                     if (nx >= a.cW) { nx -= a.cW; ++ny; }
-                    while (ny >= a.cH) ny -= a.cH;
+                    if (ny >= a.cH) ny -= a.cH;
                     px[h][i] = nx; py[h][i] = ny;
                 }
             }
@@ -352,7 +360,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     // matrix pipe together, and the pipe idles through every read section (measured: 43 % MFMA-busy).  Every wait placement below
     // keeps "wait before a phase's first barrier, read in the next phase": with the groups one barrier apart that is still at least
     // one barrier between ANY wave's wait and ANY wave's read, and a half-tile is restaged two phases after its last read.
-    const bool late = wave >= 4;
+    const bool late = wave >= 4 && a.stagger;
     if (late) G8_BAR();
     constexpr g8_ic<0> I0{}; constexpr g8_ic<1> I1{};
     for (int kt = 0; kt < nk; ++kt) {
@@ -383,7 +391,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         mma(1, 0, fb0);
         G8_BAR();
     }
-    if (!late) G8_BAR();                                             // pairs with the late group's last barrier
+    if (!late && a.stagger) G8_BAR();                                // pairs with the late group's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- epilogue: acc[2 nq + u][4 mq + t][r] = C[m0 + 128 mq + 64 wm + 16 t + fi][n0 + 128 nq + 32 wn + 16 u + 4 fg + r]
     const int fi = lane & 15, fg = lane >> 4;
@@ -442,6 +450,13 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 // kind 1: C[m][n] = sum_k A[m][k] B[k][n]   (layout 1: data gradient of nn.Linear)                           bf16 out
 // kind 2: C[m][n] = sum_k A[k][m] B[k][n]   (layout 2; conv = weight-gradient gather on B), split-K          fp32 out
 // kind 3: the same on fp8 operands (A e5m2, B e4m3, one byte per element, K tiles of 128 rows), scaled by f8_sa[0] * f8_sb[0]
+static int g8_stagger_fp8 = 1;
+extern "C" int segf_gemm8_option(int what, int value) {      // what 0: stagger of the fp8 kernels (returns the previous value)
+    if (what != 0) return SEGF_ERR_SHAPE;
+    const int prev = g8_stagger_fp8;
+    if (value == 0 || value == 1) g8_stagger_fp8 = value;
+    return prev;
+}
 int gemm8_supported(int kind, int conv, int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC) {
     if (getenv("SEGFAC_NO_GEMM8")) return 0;
     if (M % 256 || N % 256 || K % 64 || kchunk % 64 || kchunk < 256 || M / 256 > 65535) return 0;
@@ -459,7 +474,12 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     if (kind < 2 && split_k != 1) return SEGF_ERR_SHAPE;
     if (conv && kind < 2 && kchunk != K) return SEGF_ERR_SHAPE;      // the gathered forward / data gradient walks all of K (channel blocks x taps)
     Gemm8Args a{(const unsigned char*)A, (const unsigned char*)B, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, csign, f8_sa, f8_sb, bias,
-                (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr, 1, 0u, 1u, 1};
+                (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr, 1, 0u, 1u, 1, 1};
+    // fp8 operands: on some MI355X devices the staggered schedule (26 % fewer cycles) makes the chip drop its clock from 2.4 to 1.5 GHz
+    // and ends up SLOWER than the lockstep one (12.7 vs 10.9 ms on the UPerHead bottleneck; 8.3 ms on devices that hold their clock).
+    // g8_stagger_fp8 is set per process by the host layer after timing both on the device at hand (hip.py: autotune_gemm8_fp8).
+    if (fp8) a.stagger = g8_stagger_fp8;
+    if (const char* e = getenv("SEGFAC_G8_STAGGER")) a.stagger = atoi(e);
     if (const char* e = getenv("SEGFAC_G8_KORDER")) a.korder = atoi(e);
     if (const char* e = getenv("SEGFAC_G8_TILE_ORDER")) a.tile_order = atoi(e);
     if (conv && kind < 2 && cC > 0) { a.kper = (unsigned)(cC / 64); a.kmagic = (unsigned)(0x100000000ull / a.kper) + 1u; }

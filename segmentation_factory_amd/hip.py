@@ -95,6 +95,7 @@ _PROTOS = {
     'segf_add_i64': (_i, [_p, _l, _p]),
     'segf_hist_accum': (_i, [_p, _p, _l, _i, _p]),
     'segf_debug_spin': (_i, [_l, _p]),
+    'segf_gemm8_option': (_i, [_i, _i]),
     'segf_bernoulli_scale': (_i, [_p, _p, _l, _l, _p, _p]),
     'segf_layernorm_bwd_fused': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_quant_rows_fp8': (_i, [_i, _l, _i, _p, _l, _p, _l, _p, _p]),
@@ -350,6 +351,52 @@ def conv3x3_fp8(mode, xq, sx, wq, sw, B, H, W, Cin, Cout):
     _chk(_timed(key, lambda: lib().segf_conv3x3_fp8(mode, B, H, W, Cin, Cout, _ptr(xq), xq.stride(0), _ptr(sx), _ptr(wq), wq.stride(0),
                                                     _ptr(sw), _ptr(out), out.stride(0), _stream())), 'segf_conv3x3_fp8')
     return out
+
+
+_G8_FP8_STAGGER = None
+
+
+def autotune_gemm8_fp8(force=False):
+    """Pick the schedule of the fp8 eight-phase GEMM (segf_gemm8_option) for THIS device, once per process.  The staggered schedule needs
+    26 % fewer cycles, but under it some MI355X devices drop their clock from 2.4 to about 1.5 GHz and finish later than with the
+    lockstep schedule (UPerHead bottleneck conv, batch 32: 8.3 ms on devices that hold their clock, 12.7 ms on those that do not,
+    10.9 ms in lockstep on both) -- so both are timed here under sustained load (about 0.1 s) and the faster one is kept.
+    SEGFAC_G8_STAGGER=0/1 skips the measurement.  Never called while a stream is capturing."""
+    global _G8_FP8_STAGGER
+    if _G8_FP8_STAGGER is not None and not force:
+        return _G8_FP8_STAGGER
+    env = os.environ.get('SEGFAC_G8_STAGGER')
+    if env is not None:
+        _G8_FP8_STAGGER = int(env != '0')
+        lib().segf_gemm8_option(0, _G8_FP8_STAGGER)
+        return _G8_FP8_STAGGER
+    if torch.cuda.is_current_stream_capturing():
+        return int(lib().segf_gemm8_option(0, -1))
+    B, H, W, Cin, Cout = 8, 128, 128, 3072, 768
+    dev = torch.device('cuda', torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(0)
+    xq = torch.randint(0, 120, (B * H * W, Cin), dtype=torch.uint8, device=dev, generator=g)       # e4m3 bytes: finite values of mixed magnitude
+    wq = torch.randint(0, 120, (Cout, 9 * Cin), dtype=torch.uint8, device=dev, generator=g)
+    sx = torch.ones(1, device=dev)
+    sw = torch.ones(Cout, device=dev)
+    times = {0: [], 1: []}
+    for rnd in range(2):
+        for st in (1, 0):
+            lib().segf_gemm8_option(0, st)
+            conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout)
+            e1.record()
+            torch.cuda.synchronize()
+            times[st].append(e0.elapsed_time(e1) / 8)
+    _G8_FP8_STAGGER = int(min(times[1]) <= min(times[0]))
+    lib().segf_gemm8_option(0, _G8_FP8_STAGGER)
+    if os.environ.get('SEGFAC_VERBOSE'):
+        print(f'[segfac] fp8 eight-phase GEMM: staggered {min(times[1]):.3f} ms, lockstep {min(times[0]):.3f} ms -> stagger = {_G8_FP8_STAGGER}')
+    return _G8_FP8_STAGGER
 
 
 def conv3x3_fp8_wgrad_supported(B, H, W, Cin, Cout):

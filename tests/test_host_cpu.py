@@ -144,6 +144,18 @@ for mode in ("all_reduce", "rs_ag"):
                 w.wait()
         want = torch.zeros_like(buf); want[:total] = (torch.arange(total) % 17).to(dt) * 3
         assert torch.equal(buf, want), (mode, dt)
+# collective C2: rank 0's BatchNorm buffers to every rank before evaluate (train_gpu.py:233-236 broadcast_buffers=True), one flat
+# broadcast per dtype; parameters are NOT touched
+from segmentation_factory_amd.graph import broadcast_buffers_
+bn = torch.nn.Sequential(torch.nn.BatchNorm1d(3), torch.nn.Linear(3, 2), torch.nn.BatchNorm1d(2))
+with torch.no_grad():
+    for i, bnm in enumerate((bn[0], bn[2])):
+        bnm.running_mean.fill_(10.0 * rank + i); bnm.running_var.fill_(2.0 + rank); bnm.num_batches_tracked.fill_(5 + 3 * rank)
+    bn[1].weight.fill_(float(rank))
+assert broadcast_buffers_(bn) == 6
+assert float(bn[0].running_mean[0]) == 0.0 and float(bn[2].running_mean[0]) == 1.0 and float(bn[2].running_var[1]) == 2.0
+assert int(bn[0].num_batches_tracked) == 5 and bn[0].num_batches_tracked.dtype == torch.int64
+assert float(bn[1].weight[0, 0]) == float(rank)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

@@ -32,6 +32,20 @@ for cfg in (sys.argv[1:] or ['cfg3', 'cfg5']):
     ref = {k: v.grad for k, v in sdg.items() if v.grad is not None}
     gmax = max(r.abs().max().item() for r in ref.values())
     print(f'== {cfg}: {backbone} + {head}, {nc} classes, batch {B}, {H}x{W}; oracle {time.time() - t0:.0f} s; global max|grad| {gmax:.3e}')
+    # COMPARATOR: the same oracle under torch.autocast(bfloat16) on the CPU -- what autocast arithmetic (bf16 matmul / conv operands, fp32
+    # accumulation, fp32 normalisation and softmax; the reference trains under torch.cuda.amp.autocast, /root/reference/engine.py:40)
+    # costs against the fp32 oracle, tensor by tensor.  The HIP bf16 column is judged against THIS, not against zero.
+    t1 = time.time()
+    sdc = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))) for k, v in sd.items()}
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        oc, _ = ON.model_forward(sdc, x, backbone, head, training=True, lowres=True)
+        upc = torch.nn.functional.interpolate(oc.float(), size=(H, W), mode='bilinear', align_corners=False)
+        lc = OL.criterion_closed_form(upc, y, None, num_classes=nc, dice=True, ignore_index=255)
+    lc.backward()
+    cmp_err = {k: (sdc[k].grad.float() - r).abs().max().item() / (r.abs().max().item() + 0.05 * gmax) for k, r in ref.items() if sdc[k].grad is not None}
+    cs = sorted(cmp_err.values())
+    print(f'-- comparator (CPU autocast bf16 vs fp32 oracle, {time.time() - t1:.0f} s): worst {cs[-1]:.3e}, median {cs[len(cs) // 2]:.3e}; '
+          f'logits {((oc.float() - o).abs().max() / o.abs().max()).item():.2e}')
     for dtype in (torch.float32, torch.bfloat16):
         m = SegmentationModel(backbone, num_classes=nc, seg_head=head, compute_dtype=dtype)
         m.load_state_dict(sd)
@@ -53,6 +67,10 @@ for cfg in (sys.argv[1:] or ['cfg3', 'cfg5']):
         print(f'-- {str(dtype)[6:]}: {len(rows)} tensors, worst {worst:.3e}; {sum(r[0] > 0.1 * worst for r in rows)} tensors above a tenth of it; '
               f'median {rows[len(rows) // 2][0]:.3e}')
         for e, k, d, rm, shp in rows[:8]:
-            print(f'   {e:9.3e}  {k:<58} max|diff| {d:.3e}  max|ref| {rm:.3e}  {shp}')
+            print(f'   {e:9.3e}  {k:<58} max|diff| {d:.3e}  max|ref| {rm:.3e}  {shp}   comparator {cmp_err.get(k, float("nan")):.3e}')
+        if dtype == torch.bfloat16:
+            ratios = sorted((e / max(cmp_err[k], 1e-3), k) for e, k, *_ in rows if k in cmp_err)
+            print(f'   HIP bf16 error / comparator error (comparator floored at 1e-3): median {ratios[len(ratios) // 2][0]:.2f}, 90th percentile '
+                  f'{ratios[int(0.9 * len(ratios))][0]:.2f}, worst {ratios[-1][0]:.2f} ({ratios[-1][1]}); tensors above 1.5: {sum(r[0] > 1.5 for r in ratios)} of {len(ratios)}')
         del m, lo
         torch.cuda.empty_cache()
