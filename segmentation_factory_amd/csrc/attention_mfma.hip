@@ -314,11 +314,15 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
             const int row = q0 + 16 * t + c;
             Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
         }
-    f32x4 O[DT][QW];
-    float m[QW], l[QW];
+    // the softmax denominators are a fifth "value column" of ones: L[t] = ones^T P^T accumulates sum_k p in every lane (the matrix pipe
+    // sums over all 32 keys of a step, i.e. over the four lane groups too), on the SAME bf16-rounded probabilities that enter P V --
+    // one MFMA per (query tile, step) instead of eight vector adds and, at the end, no cross-lane sum
+    f32x4 O[DT][QW], L[QW];
+    float m[QW];
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
 #pragma unroll
     for (int t = 0; t < QW; ++t) {
-        m[t] = -INFINITY; l[t] = 0.f;
+        m[t] = -INFINITY; L[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < DT; ++d) O[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
                     const float mnew = fmaxf(m[t], mx[t]);
                     const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);          // exp2(-inf) = 0 on the first step
                     m[t] = mnew;
-                    l[t] *= alpha;
+                    L[t] *= alpha;
 #pragma unroll
                     for (int d = 0; d < DT; ++d) O[d][t] *= alpha;
                 }
@@ -393,14 +397,14 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
 #pragma unroll
             for (int t = 0; t < QW; ++t) {
                 const float nm = -m[t];
-                float ps = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { sv[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sv[t][kt][r], cs, nm)); ps += sv[t][kt][r]; }
-                l[t] += ps;
+                    for (int r = 0; r < 4; ++r) sv[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sv[t][kt][r], cs, nm));
                 Pf[t] = pack_acc(sv[t][0], sv[t][1]);
             }
+#pragma unroll
+            for (int t = 0; t < QW; ++t) L[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, Pf[t], L[t], 0, 0, 0);
 #pragma unroll
             for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
     bf16_t* Ob = o + (int64_t)b * N * ldo + h * HD;
 #pragma unroll
     for (int t = 0; t < QW; ++t) {
-        const float lt = xgroup_sum(l[t]);
+        const float lt = L[t][0];
         const float inv = 1.f / lt;
         const int row = q0 + 16 * t + c;
         if (row < N) {

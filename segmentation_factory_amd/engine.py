@@ -172,16 +172,15 @@ def evaluate(args, model, dataloader, device, print_freq, writer=None):
         # is no wrapper at all), so the broadcast is issued here, once, in front of the forwards that read the running statistics
         from .graph import broadcast_buffers_
         broadcast_buffers_(core)
-    use_graph = bool(getattr(args, 'hip_graph', False)) and fused
+    session = None
+    if bool(getattr(args, 'hip_graph', False)) and fused:
+        from .graph import GraphedEvalSession
+        session = GraphedEvalSession(core)                   # the eval forward as one replayed hipGraph per input shape
     for idx, (images, labels) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
         images = images.to(device, non_blocking=True)
         labels = labels.to(device, non_blocking=True)
         if fused:
-            if use_graph and images.is_cuda:
-                from .graph import graphed_eval_forward
-                lo = graphed_eval_forward(core, images)      # the eval forward as one replayed hipGraph per input shape
-            else:
-                lo = core.forward_lowres(images)
+            lo = session(images) if (session is not None and images.is_cuda) else core.forward_lowres(images)
             metric.update_lowres(lo, labels, images.shape[2:], confmat=confmat)     # one pass feeds both matrices
         else:
             outputs = model(images)

@@ -107,20 +107,28 @@ class GraphedEvalForward:
         return self.out
 
 
-def graphed_eval_forward(core, images, max_graphs: int = 8):
-    """The cached GraphedEvalForward of `core` for this input shape (validation images of a few sizes: a few graphs)."""
-    cache = core.__dict__.setdefault('_graphed_eval', {})
-    sig = _storage_signature(core)
-    if cache.get('sig') != sig:
-        cache.clear()
-        cache['sig'] = sig
-    key = (tuple(images.shape), images.dtype)
-    g = cache.get(key)
-    if g is None:
-        while len(cache) > max_graphs:                      # 'sig' + max_graphs entries: drop the oldest graph
-            cache.pop(next(k for k in cache if k != 'sig'))
-        g = cache[key] = GraphedEvalForward(core, images)
-    return g(images)
+class GraphedEvalSession:
+    """Per-`evaluate` handle on the cached eval graphs of `core` (one per input shape; validation images come in a few sizes).  The
+    storage signature is checked ONCE per session -- walking a module tree costs milliseconds, more than a batch-1 forward -- so the
+    parameters must not move while a session is open (they do not inside engine.evaluate)."""
+
+    def __init__(self, core, max_graphs: int = 8):
+        self.core, self.max_graphs = core, max_graphs
+        cache = core.__dict__.setdefault('_graphed_eval', {})
+        sig = _storage_signature(core)
+        if cache.get('sig') != sig:
+            cache.clear()
+            cache['sig'] = sig
+        self.cache = cache
+
+    def __call__(self, images):
+        key = (tuple(images.shape), images.dtype)
+        g = self.cache.get(key)
+        if g is None:
+            while len(self.cache) > self.max_graphs:           # 'sig' + max_graphs entries: drop the oldest graph
+                self.cache.pop(next(k for k in self.cache if k != 'sig'))
+            g = self.cache[key] = GraphedEvalForward(self.core, images)
+        return g(images)
 
 
 def plan_buckets(numels, bucket_elems):

@@ -261,6 +261,28 @@ def _oracle_fwd_bwd(backbone, head, nc, x, y, sd, H, W):
     return o.detach(), ref_loss.item(), {k: v.grad for k, v in sdg.items() if v.grad is not None}
 
 
+def _autocast_comparator(backbone, head, nc, x, y, sd, H, W, ref_grads):
+    """Per-tensor gradient error of the CPU oracle run under torch.autocast(bfloat16) against the fp32 oracle: what autocast arithmetic
+    (bf16 matmul / conv operands, fp32 accumulation, fp32 normalisation / softmax) -- the regime the reference trains in,
+    /root/reference/engine.py:40 -- costs on this graph.  The yardstick for the HIP bf16 gradient errors."""
+    sdc = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var'))) for k, v in sd.items()}
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        o, _ = ON.model_forward(sdc, x, backbone, head, training=True, lowres=True)
+        up = torch.nn.functional.interpolate(o.float(), size=(H, W), mode='bilinear', align_corners=False)
+        loss = OL.criterion_closed_form(up, y, None, num_classes=nc, dice=True, ignore_index=255)
+    loss.backward()
+    gmax = max(r.abs().max().item() for r in ref_grads.values())
+    return {k: (sdc[k].grad.float() - r).abs().max().item() / (r.abs().max().item() + 0.05 * gmax)
+            for k, r in ref_grads.items() if sdc[k].grad is not None}
+
+
+def _grad_errors(model, ref_grads):
+    params = dict(model.named_parameters())
+    gmax = max(r.abs().max().item() for r in ref_grads.values())
+    return {k: (params[k].grad.float().cpu() - r).abs().max().item() / (r.abs().max().item() + 0.05 * gmax)
+            for k, r in ref_grads.items() if k in params and params[k].grad is not None}
+
+
 def _grad_report(model, ref_grads, skip=()):
     """worst over parameter tensors of max|g - r| / (max|r| + 0.05 * global max|r|); returns (worst, name, n_compared)."""
     params = dict(model.named_parameters())
@@ -302,6 +324,7 @@ def test_full_size_fp32_and_bf16_vs_oracle(cfg):
     torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
     o, ref_loss, ref_grads = _oracle_fwd_bwd(backbone, head, nc, x, y, sd, H, W)
     t_oracle = time.time() - t0
+    cmp_err = _autocast_comparator(backbone, head, nc, x, y, sd, H, W, ref_grads) if cfg != 'cfg1' else None
     scale = o.abs().max()
     for dtype in (torch.float32, torch.bfloat16):
         fp32 = dtype == torch.float32
@@ -340,6 +363,19 @@ def test_full_size_fp32_and_bf16_vs_oracle(cfg):
         #         gradient is a sum of 400 products of bf16 activations), then 0.25 = the pwconv weights of stages 1 / 2, median 0.065
         #         (ppm.stages.0.* = 0.51 skipped)
         assert worst <= {'cfg2': (5e-3, 6e-2), 'cfg3': (3e-2, 0.2), 'cfg4': (2e-3, 2e-2), 'cfg5': (1.5e-2, 0.4)}[cfg][0 if fp32 else 1], (wname, worst)
+        if not fp32:
+            # CALIBRATION of the bf16 bars: every tensor's error against the fp32 oracle is compared with the error the
+            # oracle ITSELF shows under CPU autocast(bfloat16), same tensor, same normalisation (comparator floored at 1e-3 so that tensors
+            # autocast happens to get exactly do not divide by ~0).  Measured on the MI355X (profiles/r04_grad_parity_calibrated.txt):
+            # median ratio 0.79 / 0.88 / 0.59 / 0.81 (cfg2 / 3 / 4 / 5) -- the HIP path is the more accurate of the two -- 90th percentile
+            # 1.07 - 1.13, worst single tensor 1.9 (a bias / BatchNorm-bias vector), 0 - 7 tensors of 189 - 422 above 1.5
+            errs = _grad_errors(model, ref_grads)
+            ratios = sorted((e / max(cmp_err[k], 1e-3), k) for k, e in errs.items() if k in cmp_err)
+            med, p90, top = ratios[len(ratios) // 2][0], ratios[int(0.9 * len(ratios))][0], ratios[-1]
+            above = sum(r[0] > 1.5 for r in ratios)
+            print(f'[{cfg} bf16 vs CPU autocast comparator] ratio median {med:.2f}, 90th percentile {p90:.2f}, worst {top[0]:.2f} ({top[1]}), '
+                  f'{above} of {len(ratios)} tensors above 1.5')
+            assert med <= 1.0 and p90 <= 1.3 and top[0] <= 2.5 and above <= 0.03 * len(ratios), (med, p90, top, above)
         del model, lo, loss
         torch.cuda.empty_cache()
 
@@ -908,14 +944,18 @@ def test_two_rank_graphed_step_matches_manual_data_parallel(tmp_path, bucket_mb,
               ' |rank1-stat hist - rank0-stat hist| =', (metric1.hist - metric.hist).abs().sum().item())
 
 
+FP8_GRAD_BAR = 0.8          # measured 0.551 (backbone.stages.0.0.grn.gamma; bf16 on the same tensor family: 0.335) x 1.45
+
+
 def test_fp8_forward_of_cfg5_model_within_stated_tolerance():
-    """BASELINE cfg5 "fp8 MFMA weights": convnextv2_large + UPerHead, 171 classes, 640 x 640 with set_fp8() -- the pointwise
-    linears' forward products in e4m3 -- against the fp32 CPU oracle.  The reference has no fp8: the bar is a stated tolerance,
-    logits within 0.25 of their scale and loss within 3 % (measured 0.14 / 5e-5; bf16 alone: 4e-2 / 3e-5,
-    test_full_size_fp32_and_bf16_vs_oracle),
-    gradients finite and the bf16 backward still within 0.6 of the oracle's gradient scale."""
+    """BASELINE cfg5 "fp8 MFMA weights": convnextv2_large + UPerHead, 171 classes, 640 x 640, batch 4 with set_fp8() -- all three
+    products of the UPerHead / PPM 3x3 convolutions and of the stage-3 block MLPs on fp8 operands (forward e4m3 x e4m3, data and weight
+    gradients with the gradient in e5m2) -- against the fp32 CPU oracle.  The reference has no fp8: the bars are stated tolerances --
+    logits within 0.25 of their scale, loss within 3 % (measured 0.14 / 5e-5; bf16 alone: 4e-2 / 3e-5,
+    test_full_size_fp32_and_bf16_vs_oracle), gradients finite, and every parameter gradient within FP8_GRAD_BAR of its tensor's scale
+    (the bf16 bar of the same model is 0.4; ppm.stages.0.* -- a BatchNorm over 4 values per channel -- skipped as there)."""
     from segmentation_factory_amd import criterion_lowres
-    backbone, head, nc, B, H, W = 'convnextv2_large', 'UPerHead', 171, 2, 640, 640
+    backbone, head, nc, B, H, W = 'convnextv2_large', 'UPerHead', 171, 4, 640, 640
     sd = OW.make_state_dict(backbone, head, nc, 0)
     x, y = OW.synthetic_batch(B, H, W, nc, 0)
     torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
@@ -932,19 +972,23 @@ def test_fp8_forward_of_cfg5_model_within_stated_tolerance():
     print(f'[cfg5 fp8] logits {e_log:.2e}, loss {e_loss:.2e}, worst gradient error {worst:.3e} ({wname}), {n} tensors')
     assert e_log <= 0.25 and e_loss <= 3e-2
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())
+    assert worst <= FP8_GRAD_BAR, (wname, worst)
     with pytest.raises(ValueError):
         _build('MiT-B0', 'SegFormerHead', 19, OW.make_state_dict('MiT-B0', 'SegFormerHead', 19, 0), torch.bfloat16, 1).set_fp8(True)
 
 
-def test_fp8_training_curve_tracks_bf16():
+@pytest.mark.parametrize('geom', [('ConvNeXt', 19, 4, 256, 256, 30), ('convnextv2_large', 171, 4, 640, 640, 20)], ids=['convnext_t_256', 'cfg5_width_640'])
+def test_fp8_training_curve_tracks_bf16(geom):
     """Overfit-style check of the fp8 option (BASELINE cfg5 'fp8 MFMA weights'; no counterpart in the reference): ConvNeXt-T + UPerHead,
-    19 classes, 256 x 256, batch 4 -- large enough for every UPerHead 3x3 convolution (forward, data gradient and, at stride 4, the
-    weight gradient) and the block MLP forwards to take their fp8 kernels -- trained for 30 steps on one batch with the fused AGC / AdamW
-    step, once in bf16 and once with set_fp8().  Both must learn (loss down by > 25 %), and the fp8 curve must stay within 4 % of the bf16
-    curve at every step: quantisation noise, not a different optimisation trajectory."""
+    19 classes, 256 x 256, batch 4 -- large enough for every UPerHead 3x3 convolution (all three directions) to take its fp8 kernel --
+    and BASELINE cfg5's own model (convnextv2_large + UPerHead, 171 classes, 640 x 640, batch 4: 6400 stage-3 tokens, so the block MLPs
+    run on fp8 operands in all three products too), trained on one batch with the fused AGC / AdamW step, once in bf16 and once with
+    set_fp8().  Both must learn, and the fp8 curve must track the bf16 curve step by step: quantisation noise, not a different
+    optimisation trajectory."""
     from segmentation_factory_amd import criterion_lowres
     from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler, param_groups_weight_decay
-    backbone, head, nc, B, H, W, seed = 'ConvNeXt', 'UPerHead', 19, 4, 256, 256, 23
+    backbone, nc, B, H, W, nsteps = geom
+    head, seed = 'UPerHead', 23
     sd = OW.make_state_dict(backbone, head, nc, seed)
     x, y = OW.learnable_batch(B, H, W, nc, seed, block=32)          # labels a function of the colours: fittable in a few steps
     x, y = x.cuda(), y.cuda()
@@ -956,7 +1000,7 @@ def test_fp8_training_curve_tracks_bf16():
         opt = FusedAGCAdamW(param_groups_weight_decay(model, 0.025), lr=2e-4)
         scaler = NativeScaler()
         losses = []
-        for _ in range(30):
+        for _ in range(nsteps):
             opt.zero_grad(set_to_none=True)
             loss = criterion_lowres(model.forward_lowres(x), y, (H, W), None, num_classes=nc, dice=True, ignore_index=255)
             losses.append(loss.item())
@@ -966,7 +1010,9 @@ def test_fp8_training_curve_tracks_bf16():
         torch.cuda.empty_cache()
     print('bf16', [round(v, 4) for v in curves[False]])
     print('fp8 ', [round(v, 4) for v in curves[True]])
-    for c in curves.values():
-        assert all(np.isfinite(c)) and c[-1] < 0.05 * c[0], c
     dev = [abs(a - b) / b for a, b in zip(curves[True], curves[False])]
-    assert max(dev) <= 0.12 and max(dev[-10:]) <= 0.015, dev      # measured: 8.5 % at step 4 (loss falling 4x per 2 steps), <= 0.6 % at the end
+    print('max deviation', max(dev), 'last ten', max(dev[-10:]), 'bf16 loss ratio end / start', curves[False][-1] / curves[False][0])
+    for c in curves.values():
+        assert all(np.isfinite(c)) and c[-1] < (0.05 if backbone == 'ConvNeXt' else 0.6) * c[0], c
+    # ConvNeXt-T: measured 8.5 % at step 4 (loss falling 4x per 2 steps), <= 0.6 % at the end
+    assert max(dev) <= 0.12 and max(dev[-10:]) <= (0.015 if backbone == 'ConvNeXt' else 0.05), dev

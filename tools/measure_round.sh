@@ -4,7 +4,7 @@
 # default bench line (with the CPU baseline), kernel stats of the same command, PMC traffic (two passes), small-batch lines,
 # the other BASELINE configs.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 SECTIONS=${2:-main small cfgs parity}
 has() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 R=$GRAFT_REPO_ROOT
@@ -13,35 +13,35 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 if has main; then
 python3 $R/bench.py > $O/${TAG}_bench_b128.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 3 > $O/${TAG}_bench_b128_profiled.json 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 10 --warmup 3 > $O/${TAG}_bench_b128_profiled.json 2>> $O/bench.err
 python3 $R/tools/rocpd_summary.py $O/prof/stats_results.db --csv $O/${TAG}_bench_b128_kernel_stats.csv --top 12 > $O/stats_top.txt 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
 cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch 128 --out $O/pmc_traffic_b128.json > $O/pmc_top.txt 2>&1
 # the default line once more with the counter file just taken (same sources: bench.py reports roofline.traffic from it)
 cp $O/pmc_traffic_b128.json $R/profiles/pmc_traffic_b128.json && python3 bench.py > $O/${TAG}_bench_b128_final.json 2>> $O/bench.err
 fi
 if has small; then
 cd $R
-for b in 4 16 32; do python3 bench.py --batch $b --no-cpu-baseline > $O/${TAG}_bench_b${b}.json 2>> $O/bench.err; done
+for b in 4 16 32; do python3 bench.py --batch $b --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_b${b}.json 2>> $O/bench.err; done
 fi
 if has cfgs; then
 cd $R
-python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline > $O/${TAG}_bench_cfg3_b32.json 2>> $O/bench.err
-python3 bench.py --config cfg4 --batch 16 --no-cpu-baseline > $O/${TAG}_bench_cfg4_b16.json 2>> $O/bench.err
-python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline > $O/${TAG}_bench_cfg5_b8.json 2>> $O/bench.err
-python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline --fp8 > $O/${TAG}_bench_cfg5_b8_fp8.json 2>> $O/bench.err
-python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline --fp8 > $O/${TAG}_bench_cfg3_b32_fp8.json 2>> $O/bench.err
+python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg3_b32.json 2>> $O/bench.err
+python3 bench.py --config cfg4 --batch 16 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg4_b16.json 2>> $O/bench.err
+python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg5_b8.json 2>> $O/bench.err
+python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline --no-extra-legs --fp8 > $O/${TAG}_bench_cfg5_b8_fp8.json 2>> $O/bench.err
+python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline --no-extra-legs --fp8 > $O/${TAG}_bench_cfg3_b32_fp8.json 2>> $O/bench.err
 python3 tools/probe/fp8_conv_probe.py > $O/${TAG}_conv3x3_bf16_vs_fp8.txt 2>> $O/bench.err
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 # kernel statistics + counter traffic of the other BASELINE configs (the TFLOP/s and GB/s claims of DESIGN section 5 / 9)
 for cb in cfg3:32 cfg4:16 cfg5:8; do
   c=${cb%%:*}; b=${cb##*:}
   cd /tmp
-  rocprofv3 --kernel-trace --stats -d $O/prof_$c -o stats -- python3 $R/bench.py --config $c --batch $b --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>> $O/bench.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_$c -o stats -- python3 $R/bench.py --config $c --batch $b --no-cpu-baseline --no-extra-legs --steps 5 --warmup 2 > /dev/null 2>> $O/bench.err
   python3 $R/tools/rocpd_summary.py $O/prof_$c/stats_results.db --csv $O/${TAG}_${c}_b${b}_kernel_stats.csv --top 10 > $O/stats_top_$c.txt 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcf_$c -o fetch -- python3 $R/bench.py --config $c --batch $b --no-cpu-baseline --steps 1 --warmup 1 > /dev/null 2>> $O/bench.err
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmcw_$c -o write -- python3 $R/bench.py --config $c --batch $b --no-cpu-baseline --steps 1 --warmup 1 > /dev/null 2>> $O/bench.err
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcf_$c -o fetch -- python3 $R/bench.py --config $c --batch $b --no-cpu-baseline --no-extra-legs --steps 1 --warmup 1 > /dev/null 2>> $O/bench.err
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmcw_$c -o write -- python3 $R/bench.py --config $c --batch $b --no-cpu-baseline --no-extra-legs --steps 1 --warmup 1 > /dev/null 2>> $O/bench.err
   cd $R && python3 tools/pmc_traffic.py $O/pmcf_$c $O/pmcw_$c --batch $b --out $O/${TAG}_pmc_traffic_${c}_b${b}.json > $O/pmc_top_$c.txt 2>&1
   rm -rf $O/prof_$c $O/pmcf_$c $O/pmcw_$c
 done
@@ -49,7 +49,7 @@ fi
 if has parity; then
 cd $R
 # per-tensor gradient errors at full size behind the bf16 bars of test_full_size_fp32_and_bf16_vs_oracle
-python3 tools/grad_parity_fullsize.py cfg1 cfg3 cfg5 > $O/${TAG}_grad_parity_fullsize.txt 2>> $O/bench.err
+python3 tools/grad_parity_fullsize.py cfg2 cfg3 cfg4 cfg5 > $O/${TAG}_grad_parity_fullsize.txt 2>> $O/bench.err
 fi
 ls -la $O; for f in $O/stats_top*.txt; do echo "== $f"; cut -c1-150 $f; done; for f in $O/pmc_top*.txt; do echo "== $f"; head -12 $f | cut -c1-150; done; head -60 $O/*grad_parity_fullsize.txt 2>/dev/null; for f in $O/*bench*.json; do python3 -c "
 import json,sys

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ps; mkdir -p $O; rm -f $O/summary.txt
 i=0
 for set in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SALU"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o p -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o p -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 2 --warmup 1 > $O/p$i.log 2>&1
   f=$(ls $O/p$i/*counter_collection.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then python3 - "$f" >> $O/summary.txt <<'PY'
 import csv,sys,collections

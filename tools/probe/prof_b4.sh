@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pb; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python3 $R/bench.py --batch 4 --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_b4.json 2> $O/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python3 $R/bench.py --batch 4 --no-cpu-baseline --no-extra-legs --steps 20 --warmup 3 > $O/bench_b4.json 2> $O/err.txt
 f=$(ls $O/prof/*kernel_stats.csv | head -1); cp $f $O/b4_kernel_stats.csv
 python3 - $f <<'PY'
 import csv,sys
