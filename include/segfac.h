@@ -166,6 +166,22 @@ int segf_bn_affine_table(const float* mean, const float* rstd, const float* gamm
 int64_t segf_gemm_dw_db_ws(int64_t M, int64_t N, int64_t K, int split_k);
 int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                     void* C, int c_dt, int64_t ldc, int split_k, float* ws, float* dbias, void* stream);
+/* The same for SEVERAL layers in one call (the backward of a MiT / ConvNeXt block: q, kv, proj, fc1, fc2 of mit.py:43-59,98-99 -- their
+ * weight gradients do not depend on each other).  Items that take the 128-tile split-K kernel are gathered into grouped launches (one
+ * product launch + one reduce launch per up to 12 layers); the rest run exactly as segf_gemm_dw_db.  Every item's dw [M][lddw] fp32 and
+ * db [M] are bitwise what segf_gemm_dw_db(dt, M, N, K, dy, lddy, x, ldx, dw, F32, lddw, split_k, ws, db) produces; ws per item >=
+ * segf_gemm_dw_db_ws(M, N, K, split_k) floats, 16-byte aligned. */
+typedef struct SegfDwItem {
+    int64_t M, N, K;            /* dw = dy^T x: dy [K][M], x [K][N] (K = tokens) */
+    const void* dy; int64_t lddy;
+    const void* x; int64_t ldx;
+    float* dw; int64_t lddw;
+    float* db;
+    float* ws;
+    int split_k;
+    int reserved;
+} SegfDwItem;
+int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, void* stream);
 
 /* ---- LayerNorm over the last dim (nn.LayerNorm eps 1e-5 in mit.py:107,136-140,178-190; ConvNeXt's
  * channels-first LayerNorm, convnext.py:8-23, is the same kernel on NHWC rows) ---------------------- */

@@ -327,8 +327,10 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmArgs& a, int64_t m, int
 // DEEP (layouts 0 / 1, no gather): TWO K steps of operand loads in flight (two register sets, branch-free loaders) -- with K = 160 ...
 // 1024 a tile is a chain of 3 ... 16 load -> LDS -> MFMA round trips whose arithmetic is a few hundred cycles each; the MiT
 // stage-3 / 4 products ([131072 x 160] x [160 x 160]: 51 us against 14 us of HBM time) are bound by that chain, not by bytes.
+// The tile program is a device function of (arguments, logical grid, linear workgroup id) so that a GROUPED launch can run the tiles
+// of several products from one grid (gemm_bf16_dw_group_kernel: the weight gradients of up to GDW_MAX Linear layers).
 template <int LAYOUT, typename OutT, bool TR, bool CONV = false, int NBUF = 2, bool DEEP = false>
-__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const unsigned gx, const unsigned gy, const unsigned gz, const unsigned orig) {
     static_assert(!DEEP || (!CONV && NBUF == 2), "deep prefetch: no gather, double-buffered LDS");
     constexpr int SMEM_BYTES = NBUF == 2 ? 4 * GB_TILE_BYTES : (64 * GB_STG_LD * 4 > 2 * GB_TILE_BYTES ? 64 * GB_STG_LD * 4 : 2 * GB_TILE_BYTES);
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
@@ -339,9 +341,7 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
     // remapped (bijectively) such that each XCD walks a CONTIGUOUS range of logical tiles, n-tile fastest: the column tiles
     // of one row tile -- and, for split-K, all tiles of one K slab -- run back to back on one XCD and share their operand
     // through that L2 instead of each fetching it from HBM.  Speed only; any placement computes the same result.
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned nwg = gx * gy * gridDim.z;
-    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned nwg = gx * gy * gz;
     const unsigned q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     // (split-K weight-gradient launches keep the hardware order: measured slower with the remap)
     const unsigned wgid = LAYOUT == 2 ? orig : (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
@@ -610,6 +610,31 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
             gemm_epilogue4<bf16_t, OutT>(a, m, n, v, bz);
         }
     }
+}
+template <int LAYOUT, typename OutT, bool TR, bool CONV = false, int NBUF = 2, bool DEEP = false>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmArgs a) {
+    gemm_bf16_tile<LAYOUT, OutT, TR, CONV, NBUF, DEEP>(a, gridDim.x, gridDim.y, gridDim.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+}
+
+// GROUPED weight gradients: the split-K dW = dy^T x products (+ riding bias gradients) of up to GDW_MAX nn.Linear layers in ONE launch.
+// At the reference's default batch (4 per GPU, train_gpu.py:71) a MiT-B0 step issues 48 such products of ~16 us each on a handful of
+// workgroups, every one followed by its ~5 us split-K reduce -- a quarter of the step (skipping them: 4.71 -> 3.55 ms); the layers'
+// gradients do not depend on each other, so their tiles can share one grid.  Member i owns the linear workgroup ids
+// [start[i], start[i + 1]); inside its range the member's own logical grid (gx, gy, gz) and arguments are used, so every tile computes
+// exactly what the per-layer launch computes (bitwise).  The arguments travel by value (kernel-argument segment): capturable, no table.
+#define GDW_MAX 12
+struct GemmDwGroup {
+    int n;
+    unsigned start[GDW_MAX + 1];
+    unsigned gx[GDW_MAX], gy[GDW_MAX], gz[GDW_MAX];
+    GemmArgs m[GDW_MAX];
+};
+template <bool DEEP>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_dw_group_kernel(const GemmDwGroup g) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < g.n && blockIdx.x >= g.start[i + 1]) ++i;
+    gemm_bf16_tile<2, float, true, false, 2, DEEP>(g.m[i], g.gx[i], g.gy[i], g.gz[i], blockIdx.x - g.start[i]);
 }
 
 // ---- 256 x 256 x 64 tile variant (8 waves: 2 along m x 4 along n, wave tile 128 x 64 = 8 x 4 MFMA tiles) ----------------
@@ -1067,15 +1092,15 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
 // The workgroups past `main_blocks` reduce the bias-gradient slices that ride on the same product (cs_ws [split][cs_n] ->
 // cs_out [cs_n], the arithmetic of colreduce_finalize_kernel): one launch per weight gradient instead of two.
 template <typename OutT>
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
-                                                             OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
-                                                             const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
+__device__ __forceinline__ void splitk_reduce_body(const unsigned bid, const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                   OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                   const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
     __shared__ float red[16][17];
     const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const bool cs = blockIdx.x >= main_blocks;
+    const bool cs = bid >= main_blocks;
     const int64_t total = cs ? cs_n : M * N;
     const float* __restrict__ src = cs ? cs_ws : ws;
-    const int64_t i = (int64_t)(cs ? blockIdx.x - main_blocks : blockIdx.x) * 16 + o;
+    const int64_t i = (int64_t)(cs ? bid - main_blocks : bid) * 16 + o;
     float acc = 0.f;
     if (i < total) {
 #pragma unroll 4
@@ -1095,17 +1120,23 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
         }
     }
 }
+template <typename OutT>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                             OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                             const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
+    splitk_reduce_body<OutT>(blockIdx.x, ws, split, M, N, C, ldc, main_blocks, cs_ws, cs_out, cs_n);
+}
 
 // Wide form for large outputs (the weight gradients of the wider models: 3072 x 768 fp32 x 8 slices is 75 MB of partials): one
 // thread per four consecutive outputs, the slices added in order z = 0, 1, ... with four 16-byte loads in flight -- every slab is
 // read as whole contiguous rows.  (The 16 x 16 form above reads 64-byte pieces and ran at ~1 TB/s on these; it stays for small
 // outputs with many slices, where this one would leave most of the chip idle.)  N % 4 == 0, ldc % 4 == 0, ws 16-byte aligned.
 template <typename OutT>
-__global__ void __launch_bounds__(256) splitk_reduce_wide_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
-                                                                  OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
-                                                                  const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
-    if (blockIdx.x >= main_blocks) {          // bias-gradient slices riding on the product: [split][cs_n] -> [cs_n], same order
-        const int64_t i = (int64_t)(blockIdx.x - main_blocks) * 256 + threadIdx.x;
+__device__ __forceinline__ void splitk_reduce_wide_body(const unsigned bid, const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                        OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                        const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
+    if (bid >= main_blocks) {          // bias-gradient slices riding on the product: [split][cs_n] -> [cs_n], same order
+        const int64_t i = (int64_t)(bid - main_blocks) * 256 + threadIdx.x;
         if (i < cs_n) {
             float t = 0.f;
             for (int z = 0; z < split; ++z) t += cs_ws[(int64_t)z * cs_n + i];
@@ -1114,7 +1145,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_wide_kernel(const float* __
         return;
     }
     const int64_t total = M * N;
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t i = ((int64_t)bid * 256 + threadIdx.x) * 4;
     if (i >= total) return;
     const float* __restrict__ src = ws + i;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1136,14 +1167,38 @@ __global__ void __launch_bounds__(256) splitk_reduce_wide_kernel(const float* __
     if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float4*>(o) = acc;
     else { uint2 u; u.x = pack2bf(acc.x, acc.y); u.y = pack2bf(acc.z, acc.w); *reinterpret_cast<uint2*>(o) = u; }
 }
+template <typename OutT>
+__global__ void __launch_bounds__(256) splitk_reduce_wide_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                                  OutT* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                                  const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
+    splitk_reduce_wide_body<OutT>(blockIdx.x, ws, split, M, N, C, ldc, main_blocks, cs_ws, cs_out, cs_n);
+}
+// the reduces of a grouped weight-gradient launch, in one launch: member i runs its own form (wide or 16 x 16) over its own block range
+struct ReduceGroup {
+    int n;
+    unsigned start[GDW_MAX + 1], main_blocks[GDW_MAX];
+    int wide[GDW_MAX], split[GDW_MAX];
+    const float* ws[GDW_MAX]; float* C[GDW_MAX]; const float* cs_ws[GDW_MAX]; float* cs_out[GDW_MAX];
+    int64_t M[GDW_MAX], N[GDW_MAX], ldc[GDW_MAX], cs_n[GDW_MAX];
+};
+__global__ void __launch_bounds__(256) splitk_reduce_group_kernel(const ReduceGroup r) {
+    int i = 0;
+#pragma unroll 1
+    while (i + 1 < r.n && blockIdx.x >= r.start[i + 1]) ++i;
+    const unsigned bid = blockIdx.x - r.start[i];
+    if (r.wide[i]) splitk_reduce_wide_body<float>(bid, r.ws[i], r.split[i], r.M[i], r.N[i], r.C[i], r.ldc[i], r.main_blocks[i], r.cs_ws[i], r.cs_out[i], r.cs_n[i]);
+    else splitk_reduce_body<float>(bid, r.ws[i], r.split[i], r.M[i], r.N[i], r.C[i], r.ldc[i], r.main_blocks[i], r.cs_ws[i], r.cs_out[i], r.cs_n[i]);
+}
+static inline bool splitk_reduce_is_wide(const float* ws, int64_t M, int64_t N, const void* C, int64_t ldc) {
+    return M * N >= 65536 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !getenv("SEGFAC_NO_WIDE_REDUCE");
+}
 
 // one entry for every split-K product: picks the form by output size
 template <typename OutT>
 static void splitk_reduce_launch(hipStream_t st, const float* ws, int split, int64_t M, int64_t N, OutT* C, int64_t ldc,
                                  const float* cs_ws, float* cs_out, int64_t cs_n) {
     const int64_t total = M * N;
-    const bool wide = total >= 65536 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) &&
-                      !getenv("SEGFAC_NO_WIDE_REDUCE");
+    const bool wide = splitk_reduce_is_wide(ws, M, N, C, ldc);
     if (wide) {
         const unsigned blocks = (unsigned)cdiv64(total, 1024);
         const unsigned csb = cs_ws ? (unsigned)cdiv64(cs_n, 256) : 0u;
@@ -1824,6 +1879,80 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
         return segf_colsum(dt, A, lda, K, M, dbias, ws + (split_k > 1 ? (int64_t)split_k * M * N : 0), stream);
     }
     return gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, dbias, stream);
+}
+
+// The weight + bias gradients of SEVERAL nn.Linear layers in one call: items that take the 128-tile split-K kernel with the fused bias
+// column (what segf_gemm_dw_db launches for them) are gathered into grouped launches of up to GDW_MAX members -- one product launch and
+// one reduce launch per group instead of two launches per layer; every other item is executed by segf_gemm_dw_db itself.  Each item's
+// result is bitwise what segf_gemm_dw_db computes for it.
+extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, void* stream) {
+    if (n <= 0) return 0;
+    if (!items) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    GemmDwGroup g; ReduceGroup r;
+    g.n = 0; r.n = 0; g.start[0] = 0; r.start[0] = 0;
+    auto flush = [&]() -> int {
+        if (g.n == 0) return 0;
+        if (g.n == 1) {          // a lone member: the ordinary launch pair (same arithmetic)
+            const GemmArgs& a = g.m[0];
+            hipLaunchKernelGGL((gemm_bf16_kernel<2, float, true, false, 2, true>), dim3(g.gx[0], g.gy[0], g.gz[0]), dim3(256), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((gemm_bf16_dw_group_kernel<true>), dim3(g.start[g.n]), dim3(256), 0, st, g);
+        }
+        SEGF_CHECK_LAUNCH();
+        if (r.n > 0) {
+            hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(r.start[r.n]), dim3(256), 0, st, r);
+            SEGF_CHECK_LAUNCH();
+        }
+        g.n = 0; r.n = 0;
+        return 0;
+    };
+    const bool no_group = getenv("SEGFAC_NO_GROUPED_DW") != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const SegfDwItem& it = items[i];
+        int split_k = it.split_k < 1 ? 1 : it.split_k;
+        const int64_t M = it.M, N = it.N, K = it.K;
+        DwSkinny sk;
+        const bool aligned = (uintptr_t)it.dy % 16 == 0 && (it.lddy * 2) % 16 == 0 && (uintptr_t)it.x % 16 == 0 && (it.ldx * 2) % 16 == 0;
+        const bool skinny = gemm_dw_skinny_plan(M, N, K, true, sk) && sk.slices == split_k && aligned;
+        const int64_t kchunk = cdiv64(cdiv64(K, split_k), GB_BK) * GB_BK;
+        const int slices = (int)cdiv64(K > 0 ? K : 1, kchunk > 0 ? kchunk : GB_BK);
+        const bool groupable = !no_group && dt == SEGF_BF16 && M > 0 && N > 0 && K > 0 && it.dw && it.db && it.ws && !skinny && aligned &&
+                               !gemm_use_big(2, M, N, K) && !getenv("SEGFAC_GEMM_NO_FUSED_DB") && !getenv("SEGFAC_GEMM_NO_FASTLOAD") &&
+                               !getenv("SEGFAC_GEMM_NO_TR") && !getenv("SEGFAC_GEMM_NO_DEEP128") && !getenv("SEGFAC_GEMM_NO_DEEP128_L2") &&
+                               !getenv("SEGFAC_GEMM_FASTLOAD_L2") && M % 8 == 0 && N % 8 == 0 && slices > 1 && cdiv64(M, GB_BM) <= 65535;
+        if (!groupable) {                        // (the items are independent of each other: no need to close the open group)
+            const int rc = segf_gemm_dw_db(dt, M, N, K, it.dy, it.lddy, it.x, it.ldx, it.dw, SEGF_F32, it.lddw, split_k, it.ws, it.db, stream);
+            if (rc) return rc;
+            continue;
+        }
+        // the arguments gemm_impl builds for this product (layout 2, fp32 output, split-K partials in ws, bias column riding)
+        GemmArgs a;
+        a.A = it.dy; a.B = it.x; a.C = it.dw; a.bias = nullptr; a.residual = nullptr; a.rscale = nullptr;
+        a.M = M; a.N = N; a.K = K; a.lda = it.lddy; a.ldb = it.ldx; a.ldc = it.lddw; a.ldr = 0; a.rpg = 1;
+        a.kchunk = kchunk; a.ws = it.ws;
+        a.a_vec = 1; a.b_vec = 1; a.fast = 1;
+        a.c_vec = ((uintptr_t)it.dw % 16 == 0) && ((it.lddw * 4) % 16 == 0);
+        a.r_vec = 0; a.c_vec16 = a.c_vec;
+        a.use_tr = 1;
+        a.cH = a.cW = a.cC = 0; a.csign = 1;
+        a.colsum = it.db; a.colsum_ws = it.ws + (int64_t)slices * M * N;
+        a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_rpg = 1; a.pro_ld = 0; a.pro_act = 0;
+        a.f8_sa = nullptr; a.f8_sb = nullptr;
+        const unsigned gx = (unsigned)cdiv64(N, GB_BN), gy = (unsigned)cdiv64(M, GB_BM), gz = (unsigned)slices;
+        const int k = g.n;
+        g.m[k] = a; g.gx[k] = gx; g.gy[k] = gy; g.gz[k] = gz;
+        g.start[k + 1] = g.start[k] + gx * gy * gz;
+        ++g.n;
+        const bool wide = splitk_reduce_is_wide(it.ws, M, N, it.dw, it.lddw);
+        const unsigned blocks = (unsigned)cdiv64(M * N, wide ? 1024 : 16), csb = (unsigned)cdiv64(M, wide ? 256 : 16);
+        r.wide[k] = wide ? 1 : 0; r.split[k] = slices; r.ws[k] = it.ws; r.C[k] = it.dw; r.cs_ws[k] = a.colsum_ws; r.cs_out[k] = it.db;
+        r.M[k] = M; r.N[k] = N; r.ldc[k] = it.lddw; r.cs_n[k] = M; r.main_blocks[k] = blocks;
+        r.start[k + 1] = r.start[k] + blocks + csb;
+        ++r.n;
+        if (g.n == GDW_MAX) { const int rc = flush(); if (rc) return rc; }
+    }
+    return flush();
 }
 
 // Product whose activation operand is normalised on the way in (BatchNorm + ReLU + Dropout2d scale of ConvModule, heads/

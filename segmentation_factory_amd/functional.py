@@ -5,6 +5,7 @@ Activations are token-major 2-D tensors ``[B*H*W, C]`` (NHWC flattened) in the c
 Every forward/backward below is a hand-written formula over C-ABI kernel calls -- torch autograd
 only sequences them.  Nothing here falls back to eager PyTorch math.
 """
+import contextlib
 import os
 
 import torch
@@ -78,6 +79,76 @@ def _deliver(slot_info, value):
         hip.cast2d(v, d)
     if cb is not None:
         cb(slot)
+
+
+# ---- deferred, grouped weight gradients -----------------------------------------------------------------------------------------
+# The weight / bias gradients of the nn.Linear layers do not feed anything inside the backward pass, so under `defer_weight_grads()`
+# (the captured train step) their dy^T x products are QUEUED by the backward formulas and issued together: hip.gemm_dw_db_grouped runs
+# up to 12 layers per launch pair (csrc/gemm.hip: gemm_bf16_dw_group_kernel + splitk_reduce_group_kernel) instead of two launches per
+# layer.  At the reference's default batch of 4 (train_gpu.py:71) those ~100 launches of 5 - 16 us were a quarter of the step.  Results
+# are bitwise those of the per-layer launches; the queue keeps dy and x alive until the flush, and the direct-placement delivery
+# callbacks (bucket events of the data-parallel exchange) fire at the flush.
+_DW_QUEUE = None
+DW_QUEUE_MAX = 12
+
+
+def flush_weight_grads():
+    q = _DW_QUEUE
+    if not q:
+        return
+    hip.gemm_dw_db_grouped([e[0] for e in q])
+    for _, infos, post in q:
+        if post is not None:
+            post()                                    # e.g. the [O][k k][Cin] -> OIHW permute of a patch convolution's weight gradient
+        for info in infos:
+            _deliver(info, info[0])                   # the slot IS the result: no copy, only the delivery callback
+    q.clear()
+
+
+@contextlib.contextmanager
+def defer_weight_grads():
+    global _DW_QUEUE
+    prev = _DW_QUEUE
+    _DW_QUEUE = [] if not os.environ.get('SEGFAC_NO_DEFERRED_DW') else None
+    try:
+        yield
+        flush_weight_grads()
+    finally:
+        _DW_QUEUE = prev
+
+
+def _queue_dw(ctx, dy, x, n_out, n_in, tokens):
+    """Queue dW [n_out, n_in] = dy^T x and db = colsum(dy) of a Linear whose parameters both carry flat-gradient slots; False when the
+    product has to be issued by the caller (no scope, no slots)."""
+    q = _DW_QUEUE
+    slots = getattr(ctx, '_gslots', None)
+    if q is None or not slots or 1 not in slots or 2 not in slots:
+        return False
+    gw, gb = slots[1][0].view(n_out, n_in), slots[2][0]
+    if gb.numel() != n_out or not gb.is_contiguous():
+        return False
+    q.append(((dy, x, n_out, n_in, tokens, _splitk(n_out, n_in, tokens), gw, gb), (slots[1], slots[2]), None))
+    if len(q) >= DW_QUEUE_MAX:
+        flush_weight_grads()
+    return True
+
+
+def _queue_dw_post(ctx, dy, x, n_out, n_in, tokens, post_of):
+    """As _queue_dw for a layer whose weight gradient needs a layout pass behind the product: the product lands in a temporary
+    [n_out, n_in] fp32 matrix and post_of(temp, weight_slot) runs after the grouped launch."""
+    q = _DW_QUEUE
+    slots = getattr(ctx, '_gslots', None)
+    if q is None or not slots or 1 not in slots or 2 not in slots:
+        return False
+    gb = slots[2][0]
+    if gb.numel() != n_out or not gb.is_contiguous():
+        return False
+    tmp = torch.empty((n_out, n_in), dtype=torch.float32, device=dy.device)
+    gw = slots[1][0]
+    q.append(((dy, x, n_out, n_in, tokens, _splitk(n_out, n_in, tokens), tmp, gb), (slots[1], slots[2]), lambda: post_of(tmp, gw)))
+    if len(q) >= DW_QUEUE_MAX:
+        flush_weight_grads()
+    return True
 
 
 def direct_grads(*param_idx):
@@ -209,8 +280,9 @@ class LinearFn(Function):
             dx = hip.gemm(1, dys, wv, M, K, N)
         gw, gb = gslot(ctx, 1, (N, K)), gslot(ctx, 2)       # flat-gradient views (direct placement) or None
         if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
-            dw, db = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)   # one pass over dy for both
-            dw = dw.view(wshape)
+            if not _queue_dw(ctx, dys, x, N, K, M):           # deferred + grouped under defer_weight_grads(); else right here
+                dw, db = hip.gemm_dw_db(dys, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)   # one pass over dy for both
+                dw = dw.view(wshape)
         else:
             if ctx.needs_input_grad[1]:
                 dw = hip.gemm(2, dys, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
@@ -282,8 +354,9 @@ class LinearForkFn(Function):
             dx = hip.gemm(1, dy, w, M, K, N, residual=_rowmajor(dx2) if dx2 is not None else None)
         gw, gb = gslot(ctx, 1, (N, K)), gslot(ctx, 2)
         if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
-            dw, db = hip.gemm_dw_db(dy, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)
-            dw = dw.view(wshape)
+            if not _queue_dw(ctx, dy, x, N, K, M):
+                dw, db = hip.gemm_dw_db(dy, x, N, K, M, split_k=_splitk(N, K, M), out=gw, db_out=gb)
+                dw = dw.view(wshape)
         else:
             if ctx.needs_input_grad[1]:
                 dw = hip.gemm(2, dy, x, N, K, M, out=gw, out_dtype=torch.float32, split_k=_splitk(N, K, M)).view(wshape)
@@ -482,8 +555,9 @@ class ConvPatchFn(Function):
         dx = dw = db = None
         gw, gb = gslot(ctx, 1), gslot(ctx, 2)                # flat-gradient views: the permute / column sum write in place
         if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
-            dwm, db = hip.gemm_dw_db(dy, col, O, K, M, split_k=_splitk(O, K, M), db_out=gb)           # [O][(ky,kx)][ci]
-            dw = hip.permute021(dwm, O, k * k, Cin, torch.float32, out=gw).view(wshape)
+            if not (gw is not None and _queue_dw_post(ctx, dy, col, O, K, M, lambda t, g: hip.permute021(t, O, k * k, Cin, torch.float32, out=g))):
+                dwm, db = hip.gemm_dw_db(dy, col, O, K, M, split_k=_splitk(O, K, M), db_out=gb)           # [O][(ky,kx)][ci]
+                dw = hip.permute021(dwm, O, k * k, Cin, torch.float32, out=gw).view(wshape)
         else:
             if ctx.needs_input_grad[1]:
                 dwm = hip.gemm(2, dy, col, O, K, M, out_dtype=torch.float32, split_k=_splitk(O, K, M))

@@ -284,7 +284,7 @@ class GraphedTrainStep:
         else:
             scope = contextlib.nullcontext()
         self.opt.begin_backward()
-        with scope:
+        with scope, Fh.defer_weight_grads():      # the Linear layers' weight gradients are queued and issued in grouped launches
             loss = self.loss_fn(self.model, *self.static_inputs)
             # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
             loss.backward(gradient=self._seed if self.exchanging else None)

@@ -34,6 +34,7 @@ _PROTOS = {
     'segf_gemm_pro': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _i, _p, _p, _p, _l, _i, _p]),
     'segf_bn_affine_table': (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     'segf_gemm_dw_db': (_i, [_i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _i, _p, _p, _p]),
+    'segf_gemm_dw_db_grouped': (_i, [_i, _i, _p, _p]),
     'segf_layernorm_fwd': (_i, [_i, _l, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     'segf_layernorm_bwd_ws': (_l, [_l, _i]),
     'segf_layernorm_bwd': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -283,6 +284,36 @@ def gemm_dw_db(dy: torch.Tensor, x: torch.Tensor, M: int, N: int, K: int, split_
         dt_of(dy), M, N, K, _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(dw), dt_of(dw), dw.stride(0), split_k, _ptr(ws),
         _ptr(db), _stream())), 'segf_gemm_dw_db')
     return dw, db
+
+
+class SegfDwItem(C.Structure):
+    """include/segfac.h: one layer of segf_gemm_dw_db_grouped"""
+    _fields_ = [('M', C.c_int64), ('N', C.c_int64), ('K', C.c_int64), ('dy', C.c_void_p), ('lddy', C.c_int64), ('x', C.c_void_p),
+                ('ldx', C.c_int64), ('dw', C.c_void_p), ('lddw', C.c_int64), ('db', C.c_void_p), ('ws', C.c_void_p), ('split_k', C.c_int),
+                ('reserved', C.c_int)]
+
+
+def gemm_dw_db_grouped(items):
+    """items: [(dy [K, M], x [K, N], M, N, K, split_k, dw fp32 [M, N] view, db fp32 [M])]: the weight + bias gradients of several Linear
+    layers in ONE C-ABI call (grouped launches where the shapes allow; each result bitwise equal to gemm_dw_db's)."""
+    if not items:
+        return
+    arr = (SegfDwItem * len(items))()
+    keep = []
+    dt = None
+    for k, (dy, x, M, N, K, split_k, dw, db) in enumerate(items):
+        _need_cuda(dy, x, dw, db)
+        assert dy.stride(-1) == 1 and x.stride(-1) == 1 and dw.stride(-1) == 1 and dt_of(dy) == dt_of(x)
+        assert dw.dtype == torch.float32 and db.dtype == torch.float32 and db.numel() == M and db.is_contiguous()
+        dt = dt_of(dy) if dt is None else dt
+        assert dt_of(dy) == dt
+        ws = _f32(lib().segf_gemm_dw_db_ws(M, N, K, split_k), dy.device)
+        keep.append(ws)
+        it = arr[k]
+        it.M, it.N, it.K = M, N, K
+        it.dy, it.lddy, it.x, it.ldx = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+        it.dw, it.lddw, it.db, it.ws, it.split_k, it.reserved = dw.data_ptr(), dw.stride(0), db.data_ptr(), ws.data_ptr(), split_k, 0
+    _chk(lib().segf_gemm_dw_db_grouped(dt, len(items), C.cast(arr, C.c_void_p), _stream()), 'segf_gemm_dw_db_grouped')
 
 
 def gemm_pro_supported(dtype, layout, M, N, K, rows_per_group):

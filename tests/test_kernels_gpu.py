@@ -1652,3 +1652,34 @@ def test_hist_accum_matches_torch_promotion():
     h, c = hist.cuda(), counts.cuda()
     hip.hist_accum_(h, c)
     assert torch.equal(h.cpu(), want) and c.abs().sum().item() == 0
+
+
+def test_grouped_weight_gradients_equal_per_layer_launches():
+    """segf_gemm_dw_db_grouped (the deferred weight gradients of the captured train step; mit.py:43-59,98-99 backward) must give, layer by
+    layer, BITWISE what segf_gemm_dw_db gives: MiT stage-3 / 4 shapes at the reference's default batch 4 (groupable: 128-tile split-K
+    kernel), a stage-1 shape that takes the streaming kernel and a 256-tile shape (both run ungrouped inside the same call), 14 items
+    (more than one group of 12)."""
+    from segmentation_factory_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(5)
+    shapes = [(160, 160, 4096), (320, 160, 4096), (160, 160, 4096), (640, 160, 4096), (160, 640, 4096),
+              (256, 256, 1024), (512, 256, 1024), (256, 256, 1024), (1024, 256, 1024), (256, 1024, 1024),
+              (64, 64, 16384), (256, 64, 16384),
+              (32, 128, 65536),                      # streaming kernel (small output over many tokens)
+              (768, 768, 65536)]                     # 256-tile kernel
+    items, want = [], []
+    for (M, N, K) in shapes:
+        dy = (torch.randn(K, M, device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+        x = torch.randn(K, N, device='cuda', generator=g).to(torch.bfloat16)
+        sk = hip.pick_splitk(M, N, K)
+        dw_ref, db_ref = hip.gemm_dw_db(dy, x, M, N, K, split_k=sk)
+        want.append((dw_ref.clone(), db_ref.clone()))
+        items.append((dy, x, M, N, K, sk, torch.empty(M, N, device='cuda'), torch.empty(M, device='cuda')))
+    hip.gemm_dw_db_grouped(items)
+    torch.cuda.synchronize()
+    for (dy, x, M, N, K, sk, dw, db), (dw_ref, db_ref) in zip(items, want):
+        assert torch.equal(dw, dw_ref), (M, N, K, (dw - dw_ref).abs().max().item())
+        assert torch.equal(db, db_ref), (M, N, K)
+    # and against fp32 torch on one member, so that "equal" is not "equally wrong"
+    dy, x, M, N, K = items[3][0], items[3][1], *shapes[3]
+    ref = dy.float().t() @ x.float()
+    assert (items[3][6] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
