@@ -198,6 +198,12 @@ int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* d
 int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
                              const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                              float* ws, void* stream);
+/* Deferred finalize: with dgamma == NULL segf_layernorm_bwd_fused leaves its per-block partial sums [blocks][2 C] in ws
+ * (blocks = segf_layernorm_bwd_blocks(rows, C)) and the caller finalizes SEVERAL such reductions in one launch later:
+ * out[i] = sum_b partial[b][i], i < len, summed in the order of the single finalize (bitwise the same dgamma / dbeta). */
+typedef struct SegfFinalizeItem { const float* partial; float* out; int64_t len; int nblk; int reserved; } SegfFinalizeItem;
+int segf_layernorm_bwd_blocks(int64_t rows, int C);
+int segf_colreduce_finalize_grouped(int n, const SegfFinalizeItem* items, void* stream);
 
 /* ---- BatchNorm2d (train: batch statistics) + ReLU/ReLU6 + Dropout2d, NHWC rows -------------------
  * ConvModule of heads/segformer.py:21-29, layers/conv_module.py:4-9, mobilenetv2.py:5-11.

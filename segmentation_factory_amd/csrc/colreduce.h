@@ -171,6 +171,40 @@ colreduce_finalize_kernel(const float* __restrict__ partial, int nblk, int64_t n
         out[i] = t;
     }
 }
+// the finalize steps of SEVERAL two-stage reductions in one launch (the dgamma / dbeta sums of the LayerNorm backward passes of a captured
+// train step: 30 launches of ~6 us each at the reference's default batch): member i owns blocks [start[i], start[i + 1]) and is summed by
+// the same code, in the same order, as colreduce_finalize_kernel
+#define CRF_GROUP_MAX 32
+struct ColreduceGroup {
+    int n;
+    unsigned start[CRF_GROUP_MAX + 1];
+    const float* partial[CRF_GROUP_MAX]; float* out[CRF_GROUP_MAX];
+    int nblk[CRF_GROUP_MAX]; int64_t len[CRF_GROUP_MAX];
+};
+static __global__ void __launch_bounds__(CRF_OUT * CRF_SL) colreduce_finalize_group_kernel(const ColreduceGroup g) {
+    __shared__ float red[CRF_SL][CRF_OUT + 1];
+    int m = 0;
+#pragma unroll 1
+    while (m + 1 < g.n && blockIdx.x >= g.start[m + 1]) ++m;
+    const float* __restrict__ partial = g.partial[m];
+    const int nblk = g.nblk[m];
+    const int64_t n = g.len[m];
+    const int o = threadIdx.x % CRF_OUT, sl = threadIdx.x / CRF_OUT;
+    const int64_t i = (int64_t)(blockIdx.x - g.start[m]) * CRF_OUT + o;
+    float acc = 0.f;
+    if (i < n) {
+#pragma unroll 4
+        for (int b = sl; b < nblk; b += CRF_SL) acc += partial[(int64_t)b * n + i];
+    }
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < CRF_SL; ++k) t += red[k][o];
+        g.out[m][i] = t;
+    }
+}
 static inline void colreduce_finalize_launch(const float* partial, int nblk, int64_t n, float* out, hipStream_t st, int nbatch = 1) {
     hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, CRF_OUT), nbatch), dim3(CRF_OUT * CRF_SL), 0, st, partial,
                        nblk, n, out);

@@ -257,7 +257,7 @@ extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void*
     if (((uintptr_t)dy2 % 16) || ((uintptr_t)dres % 16)) return SEGF_ERR_SHAPE;
     if (C <= 0 || C % 8 != 0 || C > 3072) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
-    if (dbeta != dgamma + C) return SEGF_ERR_SHAPE;   // dgamma and dbeta are one [2][C] fp32 buffer
+    if (dgamma && dbeta != dgamma + C) return SEGF_ERR_SHAPE;   // dgamma and dbeta are one [2][C] fp32 buffer (NULL: deferred finalize)
     hipStream_t st = (hipStream_t)stream;
     int lpr_log2;
     const int vpt = ln_plan(C, lpr_log2);
@@ -265,9 +265,36 @@ extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void*
     const size_t shm = (size_t)4 * 2 * C * sizeof(float);
     SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, (const T*)dy2, (const T*)dres, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2); })
     SEGF_CHECK_LAUNCH();
+    if (!dgamma) return 0;                       // deferred: the caller finalizes ws later (segf_colreduce_finalize_grouped)
     const int64_t n = 2 * (int64_t)C;
     colreduce_finalize_launch(ws, blocks, n, dgamma, st);
     SEGF_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int segf_layernorm_bwd_blocks(int64_t rows, int C) { return rows > 0 ? ln_bwd_blocks(rows, C) : 0; }
+extern "C" int segf_colreduce_finalize_grouped(int n, const SegfFinalizeItem* items, void* stream) {
+    if (n <= 0) return 0;
+    if (!items) return SEGF_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    ColreduceGroup g;
+    g.n = 0; g.start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const SegfFinalizeItem& it = items[i];
+        if (it.len <= 0 || it.nblk <= 0) continue;
+        if (!it.partial || !it.out) return SEGF_ERR_SHAPE;
+        const int k = g.n;
+        g.partial[k] = it.partial; g.out[k] = it.out; g.nblk[k] = it.nblk; g.len[k] = it.len;
+        g.start[k + 1] = g.start[k] + (unsigned)cdiv64(it.len, CRF_OUT);
+        if (++g.n == CRF_GROUP_MAX || i == n - 1) {
+            hipLaunchKernelGGL(colreduce_finalize_group_kernel, dim3(g.start[g.n]), dim3(CRF_OUT * CRF_SL), 0, st, g);
+            SEGF_CHECK_LAUNCH();
+            g.n = 0;
+        }
+    }
+    if (g.n > 0) {
+        hipLaunchKernelGGL(colreduce_finalize_group_kernel, dim3(g.start[g.n]), dim3(CRF_OUT * CRF_SL), 0, st, g);
+        SEGF_CHECK_LAUNCH();
+    }
     return 0;
 }
 

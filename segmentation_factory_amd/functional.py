@@ -92,7 +92,39 @@ _DW_QUEUE = None
 DW_QUEUE_MAX = 12
 
 
+_FIN_QUEUE = None          # deferred finalizes of two-stage column reductions (LayerNorm dgamma / dbeta), same scope
+FIN_QUEUE_MAX = 32
+
+
+def _flush_finalizes():
+    q = _FIN_QUEUE
+    if not q:
+        return
+    hip.colreduce_finalize_grouped([e[0] for e in q])
+    for _, infos in q:
+        for info in infos:
+            _deliver(info, info[0])
+    q.clear()
+
+
+def _ln_bwd(ctx, x, dy, g, mean, rstd, dy2=None, dres=None):
+    """LayerNorm backward with the (dgamma, dbeta) finalize deferred into the scope's grouped launch when both parameters carry adjacent
+    flat-gradient slots; returns (dx, dgamma, dbeta) with None for gradients that will be delivered at the flush."""
+    gg, gb = gslot(ctx, 1), gslot(ctx, 2)
+    dgb = (gg, gb) if (gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel()) else None
+    q = _FIN_QUEUE
+    if q is not None and dgb is not None:
+        slots = ctx._gslots
+        dx, item = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, defer=True)
+        q.append((item, (slots[1], slots[2])))
+        if len(q) >= FIN_QUEUE_MAX:
+            _flush_finalizes()
+        return dx, None, None
+    return hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres)
+
+
 def flush_weight_grads():
+    _flush_finalizes()
     q = _DW_QUEUE
     if not q:
         return
@@ -107,14 +139,15 @@ def flush_weight_grads():
 
 @contextlib.contextmanager
 def defer_weight_grads():
-    global _DW_QUEUE
-    prev = _DW_QUEUE
+    global _DW_QUEUE, _FIN_QUEUE
+    prev, prevf = _DW_QUEUE, _FIN_QUEUE
     _DW_QUEUE = [] if not os.environ.get('SEGFAC_NO_DEFERRED_DW') else None
+    _FIN_QUEUE = [] if not os.environ.get('SEGFAC_NO_DEFERRED_FINALIZE') else None
     try:
         yield
         flush_weight_grads()
     finally:
-        _DW_QUEUE = prev
+        _DW_QUEUE, _FIN_QUEUE = prev, prevf
 
 
 def _queue_dw(ctx, dy, x, n_out, n_in, tokens):
@@ -390,11 +423,7 @@ class LayerNormFn(Function):
     def backward(ctx, dy):
         x, g, mean, rstd = ctx.saved_tensors
         dy = dy if dy.is_contiguous() else dy.contiguous()
-        gg, gb = gslot(ctx, 1), gslot(ctx, 2)
-        dgb = None
-        if gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel():
-            dgb = (gg, gb)                                  # weight / bias views are adjacent in the flat buffer: one [2][C] target
-        dx, dg, db = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb)
+        dx, dg, db = _ln_bwd(ctx, x, dy, g, mean, rstd)       # adjacent flat-gradient views are one [2][C] target, written in place
         return dx, dg, db, None
 
 
@@ -424,9 +453,7 @@ class LayerNormResFn(Function):
         dy = dy if dy.is_contiguous() else dy.contiguous()
         if dres is not None and not dres.is_contiguous():
             dres = dres.contiguous()
-        gg, gb = gslot(ctx, 1), gslot(ctx, 2)
-        dgb = (gg, gb) if (gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel()) else None
-        dx, dg, db = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dres=dres)
+        dx, dg, db = _ln_bwd(ctx, x, dy, g, mean, rstd, dres=dres)
         return dx, dg, db, None
 
 
@@ -456,9 +483,7 @@ class LayerNormForkFn(Function):
         dy1 = dy1 if dy1.is_contiguous() else dy1.contiguous()
         if dy2 is not None and not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        gg, gb = gslot(ctx, 1), gslot(ctx, 2)
-        dgb = (gg, gb) if (gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel()) else None
-        dx, dg, db = hip.layernorm_bwd(x, dy1, g, mean, rstd, dgb_out=dgb, dy2=dy2)
+        dx, dg, db = _ln_bwd(ctx, x, dy1, g, mean, rstd, dy2=dy2)
         return dx, dg, db, None
 
 

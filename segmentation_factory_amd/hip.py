@@ -35,6 +35,8 @@ _PROTOS = {
     'segf_bn_affine_table': (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     'segf_gemm_dw_db': (_i, [_i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _i, _p, _p, _p]),
     'segf_gemm_dw_db_grouped': (_i, [_i, _i, _p, _p]),
+    'segf_layernorm_bwd_blocks': (_i, [_l, _i]),
+    'segf_colreduce_finalize_grouped': (_i, [_i, _p, _p]),
     'segf_layernorm_fwd': (_i, [_i, _l, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
     'segf_layernorm_bwd_ws': (_l, [_l, _i]),
     'segf_layernorm_bwd': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
@@ -617,11 +619,40 @@ def bernoulli_scale(state, keep_prob, n, row_len):
     return out
 
 
-def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None):
+class SegfFinalizeItem(C.Structure):
+    """include/segfac.h: one member of segf_colreduce_finalize_grouped"""
+    _fields_ = [('partial', C.c_void_p), ('out', C.c_void_p), ('len', C.c_int64), ('nblk', C.c_int), ('reserved', C.c_int)]
+
+
+def colreduce_finalize_grouped(items):
+    """items: [(partial fp32 [nblk, n], nblk, n, out fp32 [n])]: the finalize steps of several two-stage reductions in one launch."""
+    if not items:
+        return
+    arr = (SegfFinalizeItem * len(items))()
+    for k, (partial, nblk, n, out) in enumerate(items):
+        _need_cuda(partial, out)
+        # (out may be the first of several ADJACENT views that together hold n elements: LayerNorm's dgamma | dbeta)
+        assert partial.dtype == torch.float32 and out.dtype == torch.float32 and partial.numel() >= nblk * n
+        arr[k].partial, arr[k].out, arr[k].len, arr[k].nblk, arr[k].reserved = partial.data_ptr(), out.data_ptr(), n, nblk, 0
+    _chk(lib().segf_colreduce_finalize_grouped(len(items), C.cast(arr, C.c_void_p), _stream()), 'segf_colreduce_finalize_grouped')
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None, defer=False):
     """dgb_out: optional (dgamma, dbeta) fp32 [C] views that are ADJACENT in memory (dbeta == dgamma + C): written in place.
-    dy2 / dres: optional fan-in operands, dx = LN_bwd(dy + dy2) + dres (segf_layernorm_bwd_fused)."""
+    dy2 / dres: optional fan-in operands, dx = LN_bwd(dy + dy2) + dres (segf_layernorm_bwd_fused).
+    defer=True (needs dgb_out): the kernel leaves its per-block partial sums and (dx, finalize item) is returned; the caller passes the
+    item to colreduce_finalize_grouped later."""
     rows, Cc = x.shape
     dx = torch.empty_like(x)
+    if defer:
+        dg, db = dgb_out
+        assert db.data_ptr() == dg.data_ptr() + 4 * Cc and dg.numel() == Cc and db.numel() == Cc
+        ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
+        for t in (dy2, dres):
+            assert t is None or (t.shape == x.shape and t.dtype == x.dtype and t.is_contiguous())
+        _chk(lib().segf_layernorm_bwd_fused(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(dy2), _ptr(dres), _ptr(gamma), _ptr(mean),
+                                            _ptr(rstd), _ptr(dx), None, None, _ptr(ws), _stream()), 'segf_layernorm_bwd_fused')
+        return dx, (ws, int(lib().segf_layernorm_bwd_blocks(rows, Cc)), 2 * Cc, dg)
     if dgb_out is not None:
         dg, db = dgb_out
         assert db.data_ptr() == dg.data_ptr() + 4 * Cc and dg.numel() == Cc and db.numel() == Cc
