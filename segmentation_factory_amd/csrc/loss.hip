@@ -1420,9 +1420,143 @@ __global__ void __launch_bounds__(LS_THREADS) argmax_confmat_kernel(const T* __r
     }
 }
 
+// LANE = PIXEL form for ratios 4 and 8 (every head of this library but FPNHead predicts at stride 4).  The cell kernel above puts the
+// classes on the lanes and pays two 6-step wave reductions per full-resolution pixel (maximum, then lowest index attaining it), and BOTH
+// kernels above count with two 8-byte global atomics per pixel into a [C][C] matrix -- 64 lanes, 64 unrelated addresses per instruction,
+// the slowest shape an atomic can have (MI355X_MICROARCH.md, "Global float atomics": ~0.08 TB/s): 1.75 ms for a 32-image batch of which
+// the arithmetic is a fifth.  Here
+//   * a wave owns 64 pixels (sc = 4: four cells), stages the cells' four tap rows in LDS as fp32 [cell][class][4 taps] (one 16-byte
+//     broadcast read per class and lane), and every lane walks the classes of ITS pixel with a running (best, index): the four weight
+//     products of bilinear_aten once per pixel, then 1 mul + 3 fma + compare + 2 selects per class, no cross-lane traffic.  Same value per
+//     (pixel, class) as the cell kernel (the same bilinear_aten on the same fp32 taps), lowest index on ties (strict >);
+//   * the counts go into a per-workgroup LDS matrix (uint32 [C][C], C <= 152: 92 KB; one persistent 384-thread workgroup per CU) and
+//     leave it once, at the end, as COALESCED 8-byte atomics of the non-zero entries.  `hist` differs from `mat` only in the row of
+//     an ignore_label that lies inside [0, C) (counted in mat, not in hist), so one LDS matrix serves both.
+#define AMX_CT 152
+#define AMX_WAVES 6
+template <typename T, int SC>
+__global__ void __launch_bounds__(64 * AMX_WAVES) argmax_confmat_pix_kernel(const T* __restrict__ logits, LossGeom g,
+                                                                             const int64_t* __restrict__ target, int64_t ignore_label,
+                                                                             unsigned long long* __restrict__ mat,
+                                                                             unsigned long long* __restrict__ hist, int* __restrict__ flag,
+                                                                             int64_t* __restrict__ pred_out) {
+    constexpr int PP = SC * SC, CPW = 64 / PP, NSM = (AMX_CT + 63) / 64;          // pixels per cell, cells per wave, class slots per lane
+    __shared__ __attribute__((aligned(16))) float taps[AMX_WAVES][CPW][AMX_CT][4];          // [wave][cell][class][t00, t01, t10, t11]
+    __shared__ unsigned cnt[AMX_CT * AMX_CT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nn = g.C * g.C;
+    for (int i = threadIdx.x; i < nn; i += 64 * AMX_WAVES) cnt[i] = 0u;
+    __syncthreads();
+    constexpr int off = SC >> 1;
+    constexpr float inv_sc = 1.f / (float)SC;
+    const int ncx = g.w + 1, ncell = (g.h + 1) * ncx;
+    const int cpi = (ncell + CPW - 1) / CPW;                        // chunks (of CPW cells) per image
+    const int64_t nchunk = (int64_t)g.B * cpi;
+    const int64_t npix = (int64_t)g.H * g.W;
+    const int ci = lane / PP, pl = lane - ci * PP, a = pl / SC, bb = pl - a * SC;
+    float (*tw)[AMX_CT][4] = taps[wave];
+    bool bad = false;
+    // the tap rows of the NEXT chunk travel in registers while the current chunk is evaluated (a wave's chunk is otherwise a serial
+    // chain: global loads -> LDS -> 150 dependent LDS reads, with 1.5 waves per SIMD to cover it)
+    float4 R[CPW][NSM];
+    auto fetch = [&](int64_t chunk) {
+        const int64_t cq = chunk < nchunk ? chunk : nchunk - 1;
+        const int b = (int)(cq / cpi);
+        const int cell0 = (int)(cq - (int64_t)b * cpi) * CPW;
+        const T* img = logits + (int64_t)b * g.h * g.w * g.ldl;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k) {
+            const int cell = cell0 + k < ncell ? cell0 + k : ncell - 1;
+            const Cell c = make_cell(cell / ncx - 1, cell % ncx - 1, g.h, g.w, 1);
+            const T* r00 = img + ((int64_t)c.y0 * g.w + c.x0) * g.ldl;
+            const T* r01 = img + ((int64_t)c.y0 * g.w + c.x1) * g.ldl;
+            const T* r10 = img + ((int64_t)c.y1 * g.w + c.x0) * g.ldl;
+            const T* r11 = img + ((int64_t)c.y1 * g.w + c.x1) * g.ldl;
+#pragma unroll
+            for (int s = 0; s < NSM; ++s) {
+                const int cc = lane + 64 * s < g.C ? lane + 64 * s : g.C - 1;          // clamped: every load unconditional
+                R[k][s] = make_float4(ldf<T>(r00 + cc), ldf<T>(r01 + cc), ldf<T>(r10 + cc), ldf<T>(r11 + cc));
+            }
+        }
+    };
+    const int64_t stride = (int64_t)gridDim.x * AMX_WAVES;
+    int64_t chunk = (int64_t)blockIdx.x * AMX_WAVES + wave;
+    if (chunk < nchunk) fetch(chunk);
+    for (; chunk < nchunk; chunk += stride) {
+        const int b = (int)(chunk / cpi);
+        const int cell0 = (int)(chunk - (int64_t)b * cpi) * CPW;
+        const int64_t* tg = target + (int64_t)b * npix;
+#pragma unroll
+        for (int k = 0; k < CPW; ++k)
+#pragma unroll
+            for (int s = 0; s < NSM; ++s)
+                if (lane + 64 * s < g.C) *reinterpret_cast<float4*>(tw[k][lane + 64 * s]) = R[k][s];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fetch(chunk + stride);                                       // in flight under this chunk's class walk
+        // ---- this lane's pixel
+        const int cell = cell0 + ci;
+        const int cj = cell / ncx - 1, ck = cell - (cell / ncx) * ncx - 1;
+        const int Y = SC * cj + off + a, X = SC * ck + off + bb;
+        const bool inside = cell < ncell && Y >= 0 && Y < g.H && X >= 0 && X < g.W;
+        int64_t t = ignore_label;
+        if (inside) t = tg[(int64_t)Y * g.W + X];
+        const bool in_mat = t >= 0 && t < g.C;
+        const bool need = inside && (pred_out != nullptr || in_mat);       // counted, or the prediction is wanted
+        if (inside && !in_mat && t != ignore_label) bad = true;            // label >= n that is not ignore_label (flagged, counted nowhere)
+        // ATen's weights: see the cell kernel (clamped top / left border cells carry the whole weight on the first tap)
+        const float ly = cj < 0 ? 0.f : ((float)a + 0.5f) * inv_sc, lx = ck < 0 ? 0.f : ((float)bb + 0.5f) * inv_sc;
+        const float wy0 = 1.f - ly, wx0 = 1.f - lx;
+        const float w00 = __fmul_rn(wy0, wx0), w01 = __fmul_rn(wy0, lx), w10 = __fmul_rn(ly, wx0), w11 = __fmul_rn(ly, lx);
+        float best = -INFINITY;
+        int idx = 0;
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            const float (*tc)[4] = tw[ci];
+#pragma unroll 8
+            for (int cc = 0; cc < g.C; ++cc) {
+                const float4 tp = *reinterpret_cast<const float4*>(tc[cc]);
+                const float v = __fmaf_rn(tp.w, w11, __fmaf_rn(tp.z, w10, __fmaf_rn(tp.x, w00, __fmul_rn(tp.y, w01))));
+                const bool gt = v > best;
+                best = gt ? v : best;
+                idx = gt ? cc : idx;
+            }
+        }
+        if (need) {
+            if (pred_out) pred_out[(int64_t)b * npix + (int64_t)Y * g.W + X] = idx;
+            if (in_mat) atomicAdd(&cnt[(int)t * g.C + idx], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the next iteration overwrites the tap rows
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (bad) atomicOr(flag, 1);
+    __syncthreads();
+    const int ign_row = (ignore_label >= 0 && ignore_label < g.C) ? (int)ignore_label : -1;
+    for (int i = threadIdx.x; i < nn; i += 64 * AMX_WAVES) {
+        const unsigned v = cnt[i];
+        if (v) {
+            atomicAdd(mat + i, (unsigned long long)v);
+            if (i / g.C != ign_row) atomicAdd(hist + i, (unsigned long long)v);
+        }
+    }
+}
+
 template <typename T>
 static void argmax_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                           int64_t ign, unsigned long long* mat, unsigned long long* hist, int* flag, int64_t* pred_out) {
+    if ((sc == 4 || sc == 8) && g.C <= AMX_CT && !getenv("SEGFAC_ARGMAX_CELLS")) {
+        // persistent workgroups (one per CU at most: 150 KB of LDS each), fewer when the batch is small so that the final flush of the
+        // per-workgroup matrices (C^2 entries each) does not outweigh the counting
+        const int cpw = 64 / (sc * sc);
+        const int64_t nchunk = (int64_t)g.B * (((int64_t)(g.h + 1) * (g.w + 1) + cpw - 1) / cpw);
+        int64_t nwg = nchunk / (AMX_WAVES * 8);
+        nwg = nwg < 16 ? 16 : (nwg > 256 ? 256 : nwg);
+        if (sc == 4) hipLaunchKernelGGL((argmax_confmat_pix_kernel<T, 4>), dim3((unsigned)nwg), dim3(64 * AMX_WAVES), 0, st, logits, g, target, ign, mat,
+                                        hist, flag, pred_out);
+        else hipLaunchKernelGGL((argmax_confmat_pix_kernel<T, 8>), dim3((unsigned)nwg), dim3(64 * AMX_WAVES), 0, st, logits, g, target, ign, mat,
+                                hist, flag, pred_out);
+        return;
+    }
 #define CALL(NS)                                                                                                                \
     do {                                                                                                                        \
         if (sc) hipLaunchKernelGGL((argmax_confmat_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,  \

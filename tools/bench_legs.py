@@ -233,11 +233,12 @@ def leg_eval(a):
     return {"leg": "eval", "what": "engine.evaluate (eval forward + fused upsample/argmax/confusion matrices), SegFormer-B0 512x512 150 classes, "
                                    f"{nb} batches resident in HBM", "per_gpu_batch": a.batch, "graph": res['graph'], "eager": res['eager'],
             "speedup_graph_over_eager": round(res['graph']['images_per_sec'] / res['eager']['images_per_sec'], 3),
-            "roofline": {"kernel": "argmax_confmat_cells (fused bilinear upsample + argmax + int64 confusion matrices, engine.py:89-91)",
+            "roofline": {"kernel": "argmax_confmat_pix_kernel (fused bilinear upsample + argmax + int64 confusion matrices, engine.py:89-91; lane = pixel, "
+                                   "counts privatised in LDS)",
                          "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4), "avg_launch_ms": round(ms, 4),
                          "algorithmic_bytes_per_launch": nbytes, "traffic": None,
-                         "note": "VALU-bound like the loss: the argmax runs over every full-resolution (pixel, class) pair"}}
+                         "note": "VALU / LDS-latency-bound, not HBM-bound: 1 mul + 3 fma + compare + 2 selects per full-resolution (pixel, class) pair"}}
 
 
 def main():
