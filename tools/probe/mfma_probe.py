@@ -64,10 +64,7 @@ def attn(n):
     for rnd in range(3 if len(variants) > 1 else 1):              # interleaved rounds in one process (same device, same clocks)
         for var in variants:
             if var is not None:
-                if var == 'q1':
-                    os.environ['SEGFAC_ATTN_VARIANT'] = '-1'; os.environ['SEGFAC_ATTN_QW1'] = '1'
-                else:
-                    os.environ['SEGFAC_ATTN_VARIANT'] = var; os.environ.pop('SEGFAC_ATTN_QW1', None)
+                os.environ['SEGFAC_ATTN_VARIANT'] = var
             t0 = timed(lambda: hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, scale), n)
             t1 = timed(lambda: hip.attention_bwd(q, k, v, o, do, lse, B, heads, N, Nkv, hd, scale, dk, dv), n)
             print(f'attention [{B} x {heads} x {N} x {Nkv} x {hd}] variant {var} fwd {ff:.2f} TFLOP {t0:.3f} ms ({ff / t0 * 1e3:.0f} TF/s) | bwd {2.5 * ff:.2f} TFLOP '
