@@ -216,7 +216,8 @@ def leg_eval(a):
     for mode in ('graph', 'eager'):
         args = SimpleNamespace(nb_classes=nc, ignore_label=255, hip_graph=(mode == 'graph'))
         with contextlib.redirect_stdout(sink):
-            evaluate(args, core, data[:3], torch.device('cuda'), a.print_freq)        # warm (captures the eval forward in graph mode)
+            _, mw = evaluate(args, core, data[:3], torch.device('cuda'), a.print_freq)        # warm (captures the eval forward in graph mode)
+            mw.compute_iou()                                                          # ... including the first use of the summary's own kernels
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             confmat, metric = evaluate(args, core, data, torch.device('cuda'), a.print_freq)
