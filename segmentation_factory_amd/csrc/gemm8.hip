@@ -173,10 +173,11 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
             }
             if (BLAY == 0) gB[h][i] = a.B + ((n0 + 128 * h + kc_row + 8 * i) * a.ldb + kbeg + 8 * kc_chunk) * 2;
         }
-    // CONV_A walks K with the CHANNEL BLOCK outermost and the nine taps innermost: K tile T = (64-channel block T / 9, tap T % 9).  The
-    // nine taps of one channel block read the same pixels shifted by a row / a column, back to back in time, so the gathered operand
-    // comes out of the XCD's L2 eight times out of nine; with the tap outermost (the order in which the weights store K) a tap's
-    // re-read came a whole channel sweep -- 17 MB per XCD -- later and missed: FETCH_SIZE 39 GB per launch for a 3.2 GB operand.
+    // CONV_A walks K with the CHANNEL BLOCK outermost and the nine taps innermost: K tile T = (64-channel block T / 9, tap T % 9), so
+    // that the nine taps of one channel block -- the same pixels shifted by a row / a column -- are read back to back in time.  Same-
+    // device A/B against the order in which the weights store K (tap outermost, SEGFAC_G8_KORDER=0): +1.5 % bf16, +13 % fp8; the
+    // counters do not show the L2 reuse this was meant to buy (FETCH_SIZE unchanged at ~20 M KB per launch), so the gain is elsewhere
+    // (the scalar position arithmetic is a multiply-shift by the constant 9 here, by a run-time reciprocal there).
     // (The weight operand's K tile is then the 128-byte piece at (tap, channel block) of its row: a strided walk over the same bytes.)
     const int64_t cv_row = CONV_A ? (int64_t)a.csign * a.lda * 2 : 0;          // bytes per pixel step, signed
     // RM operands (bf16): per-lane fragment addresses inside a half-tile, one per 16-column block of this wave (g8_frag_tr)
