@@ -44,6 +44,21 @@ def synthetic_batch(batch, seed):
     return torch.from_numpy(img), torch.from_numpy(lbl)
 
 
+def numpy_seed_weights(model, seed):
+    """std 0.02 for the linear (2-D) weights, fan-out normal for the convolutions (mit.py:27-40), vectors (norm scales,
+    biases, layer scales) as the modules' own initialisers left them -- all from numpy.random.default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.ndim == 2:
+                p.copy_(torch.from_numpy((rng.standard_normal(tuple(p.shape), dtype=np.float32) * 0.02)))
+            elif p.ndim == 4:
+                groups = p.shape[0] if p.shape[1] == 1 else 1                  # [O, 1, k, k] = depthwise
+                fan_out = p.shape[2] * p.shape[3] * p.shape[0] // groups
+                std = float(np.sqrt(2.0 / max(fan_out, 1)))
+                p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape), dtype=np.float32) * std))
+
+
 def kernel_source_hash():
     """Hash of the HIP sources of the kernels in the roofline objects: stamps profiles/pmc_traffic_*.json so that a counter file
     measured on other kernel code is never reported as this run's traffic."""
@@ -183,6 +198,7 @@ def main():
     core = SegmentationModel(bb_name, num_classes=NC, seg_head=head_name, compute_dtype=dtype).to(dev).train()
     if args.fp8:
         core.set_fp8(True)
+    numpy_seed_weights(core, 0)      # weights from numpy's generator (the same on every box and rank), not from torch's RNG order
     opt = FusedAGCAdamW(param_groups_weight_decay(core, 0.025), lr=2e-4)
     x, y = synthetic_batch(args.batch, seed=rank)
     x, y = x.to(dev), y.to(dev)
