@@ -42,6 +42,18 @@ int segf_cast2d(const void* src, int src_dt, int64_t ld_src, void* dst, int dst_
  * NCHW <-> NHWC at the plugin boundary (mit.py:198 permute).  */
 int segf_permute021(const void* in, int in_dt, void* out, int out_dt, int64_t A, int64_t Bd, int64_t Cd,
                     int64_t ld_out, void* stream);
+/* Several of the three jobs above in ONE launch (the small-batch step is bound by its launch count, train_gpu.py:71 default batch 4):
+ *   op 0  dst[r][c] = (dst_dt) src[r][c]                       rows x cols, leading dimensions ld_src / ld_dst (segf_cast2d)
+ *   op 1  dst[a][c][b] = (dst_dt) src[a][b][c], a < rows, b < pb, c < pc; output row length ld_dst >= pb, the rest zero (segf_permute021);
+ *         cols > 0: element distance between consecutive dst[a] blocks (default pc * ld_dst)
+ *   op 2  dst[r][c] = 0                                        rows x cols at ld_dst
+ * Jobs of one call must not overlap in what they write / read from each other: they run concurrently. */
+typedef struct SegfPrepItem {
+    const void* src; void* dst;
+    int64_t rows, cols, ld_src, ld_dst, pb, pc;
+    int32_t op, src_dt, dst_dt, reserved;
+} SegfPrepItem;
+int segf_prep_grouped(int n, const SegfPrepItem* items, void* stream);
 /* y[r][c] = x[r][c] * scale[r / rows_per_group]   (DropPath backward, models/layers/drop_path.py:18-25) */
 int segf_scale_rows(int dt, const void* x, int64_t ldx, void* y, int64_t ldy, const float* scale,
                     int64_t rows, int64_t cols, int64_t rows_per_group, void* stream);

@@ -96,6 +96,79 @@ extern "C" int segf_permute021(const void* in, int in_dt, void* out, int out_dt,
     return 0;
 }
 
+// ---- grouped tensor preparation: several cast2d / permute021 / zero-fill jobs in ONE launch -----------------------------------
+// At the reference's default batch of 4 (train_gpu.py:71) a step holds ~140 launches that move a few kilobytes each (weight re-layouts
+// of the patch / spatial-reduction convolutions, mit.py:105,47; packing of the decode head's folded weights, heads/segformer.py:42-56;
+// gradient hand-over into the optimizer's flat buffer): each costs the ~4 us launch floor.  The job table rides in the kernel
+// arguments; a block finds its job by a scan of the (wave-uniform) prefix table.  Element values are those of the single kernels.
+#define PREP_MAX 24
+struct PrepGroup { int n; int first[PREP_MAX + 1]; SegfPrepItem it[PREP_MAX]; };
+__device__ __forceinline__ float prep_ld(const void* p, int64_t i, int dt) {
+    return dt == SEGF_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void prep_st(void* p, int64_t i, int dt, float v) {
+    if (dt == SEGF_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f2bf(v);
+}
+__global__ void __launch_bounds__(256) prep_group_kernel(const PrepGroup g) {
+    __shared__ float tile[32][33];
+    int k = 0;
+    while (k + 1 < g.n && (int)blockIdx.x >= g.first[k + 1]) ++k;
+    const SegfPrepItem& it = g.it[k];
+    const int blk = blockIdx.x - g.first[k], nblk = g.first[k + 1] - g.first[k];
+    if (it.op == 1) {                                  // out[a][c][b] = in[a][b][c], columns [pb, ld_dst) of the output zero
+        const int64_t tc = (it.pc + 31) / 32, tb = (it.ld_dst + 31) / 32, ntile = it.rows * tc * tb;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int64_t t = blk; t < ntile; t += nblk) {
+            const int64_t a = t / (tc * tb), r = t - a * tc * tb;
+            const int64_t b0 = (r / tc) * 32, c0 = (r % tc) * 32;
+            const int64_t so = a * it.pb * it.pc, dof = a * (it.cols > 0 ? it.cols : it.pc * it.ld_dst);
+            for (int i = ty; i < 32; i += 8) {
+                const int64_t b = b0 + i, c = c0 + tx;
+                tile[i][tx] = (b < it.pb && c < it.pc) ? prep_ld(it.src, so + b * it.pc + c, it.src_dt) : 0.f;
+            }
+            __syncthreads();
+            for (int i = ty; i < 32; i += 8) {
+                const int64_t c = c0 + i, b = b0 + tx;
+                if (c < it.pc && b < it.ld_dst) prep_st(it.dst, dof + c * it.ld_dst + b, it.dst_dt, b < it.pb ? tile[tx][i] : 0.f);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    const int64_t total = it.rows * it.cols;
+    for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
+        const int64_t r = i / it.cols, c = i - r * it.cols;
+        prep_st(it.dst, r * it.ld_dst + c, it.dst_dt, it.op == 2 ? 0.f : prep_ld(it.src, r * it.ld_src + c, it.src_dt));
+    }
+}
+extern "C" int segf_prep_grouped(int n, const SegfPrepItem* items, void* stream) {
+    if (n <= 0) return 0;
+    if (!items) return SEGF_ERR_SHAPE;
+    for (int i = 0; i < n; ++i) {
+        const SegfPrepItem& it = items[i];
+        if (it.op < 0 || it.op > 2 || !it.dst || (it.op != 2 && !it.src)) return SEGF_ERR_SHAPE;
+        if ((it.src_dt != SEGF_F32 && it.src_dt != SEGF_BF16) || (it.dst_dt != SEGF_F32 && it.dst_dt != SEGF_BF16)) return SEGF_ERR_DTYPE;
+        if (it.rows < 0 || it.cols < 0 || it.ld_dst < 1 || (it.op == 0 && it.ld_src < 1)) return SEGF_ERR_SHAPE;
+        if (it.op == 1 && (it.pb < 1 || it.pc < 1 || it.ld_dst < it.pb)) return SEGF_ERR_SHAPE;
+    }
+    for (int base = 0; base < n; base += PREP_MAX) {
+        PrepGroup g;
+        g.n = n - base < PREP_MAX ? n - base : PREP_MAX;
+        int total = 0;
+        for (int i = 0; i < g.n; ++i) {
+            g.it[i] = items[base + i];
+            const SegfPrepItem& it = g.it[i];
+            const int64_t work = it.op == 1 ? it.rows * cdiv64(it.pc, 32) * cdiv64(it.ld_dst, 32) : cdiv64(it.rows * it.cols, 1024);
+            g.first[i] = total;
+            total += (int)imin64(work > 0 ? work : 1, 2048);
+        }
+        for (int i = g.n; i <= PREP_MAX; ++i) g.first[i] = total;
+        hipLaunchKernelGGL(prep_group_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+        SEGF_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 // ---- 2-D elementwise with leading dims ---------------------------------------------------------------
 template <typename T, int MODE>   // MODE 0: y = x * scale[row / rpg]; MODE 1: y = a + b
 __global__ void ew2d_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, T* __restrict__ y,

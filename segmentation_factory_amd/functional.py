@@ -55,6 +55,57 @@ def _splitk(n_out, k_in, tokens):
     return hip.pick_splitk(n_out, k_in, tokens)
 
 
+# ---- derived weight layouts ------------------------------------------------------------------------------------------------------
+# Several layers consume a re-laid-out copy of a parameter (the [O][(ky,kx)][ci] matrix of a patch / spatial-reduction convolution,
+# mit.py:105,47; the [49][C] table of a depthwise 7 x 7, convnext.py:29).  The copy depends on the weights alone, so inside a train
+# step (graph.GraphedTrainStep) all of them are produced by ONE hip.prep_grouped launch at the start of the step instead of one launch
+# in front of each layer: the registry learns the jobs during the first pass (where each still runs on its own) and replays them.
+_DERIVED = None
+
+
+class DerivedWeights:
+    def __init__(self):
+        self.entries = {}          # key -> (tensor handed to the layer, [prep jobs that (re)build it])
+        self.fresh = False
+
+    def refresh(self):
+        jobs = [j for _, js in self.entries.values() for j in js]
+        if jobs:
+            hip.prep_grouped(jobs)
+        self.fresh = True
+
+
+@contextlib.contextmanager
+def derived_scope(registry):
+    """Inside: derived_weight() hands out the registry's copies, rebuilt here in one launch."""
+    global _DERIVED
+    prev = _DERIVED
+    _DERIVED = registry
+    try:
+        if registry is not None:
+            registry.refresh()
+        yield
+    finally:
+        if registry is not None:
+            registry.fresh = False
+        _DERIVED = prev
+
+
+def derived_weight(param, kind, make):
+    """make() -> (tensor, jobs): allocate the derived copy and list the hip.prep_grouped jobs that fill it from `param`."""
+    reg = _DERIVED
+    key = (param.data_ptr(), kind)
+    if reg is not None and reg.fresh:
+        e = reg.entries.get(key)
+        if e is not None:
+            return e[0]
+    t, jobs = make()
+    hip.prep_grouped(jobs)
+    if reg is not None:
+        reg.entries[key] = (t, jobs)
+    return t
+
+
 # ---- direct gradient placement ---------------------------------------------------------------------------------------------
 # When the fused optimizer has re-homed the parameters into one flat buffer and `enable_direct_grads()` was called (the
 # graphed train step does), every parameter carries `_segf_grad` = its fp32 view in the flat GRADIENT buffer.  The backward
@@ -65,20 +116,40 @@ def _slot(p):
     return getattr(p, '_segf_grad', None) if isinstance(p, torch.Tensor) else None
 
 
+def _deliver_job(slot, value):
+    """The copy job (hip.prep_grouped) that puts `value` into its flat-gradient view, or None when it already lives there."""
+    if value is None or value.data_ptr() == slot.data_ptr():
+        return None
+    v = value.detach()
+    assert v.dtype == torch.float32 and v.numel() == slot.numel(), (v.dtype, v.shape, slot.shape)
+    if slot.ndim <= 1:                      # vectors (possibly a strided column of a wider buffer): copy as an [n, 1] matrix
+        v, d = v.reshape(-1).unsqueeze(1), slot.reshape(-1).unsqueeze(1)
+    else:
+        v, d = v.reshape(slot.shape[0], -1), slot.reshape(slot.shape[0], -1)
+        if v.stride(-1) != 1:
+            v = v.contiguous()
+    return ('cast', v, d)
+
+
 def _deliver(slot_info, value):
     slot, cb = slot_info
-    if value is not None and value.data_ptr() != slot.data_ptr():
-        v = value.detach()
-        assert v.dtype == torch.float32 and v.numel() == slot.numel(), (v.dtype, v.shape, slot.shape)
-        if slot.ndim <= 1:                      # vectors (possibly a strided column of a wider buffer): copy as an [n, 1] matrix
-            v, d = v.reshape(-1).unsqueeze(1), slot.reshape(-1).unsqueeze(1)
-        else:
-            v, d = v.reshape(slot.shape[0], -1), slot.reshape(slot.shape[0], -1)
-            if v.stride(-1) != 1:
-                v = v.contiguous()
-        hip.cast2d(v, d)
+    job = _deliver_job(slot, value)
+    if job is not None:
+        hip.cast2d(job[1], job[2])
     if cb is not None:
         cb(slot)
+
+
+def _deliver_many(pairs):
+    """[(slot_info, value)]: the copies of one backward formula's parameter gradients in ONE launch, then the delivery callbacks."""
+    jobs = [j for j in (_deliver_job(info[0], v) for info, v in pairs) if j is not None]
+    if len(jobs) == 1:
+        hip.cast2d(jobs[0][1], jobs[0][2])
+    elif jobs:
+        hip.prep_grouped(jobs)
+    for info, _ in pairs:
+        if info[1] is not None:
+            info[1](info[0])
 
 
 # ---- deferred, grouped weight gradients -----------------------------------------------------------------------------------------
@@ -129,9 +200,9 @@ def flush_weight_grads():
     if not q:
         return
     hip.gemm_dw_db_grouped([e[0] for e in q])
+    # the layout passes behind the products (the [O][k k][Cin] -> OIHW permutes of the patch convolutions' weight gradients): one launch
+    hip.prep_grouped([post for _, _, post in q if post is not None])
     for _, infos, post in q:
-        if post is not None:
-            post()                                    # e.g. the [O][k k][Cin] -> OIHW permute of a patch convolution's weight gradient
         for info in infos:
             _deliver(info, info[0])                   # the slot IS the result: no copy, only the delivery callback
     q.clear()
@@ -168,7 +239,7 @@ def _queue_dw(ctx, dy, x, n_out, n_in, tokens):
 
 def _queue_dw_post(ctx, dy, x, n_out, n_in, tokens, post_of):
     """As _queue_dw for a layer whose weight gradient needs a layout pass behind the product: the product lands in a temporary
-    [n_out, n_in] fp32 matrix and post_of(temp, weight_slot) runs after the grouped launch."""
+    [n_out, n_in] fp32 matrix and the hip.prep_grouped job post_of(temp, weight_slot) runs after the grouped launch."""
     q = _DW_QUEUE
     slots = getattr(ctx, '_gslots', None)
     if q is None or not slots or 1 not in slots or 2 not in slots:
@@ -178,7 +249,7 @@ def _queue_dw_post(ctx, dy, x, n_out, n_in, tokens, post_of):
         return False
     tmp = torch.empty((n_out, n_in), dtype=torch.float32, device=dy.device)
     gw = slots[1][0]
-    q.append(((dy, x, n_out, n_in, tokens, _splitk(n_out, n_in, tokens), tmp, gb), (slots[1], slots[2]), lambda: post_of(tmp, gw)))
+    q.append(((dy, x, n_out, n_in, tokens, _splitk(n_out, n_in, tokens), tmp, gb), (slots[1], slots[2]), post_of(tmp, gw)))
     if len(q) >= DW_QUEUE_MAX:
         flush_weight_grads()
     return True
@@ -209,10 +280,10 @@ def direct_grads(*param_idx):
             if not slots:
                 return out
             out = list(out) if isinstance(out, tuple) else [out]
-            for i, info in slots.items():
-                if out[i] is not None:
-                    _deliver(info, out[i])
-                    out[i] = None
+            pairs = [(info, out[i]) for i, info in slots.items() if out[i] is not None]
+            _deliver_many(pairs)
+            for i in slots:
+                out[i] = None
             return tuple(out)
         cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
         return cls
@@ -556,13 +627,20 @@ class ConvPatchFn(Function):
             ld = 160
         x = x if x.is_contiguous() else x.contiguous()
         col = hip.im2col(x, dtype, image, B, H, W, Cin, k, k, stride, pad, Ho, Wo, ld)
-        wmat = hip.permute021(weight.detach().contiguous(), O, Cin, k * k, dtype).view(O, K)   # [O][(ky,kx)][ci]
+        wsrc = weight.detach().contiguous()
         b = bias.detach() if bias is not None else None
         if stream_form:
-            wpad = hip.zeros((O, ld), dtype, x.device)
-            hip.cast2d(wmat, wpad[:, :K])
+            def make_wpad():                             # rows of [(ky,kx)][ci] at a row stride of `ld`, the pad columns zero
+                t = torch.empty((O, ld), dtype=dtype, device=x.device)
+                return t, [('perm', wsrc, t, O, Cin, k * k, Cin, ld), ('zero', t[:, K:])]
+            wpad = derived_weight(wsrc, ('patch', dtype, ld), make_wpad)
+            wmat = wpad[:, :K]
             y = hip.gemm(0, col, wpad, B * Ho * Wo, O, ld, bias=b)
         else:
+            def make_wmat():
+                t = torch.empty((O, k * k, Cin), dtype=dtype, device=x.device)
+                return t, [('perm', wsrc, t, O, Cin, k * k, Cin)]
+            wmat = derived_weight(wsrc, ('patch', dtype, K), make_wmat).view(O, K)             # [O][(ky,kx)][ci]
             y = hip.gemm(0, col, wmat, B * Ho * Wo, O, K, bias=b)
         # the im2col matrix itself is kept for the weight gradient (k*k/stride^2 <= 3.1x the conv input, < 1 GB in total
         # for SegFormer-B0 at batch 64 out of 288 GB): rebuilding it in backward costs a second pass over the image
@@ -580,7 +658,7 @@ class ConvPatchFn(Function):
         dx = dw = db = None
         gw, gb = gslot(ctx, 1), gslot(ctx, 2)                # flat-gradient views: the permute / column sum write in place
         if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
-            if not (gw is not None and _queue_dw_post(ctx, dy, col, O, K, M, lambda t, g: hip.permute021(t, O, k * k, Cin, torch.float32, out=g))):
+            if not (gw is not None and _queue_dw_post(ctx, dy, col, O, K, M, lambda t, g: ('perm', t, g, O, k * k, Cin, k * k))):
                 dwm, db = hip.gemm_dw_db(dy, col, O, K, M, split_k=_splitk(O, K, M), db_out=gb)           # [O][(ky,kx)][ci]
                 dw = hip.permute021(dwm, O, k * k, Cin, torch.float32, out=gw).view(wshape)
         else:
@@ -866,19 +944,34 @@ class SegformerFoldedFuseFn(Function):
         one_pass = (dtype == torch.bfloat16 and all(geoms[i] == (B, H1 >> i, W1 >> i) for i in (1, 2, 3))
                     and hip.fuse_map_248_supported(dtype, B, H1, W1, E, feats[0].shape[1]))
         G1, beta1 = None, None
+        # W'_i = [W_i | b_i | 0] (bias as one extra input column): one GEMM yields G_i = F_i W_i and beta_i = F_i b_i.  The packing of
+        # the four W'_i is ONE launch, the unpacking of the four products another (hip.prep_grouped) -- at batch 4 these 24 jobs were
+        # 24 launches of the launch floor each
+        xs, Wps, Gps, Gs, betas, jobs = [], [], [], [], [], []
         for i in range(4):
             x = _rowmajor(feats[i])
             Ci = x.shape[1]
-            # W'_i = [W_i | b_i | 0] (bias as one extra input column): one GEMM yields G_i = F_i W_i and beta_i = F_i b_i
-            Wp = hip.zeros((E, Ci + 8), dtype, dev)
-            hip.cast2d(weights[i].detach(), Wp[:, :Ci])
-            hip.cast2d(biases[i].detach().unsqueeze(1), Wp[:, Ci:Ci + 1])
+            Wp = torch.empty((E, Ci + 8), dtype=dtype, device=dev)
+            jobs += [('cast', weights[i].detach(), Wp[:, :Ci]), ('cast', biases[i].detach().unsqueeze(1), Wp[:, Ci:Ci + 1]),
+                     ('zero', Wp[:, Ci + 1:])]
+            xs.append(x)
+            Wps.append(Wp)
+        hip.prep_grouped(jobs)
+        jobs = []
+        for i in range(4):
+            Ci = xs[i].shape[1]
             Fi = wfc[:, (3 - i) * E:(4 - i) * E]
-            Gp = hip.gemm(1, Fi, Wp, E, Ci + 8, E, out_dtype=torch.float32)                # [E, Ci+8] fp32
+            Gp = hip.gemm(1, Fi, Wps[i], E, Ci + 8, E, out_dtype=torch.float32)                # [E, Ci+8] fp32
             G = torch.empty((E, Ci), dtype=dtype, device=dev)
-            hip.cast2d(Gp[:, :Ci], G)
             beta_i = torch.empty(E, dtype=torch.float32, device=dev)
-            hip.cast2d(Gp[:, Ci:Ci + 1], beta_i.unsqueeze(1))
+            jobs += [('cast', Gp[:, :Ci], G), ('cast', Gp[:, Ci:Ci + 1], beta_i.unsqueeze(1))]
+            Gps.append(Gp)
+            Gs.append(G)
+            betas.append(beta_i)
+        hip.prep_grouped(jobs)
+        for i in range(4):
+            x, G, beta_i, Wp = xs[i], Gs[i], betas[i], Wps[i]
+            Ci = x.shape[1]
             _, h, w = geoms[i]
             if one_pass and i == 0:
                 G1, beta1 = G, beta_i
@@ -917,6 +1010,7 @@ class SegformerFoldedFuseFn(Function):
         if (H1 % 8 == 0 and W1 % 8 == 0 and E % 8 == 0 and not os.environ.get('SEGFAC_NO_BWD248')
                 and all(geoms[i][1:] == (H1 >> i, W1 >> i) for i in (1, 2, 3))):
             dts = hip.bilinear_bwd_248(dy, B, H1, W1, E)          # the three transposed resizes in ONE pass over dy
+        dGps = []
         for i in range(4):
             x, G, Wp = sv[1 + 3 * i], sv[2 + 3 * i], sv[3 + 3 * i]
             _, h, w = geoms[i]
@@ -926,18 +1020,29 @@ class SegformerFoldedFuseFn(Function):
             pre = ctx.fold_slot.pop('dG', None) if (i == 0 and ctx.fold_slot is not None) else None
             if pre is not None and tuple(pre.shape) == (E, Ci + 8):
                 dGp = pre                          # [dy^T x_1 | colsum(dy) | 0] arrived with dy (segf_bn_cls_bwd_dw)
-                dbeta = torch.empty(E, dtype=torch.float32, device=dev)
-                hip.cast2d(dGp[:, Ci:Ci + 1], dbeta.unsqueeze(1))
+                dbeta = dGp[:, Ci]
             else:
-                dGp = hip.zeros((E, Ci + 8), torch.float32, dev)                            # d [G_i | beta_i | 0]
-            if pre is not None and tuple(pre.shape) == (E, Ci + 8):
-                pass
-            elif i == 0:
-                _, dbeta = hip.gemm_dw_db(dt, x, E, Ci, M, split_k=_splitk(E, Ci, M), out=dGp[:, :Ci])
+                dGp = torch.empty((E, Ci + 8), dtype=torch.float32, device=dev)             # d [G_i | . ]: the product fills [:, :Ci]
+                if i == 0:
+                    _, dbeta = hip.gemm_dw_db(dt, x, E, Ci, M, split_k=_splitk(E, Ci, M), out=dGp[:, :Ci])
+                else:
+                    hip.gemm(2, dt, x, E, Ci, M, out=dGp[:, :Ci], split_k=_splitk(E, Ci, M))
+            dGps.append(dGp)
+        # d [G_i | beta_i | 0] in the compute dtype, all four in one launch
+        dGcs, jobs = [], []
+        for i in range(4):
+            Ci = sv[1 + 3 * i].shape[1]
+            if dtype == torch.float32:
+                dGc = dGps[i]
+                jobs += [('zero', dGc[:, Ci + 1:])] + ([('cast', dbeta.unsqueeze(1), dGc[:, Ci:Ci + 1])] if dbeta.data_ptr() != dGc[:, Ci].data_ptr() else [])
             else:
-                hip.gemm(2, dt, x, E, Ci, M, out=dGp[:, :Ci], split_k=_splitk(E, Ci, M))
-            hip.cast2d(dbeta.unsqueeze(1), dGp[:, Ci:Ci + 1])
-            dGc = _w(dGp, dtype)
+                dGc = torch.empty((E, Ci + 8), dtype=dtype, device=dev)
+                jobs += [('cast', dGps[i][:, :Ci], dGc[:, :Ci]), ('cast', dbeta.unsqueeze(1), dGc[:, Ci:Ci + 1]), ('zero', dGc[:, Ci + 1:])]
+            dGcs.append(dGc)
+        hip.prep_grouped(jobs)
+        for i in range(4):
+            Wp, dGc = sv[3 + 3 * i], dGcs[i]
+            Ci = sv[1 + 3 * i].shape[1]
             Fi = wfc[:, (3 - i) * E:(4 - i) * E]
             hip.gemm(0, dGc, Wp, E, E, Ci + 8, out=dwf[:, (3 - i) * E:(4 - i) * E])          # dF_i = dG_i W_i^T + dbeta b_i^T
             dWp = hip.gemm(2, Fi, dGc, E, Ci + 8, E, out_dtype=torch.float32)               # [dW_i | db_i | 0] = F_i^T dG'_i
@@ -965,7 +1070,12 @@ class DWConv7Fn(Function):
     def forward(ctx, x, weight, bias, B, H, W):
         x = x if x.is_contiguous() else x.contiguous()
         Cc = x.shape[1]
-        wt = hip.permute021(weight.detach().reshape(1, Cc, 49), 1, Cc, 49, torch.float32).view(49, Cc)
+        wsrc = weight.detach().contiguous()
+
+        def make_wt():
+            t = torch.empty((49, Cc), dtype=torch.float32, device=x.device)
+            return t, [('perm', wsrc, t, 1, Cc, 49, Cc)]
+        wt = derived_weight(wsrc, ('dw7',), make_wt)                                              # [49][C] fp32
         y = hip.dwconv7x7_fwd(x, wt, bias.detach() if bias is not None else None, B, H, W, Cc)
         ctx.save_for_backward(x, wt)
         ctx.meta = (B, H, W, Cc, weight.shape, bias is not None)
@@ -993,7 +1103,13 @@ class Conv3x3Fn(Function):
     def forward(ctx, x, weight, B, H, W, fp8=False):
         x = _rowmajor(x)
         O, I = weight.shape[0], weight.shape[1]
-        wm = hip.permute021(weight.detach().reshape(O, I, 9), O, I, 9, x.dtype).view(O, 9 * I)          # [O][(ky,kx)][ci]
+        wsrc = weight.detach().contiguous()
+        cdt = x.dtype
+
+        def make_wm():
+            t = torch.empty((O, 9, I), dtype=cdt, device=x.device)
+            return t, [('perm', wsrc, t, O, I, 9, I)]
+        wm = derived_weight(wsrc, ('conv3x3', cdt), make_wm).view(O, 9 * I)                         # [O][(ky,kx)][ci]
         use8 = bool(fp8) and x.dtype == torch.bfloat16 and hip.conv3x3_fp8_supported(0, B, H, W, I, O)
         xq = sx = None
         if use8:

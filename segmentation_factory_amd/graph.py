@@ -243,6 +243,7 @@ class GraphedTrainStep:
                 self._shadow_map[p.data_ptr()] = self._shadow[o:o + p.numel()]
         self.opt.enable_direct_grads(self._on_grad_written if (self.exchanging and overlap) else None)
         self._seed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.static_inputs[0].device)
+        self._derived = None if os.environ.get('SEGFAC_NO_DERIVED_WEIGHTS') else Fh.DerivedWeights()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         # the warm-up passes run real train-mode forwards: snapshot every buffer (BatchNorm running_mean / running_var /
@@ -284,7 +285,8 @@ class GraphedTrainStep:
         else:
             scope = contextlib.nullcontext()
         self.opt.begin_backward()
-        with scope, Fh.defer_weight_grads():      # the Linear layers' weight gradients are queued and issued in grouped launches
+        # (the re-laid-out weight copies of the step in one launch; the weight gradients queued and issued in grouped launches)
+        with scope, Fh.derived_scope(self._derived), Fh.defer_weight_grads():      # the Linear layers' weight gradients are queued and issued in grouped launches
             loss = self.loss_fn(self.model, *self.static_inputs)
             # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
             loss.backward(gradient=self._seed if self.exchanging else None)

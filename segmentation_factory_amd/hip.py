@@ -22,6 +22,7 @@ _PROTOS = {
     'segf_cast': (_i, [_p, _i, _p, _i, _l, _p]),
     'segf_cast2d': (_i, [_p, _i, _l, _p, _i, _l, _l, _l, _p]),
     'segf_permute021': (_i, [_p, _i, _p, _i, _l, _l, _l, _l, _p]),
+    'segf_prep_grouped': (_i, [_i, _p, _p]),
     'segf_scale_rows': (_i, [_i, _p, _l, _p, _l, _p, _l, _l, _l, _p]),
     'segf_add': (_i, [_i, _p, _l, _p, _l, _p, _l, _l, _l, _p]),
     'segf_colsum_ws': (_l, [_l, _l]),
@@ -220,6 +221,64 @@ def permute021(x: torch.Tensor, A: int, Bd: int, Cd: int, out_dtype: torch.dtype
     _chk(lib().segf_permute021(_ptr(x), dt_of(x), _ptr(out), BF16 if out_dtype == torch.bfloat16 else F32,
                                A, Bd, Cd, ld_out, _stream()), 'segf_permute021')
     return out
+
+
+class SegfPrepItem(C.Structure):
+    """include/segfac.h: one job of segf_prep_grouped"""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('rows', C.c_int64), ('cols', C.c_int64), ('ld_src', C.c_int64),
+                ('ld_dst', C.c_int64), ('pb', C.c_int64), ('pc', C.c_int64), ('op', C.c_int32), ('src_dt', C.c_int32),
+                ('dst_dt', C.c_int32), ('reserved', C.c_int32)]
+
+
+def _as2d(src, dst):
+    if src is not None and src.ndim == 1:
+        src = src.view(1, -1) if src.stride(0) == 1 else src.unsqueeze(1)
+    if dst.ndim == 1:
+        dst = dst.view(1, -1) if dst.stride(0) == 1 else dst.unsqueeze(1)
+    return src, dst
+
+
+def prep_grouped(jobs):
+    """Several small layout jobs in one launch (segf_prep_grouped); jobs must be independent of each other:
+        ('cast', src, dst)                        dst[r, c] = src[r, c] (2-D with unit inner stride or a column, or 1-D), as cast2d
+        ('zero', dst)                             dst[r, c] = 0
+        ('perm', src, dst, A, Bd, Cd, ld_out[, a_stride])   dst[a][c][b] = src[a][b][c], last dim zero-padded to ld_out, as permute021;
+                                                  a_stride: element distance between the out[a] blocks (rows of a wider matrix)"""
+    if not jobs:
+        return
+    arr = (SegfPrepItem * len(jobs))()
+    for k, job in enumerate(jobs):
+        it = arr[k]
+        it.pb = it.pc = it.ld_src = it.cols = 0
+        it.reserved = 0
+        if job[0] == 'perm':
+            _, src, dst, A, Bd, Cd, ld_out = job[:7]
+            astride = job[7] if len(job) > 7 else 0          # optional: distance between consecutive out[a] blocks (default Cd * ld_out)
+            _need_cuda(src, dst)
+            assert src.is_contiguous() and src.numel() == A * Bd * Cd
+            if astride:
+                assert astride >= Cd * ld_out and dst.ndim == 2 and dst.shape[0] == A and dst.stride(0) == astride and dst.stride(1) == 1
+            else:
+                assert dst.is_contiguous() and dst.numel() == A * Cd * ld_out
+            it.op, it.src, it.dst, it.rows, it.pb, it.pc, it.ld_dst = 1, src.data_ptr(), dst.data_ptr(), A, Bd, Cd, ld_out
+            it.cols = astride
+            it.src_dt, it.dst_dt = dt_of(src), dt_of(dst)
+        elif job[0] == 'cast':
+            src, dst = _as2d(job[1], job[2])
+            _need_cuda(src, dst)
+            rows, cols = src.shape
+            assert tuple(dst.shape) == (rows, cols) and (cols == 1 or (src.stride(1) == 1 and dst.stride(1) == 1)), (src.shape, dst.shape)
+            it.op, it.src, it.dst, it.rows, it.cols = 0, src.data_ptr(), dst.data_ptr(), rows, cols
+            it.ld_src, it.ld_dst, it.src_dt, it.dst_dt = max(src.stride(0), 1), max(dst.stride(0), 1), dt_of(src), dt_of(dst)
+        else:
+            assert job[0] == 'zero'
+            _, dst = _as2d(None, job[1])
+            _need_cuda(dst)
+            rows, cols = dst.shape
+            assert cols == 1 or dst.stride(1) == 1
+            it.op, it.src, it.dst, it.rows, it.cols, it.ld_dst = 2, None, dst.data_ptr(), rows, cols, max(dst.stride(0), 1)
+            it.src_dt = it.dst_dt = dt_of(dst)
+    _chk(lib().segf_prep_grouped(len(jobs), C.cast(arr, C.c_void_p), _stream()), 'segf_prep_grouped')
 
 
 def scale_rows(x: torch.Tensor, scale: torch.Tensor, rows_per_group: int) -> torch.Tensor:

@@ -1683,3 +1683,99 @@ def test_grouped_weight_gradients_equal_per_layer_launches():
     dy, x, M, N, K = items[3][0], items[3][1], *shapes[3]
     ref = dy.float().t() @ x.float()
     assert (items[3][6] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_prep_grouped_equals_single_kernels():
+    """segf_prep_grouped (the small layout jobs of a step in one launch: patch / spatial-reduction conv weight re-layouts, mit.py:105,47;
+    the decode head's folded-weight packing, heads/segformer.py:42-56; gradient hand-over) must give, job by job, BITWISE what
+    segf_cast2d / segf_permute021 / segf_zero give -- 30 jobs (more than one group of 24), every dtype pair, strided columns,
+    a permute with padded rows and one into the rows of a wider matrix."""
+    from segmentation_factory_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(11)
+
+    def rnd(*shape, dtype=torch.float32):
+        return torch.randn(*shape, generator=g, device='cuda').to(dtype)
+    jobs, checks = [], []
+    for k in range(6):
+        for sdt, ddt in ((torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)):
+            rows, cols = 17 + 5 * k, 33 + 8 * k
+            src = rnd(rows, cols + 8, dtype=sdt)[:, 3:3 + cols]
+            dst = torch.full((rows, cols + 16), 7.0, dtype=ddt, device='cuda')
+            ref = dst.clone()
+            hip.cast2d(src, ref[:, 8:8 + cols])
+            jobs.append(('cast', src, dst[:, 8:8 + cols]))
+            checks.append((dst, ref))
+    # a column into a column, a 1-D vector, zero fills of a strided block and of a vector
+    src = rnd(40, 12)
+    dst = torch.full((40, 9), 3.0, device='cuda')
+    ref = dst.clone()
+    hip.cast2d(src[:, 5:6], ref[:, 2:3])
+    jobs.append(('cast', src[:, 5:6], dst[:, 2:3]))
+    checks.append((dst, ref))
+    v, dv = rnd(257), torch.empty(257, dtype=torch.bfloat16, device='cuda')
+    jobs.append(('cast', v, dv))
+    checks.append((dv, v.to(torch.bfloat16)))
+    z = torch.full((64, 40), 5.0, dtype=torch.bfloat16, device='cuda')
+    refz = z.clone()
+    refz[:, 33:] = 0
+    jobs.append(('zero', z[:, 33:]))
+    checks.append((z, refz))
+    z1 = torch.full((1000,), 2.0, device='cuda')
+    jobs.append(('zero', z1))
+    checks.append((z1, torch.zeros(1000, device='cuda')))
+    # permutes: OIHW -> O (kh kw) I in bf16 (a MiT spatial-reduction conv at sr = 8), with the last dim padded, fp32 -> fp32, and into rows of
+    # a 160-wide matrix (the stem)
+    w = rnd(64, 32, 64)
+    out = torch.empty((64, 64, 32), dtype=torch.bfloat16, device='cuda')
+    jobs.append(('perm', w, out, 64, 32, 64, 32))
+    checks.append((out, hip.permute021(w, 64, 32, 64, torch.bfloat16)))
+    w2 = rnd(5, 19, 45)
+    out2 = torch.empty((5, 45, 24), dtype=torch.float32, device='cuda')
+    jobs.append(('perm', w2, out2, 5, 19, 45, 24))
+    checks.append((out2, hip.permute021(w2, 5, 19, 45, torch.float32, ld_out=24)))
+    w3 = rnd(32, 3, 49)
+    out3 = torch.full((32, 160), 9.0, dtype=torch.bfloat16, device='cuda')
+    ref3 = out3.clone()
+    ref3[:, :147] = hip.permute021(w3, 32, 3, 49, torch.bfloat16).view(32, 147)
+    jobs.append(('perm', w3, out3, 32, 3, 49, 3, 160))
+    checks.append((out3, ref3))
+    assert len(jobs) > 24
+    hip.prep_grouped(jobs)
+    torch.cuda.synchronize()
+    for k, (got, want) in enumerate(checks):
+        assert torch.equal(got, want), k
+
+
+def test_derived_weights_registry_matches_direct_layouts():
+    """functional.derived_scope: the re-laid-out weight copies of a step come from ONE launch at the start of the step and must equal what each
+    layer used to build for itself (ConvPatchFn: mit.py:105,47; the stem's 160-column form; DWConv7Fn: convnext.py:29) -- outputs and
+    gradients of a patch conv, an spatial-reduction conv and a depthwise 7 x 7 with and without the registry, second pass (registry replayed),
+    after a weight update in between."""
+    from segmentation_factory_amd import functional as Fh
+    g = torch.Generator().manual_seed(2)
+    B = 2
+    img = torch.randn(B, 3, 128, 128, generator=g).cuda()
+    tok = torch.randn(B * 32 * 32, 32, generator=g).cuda().to(torch.bfloat16)
+    ws = [torch.randn(32, 3, 7, 7, generator=g).cuda().requires_grad_(), torch.randn(32, 32, 4, 4, generator=g).mul(0.05).cuda().requires_grad_(),
+          torch.randn(32, 1, 7, 7, generator=g).mul(0.1).cuda().requires_grad_()]
+    bs = [torch.randn(32, generator=g).cuda().requires_grad_() for _ in range(3)]
+
+    def run():
+        y1 = Fh.conv_patch(img, ws[0], bs[0], (B, 128, 128, 3, 7, 4, 3), image=True, dtype=torch.bfloat16)
+        y2 = Fh.conv_patch(tok, ws[1], bs[1], (B, 32, 32, 32, 4, 4, 0))
+        y3 = Fh.dwconv7x7(tok, ws[2], bs[2], B, 32, 32)
+        for p in ws + bs:
+            p.grad = None
+        (y1.float().sum() + y2.float().square().sum() + y3.float().square().sum()).backward()
+        return [y1, y2, y3] + [p.grad.clone() for p in ws + bs]
+    reg = Fh.DerivedWeights()
+    for step in range(3):
+        want = run()
+        with Fh.derived_scope(reg):
+            got = run()
+        assert len(reg.entries) == 3
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), step
+        with torch.no_grad():
+            for p in ws:
+                p.mul_(1.25)
