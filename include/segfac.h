@@ -213,7 +213,9 @@ int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const v
 /* Deferred finalize: with dgamma == NULL segf_layernorm_bwd_fused leaves its per-block partial sums [blocks][2 C] in ws
  * (blocks = segf_layernorm_bwd_blocks(rows, C)) and the caller finalizes SEVERAL such reductions in one launch later:
  * out[i] = sum_b partial[b][i], i < len, summed in the order of the single finalize (bitwise the same dgamma / dbeta). */
-typedef struct SegfFinalizeItem { const float* partial; float* out; int64_t len; int nblk; int reserved; } SegfFinalizeItem;
+typedef struct SegfFinalizeItem { const float* partial; float* out; int64_t len; int nblk; int scatter_c; } SegfFinalizeItem;
+/* scatter_c = C > 0 (len must be 10 C): the sums are the [10][C] partials of segf_dwconv3x3_gelu_bwd called with dw == NULL
+ * (segf_dwconv3x3_bwd_blocks(B, H, W, C) blocks in its ws) and land as out = dw[C][9] followed by db[C] (mit.py:62-71 backward). */
 int segf_layernorm_bwd_blocks(int64_t rows, int C);
 int segf_colreduce_finalize_grouped(int n, const SegfFinalizeItem* items, void* stream);
 
@@ -293,6 +295,7 @@ int segf_dwconv3x3_gelu_fwd(int dt, int B, int H, int W, int C, const void* x, c
                             const float* bias, int apply_gelu, void* y, void* stream);
 int64_t segf_dwconv3x3_bwd_ws(int B, int H, int W, int C);
 /* du = dy * gelu'(conv(x)+b) is written to `du` (same shape as x); dx = conv^T(du); dw[C][9], db[C] fp32 */
+int segf_dwconv3x3_bwd_blocks(int B, int H, int W, int C);
 int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
                             int apply_gelu, const void* dy, void* du, void* dx, float* dw, float* db,
                             float* ws, void* stream);

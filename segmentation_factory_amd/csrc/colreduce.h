@@ -180,6 +180,7 @@ struct ColreduceGroup {
     unsigned start[CRF_GROUP_MAX + 1];
     const float* partial[CRF_GROUP_MAX]; float* out[CRF_GROUP_MAX];
     int nblk[CRF_GROUP_MAX]; int64_t len[CRF_GROUP_MAX];
+    int scatter_c[CRF_GROUP_MAX];      // > 0: sums [10][C] of a depthwise 3x3 weight gradient -> out = dw[C][9] followed by db[C]
 };
 static __global__ void __launch_bounds__(CRF_OUT * CRF_SL) colreduce_finalize_group_kernel(const ColreduceGroup g) {
     __shared__ float red[CRF_SL][CRF_OUT + 1];
@@ -202,7 +203,13 @@ static __global__ void __launch_bounds__(CRF_OUT * CRF_SL) colreduce_finalize_gr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < CRF_SL; ++k) t += red[k][o];
-        g.out[m][i] = t;
+        const int sc = g.scatter_c[m];
+        if (sc > 0) {                          // what dw_scatter_kernel (conv.hip) does behind the single finalize
+            const int kk = (int)(i / sc), c = (int)(i - (int64_t)kk * sc);
+            g.out[m][kk < 9 ? c * 9 + kk : 9 * sc + c] = t;
+        } else {
+            g.out[m][i] = t;
+        }
     }
 }
 static inline void colreduce_finalize_launch(const float* partial, int nblk, int64_t n, float* out, hipStream_t st, int nbatch = 1) {

@@ -581,11 +581,16 @@ extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const
                            (const T*)nullptr, (T*)dx, B, H, W, C);
     })
     SEGF_CHECK_LAUNCH();
+    if (!dw) return 0;          // deferred: the partial sums [blocks][10 C] stay in ws for segf_colreduce_finalize_grouped (scatter_c = C)
     colreduce_finalize_launch(ws, p.nblk, 10 * (int64_t)C, sums, st);
     SEGF_CHECK_LAUNCH();
     hipLaunchKernelGGL(dw_scatter_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dw, db);
     SEGF_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int segf_dwconv3x3_bwd_blocks(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return dw_use_walk() ? dww_plan(B, H, W, C).nblk : dwg_plan(B, H, W, C).nblk;
 }
 
 // ---- depthwise 7x7 (ConvNeXt Block.dwconv, models/backbones/convnext.py:29,39; convnextv2.py:88,101) ---------------------

@@ -1193,6 +1193,23 @@ static inline bool splitk_reduce_is_wide(const float* ws, int64_t M, int64_t N, 
     return M * N >= 65536 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !getenv("SEGFAC_NO_WIDE_REDUCE");
 }
 
+// segf_gemm_dw_db_grouped collects the reduce passes of the products it cannot group (streaming / 256-tile kernels) here and issues
+// them as grouped launches too: while the sink is set, gemm_impl appends its fp32 reduce instead of launching it
+static thread_local ReduceGroup* g_reduce_sink = nullptr;
+static bool reduce_sink_take(const float* ws, int split, int64_t M, int64_t N, float* C, int64_t ldc, const float* cs_ws, float* cs_out,
+                             int64_t cs_n) {
+    ReduceGroup* r = g_reduce_sink;
+    if (!r || r->n >= GDW_MAX) return false;
+    const int k = r->n;
+    const bool wide = splitk_reduce_is_wide(ws, M, N, C, ldc);
+    const unsigned blocks = (unsigned)cdiv64(M * N, wide ? 1024 : 16), csb = cs_ws ? (unsigned)cdiv64(cs_n, wide ? 256 : 16) : 0u;
+    r->wide[k] = wide ? 1 : 0; r->split[k] = split; r->ws[k] = ws; r->C[k] = C; r->cs_ws[k] = cs_ws; r->cs_out[k] = cs_out;
+    r->M[k] = M; r->N[k] = N; r->ldc[k] = ldc; r->cs_n[k] = cs_n; r->main_blocks[k] = blocks;
+    r->start[k + 1] = r->start[k] + blocks + csb;
+    ++r->n;
+    return true;
+}
+
 // one entry for every split-K product: picks the form by output size
 template <typename OutT>
 static void splitk_reduce_launch(hipStream_t st, const float* ws, int split, int64_t M, int64_t N, OutT* C, int64_t ldc,
@@ -1907,6 +1924,15 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         g.n = 0; r.n = 0;
         return 0;
     };
+    ReduceGroup r2;
+    r2.n = 0; r2.start[0] = 0;
+    auto flush2 = [&]() -> int {
+        if (r2.n == 0) return 0;
+        hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(r2.start[r2.n]), dim3(256), 0, st, r2);
+        SEGF_CHECK_LAUNCH();
+        r2.n = 0;
+        return 0;
+    };
     const bool no_group = getenv("SEGFAC_NO_GROUPED_DW") != nullptr;
     for (int i = 0; i < n; ++i) {
         const SegfDwItem& it = items[i];
@@ -1922,8 +1948,12 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
                                !getenv("SEGFAC_GEMM_NO_TR") && !getenv("SEGFAC_GEMM_NO_DEEP128") && !getenv("SEGFAC_GEMM_NO_DEEP128_L2") &&
                                !getenv("SEGFAC_GEMM_FASTLOAD_L2") && M % 8 == 0 && N % 8 == 0 && slices > 1 && cdiv64(M, GB_BM) <= 65535;
         if (!groupable) {                        // (the items are independent of each other: no need to close the open group)
+            // its product launches now; its reduce pass joins the others' in r2 (issued when full and at the end of the call)
+            g_reduce_sink = no_group ? nullptr : &r2;
             const int rc = segf_gemm_dw_db(dt, M, N, K, it.dy, it.lddy, it.x, it.ldx, it.dw, SEGF_F32, it.lddw, split_k, it.ws, it.db, stream);
+            g_reduce_sink = nullptr;
             if (rc) return rc;
+            if (r2.n == GDW_MAX) { const int rc2 = flush2(); if (rc2) return rc2; }
             continue;
         }
         // the arguments gemm_impl builds for this product (layout 2, fp32 output, split-K partials in ws, bias column riding)
@@ -1952,7 +1982,8 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         ++r.n;
         if (g.n == GDW_MAX) { const int rc = flush(); if (rc) return rc; }
     }
-    return flush();
+    { const int rc = flush(); if (rc) return rc; }
+    return flush2();
 }
 
 // Product whose activation operand is normalised on the way in (BatchNorm + ReLU + Dropout2d scale of ConvModule, heads/
@@ -2158,6 +2189,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
 reduce:
     if (a.ws) {
         // (the bias gradient's slices ride in the same launch)
+        if (c_dt == SEGF_F32 && reduce_sink_take(ws, split_k, M, N, (float*)C, ldc, a.colsum_ws, a.colsum, M)) return 0;
         if (c_dt == SEGF_F32) splitk_reduce_launch<float>(st, ws, split_k, M, N, (float*)C, ldc, a.colsum_ws, a.colsum, M);
         else splitk_reduce_launch<bf16_t>(st, ws, split_k, M, N, (bf16_t*)C, ldc, a.colsum_ws, a.colsum, M);
         SEGF_CHECK_LAUNCH();

@@ -283,7 +283,8 @@ extern "C" int segf_colreduce_finalize_grouped(int n, const SegfFinalizeItem* it
         if (it.len <= 0 || it.nblk <= 0) continue;
         if (!it.partial || !it.out) return SEGF_ERR_SHAPE;
         const int k = g.n;
-        g.partial[k] = it.partial; g.out[k] = it.out; g.nblk[k] = it.nblk; g.len[k] = it.len;
+        if (it.scatter_c < 0 || (it.scatter_c > 0 && it.len != 10 * (int64_t)it.scatter_c)) return SEGF_ERR_SHAPE;
+        g.partial[k] = it.partial; g.out[k] = it.out; g.nblk[k] = it.nblk; g.len[k] = it.len; g.scatter_c[k] = it.scatter_c;
         g.start[k + 1] = g.start[k] + (unsigned)cdiv64(it.len, CRF_OUT);
         if (++g.n == CRF_GROUP_MAX || i == n - 1) {
             hipLaunchKernelGGL(colreduce_finalize_group_kernel, dim3(g.start[g.n]), dim3(CRF_OUT * CRF_SL), 0, st, g);

@@ -299,6 +299,26 @@ def gslot(ctx, i, shape=None):
     return v.view(shape) if shape is not None else v
 
 
+def _padded_rows(weight, bias, N, Np, K, dtype, device):
+    """(w [Np, K] in `dtype`, b [Np] fp32 or None): the layer's parameters with zero rows up to Np (a column-padded output, e.g. 150 classes
+    -> 152).  Weights-only work: inside a train step it comes from the step's one derived-weights launch."""
+    wsrc = weight.detach().reshape(N, -1)
+
+    def make_w():
+        t = torch.empty((Np, K), dtype=dtype, device=device)
+        return t, [('cast', wsrc, t[:N]), ('zero', t[N:])]
+    w = derived_weight(weight.detach(), ('padrows', dtype, Np), make_w)
+    b = None
+    if bias is not None:
+        bsrc = bias.detach()
+
+        def make_b():
+            t = torch.empty((Np,), dtype=torch.float32, device=device)
+            return t, [('cast', bsrc.unsqueeze(1), t[:N].unsqueeze(1)), ('zero', t[N:])]
+        b = derived_weight(bsrc, ('padrows', Np), make_b)
+    return w, b
+
+
 @direct_grads(1, 2)
 class LinearFn(Function):
     """y = [residual + rscale[b] *] (x W^T + bias)   (nn.Linear / 1x1 conv on tokens).
@@ -340,12 +360,7 @@ class LinearFn(Function):
             # and biases are zero, so the pad columns of y are exact zeros, every 16-byte chunk of a row is either fully
             # valid or fully padding, and the backward products take the padded gradient as it stands
             assert residual is None
-            w = hip.zeros((Np, K), x.dtype, x.device)
-            hip.cast2d(weight.detach().reshape(N, -1), w[:N])
-            b = None
-            if bias is not None:
-                b = hip.zeros((Np,), torch.float32, x.device)
-                hip.cast2d(bias.detach().unsqueeze(1), b[:N].unsqueeze(1))
+            w, b = _padded_rows(weight, bias, N, Np, K, x.dtype, x.device)
             y = hip.gemm(0, x, w, M, Np, K, bias=b)[:, :N]
         else:
             w = _w(weight.reshape(N, -1), x.dtype)
@@ -726,6 +741,15 @@ class DWConvGeluFn(Function):
         B, H, W, Cc, apply_gelu, wshape = ctx.meta
         dy = dy if dy.is_contiguous() else dy.contiguous()
         gw, gb = gslot(ctx, 1), (gslot(ctx, 2) if b is not None else None)       # flat-gradient views: written in place, no copy
+        q = _FIN_QUEUE
+        if q is not None and gw is not None and gb is not None and gb.data_ptr() == gw.data_ptr() + 4 * gw.numel() and gw.is_contiguous():
+            # the finalize of the (dw, db) partial sums joins the step's grouped finalize launches (one instead of two launches per block)
+            slots = ctx._gslots
+            dx, item = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, apply_gelu, dw_out=gw, db_out=gb, defer=True)
+            q.append((item, (slots[1], slots[2])))
+            if len(q) >= FIN_QUEUE_MAX:
+                _flush_finalizes()
+            return dx, None, None, None, None, None, None
         dx, dw, db = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, apply_gelu, dw_out=gw, db_out=gb)
         return dx, dw.view(wshape), (db if b is not None else None), None, None, None, None
 
@@ -796,12 +820,7 @@ class BnActLinearFn(Function):
             mean = running_mean.detach().clone()
             rstd = torch.rsqrt(running_var.detach() + eps)
         scale, shift = hip.bn_affine_table(mean, rstd, g, b, chan_scale, M // rps, K)
-        w = hip.zeros((Np, K), x.dtype, x.device)
-        hip.cast2d(weight.detach().reshape(N, -1), w[:N])
-        bp = None
-        if bias is not None:
-            bp = hip.zeros((Np,), torch.float32, x.device)
-            hip.cast2d(bias.detach().unsqueeze(1), bp[:N].unsqueeze(1))
+        w, bp = _padded_rows(weight, bias, N, Np, K, x.dtype, x.device)
         y = hip.gemm_pro(0, x, w, M, Np, K, scale, shift, rps, act, bias=bp)[:, :N]
         ctx.save_for_backward(x, mean, rstd, g, b, chan_scale, scale, shift, w)
         ctx.meta = (M, N, K, Np, act, rps, not training, bias is not None, weight.shape)
@@ -990,6 +1009,7 @@ class SegformerFoldedFuseFn(Function):
         if sums is None:
             sums = torch.empty(0, device=y.device)          # geometry without the fused statistics: the consumer runs its own pass
         ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(wfc, *saved)
         ctx.meta = (geoms, E, dtype)
         return y, sums
@@ -1421,12 +1441,15 @@ class UpsampleCEDiceFn(Function):
         ctx.save_for_backward(logits, target, stats, class_weight, lse)
         ctx.meta = (geom, ignore_index, dice)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)          # (no zero-fill launches for the gradients of the two auxiliary outputs)
         return loss[0], loss.detach(), stats
 
     @staticmethod
     def backward(ctx, gloss, _gparts, _gstats):
         logits, target, stats, cw, lse = ctx.saved_tensors
         (B, Cc, h, w, H, W), ignore_index, dice = ctx.meta
+        if gloss is None:                           # only the detached parts were used downstream
+            return None, None, None, None, None, None
         go = gloss.reshape(1).to(torch.float32).contiguous()
         dl = hip.ce_dice_bwd(logits, B, Cc, h, w, H, W, target, ignore_index, cw, dice, stats, go, lse=lse)[:, :Cc]
         return dl, None, None, None, None, None

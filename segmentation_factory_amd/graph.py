@@ -289,7 +289,7 @@ class GraphedTrainStep:
         with scope, Fh.derived_scope(self._derived), Fh.defer_weight_grads():      # the Linear layers' weight gradients are queued and issued in grouped launches
             loss = self.loss_fn(self.model, *self.static_inputs)
             # d(mean over ranks of the per-rank losses) / d(this rank's loss) = 1 / world: the collective then only SUMS
-            loss.backward(gradient=self._seed if self.exchanging else None)
+            loss.backward(gradient=self._seed)          # (always passed: autograd's implicit ones_like would be a fill launch per step)
         return loss
 
     def _reset_pending(self):

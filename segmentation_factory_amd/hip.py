@@ -62,6 +62,7 @@ _PROTOS = {
                                 _p, _l, _p, _l, _p, _l, _p, _p]),
     'segf_dwconv3x3_gelu_fwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     'segf_dwconv3x3_bwd_ws': (_l, [_i, _i, _i, _i]),
+    'segf_dwconv3x3_bwd_blocks': (_i, [_i, _i, _i, _i]),
     'segf_dwconv3x3_gelu_bwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     'segf_dwconv7x7_fwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'segf_dwconv7x7_bwd_ws': (_l, [_i, _i, _i, _i]),
@@ -680,19 +681,22 @@ def bernoulli_scale(state, keep_prob, n, row_len):
 
 class SegfFinalizeItem(C.Structure):
     """include/segfac.h: one member of segf_colreduce_finalize_grouped"""
-    _fields_ = [('partial', C.c_void_p), ('out', C.c_void_p), ('len', C.c_int64), ('nblk', C.c_int), ('reserved', C.c_int)]
+    _fields_ = [('partial', C.c_void_p), ('out', C.c_void_p), ('len', C.c_int64), ('nblk', C.c_int), ('scatter_c', C.c_int)]
 
 
 def colreduce_finalize_grouped(items):
-    """items: [(partial fp32 [nblk, n], nblk, n, out fp32 [n])]: the finalize steps of several two-stage reductions in one launch."""
+    """items: [(partial fp32 [nblk, n], nblk, n, out fp32 [n][, C])]: the finalize steps of several two-stage reductions in one launch."""
     if not items:
         return
     arr = (SegfFinalizeItem * len(items))()
-    for k, (partial, nblk, n, out) in enumerate(items):
+    for k, item in enumerate(items):
+        partial, nblk, n, out = item[:4]
         _need_cuda(partial, out)
-        # (out may be the first of several ADJACENT views that together hold n elements: LayerNorm's dgamma | dbeta)
+        # (out may be the first of several ADJACENT views that together hold n elements: LayerNorm's dgamma | dbeta, a depthwise
+        # convolution's dw | db -- the latter with a fifth member C: the [10][C] sums land as dw[C][9], db[C])
         assert partial.dtype == torch.float32 and out.dtype == torch.float32 and partial.numel() >= nblk * n
-        arr[k].partial, arr[k].out, arr[k].len, arr[k].nblk, arr[k].reserved = partial.data_ptr(), out.data_ptr(), n, nblk, 0
+        arr[k].partial, arr[k].out, arr[k].len, arr[k].nblk = partial.data_ptr(), out.data_ptr(), n, nblk
+        arr[k].scatter_c = item[4] if len(item) > 4 else 0
     _chk(lib().segf_colreduce_finalize_grouped(len(items), C.cast(arr, C.c_void_p), _stream()), 'segf_colreduce_finalize_grouped')
 
 
@@ -878,9 +882,18 @@ def dwconv3x3_gelu_fwd(x, w9, bias, B, H, W, Cc, apply_gelu=True):
     return y
 
 
-def dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, Cc, apply_gelu=True, dw_out=None, db_out=None):
+def dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, Cc, apply_gelu=True, dw_out=None, db_out=None, defer=False):
+    """defer=True (needs dw_out and db_out ADJACENT in memory, db right behind dw): the kernels leave their per-block partial sums and
+    (dx, finalize item) is returned; the caller passes the item to colreduce_finalize_grouped later."""
     du = torch.empty_like(x)
     dx = torch.empty_like(x)
+    if defer:
+        assert dw_out.dtype == db_out.dtype == torch.float32 and dw_out.is_contiguous() and dw_out.numel() == 9 * Cc
+        assert db_out.numel() == Cc and db_out.data_ptr() == dw_out.data_ptr() + 36 * Cc
+        ws = _f32(lib().segf_dwconv3x3_bwd_ws(B, H, W, Cc), x.device)
+        _chk(lib().segf_dwconv3x3_gelu_bwd(dt_of(x), B, H, W, Cc, _ptr(x), _ptr(w9), _ptr(bias), int(apply_gelu), _ptr(dy),
+                                           _ptr(du), _ptr(dx), None, None, _ptr(ws), _stream()), 'segf_dwconv3x3_gelu_bwd')
+        return dx, (ws, int(lib().segf_dwconv3x3_bwd_blocks(B, H, W, Cc)), 10 * Cc, dw_out, Cc)
     dw = dw_out if dw_out is not None else torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
     db = db_out if db_out is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == Cc * 9 and db.is_contiguous() and db.numel() == Cc and dw.dtype == db.dtype == torch.float32

@@ -1779,3 +1779,30 @@ def test_derived_weights_registry_matches_direct_layouts():
         with torch.no_grad():
             for p in ws:
                 p.mul_(1.25)
+
+
+def test_dwconv3x3_deferred_finalize_equals_direct():
+    """segf_dwconv3x3_gelu_bwd with dw == NULL leaves its partial sums for segf_colreduce_finalize_grouped (scatter_c = C), which must
+    write BITWISE the dw [C][9] | db [C] of the direct call (mit.py:62-71 backward) -- two layers of different geometry in one grouped
+    launch, next to a plain (LayerNorm-type) member."""
+    from segmentation_factory_amd import hip
+    g = torch.Generator(device='cuda').manual_seed(4)
+    items, checks = [], []
+    for (B, H, W, Cc) in ((2, 32, 32, 128), (4, 16, 16, 1024)):
+        x = torch.randn(B * H * W, Cc, generator=g, device='cuda').to(torch.bfloat16)
+        dy = torch.randn(B * H * W, Cc, generator=g, device='cuda').to(torch.bfloat16)
+        w9 = torch.randn(Cc, 9, generator=g, device='cuda') * 0.2
+        b = torch.randn(Cc, generator=g, device='cuda') * 0.1
+        dx0, dw0, db0 = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, True)
+        flat = torch.full((10 * Cc,), 7.0, device='cuda')
+        dx1, item = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, True, dw_out=flat[:9 * Cc].view(Cc, 9), db_out=flat[9 * Cc:], defer=True)
+        items.append(item)
+        checks.append((dx0, dx1, torch.cat([dw0.reshape(-1), db0]), flat))
+    part = torch.randn(5, 96, generator=g, device='cuda')
+    out = torch.empty(96, device='cuda')
+    items.insert(1, (part, 5, 96, out))
+    hip.colreduce_finalize_grouped(items)
+    torch.cuda.synchronize()
+    for dx0, dx1, want, got in checks:
+        assert torch.equal(dx0, dx1) and torch.equal(want, got)
+    assert torch.allclose(out, part.sum(0), rtol=1e-6, atol=1e-6)
