@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
     amp_stage(KV[0][0], KV[0][1], Kb, ldk, Vb, ldv, 0, Nkv, wave, lane);
     const float cs = scale * 1.44269504088896340736f;
     bf16x8 Qf[QW][KS], dOf[QW][KS];
-    float Dq[QW], nl2[QW];                  // nl2 = -lse in log2 units (+inf -> -inf for rows beyond N: their probabilities are 0)
+    float Dq[QW], nDq[QW], nl2[QW];         // nl2 = -lse in log2 units (+inf -> -inf for rows beyond N: their probabilities are 0)
 #pragma unroll
     for (int t = 0; t < QW; ++t) {
         const int row = q0 + 16 * t + c;
@@ -468,6 +468,7 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
             for (int j = 0; j < 8; ++j) part += (float)dOf[t][s][j] * (float)of[j];
         }
         Dq[t] = xgroup_sum(part);
+        nDq[t] = -Dq[t];
         nl2[t] = row < N ? -lse[((int64_t)b * heads + h) * N + row] * 1.44269504088896340736f : -INFINITY;
         if (g == 0 && row < N) Dbuf[((int64_t)b * heads + h) * N + row] = Dq[t];
     }
@@ -503,7 +504,8 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
                 for (int t = 0; t < QW; ++t)
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt) {
-                        S[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dP[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        // (-D is the initial value of the dP accumulators: dP - D comes out of the matrix pipe, no subtraction per score)
+                        S[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dP[t][kt] = (f32x4){nDq[t], nDq[t], nDq[t], nDq[t]};
 #pragma unroll
                         for (int s = 0; s < KS; ++s) {
                             S[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S[t][kt], 0, 0, 0);
@@ -517,7 +519,7 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float p = __builtin_amdgcn_exp2f(fmaf(S[t][kt][r], cs, nl2[t]));
-                            ds[t][kt][r] = p * (dP[t][kt][r] - Dq[t]);
+                            ds[t][kt][r] = p * dP[t][kt][r];
                         }
             }
             if (kc0 + kb + 32 > Nkv) {                          // keys beyond the last one carry no gradient (wave-uniform tail)
@@ -767,16 +769,28 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     const bool doQ = HD == 64 || threadIdx.x < NCH, doO = HD == 64 || threadIdx.x >= NCH;
     uint4 rq = make_uint4(0, 0, 0, 0), ro = make_uint4(0, 0, 0, 0);
     float rl = INFINITY, rd = 0.f;
+    // Rows beyond the chunk are read from its LAST row (finite values) and carry lse = +inf: their probabilities are exactly 0, so they
+    // add nothing -- no zero fill, no divergent loads.  The row pointers advance by a wave-uniform step per tile (the 64-bit
+    // row * stride products were ~25 vector instructions per tile in a loop whose VALU stream is as long as its MFMA stream).
+    const int row0 = qbeg + srow < qend ? qbeg + srow : qend - 1;
+    const char* qp = reinterpret_cast<const char*>(Qb + (int64_t)row0 * ldq + scol);
+    const char* op = reinterpret_cast<const char*>(dOb + (int64_t)row0 * lddo + scol);
+    const int64_t qstep = 64 * ldq, ostep = 64 * lddo;            // bytes per 32 rows
     auto fetch = [&](int qt0) {
         const int row = qt0 + srow;
-        rq = make_uint4(0, 0, 0, 0); ro = make_uint4(0, 0, 0, 0);
-        if (doQ && row < qend) rq = *reinterpret_cast<const uint4*>(Qb + (int64_t)row * ldq + scol);
-        if (doO && row < qend) ro = *reinterpret_cast<const uint4*>(dOb + (int64_t)row * lddo + scol);
+        if (row >= qend) {                                   // (only in the last tile of a chunk whose length is not a multiple of 32)
+            qp = reinterpret_cast<const char*>(Qb + (int64_t)(qend - 1) * ldq + scol);
+            op = reinterpret_cast<const char*>(dOb + (int64_t)(qend - 1) * lddo + scol);
+        }
+        if (doQ) rq = *reinterpret_cast<const uint4*>(qp);
+        if (doO) ro = *reinterpret_cast<const uint4*>(op);
+        qp += qstep; op += ostep;
         if (threadIdx.x < 32) {
             const int r2 = qt0 + threadIdx.x;
             rl = r2 < qend ? lb[r2] : INFINITY;          // exp(s - inf) = 0: rows beyond the chunk contribute nothing
             if (EX2) rl *= -1.44269504088896340736f;
             rd = r2 < qend ? Db[r2] : 0.f;
+            if (EX2) rd = -rd;                          // EX2: -D is the INITIAL VALUE of the dP accumulators (no subtraction per score)
         }
     };
     const int sswz = srow * HD + (am_chunk<HD, SWZ>(scol >> 3, srow & 7) << 3);      // swizzled LDS position of this thread's chunk
@@ -788,8 +802,10 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     fetch(qbeg);
     put(0);
     __syncthreads();
-    int buf = 0;
-    for (int qt0 = qbeg; qt0 < qend; qt0 += 32, buf ^= 1) {
+    // the tile loop is written out for the two buffers: with the buffer a compile-time constant every LDS address of a tile is a per-lane
+    // base plus an immediate (it was ~35 integer instructions per tile, a quarter of the loop's VALU stream)
+    auto tile = [&](auto BUF, int qt0) {
+        constexpr int buf = decltype(BUF)::value;
         const bool more = qt0 + 32 < qend;
         if (more) fetch(qt0 + 32);
         const bf16_t* Qs = Qs2[buf];
@@ -813,6 +829,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
 #pragma unroll
             for (int kt = 0; kt < KW; ++kt) {
                 f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f}, dP = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (EX2) dP = (f32x4){dr[0], dr[1], dr[2], dr[3]};          // = -D (negated when staged): dP - D comes out of the matrix pipe
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Qa[s], Kf[kt][s], S, 0, 0, 0);
@@ -822,7 +839,7 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
                 for (int r = 0; r < 4; ++r) {
                     const float p = EX2 ? __builtin_amdgcn_exp2f(fmaf(S[r], cs, lr[r])) : __expf(P2S ? S[r] - lr[r] : S[r] * scale - lr[r]);
                     P[qt][kt][r] = p;
-                    dS[qt][kt][r] = (P2S || EX2) ? p * (dP[r] - dr[r]) : p * (dP[r] - dr[r]) * scale;
+                    dS[qt][kt][r] = EX2 ? p * dP[r] : (P2S ? p * (dP[r] - dr[r]) : p * (dP[r] - dr[r]) * scale);
                 }
             }
         }
@@ -845,6 +862,10 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
         }
         if (more) put(buf ^ 1);          // the other buffer was last read before the barrier that ended the previous tile
         __syncthreads();
+    };
+    for (int qt0 = qbeg; qt0 < qend; qt0 += 64) {
+        tile(std::integral_constant<int, 0>{}, qt0);
+        if (qt0 + 32 < qend) tile(std::integral_constant<int, 1>{}, qt0 + 32);       // (workgroup-uniform: the barrier inside is reached by all)
     }
     if (key0 >= Nkv) return;
     const int C = heads * HD;
