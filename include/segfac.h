@@ -210,6 +210,12 @@ int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* d
 int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
                              const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                              float* ws, void* stream);
+/* ... with a second output dxs[r][c] = (dt) dx[r][c] * rscale[r / rows_per_group] (NULL, NULL: none): when dx's consumer is the backward of
+ * a residual branch x + DropPath(f(.)) (mit.py:143-146, drop_path.py:18-25), the first thing it does is this row scaling of dx --
+ * segf_scale_rows on the stored dx, bitwise.  rows < 2^22. */
+int segf_layernorm_bwd_scaled(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                              const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                              float* ws, const float* rscale, int64_t rows_per_group, void* dxs, void* stream);
 /* Deferred finalize: with dgamma == NULL segf_layernorm_bwd_fused leaves its per-block partial sums [blocks][2 C] in ws
  * (blocks = segf_layernorm_bwd_blocks(rows, C)) and the caller finalizes SEVERAL such reductions in one launch later:
  * out[i] = sum_b partial[b][i], i < len, summed in the order of the single finalize (bitwise the same dgamma / dbeta). */

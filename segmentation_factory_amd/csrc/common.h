@@ -73,6 +73,10 @@ template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { retu
 template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+// the value a store of type T keeps (fp32: itself; bf16: rounded to nearest even)
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
 
 // 8 consecutive elements <-> 8 floats.  `aligned` = pointer is 16-byte (bf16) / 16-byte (f32) aligned.
 template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);

@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, T* __restrict__ dx,
                                                       float* __restrict__ partial /*[grid][2][C]*/, int64_t rows, int C,
-                                                      int lpr_log2) {
+                                                      int lpr_log2, const float* __restrict__ rsc /*nullable: per-row-group scale of a second output*/,
+                                                      float inv_rpg, T* __restrict__ dxs /*dxs = (T) dx * rsc[row / rpg]: the DropPath backward of dx's consumer*/) {
     extern __shared__ float lds[];   // [4 waves][2][C]
     const int lpr = 1 << lpr_log2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -158,6 +159,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
                         for (int j = 0; j < 8; ++j) o[j] += rv8[j];
                     }
                     store8<T>(dx + r * C + c0, o);
+                    if (dxs) {
+                        // what segf_scale_rows computes from the STORED dx (DropPath backward, drop_path.py:18-25): the value rounded to T first.
+                        // row / rpg through the reciprocal: exact below 2^22 rows (host-checked)
+                        const float sc = rsc[(int)(((float)r + 0.5f) * inv_rpg)];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = round_to<T>(o[j]) * sc;
+                        store8<T>(dxs + r * C + c0, o);
+                    }
                 }
             }
         }
@@ -202,8 +211,9 @@ static void ln_fwd_launch(int vpt, int blocks, hipStream_t st, const T* x, const
 }
 template <typename T>
 static void ln_bwd_launch(int vpt, int blocks, size_t shm, hipStream_t st, const T* x, const T* dy, const T* dy2, const T* dres, const float* gamma,
-                          const float* mean, const float* rstd, T* dx, float* ws, int64_t rows, int C, int lpr_log2) {
-#define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, dy2, dres, gamma, mean, rstd, dx, ws, rows, C, lpr_log2)
+                          const float* mean, const float* rstd, T* dx, float* ws, int64_t rows, int C, int lpr_log2, const float* rsc,
+                          float inv_rpg, T* dxs) {
+#define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, dy2, dres, gamma, mean, rstd, dx, ws, rows, C, lpr_log2, rsc, inv_rpg, dxs)
     // C in (2048, 3072] (convnextv2_huge's 2816-wide last stage): six chunks per lane and 96 KB of dynamic LDS -- above the 64 KB
     // a kernel gets by default, so the limit is raised on the function first (160 KB per CU on gfx950)
 #define LN_B_BIG(V) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); LN_B(V); } while (0)
@@ -249,6 +259,9 @@ extern "C" int64_t segf_layernorm_bwd_ws(int64_t rows, int C) { return (int64_t)
 extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
                                         const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
                                         float* dbeta, float* ws, void* stream);
+extern "C" int segf_layernorm_bwd_scaled(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                                         const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                                         float* dbeta, float* ws, const float* rscale, int64_t rows_per_group, void* dxs, void* stream);
 extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* gamma,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                   float* ws, void* stream) {
@@ -257,7 +270,16 @@ extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, co
 extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
                                         const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
                                         float* dbeta, float* ws, void* stream) {
+    return segf_layernorm_bwd_scaled(dt, rows, C, x, dy, dy2, dres, gamma, mean, rstd, dx, dgamma, dbeta, ws, nullptr, 1, nullptr, stream);
+}
+// ... with a second output dxs[r][c] = (T) dx[r][c] * rscale[r / rows_per_group]: when dx's consumer is the backward of a residual branch
+// `x + DropPath(f(.))` (mit.py:143-146), its first step is exactly this row scaling of the incoming gradient (one launch per branch)
+extern "C" int segf_layernorm_bwd_scaled(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                                         const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                                         float* dbeta, float* ws, const float* rscale, int64_t rows_per_group, void* dxs, void* stream) {
     if (rows <= 0) return 0;
+    if ((rscale != nullptr) != (dxs != nullptr)) return SEGF_ERR_SHAPE;
+    if (rscale && (rows_per_group <= 0 || rows >= (1ll << 22) || ((uintptr_t)dxs % 16))) return SEGF_ERR_SHAPE;
     if (((uintptr_t)dy2 % 16) || ((uintptr_t)dres % 16)) return SEGF_ERR_SHAPE;
     if (C <= 0 || C % 8 != 0 || C > 3072) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
@@ -267,7 +289,8 @@ extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void*
     const int vpt = ln_plan(C, lpr_log2);
     const int blocks = ln_bwd_blocks(rows, C);
     const size_t shm = (size_t)4 * 2 * C * sizeof(float);
-    SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, (const T*)dy2, (const T*)dres, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2); })
+    const float inv_rpg = rscale ? 1.0f / (float)rows_per_group : 0.f;
+    SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, (const T*)dy2, (const T*)dres, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2, rscale, inv_rpg, (T*)dxs); })
     SEGF_CHECK_LAUNCH();
     if (!dgamma) return 0;                       // deferred: the caller finalizes ws later (segf_colreduce_finalize_grouped)
     const int64_t n = 2 * (int64_t)C;

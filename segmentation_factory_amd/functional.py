@@ -178,20 +178,43 @@ def _flush_finalizes():
     q.clear()
 
 
+# dx of a LayerNorm whose input came out of a residual branch `x + DropPath(f(.))` (mit.py:143-146): the branch's backward starts by scaling
+# that very gradient per sample (drop_path.py:18-25).  The LayerNorm backward kernel writes the scaled copy along with dx (one store more
+# instead of a launch that reads dx again); it waits here, keyed by dx's address, for LinearFn.backward to pick it up.
+_SCALED_DY = {}
+
+
+def _take_scaled(dy, rscale, rpg):
+    hit = _SCALED_DY.pop(dy.data_ptr(), None)
+    if hit is not None and hit[1] == rscale.data_ptr() and hit[2] == rpg and hit[0].shape == dy.shape and hit[0].dtype == dy.dtype:
+        return hit[0]
+    return None
+
+
 def _ln_bwd(ctx, x, dy, g, mean, rstd, dy2=None, dres=None):
     """LayerNorm backward with the (dgamma, dbeta) finalize deferred into the scope's grouped launch when both parameters carry adjacent
     flat-gradient slots; returns (dx, dgamma, dbeta) with None for gradients that will be delivered at the flush."""
     gg, gb = gslot(ctx, 1), gslot(ctx, 2)
     dgb = (gg, gb) if (gg is not None and gb is not None and gb.data_ptr() == gg.data_ptr() + 4 * gg.numel()) else None
+    dp = getattr(ctx, 'dp', None)
+    rscale, rpg = dp if dp is not None else (None, 1)
     q = _FIN_QUEUE
     if q is not None and dgb is not None:
         slots = ctx._gslots
-        dx, item = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, defer=True)
+        dx, item = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, defer=True, rscale=rscale, rows_per_group=rpg)
         q.append((item, (slots[1], slots[2])))
         if len(q) >= FIN_QUEUE_MAX:
             _flush_finalizes()
-        return dx, None, None
-    return hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres)
+        out = (dx, None, None)
+    else:
+        out = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, rscale=rscale, rows_per_group=rpg)
+    dx = out[0]
+    if getattr(dx, 'scaled', None) is not None:
+        if len(_SCALED_DY) > 64:
+            _SCALED_DY.clear()                   # (entries nobody came for: a consumer that did not need its input gradient)
+        _SCALED_DY[dx.data_ptr()] = (dx.scaled, rscale.data_ptr(), rpg)
+        dx.scaled = None
+    return out
 
 
 def flush_weight_grads():
@@ -393,7 +416,11 @@ class LinearFn(Function):
                     db = hip.colsum(dyp)[:N]
             return dx, dw, db, None, None, None, None, None
         wv = w[:N] if Np > N else w
-        dys = hip.scale_rows(dy, rscale, rpg) if rscale is not None else dy
+        dys = dy
+        if rscale is not None:
+            dys = _take_scaled(dy, rscale, rpg)              # written by the LayerNorm backward that produced dy, when there was one
+            if dys is None:
+                dys = hip.scale_rows(dy, rscale, rpg)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = hip.gemm(1, dys, wv, M, K, N)
@@ -490,7 +517,10 @@ def linear_fork(x, weight, bias=None):
 
 
 def linear(x, weight, bias=None, residual=None, rscale=None, rows_per_group=None, pad_to=None, fp8=False):
-    return LinearFn.apply(x, weight, bias, residual, rscale, rows_per_group, pad_to, fp8)
+    y = LinearFn.apply(x, weight, bias, residual, rscale, rows_per_group, pad_to, fp8)
+    if rscale is not None and not fp8:
+        y._segf_dp = (rscale, rows_per_group or 1)         # a LayerNorm that consumes y can prepare this layer's scaled gradient (_ln_bwd)
+    return y
 
 
 @direct_grads(1, 2)
@@ -498,7 +528,8 @@ class LayerNormFn(Function):
     """nn.LayerNorm over the channel dim of token rows (mit.py:107,136-140; convnext.py:8-23 in NHWC)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, dp_scale=None, dp_rpg=1):
+        ctx.dp = (dp_scale, int(dp_rpg)) if dp_scale is not None else None
         x = x if x.is_contiguous() else x.contiguous()
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         y, mean, rstd = hip.layernorm_fwd(x, g, b, eps)
@@ -510,11 +541,17 @@ class LayerNormFn(Function):
         x, g, mean, rstd = ctx.saved_tensors
         dy = dy if dy.is_contiguous() else dy.contiguous()
         dx, dg, db = _ln_bwd(ctx, x, dy, g, mean, rstd)       # adjacent flat-gradient views are one [2][C] target, written in place
-        return dx, dg, db, None
+        return dx, dg, db, None, None, None
+
+
+def _dp_of(x):
+    """(rscale, rows_per_group) when x is the output of a `residual + DropPath-scaled branch` product (functional.linear tags it)"""
+    dp = getattr(x, '_segf_dp', None)
+    return dp if dp is not None and not os.environ.get('SEGFAC_NO_SCALED_LN_BWD') else (None, 1)
 
 
 def layer_norm(x, gamma, beta, eps):
-    return LayerNormFn.apply(x, gamma, beta, eps)
+    return LayerNormFn.apply(x, gamma, beta, eps, *_dp_of(x))
 
 
 @direct_grads(1, 2)
@@ -524,7 +561,8 @@ class LayerNormResFn(Function):
     the residual-path gradient while it stores dx (no separate gradient-accumulation kernel)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, dp_scale=None, dp_rpg=1):
+        ctx.dp = (dp_scale, int(dp_rpg)) if dp_scale is not None else None
         x = x if x.is_contiguous() else x.contiguous()
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         y, mean, rstd = hip.layernorm_fwd(x, g, b, eps)
@@ -535,17 +573,17 @@ class LayerNormResFn(Function):
     def backward(ctx, dres, dy):
         x, g, mean, rstd = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None
+            return dres, None, None, None, None, None
         dy = dy if dy.is_contiguous() else dy.contiguous()
         if dres is not None and not dres.is_contiguous():
             dres = dres.contiguous()
         dx, dg, db = _ln_bwd(ctx, x, dy, g, mean, rstd, dres=dres)
-        return dx, dg, db, None
+        return dx, dg, db, None, None, None
 
 
 def layer_norm_res(x, gamma, beta, eps):
     """-> (x, LayerNorm(x)): use the returned x for the residual connection."""
-    return LayerNormResFn.apply(x, gamma, beta, eps)
+    return LayerNormResFn.apply(x, gamma, beta, eps, *_dp_of(x))
 
 
 @direct_grads(1, 2)
@@ -554,7 +592,8 @@ class LayerNormForkFn(Function):
     mit.py:196-216): returns the normalised map twice; the backward kernel sums the two incoming gradients on load."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, dp_scale=None, dp_rpg=1):
+        ctx.dp = (dp_scale, int(dp_rpg)) if dp_scale is not None else None
         x = x if x.is_contiguous() else x.contiguous()
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         y, mean, rstd = hip.layernorm_fwd(x, g, b, eps)
@@ -570,11 +609,11 @@ class LayerNormForkFn(Function):
         if dy2 is not None and not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx, dg, db = _ln_bwd(ctx, x, dy1, g, mean, rstd, dy2=dy2)
-        return dx, dg, db, None
+        return dx, dg, db, None, None, None
 
 
 def layer_norm_fork(x, gamma, beta, eps):
-    return LayerNormForkFn.apply(x, gamma, beta, eps)
+    return LayerNormForkFn.apply(x, gamma, beta, eps, *_dp_of(x))
 
 
 class ForkFn(Function):

@@ -103,6 +103,7 @@ _PROTOS = {
     'segf_gemm8_option': (_i, [_i, _i]),
     'segf_bernoulli_scale': (_i, [_p, _p, _l, _l, _p, _p]),
     'segf_layernorm_bwd_fused': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_layernorm_bwd_scaled': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
     'segf_quant_rows_fp8': (_i, [_i, _l, _i, _p, _l, _p, _l, _p, _p]),
     'segf_gemm_fp8_supported': (_i, [_l, _l, _l]),
     'segf_quant_tensor_fp8': (_i, [_i, _i, _l, _i, _p, _l, _p, _l, _p, _p, _p]),
@@ -700,34 +701,37 @@ def colreduce_finalize_grouped(items):
     _chk(lib().segf_colreduce_finalize_grouped(len(items), C.cast(arr, C.c_void_p), _stream()), 'segf_colreduce_finalize_grouped')
 
 
-def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None, defer=False):
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None, defer=False, rscale=None, rows_per_group=1):
     """dgb_out: optional (dgamma, dbeta) fp32 [C] views that are ADJACENT in memory (dbeta == dgamma + C): written in place.
     dy2 / dres: optional fan-in operands, dx = LN_bwd(dy + dy2) + dres (segf_layernorm_bwd_fused).
     defer=True (needs dgb_out): the kernel leaves its per-block partial sums and (dx, finalize item) is returned; the caller passes the
-    item to colreduce_finalize_grouped later."""
+    item to colreduce_finalize_grouped later.
+    rscale (fp32 [rows / rows_per_group]): the kernel also writes dxs = dx * rscale[row / rows_per_group] (what scale_rows(dx, ...) gives);
+    it is returned as the attribute `dx.scaled` of the first result."""
     rows, Cc = x.shape
     dx = torch.empty_like(x)
-    if defer:
-        dg, db = dgb_out
-        assert db.data_ptr() == dg.data_ptr() + 4 * Cc and dg.numel() == Cc and db.numel() == Cc
-        ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
-        for t in (dy2, dres):
-            assert t is None or (t.shape == x.shape and t.dtype == x.dtype and t.is_contiguous())
-        _chk(lib().segf_layernorm_bwd_fused(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(dy2), _ptr(dres), _ptr(gamma), _ptr(mean),
-                                            _ptr(rstd), _ptr(dx), None, None, _ptr(ws), _stream()), 'segf_layernorm_bwd_fused')
-        return dx, (ws, int(lib().segf_layernorm_bwd_blocks(rows, Cc)), 2 * Cc, dg)
+    dxs = None
+    if rscale is not None and rows < (1 << 22):
+        _need_cuda(rscale)
+        assert rscale.dtype == torch.float32 and rscale.is_contiguous() and rscale.numel() * rows_per_group >= rows
+        dxs = torch.empty_like(x)
+    ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
+    for t in (dy2, dres):
+        assert t is None or (t.shape == x.shape and t.dtype == x.dtype and t.is_contiguous())
     if dgb_out is not None:
         dg, db = dgb_out
         assert db.data_ptr() == dg.data_ptr() + 4 * Cc and dg.numel() == Cc and db.numel() == Cc
     else:
+        assert not defer
         dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
         dg, db = dgb[0], dgb[1]
-    ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
-    for t in (dy2, dres):
-        assert t is None or (t.shape == x.shape and t.dtype == x.dtype and t.is_contiguous())
-    _chk(lib().segf_layernorm_bwd_fused(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(dy2), _ptr(dres), _ptr(gamma), _ptr(mean),
-                                        _ptr(rstd), _ptr(dx), dg.data_ptr(), db.data_ptr(), _ptr(ws), _stream()),
-         'segf_layernorm_bwd_fused')
+    _chk(lib().segf_layernorm_bwd_scaled(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(dy2), _ptr(dres), _ptr(gamma), _ptr(mean),
+                                         _ptr(rstd), _ptr(dx), None if defer else dg.data_ptr(), None if defer else db.data_ptr(),
+                                         _ptr(ws), _ptr(rscale) if dxs is not None else None, int(rows_per_group), _ptr(dxs), _stream()),
+         'segf_layernorm_bwd_scaled')
+    dx.scaled = dxs
+    if defer:
+        return dx, (ws, int(lib().segf_layernorm_bwd_blocks(rows, Cc)), 2 * Cc, dg)
     return dx, dg, db
 
 

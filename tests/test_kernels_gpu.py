@@ -1806,3 +1806,48 @@ def test_dwconv3x3_deferred_finalize_equals_direct():
     for dx0, dx1, want, got in checks:
         assert torch.equal(dx0, dx1) and torch.equal(want, got)
     assert torch.allclose(out, part.sum(0), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_layernorm_backward_scaled_second_output(dtype, monkeypatch):
+    """segf_layernorm_bwd_scaled: dxs must be BITWISE segf_scale_rows(dx) (the DropPath backward of the residual branch that consumes dx,
+    mit.py:143-146 / drop_path.py:18-25), dx / dgamma / dbeta unchanged; and through the autograd Functions: a MiT-style chain
+    x1 = x0 + s1 * Linear(.), LayerNorm(x1) -> x2 = x1 + s2 * Linear(.) gives the same gradients with the fused output on and off."""
+    from segmentation_factory_amd import hip, functional as Fh
+    g = torch.Generator().manual_seed(9)
+    B, N, Cc = 3, 200, 64
+    x = _dev(torch.randn(B * N, Cc, generator=g), dtype)
+    dy = _dev(torch.randn(B * N, Cc, generator=g), dtype)
+    dres = _dev(torch.randn(B * N, Cc, generator=g), dtype)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    beta = torch.randn(Cc, generator=g).cuda()
+    sc = torch.tensor([0.0, 1.25, 1.25]).cuda()
+    _, mean, rstd = hip.layernorm_fwd(x, gamma, beta, 1e-5)
+    dx0, dg0, db0 = hip.layernorm_bwd(x, dy, gamma, mean, rstd, dres=dres)
+    dx1, dg1, db1 = hip.layernorm_bwd(x, dy, gamma, mean, rstd, dres=dres, rscale=sc, rows_per_group=N)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.equal(dx1.scaled, hip.scale_rows(dx0, sc, N))
+
+    w1 = (torch.randn(Cc, Cc, generator=g) * 0.1).cuda().requires_grad_()
+    w2 = (torch.randn(Cc, Cc, generator=g) * 0.1).cuda().requires_grad_()
+    b1 = torch.randn(Cc, generator=g).cuda().requires_grad_()
+    b2 = torch.randn(Cc, generator=g).cuda().requires_grad_()
+    ga = gamma.clone().requires_grad_()
+    be = beta.clone().requires_grad_()
+    s1, s2 = sc, torch.tensor([1.25, 0.0, 1.25]).cuda()
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('SEGFAC_NO_SCALED_LN_BWD', '1')
+        x0 = x.clone().requires_grad_()
+        for p in (w1, w2, b1, b2, ga, be):
+            p.grad = None
+        x1 = Fh.linear(x0, w1, b1, residual=x0, rscale=s1, rows_per_group=N)
+        xr, h = Fh.layer_norm_res(x1, ga, be, 1e-5)
+        x2 = Fh.linear(h, w2, b2, residual=xr, rscale=s2, rows_per_group=N)
+        y = Fh.layer_norm(x2, ga, be, 1e-5)
+        (y.float() * dy.float()).sum().backward()
+        outs.append([x0.grad.clone()] + [p.grad.clone() for p in (w1, w2, b1, b2, ga, be)])
+        assert off or len(Fh._SCALED_DY) == 0          # both scaled copies were picked up
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
