@@ -4,6 +4,7 @@
 // Used for bias gradients, BatchNorm statistics / backward sums, depthwise-conv weight gradients.
 // Stage 1: grid (row blocks, channel slabs) -> partial[blk][NOUT][C]; stage 2: colreduce_finalize.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 
 #define CR_THREADS 256
@@ -212,7 +213,39 @@ static __global__ void __launch_bounds__(CRF_OUT * CRF_SL) colreduce_finalize_gr
         }
     }
 }
+// the same sums in the same order for LARGE outputs (the classifier's riding weight gradient: 160 x 768 outputs x ~85 partial slabs = 42 MB):
+// a thread takes FOUR adjacent outputs of its slab residue class, so a 16-lane group reads 256 contiguous bytes of a slab instead of 64
+// (41 -> 13 us at cfg2; the 16 residue-class sums of an output still meet in LDS and are added in residue order: bitwise the kernel above)
+static __global__ void __launch_bounds__(CRF_OUT * CRF_SL)
+colreduce_finalize_wide_kernel(const float* __restrict__ partial, int nblk, int64_t n, float* __restrict__ out) {
+    __shared__ float4 red[CRF_SL][CRF_OUT + 1];
+    const int o = threadIdx.x % CRF_OUT, sl = threadIdx.x / CRF_OUT;
+    const int64_t i = ((int64_t)blockIdx.x * CRF_OUT + o) * 4;
+    partial += (int64_t)blockIdx.y * nblk * n;
+    out += (int64_t)blockIdx.y * n;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+#pragma unroll 4
+        for (int b = sl; b < nblk; b += CRF_SL) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)b * n + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < CRF_SL; ++k) { const float4 v = red[k][o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(out + i) = t;
+    }
+}
 static inline void colreduce_finalize_launch(const float* partial, int nblk, int64_t n, float* out, hipStream_t st, int nbatch = 1) {
+    if (n >= 16384 && n % 4 == 0 && !((uintptr_t)partial & 15) && !((uintptr_t)out & 15) && !getenv("SEGFAC_NO_WIDE_FINALIZE")) {
+        hipLaunchKernelGGL(colreduce_finalize_wide_kernel, dim3((unsigned)cdiv64(n, 4 * CRF_OUT), nbatch), dim3(CRF_OUT * CRF_SL), 0, st,
+                           partial, nblk, n, out);
+        return;
+    }
     hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((unsigned)cdiv64(n, CRF_OUT), nbatch), dim3(CRF_OUT * CRF_SL), 0, st, partial,
                        nblk, n, out);
 }

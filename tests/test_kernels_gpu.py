@@ -1460,6 +1460,14 @@ def test_bn_backward_with_classifier_dx_folded_in(hipmod, cfg):
         assert float(dwc[nc:].abs().max()) == 0.0 if nc < K else True
         dwc2 = hip.bn_cls_bwd_full(*args, x1=x1f)[4]
         assert torch.equal(dwc, dwc2)
+        # the finalize of the [K x C] partial slabs takes the wide form (four adjacent outputs per thread) when the output is large: the
+        # same sums in the same order as the 16-outputs-per-block form -- bitwise
+        os.environ['SEGFAC_NO_WIDE_FINALIZE'] = '1'
+        try:
+            narrow = hip.bn_cls_bwd_full(*args, x1=x1f)
+        finally:
+            del os.environ['SEGFAC_NO_WIDE_FINALIZE']
+        assert torch.equal(dwc, narrow[4]) and torch.equal(dgf, narrow[1]) and (x1f is None or torch.equal(dGf, narrow[3]))
 
 
 @pytest.mark.parametrize('geom', [(2, 128, 128, 512, 512), (1, 160, 160, 272, 384), (4, 96, 128, 144, 768)])
