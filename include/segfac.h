@@ -478,6 +478,11 @@ int segf_input_train(const segf_input_sample* samples /*device [B]*/, int B, int
  * uint8, and Image.resize(..., NEAREST) for the label (ImagingScaleAffine's accumulated source index); the caller computes
  * (out_h, out_w) (smaller edge -> size, other edge int(size * long / short)).  ws: segf_input_val_ws(...) BYTES, 16-byte aligned.
  * out_img fp32 [3][out_h][out_w], out_lbl int64 [out_h][out_w]. */
+/* Single-image inference preprocessing (estimate_model.py:85-97 with torchvision 0.15.2, environment.yml:22): T.Resize((out_h, out_w)) of a
+ * uint8 CHW TENSOR = bilinear, align_corners = False, no antialias, computed in float32 and rounded half-to-even back to uint8, then
+ * x / 255 and Normalize(mean, std).  img: uint8 [3][src_h][src_w] on the device; out: fp32 [3][out_h][out_w]. */
+int segf_infer_preprocess(const uint8_t* img, int src_h, int src_w, int out_h, int out_w, const float* mean3, const float* std3,
+                          float* out, void* stream);
 int64_t segf_input_val_ws(int src_h, int src_w, int out_h, int out_w);
 int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, int64_t lbl_stride, int src_h, int src_w, int out_h,
                    int out_w, void* ws, const float* mean3, const float* std3, const int64_t* label_lut, float* out_img,

@@ -321,6 +321,50 @@ extern "C" int segf_input_train(const segf_input_sample* samples, int B, int H, 
     return 0;
 }
 
+// ---- single-image inference (estimate_model.py:85-97): T.Resize((nH, nW)) on the uint8 CHW tensor + x / 255 + Normalize -----------
+// torchvision 0.15.2 (environment.yml:22) resizes a TENSOR through torch.nn.functional.interpolate(bilinear, align_corners=False,
+// antialias=False) on the float32 cast, rounds (half to even) and casts back to uint8.  ATen's arithmetic (UpSampleKernel.cpp):
+// scale = in / out in float; src = scale * (dst + 0.5) - 0.5 clamped at 0; i0 = (int) src, l1 = src - i0, l0 = 1 - l1,
+// i1 = min(i0 + 1, in - 1); out = wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11) -- IEEE float32, no contraction
+// (this file is built with -ffp-contract=off).  Then (u8 / 255 - mean) / std.
+__global__ void __launch_bounds__(256) infer_preprocess_kernel(const uint8_t* __restrict__ img, int src_h, int src_w, int out_h, int out_w,
+                                                               float sy, float sx, const float* __restrict__ mean3,
+                                                               const float* __restrict__ std3, float* __restrict__ out) {
+    const int64_t n = (int64_t)out_h * out_w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oy = (int)(i / out_w), ox = (int)(i - (int64_t)oy * out_w);
+        float fy = __fsub_rn(__fmul_rn(sy, __fadd_rn((float)oy, 0.5f)), 0.5f), fx = __fsub_rn(__fmul_rn(sx, __fadd_rn((float)ox, 0.5f)), 0.5f);
+        fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+        int y0 = (int)fy, x0 = (int)fx;
+        y0 = y0 > src_h - 1 ? src_h - 1 : y0; x0 = x0 > src_w - 1 ? src_w - 1 : x0;
+        const int y1 = y0 + 1 < src_h ? y0 + 1 : src_h - 1, x1 = x0 + 1 < src_w ? x0 + 1 : src_w - 1;
+        float ly1 = __fsub_rn(fy, (float)y0), lx1 = __fsub_rn(fx, (float)x0);
+        ly1 = ly1 < 0.f ? 0.f : (ly1 > 1.f ? 1.f : ly1); lx1 = lx1 < 0.f ? 0.f : (lx1 > 1.f ? 1.f : lx1);
+        const float ly0 = __fsub_rn(1.f, ly1), lx0 = __fsub_rn(1.f, lx1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint8_t* p = img + (int64_t)c * src_h * src_w;
+            const float v00 = (float)p[(int64_t)y0 * src_w + x0], v01 = (float)p[(int64_t)y0 * src_w + x1];
+            const float v10 = (float)p[(int64_t)y1 * src_w + x0], v11 = (float)p[(int64_t)y1 * src_w + x1];
+            const float top = __fadd_rn(__fmul_rn(lx0, v00), __fmul_rn(lx1, v01)), bot = __fadd_rn(__fmul_rn(lx0, v10), __fmul_rn(lx1, v11));
+            float v = __fadd_rn(__fmul_rn(ly0, top), __fmul_rn(ly1, bot));
+            v = rintf(v);                                                  // torch.round: half to even
+            v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);                   // (the uint8 cast)
+            out[(int64_t)c * n + i] = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), mean3[c]), std3[c]);
+        }
+    }
+}
+extern "C" int segf_infer_preprocess(const uint8_t* img, int src_h, int src_w, int out_h, int out_w, const float* mean3, const float* std3,
+                                     float* out, void* stream) {
+    if (src_h <= 0 || src_w <= 0 || out_h <= 0 || out_w <= 0 || !img || !mean3 || !std3 || !out) return SEGF_ERR_SHAPE;
+    const float sy = (float)src_h / (float)out_h, sx = (float)src_w / (float)out_w;
+    const int blocks = (int)imin64(cdiv64((int64_t)out_h * out_w, 256), 4096);
+    hipLaunchKernelGGL(infer_preprocess_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img, src_h, src_w, out_h, out_w, sy, sx,
+                       mean3, std3, out);
+    SEGF_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int64_t segf_input_val_ws(int src_h, int src_w, int out_h, int out_w) {
     if (src_h <= 0 || src_w <= 0 || out_h <= 0 || out_w <= 0) return 0;
     return val_tables(nullptr, src_h, src_w, out_h, out_w, nullptr);

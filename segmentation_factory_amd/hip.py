@@ -119,6 +119,7 @@ _PROTOS = {
     'segf_input_train': (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     'segf_input_val_ws': (_l, [_i, _i, _i, _i]),
     'segf_input_val': (_i, [_p, _l, _p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    'segf_infer_preprocess': (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
     'segf_event_create': (_i, [C.POINTER(C.c_void_p)]),
     'segf_event_destroy': (_i, [_p]),
     'segf_event_record': (_i, [_p, _p, _i]),
@@ -1058,6 +1059,16 @@ def input_val(img, lbl, out_h, out_w, mean3, std3, label_lut):
     _chk(lib().segf_input_val(_ptr(img), img.stride(0), _ptr(lbl), lbl.stride(0), h, w, out_h, out_w, _ptr(ws), _ptr(mean3),
                               _ptr(std3), _ptr(label_lut), _ptr(out_img), _ptr(out_lbl), _stream()), 'segf_input_val')
     return out_img, out_lbl
+
+
+def infer_preprocess(img, out_h, out_w, mean3, std3):
+    """segf_infer_preprocess: uint8 [3, h, w] (device) -> fp32 [1, 3, out_h, out_w]: torchvision-0.15 tensor resize + / 255 + normalise."""
+    _need_cuda(img, mean3, std3)
+    assert img.dtype == torch.uint8 and img.dim() == 3 and img.shape[0] == 3 and img.is_contiguous()
+    out = torch.empty((1, 3, out_h, out_w), dtype=torch.float32, device=img.device)
+    _chk(lib().segf_infer_preprocess(_ptr(img), int(img.shape[1]), int(img.shape[2]), out_h, out_w, _ptr(mean3), _ptr(std3), _ptr(out),
+                                     _stream()), 'segf_infer_preprocess')
+    return out
 
 
 def bilinear_bwd_248(dout, B, H, W, Cc):

@@ -15,7 +15,6 @@ so it is skipped).
 import math
 
 import torch
-import torch.nn.functional as F
 
 from . import hip
 from .backbones import TokenMap
@@ -41,15 +40,17 @@ class SemSeg:
         return int(math.ceil(nH / 32)) * 32, int(math.ceil(nW / 32)) * 32
 
     def preprocess(self, image: torch.Tensor) -> torch.Tensor:
-        """image: uint8 / float CHW in [0, 255] -> normalised fp32 [1, 3, nH, nW] on the device (host-side plumbing: one
-        antialiased bilinear resize as torchvision's T.Resize applies to tensors, /255, mean / std)."""
+        """image: uint8 CHW in [0, 255] -> normalised fp32 [1, 3, nH, nW] on the device: estimate_model.py:85-97 as ONE kernel of this
+        library (segf_infer_preprocess: T.Resize of a uint8 tensor as torchvision 0.15.2 computes it -- bilinear, no antialias, rounded
+        back to uint8 -- then / 255 and mean / std)."""
         H, W = image.shape[1:]
         nH, nW = self.inference_size(H, W)
-        x = image.to(self.device, torch.float32).unsqueeze(0)
-        x = F.interpolate(x, size=(nH, nW), mode='bilinear', align_corners=False, antialias=True)
-        mean = torch.tensor(IMAGENET_MEAN, device=self.device).view(1, 3, 1, 1)
-        std = torch.tensor(IMAGENET_STD, device=self.device).view(1, 3, 1, 1)
-        return (x / 255 - mean) / std
+        if image.dtype != torch.uint8:
+            image = image.round().clamp(0, 255).to(torch.uint8)
+        img = image.to(self.device).contiguous()
+        mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32, device=self.device)
+        std = torch.tensor(IMAGENET_STD, dtype=torch.float32, device=self.device)
+        return hip.infer_preprocess(img, nH, nW, mean, std)
 
     @torch.inference_mode()
     def model_forward(self, img: torch.Tensor) -> TokenMap:

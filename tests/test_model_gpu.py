@@ -657,6 +657,27 @@ def test_single_image_inference_matches_reference_pipeline():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [((150, 200), (128, 192)), ((37, 91), (64, 160)), ((512, 683), (512, 704)), ((1024, 2048), (512, 1024))])
+def test_inference_preprocess_kernel_matches_torchvision_tensor_resize(shape):
+    """segf_infer_preprocess = estimate_model.py:85-97 with the pinned torchvision 0.15.2 (environment.yml:22): T.Resize of a uint8 CHW tensor
+    is F.interpolate(bilinear, align_corners=False, antialias=False) on the float32 cast, rounded back to uint8; then x / 255 and
+    Normalize.  Against torch's own CPU kernels, exactly (the uint8 stage) and to float32 round-off (the normalisation)."""
+    import torch.nn.functional as F
+    from segmentation_factory_amd import hip
+    from segmentation_factory_amd.inference import IMAGENET_MEAN, IMAGENET_STD
+    (h, w), (nH, nW) = shape
+    g = torch.Generator().manual_seed(h * 7 + w)
+    img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+    mean, std = torch.tensor(IMAGENET_MEAN), torch.tensor(IMAGENET_STD)
+    u8 = torch.round(F.interpolate(img.float()[None], size=(nH, nW), mode='bilinear', align_corners=False, antialias=False)).to(torch.uint8)
+    want = (u8.float() / 255 - mean.view(1, 3, 1, 1)) / std.view(1, 3, 1, 1)
+    got = hip.infer_preprocess(img.cuda(), nH, nW, mean.cuda(), std.cuda()).cpu()
+    back = torch.round((got * std.view(1, 3, 1, 1) + mean.view(1, 3, 1, 1)) * 255).to(torch.uint8)
+    assert torch.equal(back, u8)                                      # every resized byte
+    assert (got - want).abs().max().item() <= 1e-6
+
+
+@pytest.mark.gpu
 def test_argmax_rows_kernel():
     from segmentation_factory_amd import hip
     g = torch.Generator().manual_seed(4)
