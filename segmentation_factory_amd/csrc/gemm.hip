@@ -1127,6 +1127,58 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     splitk_reduce_body<OutT>(blockIdx.x, ws, split, M, N, C, ldc, main_blocks, cs_ws, cs_out, cs_n);
 }
 
+// The 16 x 16 form with FOUR adjacent outputs per thread: the same sums in the same order (residue classes z mod 16, added in residue order
+// -- bitwise the form above), but a 16-lane group reads 256 contiguous bytes of a slab instead of 64.  N % 4 == 0, ldc % 4 == 0, ws and C
+// 16-byte aligned, fp32 output; the bias-gradient slices keep the scalar form.
+__device__ __forceinline__ void splitk_reduce_body4(const unsigned bid, const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                    float* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                    const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
+    __shared__ float4 red[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    if (bid >= main_blocks) {
+        float* r1 = reinterpret_cast<float*>(&red[0][0]);                  // [16][17] floats of the same array
+        const int64_t i = (int64_t)(bid - main_blocks) * 16 + o;
+        float acc = 0.f;
+        if (i < cs_n) {
+#pragma unroll 4
+            for (int z = sl; z < split; z += 16) acc += cs_ws[(int64_t)z * cs_n + i];
+        }
+        r1[sl * 17 + o] = acc;
+        __syncthreads();
+        if (sl == 0 && i < cs_n) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += r1[k * 17 + o];
+            cs_out[i] = t;
+        }
+        return;
+    }
+    const int64_t total = M * N;
+    const int64_t i = ((int64_t)bid * 16 + o) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total) {
+#pragma unroll 4
+        for (int z = sl; z < split; z += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)z * total + i);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float4 v = red[k][o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const int64_t m = i / N, n = i - m * N;
+        *reinterpret_cast<float4*>(C + m * ldc + n) = t;
+    }
+}
+__global__ void __launch_bounds__(256) splitk_reduce4_kernel(const float* __restrict__ ws, int split, int64_t M, int64_t N,
+                                                              float* __restrict__ C, int64_t ldc, unsigned main_blocks,
+                                                              const float* __restrict__ cs_ws, float* __restrict__ cs_out, int64_t cs_n) {
+    splitk_reduce_body4(blockIdx.x, ws, split, M, N, C, ldc, main_blocks, cs_ws, cs_out, cs_n);
+}
+
 // Wide form for large outputs (the weight gradients of the wider models: 3072 x 768 fp32 x 8 slices is 75 MB of partials): one
 // thread per four consecutive outputs, the slices added in order z = 0, 1, ... with four 16-byte loads in flight -- every slab is
 // read as whole contiguous rows.  (The 16 x 16 form above reads 64-byte pieces and ran at ~1 TB/s on these; it stays for small
@@ -1186,12 +1238,21 @@ __global__ void __launch_bounds__(256) splitk_reduce_group_kernel(const ReduceGr
 #pragma unroll 1
     while (i + 1 < r.n && blockIdx.x >= r.start[i + 1]) ++i;
     const unsigned bid = blockIdx.x - r.start[i];
-    if (r.wide[i]) splitk_reduce_wide_body<float>(bid, r.ws[i], r.split[i], r.M[i], r.N[i], r.C[i], r.ldc[i], r.main_blocks[i], r.cs_ws[i], r.cs_out[i], r.cs_n[i]);
+    if (r.wide[i] == 1) splitk_reduce_wide_body<float>(bid, r.ws[i], r.split[i], r.M[i], r.N[i], r.C[i], r.ldc[i], r.main_blocks[i], r.cs_ws[i], r.cs_out[i], r.cs_n[i]);
+    else if (r.wide[i] == 2) splitk_reduce_body4(bid, r.ws[i], r.split[i], r.M[i], r.N[i], r.C[i], r.ldc[i], r.main_blocks[i], r.cs_ws[i], r.cs_out[i], r.cs_n[i]);
     else splitk_reduce_body<float>(bid, r.ws[i], r.split[i], r.M[i], r.N[i], r.C[i], r.ldc[i], r.main_blocks[i], r.cs_ws[i], r.cs_out[i], r.cs_n[i]);
 }
 static inline bool splitk_reduce_is_wide(const float* ws, int64_t M, int64_t N, const void* C, int64_t ldc) {
     return M * N >= 65536 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !getenv("SEGFAC_NO_WIDE_REDUCE");
 }
+// form of an fp32 reduce: 1 = wide (slices in order), 2 = 16 x 16 with four outputs per thread, 0 = 16 x 16; and its block counts
+static inline int splitk_reduce_form(const float* ws, int64_t M, int64_t N, const void* C, int64_t ldc) {
+    if (splitk_reduce_is_wide(ws, M, N, C, ldc)) return 1;
+    if (M * N >= 4096 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !getenv("SEGFAC_NO_REDUCE4")) return 2;
+    return 0;
+}
+static inline unsigned splitk_reduce_main_blocks(int form, int64_t total) { return (unsigned)cdiv64(total, form == 1 ? 1024 : (form == 2 ? 64 : 16)); }
+static inline unsigned splitk_reduce_cs_blocks(int form, int64_t cs_n) { return (unsigned)cdiv64(cs_n, form == 1 ? 256 : 16); }
 
 // segf_gemm_dw_db_grouped collects the reduce passes of the products it cannot group (streaming / 256-tile kernels) here and issues
 // them as grouped launches too: while the sink is set, gemm_impl appends its fp32 reduce instead of launching it
@@ -1201,9 +1262,9 @@ static bool reduce_sink_take(const float* ws, int split, int64_t M, int64_t N, f
     ReduceGroup* r = g_reduce_sink;
     if (!r || r->n >= GDW_MAX) return false;
     const int k = r->n;
-    const bool wide = splitk_reduce_is_wide(ws, M, N, C, ldc);
-    const unsigned blocks = (unsigned)cdiv64(M * N, wide ? 1024 : 16), csb = cs_ws ? (unsigned)cdiv64(cs_n, wide ? 256 : 16) : 0u;
-    r->wide[k] = wide ? 1 : 0; r->split[k] = split; r->ws[k] = ws; r->C[k] = C; r->cs_ws[k] = cs_ws; r->cs_out[k] = cs_out;
+    const int form = splitk_reduce_form(ws, M, N, C, ldc);
+    const unsigned blocks = splitk_reduce_main_blocks(form, M * N), csb = cs_ws ? splitk_reduce_cs_blocks(form, cs_n) : 0u;
+    r->wide[k] = form; r->split[k] = split; r->ws[k] = ws; r->C[k] = C; r->cs_ws[k] = cs_ws; r->cs_out[k] = cs_out;
     r->M[k] = M; r->N[k] = N; r->ldc[k] = ldc; r->cs_n[k] = cs_n; r->main_blocks[k] = blocks;
     r->start[k + 1] = r->start[k] + blocks + csb;
     ++r->n;
@@ -1216,6 +1277,13 @@ static void splitk_reduce_launch(hipStream_t st, const float* ws, int split, int
                                  const float* cs_ws, float* cs_out, int64_t cs_n) {
     const int64_t total = M * N;
     const bool wide = splitk_reduce_is_wide(ws, M, N, C, ldc);
+    if constexpr (sizeof(OutT) == 4) {
+        if (splitk_reduce_form(ws, M, N, C, ldc) == 2) {
+            const unsigned blocks = splitk_reduce_main_blocks(2, total), csb = cs_ws ? splitk_reduce_cs_blocks(2, cs_n) : 0u;
+            hipLaunchKernelGGL(splitk_reduce4_kernel, dim3(blocks + csb), dim3(256), 0, st, ws, split, M, N, (float*)C, ldc, blocks, cs_ws, cs_out, cs_n);
+            return;
+        }
+    }
     if (wide) {
         const unsigned blocks = (unsigned)cdiv64(total, 1024);
         const unsigned csb = cs_ws ? (unsigned)cdiv64(cs_n, 256) : 0u;
@@ -1974,9 +2042,9 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         g.m[k] = a; g.gx[k] = gx; g.gy[k] = gy; g.gz[k] = gz;
         g.start[k + 1] = g.start[k] + gx * gy * gz;
         ++g.n;
-        const bool wide = splitk_reduce_is_wide(it.ws, M, N, it.dw, it.lddw);
-        const unsigned blocks = (unsigned)cdiv64(M * N, wide ? 1024 : 16), csb = (unsigned)cdiv64(M, wide ? 256 : 16);
-        r.wide[k] = wide ? 1 : 0; r.split[k] = slices; r.ws[k] = it.ws; r.C[k] = it.dw; r.cs_ws[k] = a.colsum_ws; r.cs_out[k] = it.db;
+        const int form = splitk_reduce_form(it.ws, M, N, it.dw, it.lddw);
+        const unsigned blocks = splitk_reduce_main_blocks(form, M * N), csb = splitk_reduce_cs_blocks(form, M);
+        r.wide[k] = form; r.split[k] = slices; r.ws[k] = it.ws; r.C[k] = it.dw; r.cs_ws[k] = a.colsum_ws; r.cs_out[k] = it.db;
         r.M[k] = M; r.N[k] = N; r.ldc[k] = it.lddw; r.cs_n[k] = M; r.main_blocks[k] = blocks;
         r.start[k + 1] = r.start[k] + blocks + csb;
         ++r.n;

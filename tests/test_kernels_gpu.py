@@ -1691,6 +1691,18 @@ def test_grouped_weight_gradients_equal_per_layer_launches():
     dy, x, M, N, K = items[3][0], items[3][1], *shapes[3]
     ref = dy.float().t() @ x.float()
     assert (items[3][6] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    # the split-K reduce reads four adjacent outputs per thread where the shape allows (r04): the same sums in the same order as the
+    # one-output form -- bitwise, grouped and per layer
+    os.environ['SEGFAC_NO_REDUCE4'] = '1'
+    try:
+        items1 = [(dy, x, M, N, K, sk, torch.empty(M, N, device='cuda'), torch.empty(M, device='cuda')) for (dy, x, M, N, K, sk, _, _) in items]
+        hip.gemm_dw_db_grouped(items1)
+        single = [hip.gemm_dw_db(it[0], it[1], it[2], it[3], it[4], split_k=it[5]) for it in items]
+    finally:
+        del os.environ['SEGFAC_NO_REDUCE4']
+    torch.cuda.synchronize()
+    for a, b, c in zip(items, items1, single):
+        assert torch.equal(a[6], b[6]) and torch.equal(a[7], b[7]) and torch.equal(a[6], c[0]) and torch.equal(a[7], c[1]), a[2:5]
 
 
 def test_prep_grouped_equals_single_kernels():
