@@ -216,6 +216,16 @@ int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void* x, const v
 int segf_layernorm_bwd_scaled(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
                               const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                               float* ws, const float* rscale, int64_t rows_per_group, void* dxs, void* stream);
+/* The spatial-reduction convolution of MiT's attention (mit.py:20-22,47-48: Conv2d(dim, dim, sr, sr) on the LayerNorm output) without
+ * im2col / col2im passes: segf_layernorm_fwd_patch also writes its output in the PATCH-MAJOR row order of that convolution's im2col matrix
+ * (token (b, y, x) -> row ((b Ho + y / sr) Wo + x / sr), chunk (y % sr, x % sr)), so y2 viewed as [rows / sr^2][sr^2 C] is the matrix itself;
+ * segf_layernorm_bwd_patch reads its fan-in operand dy2 in the same order -- the data gradient of the convolution as its product leaves it.
+ * Map width W = 2^log2_w, sr = 2^log2_sr, rows % (W sr) == 0; log2_w < 0 in the backward: dy2 in token order (segf_layernorm_bwd_scaled). */
+int segf_layernorm_fwd_patch(int dt, int64_t rows, int C, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                             float* mean, float* rstd, void* y2, int log2_w, int log2_sr, void* stream);
+int segf_layernorm_bwd_patch(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                             const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                             float* ws, const float* rscale, int64_t rows_per_group, void* dxs, int log2_w, int log2_sr, void* stream);
 /* Deferred finalize: with dgamma == NULL segf_layernorm_bwd_fused leaves its per-block partial sums [blocks][2 C] in ws
  * (blocks = segf_layernorm_bwd_blocks(rows, C)) and the caller finalizes SEVERAL such reductions in one launch later:
  * out[i] = sum_b partial[b][i], i < len, summed in the order of the single finalize (bitwise the same dgamma / dbeta). */

@@ -62,8 +62,19 @@ class Attention(nn.Module):
             self.norm = LayerNormWeights(dim)
         self.apply(init_mit_style)
 
-    def tokens(self, h, B, H, W, residual, rscale):
+    def tokens(self, h, B, H, W, residual, rscale, col=None):
         N = H * W
+        if col is not None:
+            # the norm in front already wrote its output as the im2col matrix of the spatial-reduction convolution (layer_norm_res_patch):
+            # no im2col / col2im passes, and the two consumers' gradients meet in the LayerNorm backward
+            sr = self.sr_ratio
+            q = Fh.linear(h, self.q.weight, self.q.bias)
+            xr = Fh.conv_from_col(col, self.sr.weight, self.sr.bias, sr)
+            xr = Fh.layer_norm(xr, self.norm.weight, self.norm.bias, self.norm.eps)
+            Nkv = (H // sr) * (W // sr)
+            kv = Fh.linear(xr, self.kv.weight, self.kv.bias)
+            o = Fh.attention(q, kv, B, N, Nkv, self.head)
+            return Fh.linear(o, self.proj.weight, self.proj.bias, residual=residual, rscale=rscale, rows_per_group=N)
         # two consumers (q and the key / value path): the key / value path's gradient joins inside q's data-gradient product
         q, h = Fh.linear_fork(h, self.q.weight, self.q.bias)
         if self.sr_ratio > 1:
@@ -131,8 +142,13 @@ class Block(nn.Module):
 
     def tokens(self, x, B, H, W, scales):
         s1, s2 = scales
-        x, h = Fh.layer_norm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)     # x passes through for the residual
-        x = self.attn.tokens(h, B, H, W, x, s1)
+        sr = self.attn.sr_ratio
+        if Fh.patch_layout_ok(W, H, sr) and x.is_cuda:
+            x, h, col = Fh.layer_norm_res_patch(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, W, sr)
+            x = self.attn.tokens(h, B, H, W, x, s1, col=col)
+        else:
+            x, h = Fh.layer_norm_res(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)     # x passes through for the residual
+            x = self.attn.tokens(h, B, H, W, x, s1)
         x, h = Fh.layer_norm_res(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp.tokens(h, B, H, W, x, s2)
 

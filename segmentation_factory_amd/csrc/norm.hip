@@ -8,11 +8,19 @@
 // ---- LayerNorm -----------------------------------------------------------------------------------------
 // A row is spread over LPR = 2^lpr_log2 lanes (8 elements per lane per step, VPT steps); a wave handles
 // 64/LPR rows at once.  Two-pass statistics in registers (mean, then centred variance), fp32.
+// Patch-major token order of a spatial-reduction convolution's im2col matrix (mit.py:47, k = s = sr): token (b, y, x) of a [B, H, W] map
+// is row ((b Ho + y / sr) Wo + x / sr) of the matrix and chunk (y % sr, x % sr) of that row -- a PERMUTATION of the token rows.  With W
+// and sr powers of two (H a multiple of sr): t = r >> lw = b H + y, x = r & (W - 1).
+__device__ __forceinline__ int64_t patch_row(int64_t r, int lw, int ls) {
+    const int64_t t = r >> lw, x = r & (((int64_t)1 << lw) - 1), sm = ((int64_t)1 << ls) - 1;
+    return ((((t >> ls) << (lw - ls)) + (x >> ls)) << (2 * ls)) + ((t & sm) << ls) + (x & sm);
+}
 template <typename T, int VPT>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, T* __restrict__ y,
                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                      int64_t rows, int C, float eps, int lpr_log2) {
+                                                      int64_t rows, int C, float eps, int lpr_log2,
+                                                      T* __restrict__ y2 /*nullable: the same rows in patch-major order*/, int lw, int ls) {
     const int lpr = 1 << lpr_log2;
     const int lane = threadIdx.x & 63;
     const int sub = lane & (lpr - 1), rin = lane >> lpr_log2;
@@ -65,6 +73,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
                     for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[i][j] + b[i][j];
                     store8<T>(y + r * C + c0, o);
+                    if (y2) store8<T>(y2 + patch_row(r, lw, ls) * C + c0, o);
                 }
             }
             if (sub == 0) { mean_out[r] = mu; rstd_out[r] = rs; }
@@ -81,7 +90,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
                                                       const float* __restrict__ rstd, T* __restrict__ dx,
                                                       float* __restrict__ partial /*[grid][2][C]*/, int64_t rows, int C,
                                                       int lpr_log2, const float* __restrict__ rsc /*nullable: per-row-group scale of a second output*/,
-                                                      float inv_rpg, T* __restrict__ dxs /*dxs = (T) dx * rsc[row / rpg]: the DropPath backward of dx's consumer*/) {
+                                                      float inv_rpg, T* __restrict__ dxs /*dxs = (T) dx * rsc[row / rpg]: the DropPath backward of dx's consumer*/,
+                                                      int lw /*>= 0: dy2 is stored in patch-major row order (patch_row)*/, int ls) {
     extern __shared__ float lds[];   // [4 waves][2][C]
     const int lpr = 1 << lpr_log2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,7 +121,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
             const int c0 = (sub + i * lpr) * 8, cc = c0 < C ? c0 : 0;
             rx[i] = load8_raw<T>(x + rc * C + cc);
             rd[i] = load8_raw<T>(dy + rc * C + cc);
-            if (dy2) rd2[i] = load8_raw<T>(dy2 + rc * C + cc);          // workgroup-uniform branches: the loads stay batched
+            if (dy2) rd2[i] = load8_raw<T>(dy2 + (lw >= 0 ? patch_row(rc, lw, ls) : rc) * C + cc);          // workgroup-uniform branches: the loads stay batched
             if (dres) rr[i] = load8_raw<T>(dres + rc * C + cc);
         }
         SEGF_LOADS_ISSUED();
@@ -204,16 +214,16 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const T* __restrict__ x, co
 
 template <typename T>
 static void ln_fwd_launch(int vpt, int blocks, hipStream_t st, const T* x, const float* gamma, const float* beta, T* y,
-                          float* mean, float* rstd, int64_t rows, int C, float eps, int lpr_log2) {
-#define LN_F(V) hipLaunchKernelGGL((ln_fwd_kernel<T, V>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, C, eps, lpr_log2)
+                          float* mean, float* rstd, int64_t rows, int C, float eps, int lpr_log2, T* y2, int lw, int ls) {
+#define LN_F(V) hipLaunchKernelGGL((ln_fwd_kernel<T, V>), dim3(blocks), dim3(256), 0, st, x, gamma, beta, y, mean, rstd, rows, C, eps, lpr_log2, y2, lw, ls)
     if (vpt == 1) LN_F(1); else if (vpt == 2) LN_F(2); else if (vpt == 3) LN_F(3); else if (vpt == 4) LN_F(4); else if (vpt == 5) LN_F(5); else LN_F(6);
 #undef LN_F
 }
 template <typename T>
 static void ln_bwd_launch(int vpt, int blocks, size_t shm, hipStream_t st, const T* x, const T* dy, const T* dy2, const T* dres, const float* gamma,
                           const float* mean, const float* rstd, T* dx, float* ws, int64_t rows, int C, int lpr_log2, const float* rsc,
-                          float inv_rpg, T* dxs) {
-#define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, dy2, dres, gamma, mean, rstd, dx, ws, rows, C, lpr_log2, rsc, inv_rpg, dxs)
+                          float inv_rpg, T* dxs, int lw, int ls) {
+#define LN_B(V) hipLaunchKernelGGL((ln_bwd_kernel<T, V>), dim3(blocks), dim3(256), shm, st, x, dy, dy2, dres, gamma, mean, rstd, dx, ws, rows, C, lpr_log2, rsc, inv_rpg, dxs, lw, ls)
     // C in (2048, 3072] (convnextv2_huge's 2816-wide last stage): six chunks per lane and 96 KB of dynamic LDS -- above the 64 KB
     // a kernel gets by default, so the limit is raised on the function first (160 KB per CU on gfx950)
 #define LN_B_BIG(V) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); LN_B(V); } while (0)
@@ -229,9 +239,21 @@ static inline int ln_plan(int C, int& lpr_log2) {
     return (nchunk + (1 << lpr_log2) - 1) >> lpr_log2;   // VPT
 }
 
+extern "C" int segf_layernorm_fwd_patch(int dt, int64_t rows, int C, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                                        float* mean, float* rstd, void* y2, int log2_w, int log2_sr, void* stream);
+static int patch_geom_ok(int64_t rows, int log2_w, int log2_sr) {
+    return log2_sr >= 1 && log2_w >= log2_sr && log2_w <= 20 && ((rows >> log2_w) << log2_w) == rows && ((rows >> log2_w) & (((int64_t)1 << log2_sr) - 1)) == 0;
+}
 extern "C" int segf_layernorm_fwd(int dt, int64_t rows, int C, const void* x, const float* gamma, const float* beta,
                                   float eps, void* y, float* mean, float* rstd, void* stream) {
+    return segf_layernorm_fwd_patch(dt, rows, C, x, gamma, beta, eps, y, mean, rstd, nullptr, 0, 0, stream);
+}
+// ... with a second copy y2 of the output in the PATCH-MAJOR row order of a k = s = sr convolution's im2col matrix (mit.py:47): y2 viewed as
+// [rows / sr^2][sr^2 C] IS that matrix (no segf_im2col pass over y).  The map width W = 2^log2_w and sr = 2^log2_sr; rows % (W sr) == 0.
+extern "C" int segf_layernorm_fwd_patch(int dt, int64_t rows, int C, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                                        float* mean, float* rstd, void* y2, int log2_w, int log2_sr, void* stream) {
     if (rows <= 0) return 0;
+    if (y2 && (!patch_geom_ok(rows, log2_w, log2_sr) || ((uintptr_t)y2 % 16))) return SEGF_ERR_SHAPE;
     if (C <= 0 || C % 8 != 0 || C > 3072) return SEGF_ERR_SHAPE;
     if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((uintptr_t)gamma % 16) || ((uintptr_t)beta % 16)) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -239,7 +261,7 @@ extern "C" int segf_layernorm_fwd(int dt, int64_t rows, int C, const void* x, co
     const int vpt = ln_plan(C, lpr_log2);
     const int rows_per_block = 4 * (64 >> lpr_log2);
     const int blocks = (int)imin64(cdiv64(rows, rows_per_block), 4096);
-    SEGF_DISPATCH_DT(dt, T, { ln_fwd_launch<T>(vpt, blocks, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, lpr_log2); })
+    SEGF_DISPATCH_DT(dt, T, { ln_fwd_launch<T>(vpt, blocks, st, (const T*)x, gamma, beta, (T*)y, mean, rstd, rows, C, eps, lpr_log2, (T*)y2, log2_w, log2_sr); })
     SEGF_CHECK_LAUNCH();
     return 0;
 }
@@ -262,6 +284,10 @@ extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void*
 extern "C" int segf_layernorm_bwd_scaled(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
                                          const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
                                          float* dbeta, float* ws, const float* rscale, int64_t rows_per_group, void* dxs, void* stream);
+extern "C" int segf_layernorm_bwd_patch(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                                        const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                                        float* dbeta, float* ws, const float* rscale, int64_t rows_per_group, void* dxs, int log2_w,
+                                        int log2_sr, void* stream);
 extern "C" int segf_layernorm_bwd(int dt, int64_t rows, int C, const void* x, const void* dy, const float* gamma,
                                   const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                                   float* ws, void* stream) {
@@ -277,7 +303,16 @@ extern "C" int segf_layernorm_bwd_fused(int dt, int64_t rows, int C, const void*
 extern "C" int segf_layernorm_bwd_scaled(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
                                          const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
                                          float* dbeta, float* ws, const float* rscale, int64_t rows_per_group, void* dxs, void* stream) {
+    return segf_layernorm_bwd_patch(dt, rows, C, x, dy, dy2, dres, gamma, mean, rstd, dx, dgamma, dbeta, ws, rscale, rows_per_group, dxs, -1, 0, stream);
+}
+// ... with dy2 stored in the patch-major row order of segf_layernorm_fwd_patch's y2 (log2_w >= 0): the gradient of that second output, as the
+// data-gradient product of the convolution leaves it (no segf_col2im pass)
+extern "C" int segf_layernorm_bwd_patch(int dt, int64_t rows, int C, const void* x, const void* dy, const void* dy2, const void* dres,
+                                        const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                                        float* dbeta, float* ws, const float* rscale, int64_t rows_per_group, void* dxs, int log2_w,
+                                        int log2_sr, void* stream) {
     if (rows <= 0) return 0;
+    if (log2_w >= 0 && (!dy2 || !patch_geom_ok(rows, log2_w, log2_sr))) return SEGF_ERR_SHAPE;
     if ((rscale != nullptr) != (dxs != nullptr)) return SEGF_ERR_SHAPE;
     if (rscale && (rows_per_group <= 0 || rows >= (1ll << 22) || ((uintptr_t)dxs % 16))) return SEGF_ERR_SHAPE;
     if (((uintptr_t)dy2 % 16) || ((uintptr_t)dres % 16)) return SEGF_ERR_SHAPE;
@@ -290,7 +325,7 @@ extern "C" int segf_layernorm_bwd_scaled(int dt, int64_t rows, int C, const void
     const int blocks = ln_bwd_blocks(rows, C);
     const size_t shm = (size_t)4 * 2 * C * sizeof(float);
     const float inv_rpg = rscale ? 1.0f / (float)rows_per_group : 0.f;
-    SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, (const T*)dy2, (const T*)dres, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2, rscale, inv_rpg, (T*)dxs); })
+    SEGF_DISPATCH_DT(dt, T, { ln_bwd_launch<T>(vpt, blocks, shm, st, (const T*)x, (const T*)dy, (const T*)dy2, (const T*)dres, gamma, mean, rstd, (T*)dx, ws, rows, C, lpr_log2, rscale, inv_rpg, (T*)dxs, log2_w, log2_sr); })
     SEGF_CHECK_LAUNCH();
     if (!dgamma) return 0;                       // deferred: the caller finalizes ws later (segf_colreduce_finalize_grouped)
     const int64_t n = 2 * (int64_t)C;

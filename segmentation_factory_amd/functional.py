@@ -191,7 +191,7 @@ def _take_scaled(dy, rscale, rpg):
     return None
 
 
-def _ln_bwd(ctx, x, dy, g, mean, rstd, dy2=None, dres=None):
+def _ln_bwd(ctx, x, dy, g, mean, rstd, dy2=None, dres=None, dy2_patch=None):
     """LayerNorm backward with the (dgamma, dbeta) finalize deferred into the scope's grouped launch when both parameters carry adjacent
     flat-gradient slots; returns (dx, dgamma, dbeta) with None for gradients that will be delivered at the flush."""
     gg, gb = gslot(ctx, 1), gslot(ctx, 2)
@@ -201,13 +201,14 @@ def _ln_bwd(ctx, x, dy, g, mean, rstd, dy2=None, dres=None):
     q = _FIN_QUEUE
     if q is not None and dgb is not None:
         slots = ctx._gslots
-        dx, item = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, defer=True, rscale=rscale, rows_per_group=rpg)
+        dx, item = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, defer=True, rscale=rscale, rows_per_group=rpg,
+                                     dy2_patch=dy2_patch)
         q.append((item, (slots[1], slots[2])))
         if len(q) >= FIN_QUEUE_MAX:
             _flush_finalizes()
         out = (dx, None, None)
     else:
-        out = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, rscale=rscale, rows_per_group=rpg)
+        out = hip.layernorm_bwd(x, dy, g, mean, rstd, dgb_out=dgb, dy2=dy2, dres=dres, rscale=rscale, rows_per_group=rpg, dy2_patch=dy2_patch)
     dx = out[0]
     if getattr(dx, 'scaled', None) is not None:
         if len(_SCALED_DY) > 64:
@@ -584,6 +585,99 @@ class LayerNormResFn(Function):
 def layer_norm_res(x, gamma, beta, eps):
     """-> (x, LayerNorm(x)): use the returned x for the residual connection."""
     return LayerNormResFn.apply(x, gamma, beta, eps, *_dp_of(x))
+
+
+@direct_grads(1, 2)
+class LayerNormResPatchFn(Function):
+    """LayerNormResFn for the norm in front of a MiT attention with spatial reduction (mit.py:143, 47): besides (x, norm(x)) it returns
+    norm(x) a second time in the patch-major row order of the k = s = sr convolution's im2col matrix, [B Ho Wo, sr sr C] -- written by the same
+    kernel (no im2col pass); the backward reads that output's gradient in the same order (no col2im pass) and sums it with the other
+    consumer's on load, as LayerNormForkFn does for two consumers in token order."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, lw, ls, dp_scale=None, dp_rpg=1):
+        ctx.dp = (dp_scale, int(dp_rpg)) if dp_scale is not None else None
+        ctx.patch = (int(lw), int(ls))
+        x = x if x.is_contiguous() else x.contiguous()
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y, mean, rstd, col = hip.layernorm_fwd(x, g, b, eps, patch=ctx.patch)
+        ctx.save_for_backward(x, g, mean, rstd)
+        return x.view_as(x), y, col
+
+    @staticmethod
+    def backward(ctx, dres, dy, dcol):
+        x, g, mean, rstd = ctx.saved_tensors
+        if dy is None and dcol is None:
+            return dres, None, None, None, None, None, None, None
+        if dy is None:                       # (only the convolution consumed the norm: its gradient back in token order first)
+            raise RuntimeError('layer_norm_res_patch: the token-order output received no gradient')
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        if dres is not None and not dres.is_contiguous():
+            dres = dres.contiguous()
+        if dcol is not None and not dcol.is_contiguous():
+            dcol = dcol.contiguous()
+        dx, dg, db = _ln_bwd(ctx, x, dy, g, mean, rstd, dy2=dcol, dres=dres, dy2_patch=ctx.patch if dcol is not None else None)
+        return dx, dg, db, None, None, None, None, None
+
+
+def patch_layout_ok(W, H, sr):
+    """layer_norm_res_patch covers maps whose width and reduction ratio are powers of two (every BASELINE geometry)"""
+    return (sr > 1 and (sr & (sr - 1)) == 0 and (W & (W - 1)) == 0 and W >= sr and H % sr == 0
+            and not os.environ.get('SEGFAC_NO_LN_PATCH'))
+
+
+def layer_norm_res_patch(x, gamma, beta, eps, W, sr):
+    """-> (x, LayerNorm(x), im2col matrix of LayerNorm(x) for a k = s = sr convolution [rows / sr^2, sr^2 C])"""
+    return LayerNormResPatchFn.apply(x, gamma, beta, eps, W.bit_length() - 1, sr.bit_length() - 1, *_dp_of(x))
+
+
+@direct_grads(1, 2)
+class ConvFromColFn(Function):
+    """The k = s = sr convolution of MiT's spatial reduction (mit.py:21,48) on an im2col matrix that already exists
+    (layer_norm_res_patch): y = col W^T + b; the data gradient is returned in the matrix's own layout."""
+
+    @staticmethod
+    def forward(ctx, col, weight, bias, k):
+        col = _rowmajor(col)
+        M, K = col.shape
+        O, Cin = weight.shape[0], weight.shape[1]
+        assert K == k * k * Cin
+        dtype = col.dtype
+        wsrc = weight.detach().contiguous()
+
+        def make_wmat():
+            t = torch.empty((O, k * k, Cin), dtype=dtype, device=col.device)
+            return t, [('perm', wsrc, t, O, Cin, k * k, Cin)]
+        wmat = derived_weight(wsrc, ('patch', dtype, K), make_wmat).view(O, K)                 # [O][(ky,kx)][ci]
+        y = hip.gemm(0, col, wmat, M, O, K, bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(col, wmat)
+        ctx.meta = (M, O, K, k, Cin, bias is not None, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        col, wmat = ctx.saved_tensors
+        M, O, K, k, Cin, has_bias, wshape = ctx.meta
+        dy = _rowmajor(dy)
+        dcol = dw = db = None
+        gw, gb = gslot(ctx, 1), gslot(ctx, 2)
+        if ctx.needs_input_grad[1] and has_bias and ctx.needs_input_grad[2]:
+            if not (gw is not None and _queue_dw_post(ctx, dy, col, O, K, M, lambda t, g: ('perm', t, g, O, k * k, Cin, k * k))):
+                dwm, db = hip.gemm_dw_db(dy, col, O, K, M, split_k=_splitk(O, K, M), db_out=gb)           # [O][(ky,kx)][ci]
+                dw = hip.permute021(dwm, O, k * k, Cin, torch.float32, out=gw).view(wshape)
+        else:
+            if ctx.needs_input_grad[1]:
+                dwm = hip.gemm(2, dy, col, O, K, M, out_dtype=torch.float32, split_k=_splitk(O, K, M))
+                dw = hip.permute021(dwm, O, k * k, Cin, torch.float32, out=gw).view(wshape)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = hip.colsum(dy, out=gb)
+        if ctx.needs_input_grad[0]:
+            dcol = hip.gemm(1, dy, wmat, M, K, O)
+        return dcol, dw, db, None
+
+
+def conv_from_col(col, weight, bias, k):
+    return ConvFromColFn.apply(col, weight, bias, k)
 
 
 @direct_grads(1, 2)

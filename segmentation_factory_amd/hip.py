@@ -39,6 +39,8 @@ _PROTOS = {
     'segf_layernorm_bwd_blocks': (_i, [_l, _i]),
     'segf_colreduce_finalize_grouped': (_i, [_i, _p, _p]),
     'segf_layernorm_fwd': (_i, [_i, _l, _i, _p, _p, _p, _f, _p, _p, _p, _p]),
+    'segf_layernorm_fwd_patch': (_i, [_i, _l, _i, _p, _p, _p, _f, _p, _p, _p, _p, _i, _i, _p]),
+    'segf_layernorm_bwd_patch': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _i, _i, _p]),
     'segf_layernorm_bwd_ws': (_l, [_l, _i]),
     'segf_layernorm_bwd': (_i, [_i, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'segf_bn_ws': (_l, [_l, _i]),
@@ -633,12 +635,20 @@ def pick_splitk(M, N, K):
 
 
 # ---- norms ---------------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps):
+def layernorm_fwd(x, gamma, beta, eps, patch=None):
+    """patch = (log2 W, log2 sr): also returns the output in the patch-major row order of a k = s = sr convolution's im2col matrix,
+    [rows / sr^2, sr^2 C] (segf_layernorm_fwd_patch) -> (y, mean, rstd, col)."""
     _need_cuda(x, gamma, beta)
     rows, Cc = x.shape
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if patch is not None:
+        lw, ls = patch
+        col = torch.empty((rows >> (2 * ls), Cc << (2 * ls)), dtype=x.dtype, device=x.device)
+        _chk(lib().segf_layernorm_fwd_patch(dt_of(x), rows, Cc, _ptr(x), _ptr(gamma), _ptr(beta), eps, _ptr(y), _ptr(mean), _ptr(rstd),
+                                            _ptr(col), lw, ls, _stream()), 'segf_layernorm_fwd_patch')
+        return y, mean, rstd, col
     _chk(lib().segf_layernorm_fwd(dt_of(x), rows, Cc, _ptr(x), _ptr(gamma), _ptr(beta), eps, _ptr(y), _ptr(mean),
                                   _ptr(rstd), _stream()), 'segf_layernorm_fwd')
     return y, mean, rstd
@@ -702,7 +712,7 @@ def colreduce_finalize_grouped(items):
     _chk(lib().segf_colreduce_finalize_grouped(len(items), C.cast(arr, C.c_void_p), _stream()), 'segf_colreduce_finalize_grouped')
 
 
-def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None, defer=False, rscale=None, rows_per_group=1):
+def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None, defer=False, rscale=None, rows_per_group=1, dy2_patch=None):
     """dgb_out: optional (dgamma, dbeta) fp32 [C] views that are ADJACENT in memory (dbeta == dgamma + C): written in place.
     dy2 / dres: optional fan-in operands, dx = LN_bwd(dy + dy2) + dres (segf_layernorm_bwd_fused).
     defer=True (needs dgb_out): the kernel leaves its per-block partial sums and (dx, finalize item) is returned; the caller passes the
@@ -717,8 +727,9 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None, d
         assert rscale.dtype == torch.float32 and rscale.is_contiguous() and rscale.numel() * rows_per_group >= rows
         dxs = torch.empty_like(x)
     ws = _f32(lib().segf_layernorm_bwd_ws(rows, Cc), x.device)
-    for t in (dy2, dres):
-        assert t is None or (t.shape == x.shape and t.dtype == x.dtype and t.is_contiguous())
+    # (dy2_patch = (log2 W, log2 sr): dy2 holds the same elements in patch-major row order, [rows / sr^2, sr^2 C])
+    assert dres is None or (dres.shape == x.shape and dres.dtype == x.dtype and dres.is_contiguous())
+    assert dy2 is None or (dy2.numel() == x.numel() and dy2.dtype == x.dtype and dy2.is_contiguous() and (dy2_patch is not None or dy2.shape == x.shape))
     if dgb_out is not None:
         dg, db = dgb_out
         assert db.data_ptr() == dg.data_ptr() + 4 * Cc and dg.numel() == Cc and db.numel() == Cc
@@ -726,10 +737,11 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dgb_out=None, dy2=None, dres=None, d
         assert not defer
         dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
         dg, db = dgb[0], dgb[1]
-    _chk(lib().segf_layernorm_bwd_scaled(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(dy2), _ptr(dres), _ptr(gamma), _ptr(mean),
-                                         _ptr(rstd), _ptr(dx), None if defer else dg.data_ptr(), None if defer else db.data_ptr(),
-                                         _ptr(ws), _ptr(rscale) if dxs is not None else None, int(rows_per_group), _ptr(dxs), _stream()),
-         'segf_layernorm_bwd_scaled')
+    lw, ls = dy2_patch if (dy2_patch is not None and dy2 is not None) else (-1, 0)
+    _chk(lib().segf_layernorm_bwd_patch(dt_of(x), rows, Cc, _ptr(x), _ptr(dy), _ptr(dy2), _ptr(dres), _ptr(gamma), _ptr(mean),
+                                        _ptr(rstd), _ptr(dx), None if defer else dg.data_ptr(), None if defer else db.data_ptr(),
+                                        _ptr(ws), _ptr(rscale) if dxs is not None else None, int(rows_per_group), _ptr(dxs), lw, ls,
+                                        _stream()), 'segf_layernorm_bwd_patch')
     dx.scaled = dxs
     if defer:
         return dx, (ws, int(lib().segf_layernorm_bwd_blocks(rows, Cc)), 2 * Cc, dg)

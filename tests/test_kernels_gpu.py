@@ -1871,3 +1871,59 @@ def test_layernorm_backward_scaled_second_output(dtype, monkeypatch):
         assert off or len(Fh._SCALED_DY) == 0          # both scaled copies were picked up
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('geom', [(2, 32, 32, 64, 4), (1, 24, 64, 32, 8), (3, 16, 16, 160, 2)])
+def test_layernorm_patch_major_second_output(dtype, geom):
+    """segf_layernorm_fwd_patch / segf_layernorm_bwd_patch: the norm in front of MiT's spatial-reduction convolution (mit.py:143, 47) writes
+    its output a second time as the im2col matrix of the k = s = sr convolution (BITWISE segf_im2col of the first output) and reads that
+    output's gradient in the same order (BITWISE the backward with dy2 = segf_col2im of it)."""
+    from segmentation_factory_amd import hip
+    B, H, W, Cc, sr = geom
+    g = torch.Generator().manual_seed(13)
+    x = _dev(torch.randn(B * H * W, Cc, generator=g), dtype)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    beta = torch.randn(Cc, generator=g).cuda()
+    lw, ls = W.bit_length() - 1, sr.bit_length() - 1
+    y0, mean0, rstd0 = hip.layernorm_fwd(x, gamma, beta, 1e-5)
+    y, mean, rstd, col = hip.layernorm_fwd(x, gamma, beta, 1e-5, patch=(lw, ls))
+    Ho, Wo = H // sr, W // sr
+    assert torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+    assert col.shape == (B * Ho * Wo, sr * sr * Cc)
+    assert torch.equal(col, hip.im2col(y0, dtype, False, B, H, W, Cc, sr, sr, sr, 0, Ho, Wo, sr * sr * Cc))
+    dy = _dev(torch.randn(B * H * W, Cc, generator=g), dtype)
+    dcol = _dev(torch.randn(B * Ho * Wo, sr * sr * Cc, generator=g), dtype)
+    dres = _dev(torch.randn(B * H * W, Cc, generator=g), dtype)
+    want = hip.layernorm_bwd(x, dy, gamma, mean, rstd, dy2=hip.col2im(dcol, B, H, W, Cc, sr, sr, sr, 0, Ho, Wo), dres=dres)
+    got = hip.layernorm_bwd(x, dy, gamma, mean, rstd, dy2=dcol, dres=dres, dy2_patch=(lw, ls))
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
+def test_mit_block_with_patch_major_norm_matches_im2col_path(monkeypatch):
+    """backbones.Block with spatial reduction: the path without im2col / col2im passes (layer_norm_res_patch + conv_from_col) against the
+    im2col path (SEGFAC_NO_LN_PATCH=1): forward bitwise; gradients equal up to ONE bf16 rounding (the two consumers' gradients of the
+    norm now meet in fp32 inside the LayerNorm backward instead of in the epilogue of q's data-gradient product)."""
+    from segmentation_factory_amd.backbones import Block
+    torch.manual_seed(5)
+    B, H, W, dim = 2, 32, 32, 64
+    blk = Block(dim, 2, sr_ratio=4, dpr=0.0).cuda()
+    x0 = torch.randn(B * H * W, dim).cuda().to(torch.bfloat16)
+    dy = torch.randn(B * H * W, dim).cuda().to(torch.bfloat16)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('SEGFAC_NO_LN_PATCH', '1')
+        x = x0.clone().requires_grad_()
+        for p in blk.parameters():
+            p.grad = None
+        y = blk.tokens(x, B, H, W, (None, None))
+        y.backward(dy)
+        outs.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    sc = outs[1][1].float().abs().max().item()
+    assert (outs[0][1].float() - outs[1][1].float()).abs().max().item() <= 2.0 ** -7 * sc
+    for k, gnew in outs[0][2].items():
+        gold = outs[1][2][k]
+        assert (gnew - gold).abs().max().item() <= 2e-2 * gold.abs().max().item() + 1e-6, k
