@@ -310,8 +310,9 @@ int segf_attention_bwd(int dt, int B, int heads, int N, int Nkv, int hd, const v
 int segf_dwconv3x3_gelu_fwd(int dt, int B, int H, int W, int C, const void* x, const float* w /*[C][9]*/,
                             const float* bias, int apply_gelu, void* y, void* stream);
 int64_t segf_dwconv3x3_bwd_ws(int B, int H, int W, int C);
-/* du = dy * gelu'(conv(x)+b) is written to `du` (same shape as x); dx = conv^T(du); dw[C][9], db[C] fp32 */
-int segf_dwconv3x3_bwd_blocks(int B, int H, int W, int C);
+/* du = dy * gelu'(conv(x)+b): `du` (same shape as x) is SCRATCH -- written by the three-pass forms, left untouched by the one-launch form of
+ * small maps (H W <= 1024 in bf16 / 512 in fp32: the whole backward in LDS); dx = conv^T(du); dw[C][9], db[C] fp32 */
+int segf_dwconv3x3_bwd_blocks(int dt, int B, int H, int W, int C);
 int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
                             int apply_gelu, const void* dy, void* du, void* dx, float* dw, float* db,
                             float* ws, void* stream);

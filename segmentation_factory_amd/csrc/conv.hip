@@ -542,10 +542,163 @@ __global__ void dw_scatter_kernel(const float* __restrict__ sums, int C, float* 
     db[c] = sums[9 * C + c];
 }
 
+// ---- small maps: the whole backward of the depthwise 3x3 (+ GELU) in ONE launch ---------------------------------------------------
+// MiT stages 3 / 4 at 512^2 (32 x 32 and 16 x 16 maps, mit.py:62-71): the three passes above (du = dy gelu'(conv(x) + b); dw / db partial
+// sums; dx = conv^T(du)) are three launches over maps that fit the LDS of one workgroup many times over -- at the reference's default
+// batch each is a dependent link of 9 - 16 us in the step's launch chain.  Here a workgroup owns the map of one image for 8 nch channels:
+// x is staged once, z and du are formed per (pixel, 8-channel chunk) in the tap order of the walk kernels (same fused multiply-adds, the
+// same eight-wide GELU helper: du and dx are BITWISE what the three-pass form gives), du stays in LDS (rounded to T, as the three-pass form
+// stores it), dx is formed from it, and the weight / bias sums are taken over the staged tiles in a fixed order (another summation order
+// than the three-pass form: fp32 round-off).  Partials: part[b][10][C], finalized like the other forms (nblk = B).
+template <typename T>
+__global__ void __launch_bounds__(256) dwconv3x3_bwd_small_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ bias, int apply_gelu,
+                                                                   const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part,
+                                                                   int B, int H, int W, int C, int nch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dws_smem[];
+    const int HW = H * W, U = HW * nch, groups = C / (8 * nch);
+    const int b = blockIdx.x / groups, cbase = (blockIdx.x - b * groups) * 8 * nch;
+    T* xs = reinterpret_cast<T*>(dws_smem);                        // [nch][HW][8]
+    T* dus = xs + (size_t)U * 8;                                   // [nch][HW][8]
+    float* wsh = reinterpret_cast<float*>(dus + (size_t)U * 8);   // [nch][10][8]: nine taps + bias, the 8 channels of a chunk contiguous
+    float* red = wsh + nch * 80;                                   // [slices][10 nch][8]
+    const T* xb = x + (int64_t)b * HW * C + cbase;
+    const T* gb = dy + (int64_t)b * HW * C + cbase;
+    T* ob = dx + (int64_t)b * HW * C + cbase;
+    for (int i = threadIdx.x; i < nch * 80; i += 256) {
+        const int ch = i / 80, r = i - ch * 80, k = r >> 3, c = r & 7;
+        wsh[i] = k < 9 ? w[(cbase + 8 * ch + c) * 9 + k] : (bias ? bias[cbase + 8 * ch + c] : 0.f);
+    }
+    for (int u = threadIdx.x; u < U; u += 256) {
+        const int ch = u / HW, p = u - ch * HW;
+        *reinterpret_cast<Raw8<T>*>(xs + (size_t)u * 8) = load8_raw<T>(xb + (int64_t)p * C + 8 * ch);
+    }
+    __syncthreads();
+    // du = dy gelu'(conv(x) + b), rounded to T (what the three-pass form stores): chunk by chunk, the chunk's taps in registers
+    for (int ch = 0; ch < nch; ++ch) {
+        f32x2_t wk[10][4];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float4 lo = *reinterpret_cast<const float4*>(wsh + ch * 80 + k * 8), hi = *reinterpret_cast<const float4*>(wsh + ch * 80 + k * 8 + 4);
+            wk[k][0] = f32x2_t{lo.x, lo.y}; wk[k][1] = f32x2_t{lo.z, lo.w}; wk[k][2] = f32x2_t{hi.x, hi.y}; wk[k][3] = f32x2_t{hi.z, hi.w};
+        }
+        const T* xc = xs + (size_t)ch * HW * 8;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int py = p / W, px = p - py * W;
+            const Raw8<T> graw = load8_raw<T>(gb + (int64_t)p * C + 8 * ch);
+            f32x2_t z[4] = {wk[9][0], wk[9][1], wk[9][2], wk[9][3]};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = py + ky - 1, xx = px + kx - 1;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        f32x2_t v[4];
+                        unpack8v<T>(*reinterpret_cast<const Raw8<T>*>(xc + (size_t)(yy * W + xx) * 8), v);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) z[jj] = wk[ky * 3 + kx][jj] * v[jj] + z[jj];
+                    }
+                }
+            f32x2_t gy[4];
+            unpack8v<T>(graw, gy);
+            if (apply_gelu) gelu_erf8<true>(z, gy);
+            else { z[0] = gy[0]; z[1] = gy[1]; z[2] = gy[2]; z[3] = gy[3]; }
+            store8v<T>(dus + ((size_t)ch * HW + p) * 8, z);
+        }
+    }
+    __syncthreads();
+    // dx = conv^T(du): output (py, px) gathers du at (py + ky - 1, px + kx - 1) with the flipped tap, in the walk kernel's order
+    for (int ch = 0; ch < nch; ++ch) {
+        f32x2_t wk[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float4 lo = *reinterpret_cast<const float4*>(wsh + ch * 80 + k * 8), hi = *reinterpret_cast<const float4*>(wsh + ch * 80 + k * 8 + 4);
+            wk[k][0] = f32x2_t{lo.x, lo.y}; wk[k][1] = f32x2_t{lo.z, lo.w}; wk[k][2] = f32x2_t{hi.x, hi.y}; wk[k][3] = f32x2_t{hi.z, hi.w};
+        }
+        const T* dc = dus + (size_t)ch * HW * 8;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const int py = p / W, px = p - py * W;
+            f32x2_t a[4] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = py + ky - 1, xx = px + kx - 1;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        f32x2_t v[4];
+                        unpack8v<T>(*reinterpret_cast<const Raw8<T>*>(dc + (size_t)(yy * W + xx) * 8), v);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) a[jj] = wk[8 - (ky * 3 + kx)][jj] * v[jj] + a[jj];
+                    }
+                }
+            store8v<T>(ob + (int64_t)p * C + 8 * ch, a);
+        }
+    }
+    // dw[c][k] = sum_p du[p][c] x[p + off(k)][c], db[c] = sum_p du[p][c]: a thread takes (chunk, tap) for one contiguous slice of the pixels,
+    // all 8 channels at once; the slices meet in LDS and are added in slice order
+    const int T4 = 10 * nch, S = 256 / T4;
+    {
+        const int tc = threadIdx.x % T4, sl = threadIdx.x / T4;
+        if (sl < S) {
+            const int ch = tc / 10, k = tc - ch * 10;
+            const int p0 = (int)((int64_t)HW * sl / S), p1 = (int)((int64_t)HW * (sl + 1) / S);
+            const int dyk = k < 9 ? k / 3 - 1 : 0, dxk = k < 9 ? k % 3 - 1 : 0;
+            const T* dc = dus + (size_t)ch * HW * 8;
+            const T* xc = xs + (size_t)ch * HW * 8;
+            f32x2_t acc[4] = {f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}, f32x2_t{0.f, 0.f}};
+            int py = p0 / W, px = p0 - py * W;
+            for (int p = p0; p < p1; ++p) {
+                f32x2_t d[4];
+                unpack8v<T>(*reinterpret_cast<const Raw8<T>*>(dc + (size_t)p * 8), d);
+                if (k == 9) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[jj] = acc[jj] + d[jj];
+                } else {
+                    const int yy = py + dyk, xx = px + dxk;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        f32x2_t v[4];
+                        unpack8v<T>(*reinterpret_cast<const Raw8<T>*>(xc + (size_t)(yy * W + xx) * 8), v);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[jj] = d[jj] * v[jj] + acc[jj];
+                    }
+                }
+                if (++px == W) { px = 0; ++py; }
+            }
+            float* r = red + ((size_t)sl * T4 + tc) * 8;
+            *reinterpret_cast<float4*>(r) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+            *reinterpret_cast<float4*>(r + 4) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < T4 * 8; o += 256) {
+        const int tc = o >> 3, c = o & 7, ch = tc / 10, k = tc - ch * 10;
+        float t = red[o];
+        for (int q = 1; q < S; ++q) t += red[(size_t)q * T4 * 8 + o];
+        part[((int64_t)b * 10 + k) * C + cbase + 8 * ch + c] = t;
+    }
+}
+// nch (8-channel chunks per workgroup) of the one-launch form, 0 when the map does not take it
+static inline int dw_small_nch(int dt, int B, int H, int W, int C) {
+    if (getenv("SEGFAC_DW_NO_SMALL") || C % 8 || B > 4096) return 0;
+    const int HW = H * W, umax = dt == SEGF_BF16 ? 1024 : 512;
+    if (HW > umax || HW < 16) return 0;
+    for (int nch = 4; nch >= 1; nch >>= 1)
+        if (HW * nch <= umax && (C / 8) % nch == 0) {
+            // one round of workgroups at most: a workgroup walks its map serially (26 - 33 us whatever the batch), which beats the three
+            // launches (39 - 42 us) only while the launch chain, not the arithmetic, is what the step waits for (measured: batch 4 +0.6 %,
+            // batch 16 -0.7 %, batch 128 -1.8 % without this bound)
+            if ((int64_t)B * (C / (8 * nch)) > 512 && !getenv("SEGFAC_DW_SMALL_ALWAYS")) return 0;
+            return nch;
+        }
+    return 0;
+}
+
 extern "C" int64_t segf_dwconv3x3_bwd_ws(int B, int H, int W, int C) {
     DwgPlan p = dwg_plan(B, H, W, C > 0 ? C : 8);
     DwwPlan q = dww_plan(B, H > 0 ? H : 1, W > 0 ? W : 1, C > 0 ? C : 8);
-    return (int64_t)(p.nblk > q.nblk ? p.nblk : q.nblk) * 10 * C + 10 * (int64_t)C;
+    int nblk = p.nblk > q.nblk ? p.nblk : q.nblk;
+    if (B > nblk) nblk = B;                       // (the one-launch form of small maps leaves one partial slab per image)
+    return (int64_t)nblk * 10 * C + 10 * (int64_t)C;
 }
 
 extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const void* x, const float* w, const float* bias,
@@ -557,6 +710,23 @@ extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const
     if ((int64_t)B * H * W >= (1ll << 31)) return SEGF_ERR_SHAPE;
     if (!ws) return SEGF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (const int nch = dw_small_nch(dt, B, H, W, C)) {
+        const size_t esz = dt == SEGF_BF16 ? 2 : 4;
+        const size_t shm = (size_t)H * W * nch * 8 * esz * 2 + (size_t)nch * 80 * 4 + 256 * 8 * 4;      // tiles + taps + slice sums
+        const int blocks = B * (C / (8 * nch));
+        SEGF_DISPATCH_DT(dt, T, {
+            hipLaunchKernelGGL((dwconv3x3_bwd_small_kernel<T>), dim3(blocks), dim3(256), shm, st, (const T*)x, w, bias, apply_gelu,
+                               (const T*)dy, (T*)dx, ws, B, H, W, C, nch);
+        })
+        SEGF_CHECK_LAUNCH();
+        if (!dw) return 0;          // deferred: [B][10 C] partial sums stay in ws (segf_dwconv3x3_bwd_blocks == B)
+        float* sums_s = ws + (int64_t)B * 10 * C;
+        colreduce_finalize_launch(ws, B, 10 * (int64_t)C, sums_s, st);
+        SEGF_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dw_scatter_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums_s, C, dw, db);
+        SEGF_CHECK_LAUNCH();
+        return 0;
+    }
     DwgPlan p = dwg_plan(B, H, W, C);
     const DwwPlan q = dww_plan(B, H, W, C);
     const bool walk = dw_use_walk();
@@ -588,8 +758,9 @@ extern "C" int segf_dwconv3x3_gelu_bwd(int dt, int B, int H, int W, int C, const
     SEGF_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int segf_dwconv3x3_bwd_blocks(int B, int H, int W, int C) {
+extern "C" int segf_dwconv3x3_bwd_blocks(int dt, int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    if (dw_small_nch(dt, B, H, W, C)) return B;
     return dw_use_walk() ? dww_plan(B, H, W, C).nblk : dwg_plan(B, H, W, C).nblk;
 }
 

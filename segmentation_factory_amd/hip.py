@@ -64,7 +64,7 @@ _PROTOS = {
                                 _p, _l, _p, _l, _p, _l, _p, _p]),
     'segf_dwconv3x3_gelu_fwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     'segf_dwconv3x3_bwd_ws': (_l, [_i, _i, _i, _i]),
-    'segf_dwconv3x3_bwd_blocks': (_i, [_i, _i, _i, _i]),
+    'segf_dwconv3x3_bwd_blocks': (_i, [_i, _i, _i, _i, _i]),
     'segf_dwconv3x3_gelu_bwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p]),
     'segf_dwconv7x7_fwd': (_i, [_i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     'segf_dwconv7x7_bwd_ws': (_l, [_i, _i, _i, _i]),
@@ -910,7 +910,7 @@ def dwconv3x3_gelu_bwd(x, w9, bias, dy, B, H, W, Cc, apply_gelu=True, dw_out=Non
         ws = _f32(lib().segf_dwconv3x3_bwd_ws(B, H, W, Cc), x.device)
         _chk(lib().segf_dwconv3x3_gelu_bwd(dt_of(x), B, H, W, Cc, _ptr(x), _ptr(w9), _ptr(bias), int(apply_gelu), _ptr(dy),
                                            _ptr(du), _ptr(dx), None, None, _ptr(ws), _stream()), 'segf_dwconv3x3_gelu_bwd')
-        return dx, (ws, int(lib().segf_dwconv3x3_bwd_blocks(B, H, W, Cc)), 10 * Cc, dw_out, Cc)
+        return dx, (ws, int(lib().segf_dwconv3x3_bwd_blocks(dt_of(x), B, H, W, Cc)), 10 * Cc, dw_out, Cc)
     dw = dw_out if dw_out is not None else torch.empty((Cc, 9), dtype=torch.float32, device=x.device)
     db = db_out if db_out is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == Cc * 9 and db.is_contiguous() and db.numel() == Cc and dw.dtype == db.dtype == torch.float32

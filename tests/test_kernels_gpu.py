@@ -1927,3 +1927,35 @@ def test_mit_block_with_patch_major_norm_matches_im2col_path(monkeypatch):
     for k, gnew in outs[0][2].items():
         gold = outs[1][2][k]
         assert (gnew - gold).abs().max().item() <= 2e-2 * gold.abs().max().item() + 1e-6, k
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('geom', [(4, 16, 16, 1024), (2, 32, 32, 640), (3, 8, 8, 64), (2, 24, 20, 40), (1, 16, 16, 32)])
+def test_dwconv3x3_backward_one_launch_form_of_small_maps(dtype, geom, monkeypatch):
+    """dwconv3x3_bwd_small_kernel (MiT stages 3 / 4 at 512^2, mit.py:62-71 backward: the map of one image in LDS, du / dx / dw / db in one
+    launch) against the three-pass walk form of the same library (SEGFAC_DW_NO_SMALL=1): dx BITWISE (same tap order, same GELU helper, du
+    rounded to the storage type in between), dw / db to fp32 round-off (another summation order); the deferred-finalize form likewise."""
+    from segmentation_factory_amd import hip
+    B, H, W, Cc = geom
+    if dtype == torch.float32 and H * W > 512:
+        pytest.skip('fp32: maps up to 512 pixels take the one-launch form')
+    g = torch.Generator().manual_seed(23)
+    x = _dev(torch.randn(B * H * W, Cc, generator=g), dtype)
+    dy = _dev(torch.randn(B * H * W, Cc, generator=g), dtype)
+    w9 = (torch.randn(Cc, 9, generator=g) * 0.3).cuda()
+    b = (torch.randn(Cc, generator=g) * 0.2).cuda()
+    monkeypatch.setenv('SEGFAC_DW_SMALL_ALWAYS', '1')          # (the dispatch takes this form up to one round of workgroups only)
+    assert hip.lib().segf_dwconv3x3_bwd_blocks(hip.dt_of(x), B, H, W, Cc) == B
+    for gelu in (True, False):
+        dx1, dw1, db1 = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, gelu)
+        flat = torch.empty(10 * Cc, device='cuda')
+        dx2, item = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, gelu, dw_out=flat[:9 * Cc].view(Cc, 9), db_out=flat[9 * Cc:], defer=True)
+        hip.colreduce_finalize_grouped([item])
+        monkeypatch.setenv('SEGFAC_DW_NO_SMALL', '1')
+        dx0, dw0, db0 = hip.dwconv3x3_gelu_bwd(x, w9, b, dy, B, H, W, Cc, gelu)
+        monkeypatch.delenv('SEGFAC_DW_NO_SMALL')
+        torch.cuda.synchronize()
+        assert torch.equal(dx1, dx0) and torch.equal(dx2, dx0)
+        assert torch.equal(flat[:9 * Cc].view(Cc, 9), dw1) and torch.equal(flat[9 * Cc:], db1)
+        sc = dw0.abs().max().item()
+        assert (dw1 - dw0).abs().max().item() <= 2e-5 * sc + 1e-6 and (db1 - db0).abs().max().item() <= 2e-5 * db0.abs().max().item() + 1e-6
