@@ -231,7 +231,7 @@ int segf_layernorm_bwd_patch(int dt, int64_t rows, int C, const void* x, const v
  * out[i] = sum_b partial[b][i], i < len, summed in the order of the single finalize (bitwise the same dgamma / dbeta). */
 typedef struct SegfFinalizeItem { const float* partial; float* out; int64_t len; int nblk; int scatter_c; } SegfFinalizeItem;
 /* scatter_c = C > 0 (len must be 10 C): the sums are the [10][C] partials of segf_dwconv3x3_gelu_bwd called with dw == NULL
- * (segf_dwconv3x3_bwd_blocks(B, H, W, C) blocks in its ws) and land as out = dw[C][9] followed by db[C] (mit.py:62-71 backward). */
+ * (segf_dwconv3x3_bwd_blocks(dt, B, H, W, C) blocks in its ws) and land as out = dw[C][9] followed by db[C] (mit.py:62-71 backward). */
 int segf_layernorm_bwd_blocks(int64_t rows, int C);
 int segf_colreduce_finalize_grouped(int n, const SegfFinalizeItem* items, void* stream);
 
