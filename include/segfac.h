@@ -181,7 +181,7 @@ int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const void* A, int6
 /* The same for SEVERAL layers in one call (the backward of a MiT / ConvNeXt block: q, kv, proj, fc1, fc2 of mit.py:43-59,98-99 -- their
  * weight gradients do not depend on each other).  Items that take the 128-tile split-K kernel are gathered into grouped launches (one
  * product launch + one reduce launch per up to 12 layers); the rest run exactly as segf_gemm_dw_db.  Every item's dw [M][lddw] fp32 and
- * db [M] are bitwise what segf_gemm_dw_db(dt, M, N, K, dy, lddy, x, ldx, dw, F32, lddw, split_k, ws, db) produces; ws per item >=
+ * db [M] are (with shared_split == 0) bitwise what segf_gemm_dw_db(dt, M, N, K, dy, lddy, x, ldx, dw, F32, lddw, split_k, ws, db) produces; ws per item >=
  * segf_gemm_dw_db_ws(M, N, K, split_k) floats, 16-byte aligned. */
 typedef struct SegfDwItem {
     int64_t M, N, K;            /* dw = dy^T x: dy [K][M], x [K][N] (K = tokens) */
@@ -191,7 +191,9 @@ typedef struct SegfDwItem {
     float* db;
     float* ws;
     int split_k;
-    int reserved;
+    int shared_split;           /* != 0: split_k is an UPPER BOUND -- inside a group the flagged members may run with fewer slices (one common
+                                 * K range per slice, chosen so that the group as a whole fills the chip); 0: exactly split_k, bitwise
+                                 * segf_gemm_dw_db */
 } SegfDwItem;
 int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, void* stream);
 

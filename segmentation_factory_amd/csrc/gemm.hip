@@ -1975,9 +1975,75 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
     if (!items) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     GemmDwGroup g; ReduceGroup r;
-    g.n = 0; r.n = 0; g.start[0] = 0; r.start[0] = 0;
+    int pend[GDW_MAX], npend = 0;                 // indices of the groupable items of the open group
+    const bool no_group = getenv("SEGFAC_NO_GROUPED_DW") != nullptr;
+    const bool no_shared = getenv("SEGFAC_DW_NO_SHARED_SPLIT") != nullptr;
     auto flush = [&]() -> int {
-        if (g.n == 0) return 0;
+        if (npend == 0) return 0;
+        // Slice counts.  Each item arrives with the count segf_gemm_pick_splitk gives a product that runs ALONE (enough slices to fill the
+        // chip by itself); in a group the members fill it together, and a member whose `shared_split` flag is set lets the library lower
+        // its count: all flagged members then take one common K range per slice, the smallest that brings the group down to ~3 rounds of
+        // resident workgroups (or keeps it where it is).  At batch 16 the stage-3 / 4 layers ran 64 slices of FOUR K steps each -- a
+        // 64 KB partial tile written and summed per 8 MFLOP; with the shared range they run 8 - 16 slices.
+        int64_t kslice[GDW_MAX];
+        bool any_flag = false;
+        for (int j = 0; j < npend; ++j) {
+            const SegfDwItem& it = items[pend[j]];
+            const int split_k = it.split_k < 1 ? 1 : it.split_k;
+            kslice[j] = cdiv64(cdiv64(it.K, split_k), GB_BK) * GB_BK;
+            any_flag |= it.shared_split != 0;
+        }
+        if (any_flag && !no_shared && npend > 1) {
+            auto total_wg = [&](int64_t kap) {
+                int64_t t = 0;
+                for (int j = 0; j < npend; ++j) {
+                    const SegfDwItem& it = items[pend[j]];
+                    const int64_t ks = it.shared_split ? (kap > kslice[j] ? kap : kslice[j]) : kslice[j];
+                    t += cdiv64(it.M, GB_BM) * cdiv64(it.N, GB_BN) * cdiv64(it.K, ks);
+                }
+                return t;
+            };
+            const int64_t target = 1536;          // 3 rounds of 2 resident workgroups on 256 CUs
+            int64_t kap = 4 * GB_BK;
+            // (at most 32 K steps per slice: with long slices the members' different tile shapes leave an uneven last round -- batch 128
+            // measured -0.4 % without this cap, and there the per-layer counts already give slices of 16 steps)
+            while (total_wg(kap) > target && kap < 32 * GB_BK) kap += GB_BK;
+            for (int j = 0; j < npend; ++j) {
+                const SegfDwItem& it = items[pend[j]];
+                if (it.shared_split && kap > kslice[j] && cdiv64(it.K, kap) >= 2) kslice[j] = kap;      // (never below two slices: the reduce pass carries the output)
+            }
+        }
+        g.n = 0; r.n = 0; g.start[0] = 0; r.start[0] = 0;
+        for (int j = 0; j < npend; ++j) {
+            const SegfDwItem& it = items[pend[j]];
+            const int64_t M = it.M, N = it.N, K = it.K, kchunk = kslice[j];
+            const int slices = (int)cdiv64(K, kchunk);
+            // the arguments gemm_impl builds for this product (layout 2, fp32 output, split-K partials in ws, bias column riding)
+            GemmArgs a;
+            a.A = it.dy; a.B = it.x; a.C = it.dw; a.bias = nullptr; a.residual = nullptr; a.rscale = nullptr;
+            a.M = M; a.N = N; a.K = K; a.lda = it.lddy; a.ldb = it.ldx; a.ldc = it.lddw; a.ldr = 0; a.rpg = 1;
+            a.kchunk = kchunk; a.ws = it.ws;
+            a.a_vec = 1; a.b_vec = 1; a.fast = 1;
+            a.c_vec = ((uintptr_t)it.dw % 16 == 0) && ((it.lddw * 4) % 16 == 0);
+            a.r_vec = 0; a.c_vec16 = a.c_vec;
+            a.use_tr = 1;
+            a.cH = a.cW = a.cC = 0; a.csign = 1;
+            a.colsum = it.db; a.colsum_ws = it.ws + (int64_t)slices * M * N;
+            a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_rpg = 1; a.pro_ld = 0; a.pro_act = 0;
+            a.f8_sa = nullptr; a.f8_sb = nullptr;
+            const unsigned gx = (unsigned)cdiv64(N, GB_BN), gy = (unsigned)cdiv64(M, GB_BM), gz = (unsigned)slices;
+            const int k = g.n;
+            g.m[k] = a; g.gx[k] = gx; g.gy[k] = gy; g.gz[k] = gz;
+            g.start[k + 1] = g.start[k] + gx * gy * gz;
+            ++g.n;
+            const int form = splitk_reduce_form(it.ws, M, N, it.dw, it.lddw);
+            const unsigned blocks = splitk_reduce_main_blocks(form, M * N), csb = splitk_reduce_cs_blocks(form, M);
+            r.wide[k] = form; r.split[k] = slices; r.ws[k] = it.ws; r.C[k] = it.dw; r.cs_ws[k] = a.colsum_ws; r.cs_out[k] = it.db;
+            r.M[k] = M; r.N[k] = N; r.ldc[k] = it.lddw; r.cs_n[k] = M; r.main_blocks[k] = blocks;
+            r.start[k + 1] = r.start[k] + blocks + csb;
+            ++r.n;
+        }
+        npend = 0;
         if (g.n == 1) {          // a lone member: the ordinary launch pair (same arithmetic)
             const GemmArgs& a = g.m[0];
             hipLaunchKernelGGL((gemm_bf16_kernel<2, float, true, false, 2, true>), dim3(g.gx[0], g.gy[0], g.gz[0]), dim3(256), 0, st, a);
@@ -1989,7 +2055,6 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
             hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3(r.start[r.n]), dim3(256), 0, st, r);
             SEGF_CHECK_LAUNCH();
         }
-        g.n = 0; r.n = 0;
         return 0;
     };
     ReduceGroup r2;
@@ -2001,7 +2066,6 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         r2.n = 0;
         return 0;
     };
-    const bool no_group = getenv("SEGFAC_NO_GROUPED_DW") != nullptr;
     for (int i = 0; i < n; ++i) {
         const SegfDwItem& it = items[i];
         int split_k = it.split_k < 1 ? 1 : it.split_k;
@@ -2024,31 +2088,8 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
             if (r2.n == GDW_MAX) { const int rc2 = flush2(); if (rc2) return rc2; }
             continue;
         }
-        // the arguments gemm_impl builds for this product (layout 2, fp32 output, split-K partials in ws, bias column riding)
-        GemmArgs a;
-        a.A = it.dy; a.B = it.x; a.C = it.dw; a.bias = nullptr; a.residual = nullptr; a.rscale = nullptr;
-        a.M = M; a.N = N; a.K = K; a.lda = it.lddy; a.ldb = it.ldx; a.ldc = it.lddw; a.ldr = 0; a.rpg = 1;
-        a.kchunk = kchunk; a.ws = it.ws;
-        a.a_vec = 1; a.b_vec = 1; a.fast = 1;
-        a.c_vec = ((uintptr_t)it.dw % 16 == 0) && ((it.lddw * 4) % 16 == 0);
-        a.r_vec = 0; a.c_vec16 = a.c_vec;
-        a.use_tr = 1;
-        a.cH = a.cW = a.cC = 0; a.csign = 1;
-        a.colsum = it.db; a.colsum_ws = it.ws + (int64_t)slices * M * N;
-        a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_rpg = 1; a.pro_ld = 0; a.pro_act = 0;
-        a.f8_sa = nullptr; a.f8_sb = nullptr;
-        const unsigned gx = (unsigned)cdiv64(N, GB_BN), gy = (unsigned)cdiv64(M, GB_BM), gz = (unsigned)slices;
-        const int k = g.n;
-        g.m[k] = a; g.gx[k] = gx; g.gy[k] = gy; g.gz[k] = gz;
-        g.start[k + 1] = g.start[k] + gx * gy * gz;
-        ++g.n;
-        const int form = splitk_reduce_form(it.ws, M, N, it.dw, it.lddw);
-        const unsigned blocks = splitk_reduce_main_blocks(form, M * N), csb = splitk_reduce_cs_blocks(form, M);
-        r.wide[k] = form; r.split[k] = slices; r.ws[k] = it.ws; r.C[k] = it.dw; r.cs_ws[k] = a.colsum_ws; r.cs_out[k] = it.db;
-        r.M[k] = M; r.N[k] = N; r.ldc[k] = it.lddw; r.cs_n[k] = M; r.main_blocks[k] = blocks;
-        r.start[k + 1] = r.start[k] + blocks + csb;
-        ++r.n;
-        if (g.n == GDW_MAX) { const int rc = flush(); if (rc) return rc; }
+        pend[npend++] = i;
+        if (npend == GDW_MAX) { const int rc = flush(); if (rc) return rc; }
     }
     { const int rc = flush(); if (rc) return rc; }
     return flush2();

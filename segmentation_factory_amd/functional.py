@@ -223,7 +223,8 @@ def flush_weight_grads():
     q = _DW_QUEUE
     if not q:
         return
-    hip.gemm_dw_db_grouped([e[0] for e in q])
+    # (the members' split-K counts were chosen per layer; inside a group they may share one smaller count: hip / segfac.h shared_split)
+    hip.gemm_dw_db_grouped([e[0] for e in q], shared_split=not os.environ.get('SEGFAC_DW_NO_SHARED_SPLIT'))
     # the layout passes behind the products (the [O][k k][Cin] -> OIHW permutes of the patch convolutions' weight gradients): one launch
     hip.prep_grouped([post for _, _, post in q if post is not None])
     for _, infos, post in q:

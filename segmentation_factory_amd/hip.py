@@ -356,10 +356,10 @@ class SegfDwItem(C.Structure):
     """include/segfac.h: one layer of segf_gemm_dw_db_grouped"""
     _fields_ = [('M', C.c_int64), ('N', C.c_int64), ('K', C.c_int64), ('dy', C.c_void_p), ('lddy', C.c_int64), ('x', C.c_void_p),
                 ('ldx', C.c_int64), ('dw', C.c_void_p), ('lddw', C.c_int64), ('db', C.c_void_p), ('ws', C.c_void_p), ('split_k', C.c_int),
-                ('reserved', C.c_int)]
+                ('shared_split', C.c_int)]
 
 
-def gemm_dw_db_grouped(items):
+def gemm_dw_db_grouped(items, shared_split=False):
     """items: [(dy [K, M], x [K, N], M, N, K, split_k, dw fp32 [M, N] view, db fp32 [M])]: the weight + bias gradients of several Linear
     layers in ONE C-ABI call (grouped launches where the shapes allow; each result bitwise equal to gemm_dw_db's)."""
     if not items:
@@ -378,7 +378,7 @@ def gemm_dw_db_grouped(items):
         it = arr[k]
         it.M, it.N, it.K = M, N, K
         it.dy, it.lddy, it.x, it.ldx = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
-        it.dw, it.lddw, it.db, it.ws, it.split_k, it.reserved = dw.data_ptr(), dw.stride(0), db.data_ptr(), ws.data_ptr(), split_k, 0
+        it.dw, it.lddw, it.db, it.ws, it.split_k, it.shared_split = dw.data_ptr(), dw.stride(0), db.data_ptr(), ws.data_ptr(), split_k, int(shared_split)
     _chk(lib().segf_gemm_dw_db_grouped(dt, len(items), C.cast(arr, C.c_void_p), _stream()), 'segf_gemm_dw_db_grouped')
 
 

@@ -1703,6 +1703,19 @@ def test_grouped_weight_gradients_equal_per_layer_launches():
     torch.cuda.synchronize()
     for a, b, c in zip(items, items1, single):
         assert torch.equal(a[6], b[6]) and torch.equal(a[7], b[7]) and torch.equal(a[6], c[0]) and torch.equal(a[7], c[1]), a[2:5]
+    # shared_split (what the captured step passes): the members of a group may run with FEWER slices than they were given (one common K
+    # range per slice, so that the group as a whole fills the chip): another summation order -- fp32 round-off against the per-layer
+    # results -- and deterministic
+    outs = []
+    for _ in range(2):
+        items2 = [(dy, x, M, N, K, sk, torch.empty(M, N, device='cuda'), torch.empty(M, device='cuda')) for (dy, x, M, N, K, sk, _, _) in items]
+        hip.gemm_dw_db_grouped(items2, shared_split=True)
+        torch.cuda.synchronize()
+        outs.append(items2)
+    for a, b, c in zip(items, outs[0], outs[1]):
+        assert torch.equal(b[6], c[6]) and torch.equal(b[7], c[7])
+        assert (a[6] - b[6]).abs().max().item() <= 2e-5 * a[6].abs().max().item() + 1e-6, a[2:5]
+        assert (a[7] - b[7]).abs().max().item() <= 2e-5 * a[7].abs().max().item() + 1e-6, a[2:5]
 
 
 def test_prep_grouped_equals_single_kernels():
