@@ -333,6 +333,13 @@ int segf_dwconv7x7_bwd(int dt, int B, int H, int W, int C, const void* x, const 
  *   mode 0: y[P][ldy]  = conv(x[P][ldx], w[Cout][9*Cin])            (+ bias[Cout], nullable)
  *   mode 1: y = dx[P][ldy] = conv^T: x := dy[P][ldx], w := wt[Cin][9*Cout] (weights transposed to [ci][tap][co])
  *   mode 2: y = dw fp32 [Cout][9*Cin] (ldy): x[P][ldx], w := dy[P][ldw]; split_k slices P, ws >= split_k*Cout*9*Cin floats */
+/* Modes 0 / 1 with FEW output tiles over a long reduction (PPM bottleneck 3840 -> 768 on 16 x 16, ppm.py:19; the 40 x 40 / 20 x 20 levels):
+ * segf_conv3x3_fwd_splitk > 1 = run with that split_k and ws of split_k * P * N floats (bf16 output, no bias): K slices of the eight-phase
+ * tile, fp32 partials, one reduce pass.  Any other split_k for modes 0 / 1 is ignored. */
+int segf_conv3x3_fwd_splitk(int mode, int B, int H, int W, int Cin, int Cout);
+/* split-K count for mode 2 of segf_conv3x3 (size ws with it): segf_gemm_pick_splitk for the shapes that take the generic rule, a few slices
+ * of the eight-phase tile for large outputs over short reductions (the FPN levels of UPerHead, upernet.py:26-28) */
+int segf_conv3x3_pick_splitk(int Cin, int Cout, int64_t P);
 int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, const void* x, int64_t ldx, const void* w, int64_t ldw,
                  void* y, int y_dt, int64_t ldy, const float* bias, int split_k, float* ws, void* stream);
 

@@ -2313,6 +2313,51 @@ reduce:
 //   mode 1  dx[pix][ci] = sum_{tap,co} dy[pix-off(tap)][co] * wt[ci][tap*Cout+co]     x := dy [P][ldx], w := wt [Cin][9*Cout]
 //   mode 2  dw[co][tap*Cin+ci] = sum_pix dy[pix][co] * x[pix+off(tap)][ci]            x: [P][ldx], w := dy [P][ldw], y := dw fp32
 // P = B*H*W.  bf16 only (the fp32 parity mode goes through segf_im2col + segf_gemm).  Channel counts must be multiples of 8.
+// The 3x3 weight gradient has a LARGE output (Cout x 9 Cin: 81 tiles of 256^2 at 768 -> 768) even where its reduction is short (the
+// 32^2 .. 80^2 maps of UPerHead's FPN, upernet.py:26-28): the eight-phase tile with a few slices then beats the 128-tile kernel that
+// gemm_use_big's token-count rule (made for the small outputs of nn.Linear) sends it to -- [8 x 80 x 80, 768 -> 768]: 381 -> 577 TFLOP/s.
+static inline bool conv3x3_wgrad_big(int64_t M, int64_t N, int64_t K) {
+    if (gemm_use_big(2, M, N, K)) return true;
+    return !getenv("SEGFAC_GEMM_NO_BIG") && !getenv("SEGFAC_CONV_WGRAD_OLD_RULE") && M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 48 && K >= 4096;
+}
+// Forward / data gradient of a 3x3 convolution whose output has too few 256 x 256 tiles to fill the chip but a long reduction (UPerHead's PPM
+// bottleneck 3840 -> 768 on a 16 x 16 map, ppm.py:19: 96 tiles at batch 32; the 40 x 40 / 20 x 20 levels of cfg5): split the (channel block,
+// tap) walk over 2 - 8 slices of the eight-phase tile, fp32 partials, one reduce pass to bf16.  0 / 1 = no split (the caller passes ws
+// of split * P * Cout floats otherwise; no bias in this form).
+extern "C" int segf_conv3x3_fwd_splitk(int mode, int B, int H, int W, int Cin, int Cout) {
+    if (mode < 0 || mode > 1 || getenv("SEGFAC_CONV_NO_FWD_SPLIT") || getenv("SEGFAC_NO_GEMM8")) return 1;
+    const int64_t M = (int64_t)B * H * W, N = mode == 0 ? Cout : Cin, Kc = mode == 0 ? Cin : Cout, K = 9 * Kc;
+    if (M % 256 || N % 256 || Kc % 64 || M <= 0) return 1;
+    const int64_t tiles = (M / 256) * (N / 256);
+    if (tiles >= 160 || K < 4096) return 1;
+    int best = 1;
+    double bu = (double)tiles / 256.0;
+    for (int c = 2; c <= 8; ++c) {
+        if (K / c < 24 * 64) break;                     // slices of at least 24 K steps
+        const int64_t wg = tiles * c;
+        const double u = (double)wg / (double)(cdiv64(wg, 256) * 256);
+        if (u > bu + 0.05) { bu = u; best = c; }
+        if (u >= 0.9) break;
+    }
+    return best;
+}
+// split-K count for segf_conv3x3 mode 2 (the caller sizes ws with it)
+extern "C" int segf_conv3x3_pick_splitk(int Cin, int Cout, int64_t P) {
+    const int64_t M = Cout, N = 9 * (int64_t)Cin;
+    if (gemm_use_big(2, M, N, P) || !conv3x3_wgrad_big(M, N, P)) return segf_gemm_pick_splitk(M, N, P);
+    // fewest slices (<= 8) whose last round of 256 workgroups is >= 90 % full, slices of at least 16 K steps
+    const int64_t tiles = (M / 256) * (N / 256);
+    int best = 1;
+    double bu = 0.0;
+    for (int c = 1; c <= 8; ++c) {
+        if (P / c < 16 * 64) break;
+        const int64_t wg = tiles * c;
+        const double u = (double)wg / (double)(cdiv64(wg, 256) * 256);
+        if (u > bu + 0.02) { bu = u; best = c; }
+        if (u >= 0.9) break;
+    }
+    return best;
+}
 extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, const void* x, int64_t ldx, const void* w, int64_t ldw,
                             void* y, int y_dt, int64_t ldy, const float* bias, int split_k, float* ws, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -2334,7 +2379,8 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     if (mode == 2 && bias) return SEGF_ERR_SHAPE;
     a.C = y; a.ldc = ldy;
     if (split_k < 1) split_k = 1;
-    if (mode != 2) split_k = 1;
+    // forward / data gradient: split-K only in the form segf_conv3x3_fwd_splitk proposes (few output tiles, long reduction)
+    if (mode != 2 && !(split_k > 1 && ws && y_dt == SEGF_BF16 && !bias && split_k == segf_conv3x3_fwd_splitk(mode, B, H, W, Cin, Cout))) split_k = 1;
     if (split_k > 1 && !ws) return SEGF_ERR_WORKSPACE;
     int64_t kchunk = cdiv64(cdiv64(a.K, split_k), GB_BK) * GB_BK;
     split_k = (int)cdiv64(a.K, kchunk);
@@ -2344,10 +2390,16 @@ extern "C" int segf_conv3x3(int mode, int B, int H, int W, int Cin, int Cout, co
     a.c_vec = ((uintptr_t)y % (4 * csz) == 0) && ((ldy * csz) % (4 * csz) == 0);
     a.c_vec16 = ((uintptr_t)y % 16 == 0) && ((ldy * csz) % 16 == 0);
     const bool f32out = y_dt == SEGF_F32 || a.ws;
+    if (layout == 0 && mode != 2 && a.ws) {      // the few-tiles form: eight-phase tiles over K slices, fp32 partials, one reduce to bf16
+        const int rc8 = gemm8_launch(0, 1, 0, a.M, a.N, a.K, a.kchunk, split_k, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, nullptr, nullptr,
+                                     nullptr, nullptr, 0, nullptr, 1, a.ws, st);
+        if (rc8) return rc8;
+        goto reduce3;
+    }
     if (layout == 0 && !f32out && gemm8_supported(0, 1, a.M, a.N, a.K, a.kchunk, a.cC))
         return gemm8_launch(0, 1, 0, a.M, a.N, a.K, a.kchunk, 1, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, a.csign, nullptr, nullptr, bias,
                             nullptr, 0, nullptr, 1, nullptr, st);
-    if (layout == 2 && y_dt == SEGF_F32 && gemm_use_big(2, a.M, a.N, a.K) && gemm8_supported(2, 1, a.M, a.N, a.K, a.kchunk, a.cC)) {
+    if (layout == 2 && y_dt == SEGF_F32 && conv3x3_wgrad_big(a.M, a.N, a.K) && gemm8_supported(2, 1, a.M, a.N, a.K, a.kchunk, a.cC)) {
         const int rc8 = gemm8_launch(2, 1, 0, a.M, a.N, a.K, a.kchunk, split_k, a.A, a.lda, a.B, a.ldb, y, ldy, H, W, a.cC, 1, nullptr, nullptr,
                                      nullptr, nullptr, 0, nullptr, 1, a.ws, st);
         if (rc8) return rc8;

@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                     gA[h][i] = a.A + (m * a.lda + kbeg + 8 * kc_chunk) * 2;
                 }
             }
-            if (BLAY == 0) gB[h][i] = a.B + ((n0 + 128 * h + kc_row + 8 * i) * a.ldb + kbeg + 8 * kc_chunk) * 2;
+            // (CONV_A: the weight row's K position is the absolute (tap, channel block) piece of each stage -- kbeg joins there)
+            if (BLAY == 0) gB[h][i] = a.B + ((n0 + 128 * h + kc_row + 8 * i) * a.ldb + (CONV_A ? 0 : kbeg) + 8 * kc_chunk) * 2;
         }
     // CONV_A walks K with the CHANNEL BLOCK outermost and the nine taps innermost: K tile T = (64-channel block T / 9, tap T % 9), so
     // that the nine taps of one channel block -- the same pixels shifted by a row / a column -- are read back to back in time.  Same-
@@ -227,9 +228,11 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
             unsigned char* dst = lds_half(kt & 1, half) + (16 * wave) * 128;
             if (CONV_A) {
                 // wave-uniform (scalar): channel block and tap of K tile ktc; / 9 and / 3 by multiply-shift
+                // (split-K over the gathered K walk: this slice starts at tile kbeg / KT of the (channel block, tap) sequence)
+                const unsigned kabs = (unsigned)ktc + (unsigned)(kbeg / KT);
                 unsigned chb, tap;
-                if (a.korder) { chb = __umulhi((unsigned)ktc, 0x38E38E39u) >> 1; tap = (unsigned)ktc - 9u * chb; }
-                else { tap = __umulhi((unsigned)ktc, a.kmagic); chb = (unsigned)ktc - tap * a.kper; }
+                if (a.korder) { chb = __umulhi(kabs, 0x38E38E39u) >> 1; tap = kabs - 9u * chb; }
+                else { tap = __umulhi(kabs, a.kmagic); chb = kabs - tap * a.kper; }
                 if (isA) {
                     const int t3 = (int)((tap * 11u) >> 5);                             // tap / 3 for tap < 9
                     const int64_t off = (int64_t)((t3 - 1) * a.cW + ((int)tap - 3 * t3 - 1)) * cv_row + (int64_t)chb * 128;
@@ -472,8 +475,8 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
                  hipStream_t st) {
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 || (lda * (kind == 3 ? 1 : 2)) % 16 || (ldb * (kind == 3 ? 1 : 2)) % 16 || ldc % 4) return SEGF_ERR_SHAPE;
     if (residual && (((uintptr_t)residual % 8) || ldr % 4)) return SEGF_ERR_SHAPE;
-    if (kind < 2 && split_k != 1) return SEGF_ERR_SHAPE;
-    if (conv && kind < 2 && kchunk != K) return SEGF_ERR_SHAPE;      // the gathered forward / data gradient walks all of K (channel blocks x taps)
+    if (kind < 2 && split_k != 1 && !(conv && kind == 0 && !fp8 && ws)) return SEGF_ERR_SHAPE;      // (the gathered forward has a split-K form)
+    if (conv && kind < 2 && kchunk != K && (fp8 || split_k < 2 || !ws || bias || residual)) return SEGF_ERR_SHAPE;      // gathered forward / data gradient: all of K, or fp32 split-K partials (bf16 operands, plain epilogue)
     Gemm8Args a{(const unsigned char*)A, (const unsigned char*)B, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, csign, f8_sa, f8_sb, bias,
                 (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr, 1, 0u, 1u, 1, 1};
     // fp8 operands: on some MI355X devices the staggered schedule (26 % fewer cycles) makes the chip drop its clock from 2.4 to 1.5 GHz
@@ -487,7 +490,8 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     const dim3 grid((unsigned)(N / 256), (unsigned)(M / 256), (unsigned)split_k);
 #define G8_GO(...) hipLaunchKernelGGL((gemm8_kernel<__VA_ARGS__>), grid, dim3(512), 0, st, a)
     if (kind == 0) {
-        if (conv) { if (fp8 == 0) G8_GO(0, 0, true, 0, bf16_t); else if (fp8 == 1) G8_GO(0, 0, true, 1, bf16_t); else G8_GO(0, 0, true, 2, bf16_t); }
+        if (conv && fp8 == 0 && split_k > 1) G8_GO(0, 0, true, 0, float);          // split-K partials [z][M][N] in ws (summed by the caller)
+        else if (conv) { if (fp8 == 0) G8_GO(0, 0, true, 0, bf16_t); else if (fp8 == 1) G8_GO(0, 0, true, 1, bf16_t); else G8_GO(0, 0, true, 2, bf16_t); }
         else { if (fp8 == 0) G8_GO(0, 0, false, 0, bf16_t); else if (fp8 == 1) G8_GO(0, 0, false, 1, bf16_t); else G8_GO(0, 0, false, 2, bf16_t); }
     } else if (kind == 1) {
         if (conv || fp8) return SEGF_ERR_SHAPE;

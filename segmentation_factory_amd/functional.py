@@ -1299,7 +1299,7 @@ class Conv3x3Fn(Function):
             if gq is not None and xq is not None:
                 dwm = hip.conv3x3_fp8_wgrad(xq, sx, gq, sg, B, H, W, I, O)
             else:
-                dwm = hip.conv3x3(2, x, dy, B, H, W, I, O, split_k=_splitk(O, 9 * I, B * H * W))           # [O][(ky,kx)][ci] fp32
+                dwm = hip.conv3x3(2, x, dy, B, H, W, I, O, split_k=hip.pick_splitk_conv3x3(I, O, B * H * W))           # [O][(ky,kx)][ci] fp32
             dw = hip.permute021(dwm.view(O, 9, I), O, 9, I, torch.float32).view(wshape)
         return dx, dw, None, None, None, None
 

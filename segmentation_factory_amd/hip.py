@@ -29,6 +29,8 @@ _PROTOS = {
     'segf_colsum': (_i, [_i, _p, _l, _l, _l, _p, _p, _p]),
     'segf_gemm': (_i, [_i, _i, _l, _l, _l, _p, _l, _p, _l, _p, _i, _l, _p, _p, _l, _p, _l, _i, _p, _p]),
     'segf_gemm_pick_splitk': (_i, [_l, _l, _l]),
+    'segf_conv3x3_pick_splitk': (_i, [_i, _i, _l]),
+    'segf_conv3x3_fwd_splitk': (_i, [_i, _i, _i, _i, _i, _i]),
     'segf_argmax_rows': (_i, [_i, _l, _i, _p, _l, _p, _p]),
     'segf_gemm_dw_db_ws': (_l, [_l, _l, _l, _i]),
     'segf_gemm_pro_supported': (_i, [_i, _i, _l, _l, _l, _l]),
@@ -634,6 +636,10 @@ def pick_splitk(M, N, K):
     return lib().segf_gemm_pick_splitk(M, N, K)
 
 
+def pick_splitk_conv3x3(Cin, Cout, P):
+    return lib().segf_conv3x3_pick_splitk(Cin, Cout, P)
+
+
 # ---- norms ---------------------------------------------------------------------------------------
 def layernorm_fwd(x, gamma, beta, eps, patch=None):
     """patch = (log2 W, log2 sr): also returns the output in the patch-major row order of a k = s = sr convolution's im2col matrix,
@@ -948,7 +954,10 @@ def conv3x3(mode, x, w, B, H, W, Cin, Cout, out=None, out_dtype=None, bias=None,
     shape = {0: (P, Cout), 1: (P, Cin), 2: (Cout, 9 * Cin)}[mode]
     if out is None:
         out = torch.empty(shape, dtype=out_dtype or (torch.float32 if mode == 2 else x.dtype), device=x.device)
-    ws = _f32(split_k * shape[0] * shape[1], x.device) if (mode == 2 and split_k > 1) else None
+    if mode != 2:
+        # few output tiles over a long reduction (PPM bottleneck, the small FPN levels): split-K slices of the eight-phase tile (segfac.h)
+        split_k = int(lib().segf_conv3x3_fwd_splitk(mode, B, H, W, Cin, Cout)) if (bias is None and out.dtype == torch.bfloat16) else 1
+    ws = _f32(split_k * shape[0] * shape[1], x.device) if split_k > 1 else None
     key = ('conv3x3', mode, P, Cin, Cout)
     _chk(_timed(key, lambda: lib().segf_conv3x3(mode, B, H, W, Cin, Cout, _ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(out),
                                                 dt_of(out), out.stride(0), _ptr(bias), split_k, _ptr(ws), _stream())),

@@ -1972,3 +1972,30 @@ def test_dwconv3x3_backward_one_launch_form_of_small_maps(dtype, geom, monkeypat
         assert torch.equal(flat[:9 * Cc].view(Cc, 9), dw1) and torch.equal(flat[9 * Cc:], db1)
         sc = dw0.abs().max().item()
         assert (dw1 - dw0).abs().max().item() <= 2e-5 * sc + 1e-6 and (db1 - db0).abs().max().item() <= 2e-5 * db0.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize('geom', [(32, 16, 16, 3840, 768), (8, 40, 40, 768, 768), (4, 32, 32, 512, 256)])
+def test_conv3x3_split_k_form_of_few_tile_outputs(geom, monkeypatch):
+    """segf_conv3x3 modes 0 / 1 over K slices (segf_conv3x3_fwd_splitk: UPerHead's PPM bottleneck, ppm.py:19, and the small FPN levels have too
+    few 256 x 256 output tiles to fill the chip): against the unsplit form of the same library -- the fp32 sums differ in order only, so the
+    bf16 outputs agree to one rounding -- and against fp64 torch.conv2d on a sample."""
+    from segmentation_factory_amd import hip
+    B, H, W, Cin, Cout = geom
+    P = B * H * W
+    assert hip.lib().segf_conv3x3_fwd_splitk(0, B, H, W, Cin, Cout) > 1
+    g = torch.Generator(device='cuda').manual_seed(31)
+    x = torch.randn(P, Cin, device='cuda', generator=g).to(torch.bfloat16)
+    dy = torch.randn(P, Cout, device='cuda', generator=g).to(torch.bfloat16)
+    wm = (torch.randn(Cout, 9 * Cin, device='cuda', generator=g) / (9 * Cin) ** 0.5).to(torch.bfloat16)
+    wt = (torch.randn(Cin, 9 * Cout, device='cuda', generator=g) / (9 * Cout) ** 0.5).to(torch.bfloat16)
+    y1, d1 = hip.conv3x3(0, x, wm, B, H, W, Cin, Cout), hip.conv3x3(1, dy, wt, B, H, W, Cin, Cout)
+    monkeypatch.setenv('SEGFAC_CONV_NO_FWD_SPLIT', '1')
+    y0, d0 = hip.conv3x3(0, x, wm, B, H, W, Cin, Cout), hip.conv3x3(1, dy, wt, B, H, W, Cin, Cout)
+    for a, b in ((y1, y0), (d1, d0)):
+        sc = b.float().abs().max().item()
+        assert (a.float() - b.float()).abs().max().item() <= 2.0 ** -7 * sc
+        assert (a != b).float().mean().item() < 0.2            # most outputs round to the same bf16
+    # a sample of output pixels of the forward against fp64
+    wd = wm.double().cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(x.double().cpu().view(B, H, W, Cin)[:1].permute(0, 3, 1, 2), wd, padding=1).permute(0, 2, 3, 1).reshape(H * W, Cout)
+    assert (y1[:H * W].double().cpu() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item() + 1e-6

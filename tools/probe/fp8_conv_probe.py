@@ -25,7 +25,7 @@ for (B, H, W, Cin, Cout) in [(8, 160, 160, 3072, 768), (8, 160, 160, 768, 768), 
     fl = 2.0 * P * 9 * Cin * Cout / 1e12
     t0 = timed(lambda: hip.conv3x3(0, x, wm, B, H, W, Cin, Cout))
     t1 = timed(lambda: hip.conv3x3(1, dy, wt, B, H, W, Cin, Cout))
-    t2 = timed(lambda: hip.conv3x3(2, x, dy, B, H, W, Cin, Cout, split_k=hip.pick_splitk(Cout, 9 * Cin, P)))
+    t2 = timed(lambda: hip.conv3x3(2, x, dy, B, H, W, Cin, Cout, split_k=hip.pick_splitk_conv3x3(Cin, Cout, P)))
     xq, sx = hip.quant_tensor_fp8(x); wq, sw = hip.quant_rows_fp8(wm)
     gq, sg = hip.quant_tensor_fp8(dy, e5m2=True); wtq, swt = hip.quant_rows_fp8(wt)
     f0 = timed(lambda: hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout))

@@ -35,7 +35,7 @@ def conv(n):
                 os.environ['SEGFAC_G8_KORDER'] = od; os.environ['SEGFAC_G8_TILE_ORDER'] = od
             t0 = timed(lambda: hip.conv3x3(0, x, wm, B, H, W, Cin, Cout), n)
             t1 = timed(lambda: hip.conv3x3(1, dy, wt, B, H, W, Cin, Cout), n)
-            t2 = timed(lambda: hip.conv3x3(2, x, dy, B, H, W, Cin, Cout, split_k=hip.pick_splitk(Cout, 9 * Cin, P)), n)
+            t2 = timed(lambda: hip.conv3x3(2, x, dy, B, H, W, Cin, Cout, split_k=hip.pick_splitk_conv3x3(Cin, Cout, P)), n)
             f0 = timed(lambda: hip.conv3x3_fp8(0, xq, sx, wq, sw, B, H, W, Cin, Cout), n)
             print(f'conv3x3 [{B}x{H}x{W} {Cin}->{Cout}] order {od} {fl:.2f} TFLOP | bf16 fwd {t0:.2f} ms ({fl / t0 * 1e3:.0f} TF/s) dgrad {t1:.2f} ({fl / t1 * 1e3:.0f}) '
                   f'wgrad {t2:.2f} ({fl / t2 * 1e3:.0f}) | fp8 fwd {f0:.2f} ({fl / f0 * 1e3:.0f})', flush=True)
