@@ -2327,8 +2327,8 @@ static inline bool conv3x3_wgrad_big(int64_t M, int64_t N, int64_t K) {
 extern "C" int segf_conv3x3_fwd_splitk(int mode, int B, int H, int W, int Cin, int Cout) {
     if (mode < 0 || mode > 1 || getenv("SEGFAC_CONV_NO_FWD_SPLIT") || getenv("SEGFAC_NO_GEMM8")) return 1;
     const int64_t M = (int64_t)B * H * W, N = mode == 0 ? Cout : Cin, Kc = mode == 0 ? Cin : Cout, K = 9 * Kc;
-    if (M % 256 || N % 256 || Kc % 64 || M <= 0) return 1;
-    const int64_t tiles = (M / 256) * (N / 256);
+    if (N % 256 || Kc % 64 || M <= 0) return 1;                  // (any pixel count: the last row tile may be ragged)
+    const int64_t tiles = cdiv64(M, 256) * (N / 256);
     if (tiles >= 160 || K < 4096) return 1;
     int best = 1;
     double bu = (double)tiles / 256.0;

@@ -165,8 +165,10 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                         const int yy = y + a.csign * (t / 3 - 1), xx = x + a.csign * (t % 3 - 1);
                         mk |= (unsigned)(yy >= 0 && yy < a.cH && xx >= 0 && xx < a.cW) << t;
                     }
-                    amask[h][i] = mk;
-                    gA[h][i] = a.A + (m * a.lda + 8 * kc_chunk) * 2;           // the K position (tap, channel) joins per stage
+                    // (a ragged last row tile -- pixel counts that are not multiples of 256, e.g. 8 x 20 x 20: rows past the end read the
+                    // zero page for every tap and are not stored)
+                    amask[h][i] = m < a.M ? mk : 0u;
+                    gA[h][i] = a.A + ((m < a.M ? m : 0) * a.lda + 8 * kc_chunk) * 2;           // the K position (tap, channel) joins per stage
                 } else {
                     gA[h][i] = a.A + (m * a.lda + kbeg + 8 * kc_chunk) * 2;
                 }
@@ -413,6 +415,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int64_t m = m0 + 128 * mq + 64 * wm + 16 * t + fi;
+                        if (CONV_A && m >= a.M) continue;
                         *reinterpret_cast<g8_f32x4*>(out + m * ldo + n) = FP8 ? acc[2 * nq + u][4 * mq + t] * sc8 : acc[2 * nq + u][4 * mq + t];
                     }
             }
@@ -435,6 +438,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int64_t m = m0 + 128 * mq + 64 * wm + 16 * t + fi;
+                        if (CONV_A && m >= a.M) continue;
                         const g8_f32x4 c = acc[2 * nq + u][4 * mq + t];
                         float v[4] = {fmaf(c[0], sc[0], bs[0]), fmaf(c[1], sc[1], bs[1]), fmaf(c[2], sc[2], bs[2]), fmaf(c[3], sc[3], bs[3])};
                         if (a.residual) {
@@ -476,6 +480,7 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 || (lda * (kind == 3 ? 1 : 2)) % 16 || (ldb * (kind == 3 ? 1 : 2)) % 16 || ldc % 4) return SEGF_ERR_SHAPE;
     if (residual && (((uintptr_t)residual % 8) || ldr % 4)) return SEGF_ERR_SHAPE;
     if (kind < 2 && split_k != 1 && !(conv && kind == 0 && !fp8 && ws)) return SEGF_ERR_SHAPE;      // (the gathered forward has a split-K form)
+    if (M % 256 && !(conv && kind == 0)) return SEGF_ERR_SHAPE;
     if (conv && kind < 2 && kchunk != K && (fp8 || split_k < 2 || !ws || bias || residual)) return SEGF_ERR_SHAPE;      // gathered forward / data gradient: all of K, or fp32 split-K partials (bf16 operands, plain epilogue)
     Gemm8Args a{(const unsigned char*)A, (const unsigned char*)B, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, csign, f8_sa, f8_sb, bias,
                 (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr, 1, 0u, 1u, 1, 1};
@@ -487,7 +492,7 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     if (const char* e = getenv("SEGFAC_G8_KORDER")) a.korder = atoi(e);
     if (const char* e = getenv("SEGFAC_G8_TILE_ORDER")) a.tile_order = atoi(e);
     if (conv && kind < 2 && cC > 0) { a.kper = (unsigned)(cC / 64); a.kmagic = (unsigned)(0x100000000ull / a.kper) + 1u; }
-    const dim3 grid((unsigned)(N / 256), (unsigned)(M / 256), (unsigned)split_k);
+    const dim3 grid((unsigned)(N / 256), (unsigned)((M + 255) / 256), (unsigned)split_k);      // (a ragged last row tile: the gathered forward only)
 #define G8_GO(...) hipLaunchKernelGGL((gemm8_kernel<__VA_ARGS__>), grid, dim3(512), 0, st, a)
     if (kind == 0) {
         if (conv && fp8 == 0 && split_k > 1) G8_GO(0, 0, true, 0, float);          // split-K partials [z][M][N] in ws (summed by the caller)

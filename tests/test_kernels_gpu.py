@@ -1974,10 +1974,10 @@ def test_dwconv3x3_backward_one_launch_form_of_small_maps(dtype, geom, monkeypat
         assert (dw1 - dw0).abs().max().item() <= 2e-5 * sc + 1e-6 and (db1 - db0).abs().max().item() <= 2e-5 * db0.abs().max().item() + 1e-6
 
 
-@pytest.mark.parametrize('geom', [(32, 16, 16, 3840, 768), (8, 40, 40, 768, 768), (4, 32, 32, 512, 256)])
+@pytest.mark.parametrize('geom', [(32, 16, 16, 3840, 768), (8, 40, 40, 768, 768), (4, 32, 32, 512, 256), (8, 20, 20, 3840, 768), (6, 20, 20, 1024, 512)])
 def test_conv3x3_split_k_form_of_few_tile_outputs(geom, monkeypatch):
     """segf_conv3x3 modes 0 / 1 over K slices (segf_conv3x3_fwd_splitk: UPerHead's PPM bottleneck, ppm.py:19, and the small FPN levels have too
-    few 256 x 256 output tiles to fill the chip): against the unsplit form of the same library -- the fp32 sums differ in order only, so the
+    few 256 x 256 output tiles to fill the chip; pixel counts that are not multiples of 256 end in a ragged row tile): against the unsplit form of the same library -- the fp32 sums differ in order only, so the
     bf16 outputs agree to one rounding -- and against fp64 torch.conv2d on a sample."""
     from segmentation_factory_amd import hip
     B, H, W, Cin, Cout = geom
