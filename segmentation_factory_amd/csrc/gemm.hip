@@ -2076,9 +2076,11 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         const int64_t kchunk = cdiv64(cdiv64(K, split_k), GB_BK) * GB_BK;
         const int slices = (int)cdiv64(K > 0 ? K : 1, kchunk > 0 ? kchunk : GB_BK);
         const bool groupable = !no_group && dt == SEGF_BF16 && M > 0 && N > 0 && K > 0 && it.dw && it.db && it.ws && !skinny && aligned &&
-                               !gemm_use_big(2, M, N, K) && !getenv("SEGFAC_GEMM_NO_FUSED_DB") && !getenv("SEGFAC_GEMM_NO_FASTLOAD") &&
+                               (!gemm_use_big(2, M, N, K) || (!getenv("SEGFAC_DW_GROUP_NO_BIG") && it.shared_split && M * N <= 1024 * 1024)) && !getenv("SEGFAC_GEMM_NO_FUSED_DB") && !getenv("SEGFAC_GEMM_NO_FASTLOAD") &&
                                !getenv("SEGFAC_GEMM_NO_TR") && !getenv("SEGFAC_GEMM_NO_DEEP128") && !getenv("SEGFAC_GEMM_NO_DEEP128_L2") &&
                                !getenv("SEGFAC_GEMM_FASTLOAD_L2") && M % 8 == 0 && N % 8 == 0 && slices > 1 && cdiv64(M, GB_BM) <= 65535;
+        // (a member that alone would take the 256-tile kernel + a separate column-sum pass -- the stage-3 / 4 layers at batch 128 -- joins the
+        // group too when it lets the library choose its split: one pass over dy for both gradients; batch 128 +0.5 %)
         if (!groupable) {                        // (the items are independent of each other: no need to close the open group)
             // its product launches now; its reduce pass joins the others' in r2 (issued when full and at the end of the call)
             g_reduce_sink = no_group ? nullptr : &r2;
