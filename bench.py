@@ -368,7 +368,7 @@ def main():
                                    f", {NC} classes, {H}x{W}, " +
                                    ("full train step (zero_grad+fwd+CE/Dice+bwd+AGC/AdamW)" if with_opt else "forward+loss+backward only"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "init": "random (reference initialisers)", "loss_after": round(final_loss, 4),
+                       "init": "random, numpy default_rng(0): std 0.02 normal for linears, fan-out normal for convolutions (SURVEY 8d)", "loss_after": round(final_loss, 4),
                        "fp8": bool(args.fp8),
                        "inputs": "resident in HBM" + ("; copied into the captured step's input buffers every step" if (args.copy_inputs or args.eager)
                                                        else " in the captured step's input buffers (zero-copy feed)"),
