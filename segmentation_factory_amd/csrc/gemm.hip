@@ -1970,6 +1970,11 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
 // column (what segf_gemm_dw_db launches for them) are gathered into grouped launches of up to GDW_MAX members -- one product launch and
 // one reduce launch per group instead of two launches per layer; every other item is executed by segf_gemm_dw_db itself.  Each item's
 // result is bitwise what segf_gemm_dw_db computes for it.
+// largest output (elements) of a member that alone would take the 256-tile kernel and still joins a group (A/B: SEGFAC_DW_GROUP_BIG_MAX)
+static inline int64_t dw_group_big_max() {
+    if (const char* e = getenv("SEGFAC_DW_GROUP_BIG_MAX")) return atoll(e);
+    return 1024 * 1024;
+}
 extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, void* stream) {
     if (n <= 0) return 0;
     if (!items) return SEGF_ERR_SHAPE;
@@ -2076,7 +2081,7 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         const int64_t kchunk = cdiv64(cdiv64(K, split_k), GB_BK) * GB_BK;
         const int slices = (int)cdiv64(K > 0 ? K : 1, kchunk > 0 ? kchunk : GB_BK);
         const bool groupable = !no_group && dt == SEGF_BF16 && M > 0 && N > 0 && K > 0 && it.dw && it.db && it.ws && !skinny && aligned &&
-                               (!gemm_use_big(2, M, N, K) || (!getenv("SEGFAC_DW_GROUP_NO_BIG") && it.shared_split && M * N <= 1024 * 1024)) && !getenv("SEGFAC_GEMM_NO_FUSED_DB") && !getenv("SEGFAC_GEMM_NO_FASTLOAD") &&
+                               (!gemm_use_big(2, M, N, K) || (!getenv("SEGFAC_DW_GROUP_NO_BIG") && it.shared_split && M * N <= dw_group_big_max())) && !getenv("SEGFAC_GEMM_NO_FUSED_DB") && !getenv("SEGFAC_GEMM_NO_FASTLOAD") &&
                                !getenv("SEGFAC_GEMM_NO_TR") && !getenv("SEGFAC_GEMM_NO_DEEP128") && !getenv("SEGFAC_GEMM_NO_DEEP128_L2") &&
                                !getenv("SEGFAC_GEMM_FASTLOAD_L2") && M % 8 == 0 && N % 8 == 0 && slices > 1 && cdiv64(M, GB_BM) <= 65535;
         // (a member that alone would take the 256-tile kernel + a separate column-sum pass -- the stage-3 / 4 layers at batch 128 -- joins the
