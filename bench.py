@@ -59,17 +59,26 @@ def numpy_seed_weights(model, seed):
                 p.copy_(torch.from_numpy(rng.standard_normal(tuple(p.shape), dtype=np.float32) * std))
 
 
-def kernel_source_hash():
-    """Hash of the HIP sources of the kernels in the roofline objects: stamps profiles/pmc_traffic_*.json so that a counter file
-    measured on other kernel code is never reported as this run's traffic."""
+# sources a kernel's counter traffic depends on (its own files + the shared headers + the build flags): a gemm.hip edit must not
+# void the loss kernel's figure and vice versa
+KERNEL_SOURCES = {'loss_bwd': ('loss.hip', 'loss_band.hip', 'loss_geom.h', 'common.h', 'Makefile'),
+                  'gemm_pro': ('gemm.hip', 'common.h', 'colreduce.h', 'Makefile')}
+
+
+def kernel_source_hash(which=None):
+    """Hash of the HIP sources behind one roofline object ('loss_bwd' / 'gemm_pro'; None -> {name: hash}): stamps
+    profiles/pmc_traffic_*.json so that a counter file measured on other kernel code is never reported as this run's traffic."""
     import hashlib
-    h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'segmentation_factory_amd', 'csrc')
-    # the sources of the two kernels whose traffic is reported (+ the shared headers and the build flags)
-    for f in sorted(os.path.join(csrc, n) for n in ('loss.hip', 'loss_band.hip', 'loss_geom.h', 'gemm.hip', 'common.h', 'colreduce.h', 'Makefile')):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, 'rb').read())
-    return h.hexdigest()[:16]
+    out = {}
+    for key, names in KERNEL_SOURCES.items():
+        h = hashlib.sha256()
+        for n in sorted(names):
+            h.update(n.encode())
+            with open(os.path.join(csrc, n), 'rb') as fh:
+                h.update(fh.read())
+        out[key] = h.hexdigest()[:16]
+    return out if which is None else out[which]
 
 
 def cpu_baseline(sample_batch=2, timed_steps=3, loop_timed_steps=2):
@@ -127,6 +136,7 @@ def extra_legs(budget_s):
             ('other_configs', ['config', 'cfg2', '--batch', '16', '--steps', '20', '--warmup', '5']),
             ('train_loop', ['train_loop', '--batch', '128', '--steps', '10', '--epochs', '2']),
             ('train_loop', ['train_loop', '--batch', '4', '--steps', '100', '--epochs', '2']),
+            ('train_loop', ['default_cli', '--batch', '4', '--steps', '50', '--epochs', '2']),
             ('eval', ['eval', '--batch', '1', '--steps', '100']), ('eval', ['eval', '--batch', '32', '--steps', '10'])]
     res = {'other_configs': [], 'train_loop': [], 'eval': []}
     t0 = time.time()
@@ -170,7 +180,7 @@ def main():
     ap.add_argument('--fp8', action='store_true', help='cfg3 / cfg5: the UPerHead 3x3 convolutions and the ConvNeXt block MLPs on fp8 operands in all three '
                                                       'products (forward e4m3 x e4m3, gradients e5m2; set_fp8)')
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the secondary legs (other BASELINE configs, train loop, evaluate)')
-    ap.add_argument('--legs-budget-s', type=float, default=150.0, help='wall-clock budget for the secondary legs; legs that do not fit are listed as skipped')
+    ap.add_argument('--legs-budget-s', type=float, default=210.0, help='wall-clock budget for the secondary legs; legs that do not fit are listed as skipped')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -335,23 +345,32 @@ def main():
 
     # HBM traffic per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command,
     # corrected as MI355X_MICROARCH.md prescribes; committed under profiles/): reported only for the batch it was measured at
-    traffic, traffic_note = {}, 'no counter file for this batch / configuration'
+    traffic, traffic_note = {}, {}
     try:
         with open(os.path.join(ROOT, 'profiles', f'pmc_traffic_b{args.batch}.json')) as fh:
             pmc = json.load(fh)
-        if pmc.get('source_hash') != kernel_source_hash():
-            traffic_note = f"profiles/pmc_traffic_b{args.batch}.json was measured on other kernel sources (hash {pmc.get('source_hash')}): not reported"
-        elif pmc.get('batch') == args.batch and args.config == 'cfg2' and args.dtype == 'bf16':
-            traffic_note = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, kernel sources {pmc['source_hash']}"
-            for kname, v in pmc['kernels'].items():
-                if kname.startswith('ce_dice_bwd'):        # the retry kernel shares the prefix and moves no data: keep the larger
-                    traffic['loss_bwd'] = max(traffic.get('loss_bwd', 0), v['total_bytes'])
-                if kname.startswith('gemm_bf16_big_kernel<0'):        # template arguments: layout, out type, CONV, PRO, SHAPE, DEEP
-                    targs = [t.strip() for t in kname[kname.index('<') + 1:kname.rindex('>')].split(',')]
-                    if len(targs) > 3 and targs[3] == 'true':
-                        traffic['gemm_pro'] = max(traffic.get('gemm_pro', 0), v['total_bytes'])
+        have = pmc.get('source_hashes') or {}
+        now = kernel_source_hash()
+        usable = pmc.get('batch') == args.batch and args.config == 'cfg2' and args.dtype == 'bf16'
+        for key in KERNEL_SOURCES:
+            if not usable:
+                traffic_note[key] = 'no counter file for this batch / configuration'
+            elif have.get(key) != now[key]:
+                traffic_note[key] = (f"profiles/pmc_traffic_b{args.batch}.json was measured on other sources of this kernel "
+                                     f"(hash {have.get(key)}, now {now[key]}): not reported")
+            else:
+                traffic_note[key] = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, kernel sources {now[key]}"
+        for kname, v in pmc['kernels'].items():
+            if kname.startswith('ce_dice_bwd') and traffic_note.get('loss_bwd', '').startswith('rocprofv3'):
+                traffic['loss_bwd'] = max(traffic.get('loss_bwd', 0), v['total_bytes'])      # (the retry kernel shares the prefix and moves no data)
+            if kname.startswith('gemm_bf16_big_kernel<0') and traffic_note.get('gemm_pro', '').startswith('rocprofv3'):
+                targs = [t.strip() for t in kname[kname.index('<') + 1:kname.rindex('>')].split(',')]    # layout, out type, CONV, PRO, SHAPE, DEEP
+                if len(targs) > 3 and targs[3] == 'true':
+                    traffic['gemm_pro'] = max(traffic.get('gemm_pro', 0), v['total_bytes'])
     except (OSError, ValueError, KeyError):
         pass
+    for key in KERNEL_SOURCES:
+        traffic_note.setdefault(key, 'no counter file for this batch / configuration')
     if rank == 0:
         summ = kt.summary()
         nl, avg_ms = summ.get(loss_key, (0, float('nan')))
@@ -384,7 +403,8 @@ def main():
             "roofline": {"kernel": "ce_dice_bwd_band_kernel (dominant kernel by GPU time): fused transposed upsample + softmax + CE/Dice "
                                    f"backward, low-res logits [B,{hq},{wq},{ld}] -> d logits, labels int64 [B,{H},{W}]",
                          "bound": "hbm", "achieved": round(loss_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note,
+                         "frac": round(loss_bytes / (avg_ms * 1e-3) / HBM_PEAK, 4), "traffic": traffic.get('loss_bwd'), "traffic_source": traffic_note['loss_bwd'],
+                         "traffic_over_algorithmic": round(traffic['loss_bwd'] / loss_bytes, 3) if traffic.get('loss_bwd') else None,
                          "launches_timed": nl, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": loss_bytes,
                          "padded_row_bytes_per_launch": loss_bytes_padded,
                          "note": "VALU-issue-bound, not HBM-bound: one v_exp_f32 per (full-resolution pixel, class) plus ~3.6 other VALU "
@@ -396,15 +416,29 @@ def main():
                                         f"gemm_bf16_big_kernel<0>: classifier 1x1 conv [B*{hq}*{wq},768]x[768,{ld}]",
                               "bound": "hbm", "achieved": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
                               "unit": "GB/s", "frac": round(gemm_bytes / (gemm_ms * 1e-3) / HBM_PEAK, 4),
-                              "traffic": traffic.get('gemm_pro'), "launches_timed": ng,
+                              "traffic": traffic.get('gemm_pro'), "traffic_source": traffic_note['gemm_pro'],
+                              "traffic_over_algorithmic": round(traffic['gemm_pro'] / gemm_bytes, 3) if traffic.get('gemm_pro') else None,
+                              "launches_timed": ng,
                               "avg_launch_ms": round(gemm_ms, 4), "algorithmic_bytes_per_launch": gemm_bytes,
                               "flops_per_launch": 2.0 * M * ld * K},
         }
+        if args.config != 'cfg2':
+            # the loss kernel is NOT what carries these steps (cfg3 / cfg5: the UPerHead 3x3 implicit GEMMs, 68 % / 37 % of the GPU time;
+            # cfg4: head-dim-64 attention, 36 %): `roofline` prices that config's own dominant kernel, the loss kernel moves aside
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from bench_legs import dominant_kernel
+            out["roofline_loss"] = out["roofline"]
+            gs = step = None
+            torch.cuda.empty_cache()
+            out["roofline"] = dominant_kernel(args.config, args.batch, NC, H, W, args.fp8)
         if inp is not None:
             out["input_pipeline"] = inp
-        if world == 1 and not args.no_extra_legs and args.config == 'cfg2' and not args.eager:
+        # (never under a profiler: its preloaded library has initialised the GPU in this process, and a child process started from
+        # here is the forbidden exec-after-GPU-init)
+        profiled = 'rocprofiler' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+        if world == 1 and not args.no_extra_legs and not profiled and args.config == 'cfg2' and not args.eager:
             # free this process's share of the HBM first: the children build their own models and graphs
-            del gs
+            gs = None
             torch.cuda.empty_cache()
             out.update(extra_legs(args.legs_budget_s))
         if not args.no_cpu_baseline and world == 1:

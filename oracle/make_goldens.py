@@ -118,6 +118,22 @@ def e2e_case(tag, backbone, head, nc, B, H, Wd, seed=1234, dice=True, compact=Fa
     np.savez_compressed(os.path.join(OUT, f'e2e_{tag}.npz'), **out)
 
 
+ODD_SIZE_CASES = [
+    # Validation images keep their aspect ratio (ExtResize(int) resizes the SHORTER side, datasets/build_datasets.py:24-29) and
+    # --val_batch_size is 1 (train_gpu.py:72): evaluate sees H, W that are not multiples of 32.  Overlapping patch embeddings
+    # (mit.py:102-131) then produce 19 x 25 -> 10 x 13 -> 5 x 7 -> 3 x 4 maps, the k = s spatial-reduction convolutions drop the
+    # remainder rows / columns (mit.py:47-48), the decode heads resize between maps whose ratios are not 2 / 4 / 8.
+    ('segformer_b0_75x100', 'MiT-B0', 'SegFormerHead', 7, 2, 75, 100, 311, False),
+    ('convnext_uper_90x123', 'ConvNeXt', 'UPerHead', 19, 2, 90, 123, 312, True),
+    ('mbv2_fpn_70x94', 'MobileNetV2', 'FPNHead', 21, 2, 70, 94, 313, True),
+]
+
+
+def odd_size_cases():
+    for tag, backbone, head, nc, B, H, Wd, seed, compact in ODD_SIZE_CASES:
+        e2e_case(tag, backbone, head, nc, B, H, Wd, seed=seed, compact=compact)
+
+
 def loss_cases():
     ref = ref_shim.load()
     rng = np.random.default_rng(7)
@@ -378,6 +394,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'odd':          # only the non-/32 fixtures (the others are unchanged)
+        odd_size_cases()
+        return 0
     loss_cases()
     metrics_case()
     e2e_case('segformer_b0_64', 'MiT-B0', 'SegFormerHead', 19, 2, 64, 64)
@@ -389,6 +408,7 @@ def main():
     e2e_case('convnext_uper_128', 'ConvNeXt', 'UPerHead', 19, 4, 128, 128, seed=77, compact=True)
     e2e_case('convnextv2_tiny_uper_128', 'convnextv2_tiny', 'UPerHead', 19, 4, 128, 128, seed=78, compact=True)
     e2e_case('mbv2_fpn_128', 'MobileNetV2', 'FPNHead', 21, 2, 128, 128, seed=79, compact=True)
+    odd_size_cases()
     train_loop_case()
     train_overfit_case()
     scheduler_cases()

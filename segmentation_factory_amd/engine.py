@@ -82,6 +82,45 @@ def _flush_losses(pending, metric_logger, writer, print_freq, it0):
             writer.add_scalar('train_lr', lr, it)
 
 
+def _graph_step_wanted(args, model, core, optimizer, loss_scaler, device):
+    """The step runs as a replayed hipGraph (graph.GraphedTrainStep) unless the caller opted out.  `args.hip_graph`: True = required
+    (a capture failure raises), False = eager launches, absent / None = AUTO: what `python train_gpu.py ...` as the reference's
+    README launches it gets (train_gpu.py:325) -- the graph whenever the pieces it drives are the product's own (a model with
+    `forward_lowres`, the fused AGC/AdamW optimizer, the no-scaling NativeScaler) and the model is not already wrapped in
+    DistributedDataParallel (whose hooks then carry the exchange); an earlier failed capture on this model keeps it eager."""
+    from .optim import FusedAGCAdamW, NativeScaler
+    pref = getattr(args, 'hip_graph', None)
+    if pref is not None and not pref:
+        return False
+    ok = (hasattr(core, 'forward_lowres') and isinstance(optimizer, FusedAGCAdamW) and torch.device(device).type == 'cuda')
+    if pref:
+        return ok
+    return (ok and isinstance(loss_scaler, NativeScaler) and not hasattr(model, 'module')
+            and getattr(core, '_graph_disabled', None) is None)
+
+
+def _fall_back_to_eager(core, model, optimizer, device, err):
+    """AUTO mode only: the capture of the train step failed (a plugin module that synchronises or allocates on another stream, tied
+    weights, out of memory during the warm-up passes ...).  Say why, undo what the attempt armed, and continue with per-kernel
+    launches in THIS process -- never a re-exec.  Under several ranks the graph path would have carried the gradient exchange: a
+    DistributedDataParallel wrapper (the reference's own, train_gpu.py:233-236) takes it over."""
+    print(f'[segmentation_factory_amd] hipGraph capture of the train step failed ({type(err).__name__}: {str(err)[:300]}); '
+          'continuing with eager launches (pass --no-hip-graph to skip the attempt)', flush=True)
+    core._graph_disabled = f'{type(err).__name__}: {err}'
+    core._graphed_step = None
+    if hasattr(optimizer, 'disable_direct_grads'):
+        optimizer.disable_direct_grads()
+    for p in core.parameters():
+        p.grad = None
+    torch.cuda.synchronize()
+    if utils.get_world_size() > 1 and not hasattr(model, 'module'):
+        dev = torch.device(device)
+        core._ddp_fallback = torch.nn.parallel.DistributedDataParallel(
+            core, device_ids=[dev.index if dev.index is not None else torch.cuda.current_device()], find_unused_parameters=True)
+        return core._ddp_fallback
+    return model
+
+
 def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, clip_grad, clip_mode, loss_scaler,
                     writer=None, args=None):
     model.train()
@@ -92,7 +131,9 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
     loss_weight = torch.as_tensor([1.0, 2.0], device=device) if args.nb_classes == 2 else None   # engine.py:28-32
     core = model.module if hasattr(model, 'module') else model
     fused = hasattr(core, 'forward_lowres')
-    use_graph = bool(getattr(args, 'hip_graph', False)) and fused
+    use_graph = _graph_step_wanted(args, model, core, optimizer, loss_scaler, device)
+    if getattr(core, '_ddp_fallback', None) is not None:
+        model = core._ddp_fallback      # an earlier capture failed under several ranks: DistributedDataParallel carries the exchange
 
     pending = None
     for idx, (img, lbl) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
@@ -108,10 +149,21 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
                 def loss_fn(m, x, y, _lw=loss_weight, _hw=tuple(img.shape[2:])):
                     return criterion_lowres(m.forward_lowres(x), y, _hw, _lw, num_classes=args.nb_classes, dice=args.dice,
                                             ignore_index=args.ignore_index)
-                gs = GraphedTrainStep(core, optimizer, loss_fn, (img, lbl), clip_grad=clip_grad, clip_mode=clip_mode,
-                                      exchange=getattr(args, 'grad_exchange', None), payload=getattr(args, 'grad_payload', None))
-                gs.key = key
-                core._graphed_step = gs
+                core._graphed_step = gs = None
+                try:
+                    gs = GraphedTrainStep(core, optimizer, loss_fn, (img, lbl), clip_grad=clip_grad, clip_mode=clip_mode,
+                                          exchange=getattr(args, 'grad_exchange', None), payload=getattr(args, 'grad_payload', None))
+                except Exception as e:      # noqa: BLE001 -- whatever stopped the capture, the eager launches below still train
+                    if getattr(args, 'hip_graph', None):
+                        raise               # asked for explicitly (--hip-graph): the failure is the caller's to see
+                    model = _fall_back_to_eager(core, model, optimizer, device, e)
+                    use_graph = False
+                if gs is not None:
+                    gs.key = key
+                    core._graphed_step = gs
+                    print(f'[segmentation_factory_amd] train step captured as one hipGraph (input {tuple(img.shape)}, '
+                          f'{"bucketed gradient exchange over " + str(gs.world) + " ranks" if gs.exchanging else "single rank"})', flush=True)
+        if use_graph:
             if getattr(dataloader, 'bind_output', None) is not None and getattr(dataloader, 'out', None) is None:
                 dataloader.bind_output(gs.static_inputs)    # device-side input pipeline: later batches land in the step's buffers
             loss = gs.step(img, lbl)
@@ -157,8 +209,14 @@ def train_one_epoch(model, optimizer, dataloader, epoch, device, print_freq, cli
     return metric_logger.meters["loss"].global_avg, lr
 
 
+EVAL_DTYPES = {'fp32': torch.float32, 'bf16': torch.bfloat16}
+
+
 @torch.inference_mode()
 def evaluate(args, model, dataloader, device, print_freq, writer=None):
+    """engine.py:74-104.  The reference evaluates in fp32 with autocast deliberately off (engine.py:86-88), whatever precision it
+    trained in -- so does this: the forward runs the exact-fp32 kernels unless `args.eval_dtype == 'bf16'` (train_gpu.py
+    --eval-dtype bf16: the production storage type, ~5x the rate; tests/test_model_gpu.py measures what it flips)."""
     model.eval()
     metric = Metrics(args.nb_classes, args.ignore_label, device)
     confmat = utils.ConfusionMatrix(args.nb_classes)
@@ -166,6 +224,19 @@ def evaluate(args, model, dataloader, device, print_freq, writer=None):
     header = 'Test:'
     core = model.module if hasattr(model, 'module') else model
     fused = hasattr(core, 'forward_lowres')
+    eval_dtype = EVAL_DTYPES[str(getattr(args, 'eval_dtype', None) or 'fp32')]
+    trained_dtype = getattr(core, 'compute_dtype', None)
+    switch = hasattr(core, 'set_compute_dtype') and trained_dtype is not None and trained_dtype != eval_dtype
+    if switch:
+        core.set_compute_dtype(eval_dtype)
+    try:
+        return _evaluate(args, model, core, fused, dataloader, device, print_freq, writer, metric, confmat, metric_logger, header)
+    finally:
+        if switch:
+            core.set_compute_dtype(trained_dtype)
+
+
+def _evaluate(args, model, core, fused, dataloader, device, print_freq, writer, metric, confmat, metric_logger, header):
     if utils.get_world_size() > 1:
         # collective C2: the reference evaluates the DDP-wrapped model, whose forward first hands every rank rank 0's BatchNorm
         # buffers (train_gpu.py:233-236, broadcast_buffers=True).  The forwards below call the core module directly (graph path: there
@@ -173,9 +244,10 @@ def evaluate(args, model, dataloader, device, print_freq, writer=None):
         from .graph import broadcast_buffers_
         broadcast_buffers_(core)
     session = None
-    if bool(getattr(args, 'hip_graph', False)) and fused:
+    graph_pref = getattr(args, 'hip_graph', None)            # None = auto (on), as in train_one_epoch
+    if (graph_pref is None or bool(graph_pref)) and fused and torch.device(device).type == 'cuda':
         from .graph import GraphedEvalSession
-        session = GraphedEvalSession(core)                   # the eval forward as one replayed hipGraph per input shape
+        session = GraphedEvalSession(core)                   # the eval forward as a replayed hipGraph per RECURRING input shape
     for idx, (images, labels) in enumerate(metric_logger.log_every(dataloader, print_freq, header)):
         images = images.to(device, non_blocking=True)
         labels = labels.to(device, non_blocking=True)

@@ -186,7 +186,10 @@ _SCALED_DY = {}
 
 def _take_scaled(dy, rscale, rpg):
     hit = _SCALED_DY.pop(dy.data_ptr(), None)
-    if hit is not None and hit[1] == rscale.data_ptr() and hit[2] == rpg and hit[0].shape == dy.shape and hit[0].dtype == dy.dtype:
+    # hit[3]: dx's version when the entry was made.  The hand-over is only right while the tagged tensor has ONE consumer: a second
+    # one makes autograd accumulate into dx in place (same address, version bumped) and the parked copy would be that of a partial sum
+    if (hit is not None and hit[1] == rscale.data_ptr() and hit[2] == rpg and hit[0].shape == dy.shape and hit[0].dtype == dy.dtype
+            and hit[3] == dy._version):
         return hit[0]
     return None
 
@@ -213,7 +216,7 @@ def _ln_bwd(ctx, x, dy, g, mean, rstd, dy2=None, dres=None, dy2_patch=None):
     if getattr(dx, 'scaled', None) is not None:
         if len(_SCALED_DY) > 64:
             _SCALED_DY.clear()                   # (entries nobody came for: a consumer that did not need its input gradient)
-        _SCALED_DY[dx.data_ptr()] = (dx.scaled, rscale.data_ptr(), rpg)
+        _SCALED_DY[dx.data_ptr()] = (dx.scaled, rscale.data_ptr(), rpg, dx._version)
         dx.scaled = None
     return out
 
@@ -244,6 +247,7 @@ def defer_weight_grads():
         flush_weight_grads()
     finally:
         _DW_QUEUE, _FIN_QUEUE = prev, prevf
+        _SCALED_DY.clear()          # entries nobody collected must not outlive the backward they belong to (their addresses get reused)
 
 
 def _queue_dw(ctx, dy, x, n_out, n_in, tokens):

@@ -16,6 +16,7 @@ keeps executing the rest of backward on the compute stream.  Same arithmetic as 
 the loss gradient is pre-scaled by 1/world and the collective sums), same bucket idea, no per-parameter Python hooks.
 BatchNorm stays per-rank, as in the reference (plain nn.BatchNorm2d, no SyncBN).
 """
+import collections
 import contextlib
 import os
 
@@ -108,26 +109,50 @@ class GraphedEvalForward:
 
 
 class GraphedEvalSession:
-    """Per-`evaluate` handle on the cached eval graphs of `core` (one per input shape; validation images come in a few sizes).  The
-    storage signature is checked ONCE per session -- walking a module tree costs milliseconds, more than a batch-1 forward -- so the
-    parameters must not move while a session is open (they do not inside engine.evaluate)."""
+    """Per-`evaluate` handle on the cached eval graphs of `core`.  The reference's validation transform keeps the aspect ratio
+    (ExtResize(int), datasets/build_datasets.py:24-29) and --val_batch_size is 1 (train_gpu.py:72): ADE20K / VOC / COCO-Stuff hand
+    `evaluate` MANY distinct (H, W), Cityscapes a single one.  A capture costs a clone, an eager warm-up forward, the capture and an
+    instantiation -- several eager forwards' worth -- so:
 
-    def __init__(self, core, max_graphs: int = 8):
-        self.core, self.max_graphs = core, max_graphs
+      * a shape is captured on its SECOND sighting; the first runs eagerly (a shape seen once never pays for a graph),
+      * at most `max_captures` captures per session, after which unseen shapes stay eager (`core.forward_lowres`),
+      * the cache holds `max_graphs` graphs and evicts the LEAST RECENTLY USED,
+      * sighting counts and graphs persist on the model across sessions (the next epoch's `evaluate` replays from image one).
+
+    The key includes the compute dtype (`evaluate` runs fp32 by default, --eval-dtype bf16 on request).  The storage signature is
+    checked ONCE per session -- walking a module tree costs milliseconds, more than a batch-1 forward -- so the parameters must not
+    move while a session is open (they do not inside engine.evaluate)."""
+
+    def __init__(self, core, max_graphs: int = 8, max_captures: int = 8):
+        self.core, self.max_graphs, self.max_captures = core, max_graphs, max_captures
         cache = core.__dict__.setdefault('_graphed_eval', {})
         sig = _storage_signature(core)
         if cache.get('sig') != sig:
             cache.clear()
             cache['sig'] = sig
-        self.cache = cache
+        self.graphs = cache.setdefault('graphs', collections.OrderedDict())      # key -> GraphedEvalForward, LRU order
+        self.seen = cache.setdefault('seen', {})                                  # key -> sightings without a graph
+        self.captures = self.replays = self.eager = 0
 
     def __call__(self, images):
-        key = (tuple(images.shape), images.dtype)
-        g = self.cache.get(key)
-        if g is None:
-            while len(self.cache) > self.max_graphs:           # 'sig' + max_graphs entries: drop the oldest graph
-                self.cache.pop(next(k for k in self.cache if k != 'sig'))
-            g = self.cache[key] = GraphedEvalForward(self.core, images)
+        key = (tuple(images.shape), images.dtype, getattr(self.core, 'compute_dtype', None))
+        g = self.graphs.get(key)
+        if g is not None:
+            self.graphs.move_to_end(key)
+            self.replays += 1
+            return g(images)
+        n = self.seen.get(key, 0) + 1
+        if n < 2 or self.captures >= self.max_captures:
+            if len(self.seen) > 4096:
+                self.seen.clear()
+            self.seen[key] = n
+            self.eager += 1
+            return self.core.forward_lowres(images)
+        while len(self.graphs) >= self.max_graphs:
+            self.graphs.popitem(last=False)
+        self.seen.pop(key, None)
+        g = self.graphs[key] = GraphedEvalForward(self.core, images)
+        self.captures += 1
         return g(images)
 
 

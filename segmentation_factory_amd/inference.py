@@ -46,7 +46,10 @@ class SemSeg:
         H, W = image.shape[1:]
         nH, nW = self.inference_size(H, W)
         if image.dtype != torch.uint8:
-            image = image.round().clamp(0, 255).to(torch.uint8)
+            # the reference feeds torchvision.io.read_image's uint8 tensor (estimate_model.py:117-118), and T.Resize of a uint8 tensor
+            # rounds back to uint8 where a float tensor would be interpolated in float: silently rounding a float image here would
+            # match neither.  Only the byte path is pinned (byte-equal to torch's CPU resize), so only it is accepted
+            raise TypeError(f'SemSeg.preprocess takes the uint8 CHW image torchvision.io.read_image returns, got {image.dtype}')
         img = image.to(self.device).contiguous()
         mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32, device=self.device)
         std = torch.tensor(IMAGENET_STD, dtype=torch.float32, device=self.device)

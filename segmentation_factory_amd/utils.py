@@ -216,13 +216,14 @@ def init_distributed_mode(args):
     setup_for_distributed(args.rank == 0 or bool(os.environ.get('SEGFAC_PRINT_ALL_RANKS')))     # the override: multi-rank tests read every rank's lines
 
 
-def load_model(path):
-    """Checkpoint reader with the reference's key handling (util/utils.py:313-324): unwrap 'state_dict', and for
-    NVIDIA SegFormer files drop decode_head.conv_seg.*"""
-    ckpt = torch.load(path, map_location='cpu')
+def load_model(modelpath, model=None):
+    """Checkpoint reader with the reference's signature and key handling (util/utils.py:313-324; called as
+    `utils.load_model(args.finetune, model)` at train_gpu.py:243 -- the reference never touches `model` either): unwrap
+    'state_dict', and for NVIDIA SegFormer files drop decode_head.conv_seg.*"""
+    ckpt = torch.load(modelpath, map_location='cpu')
     if isinstance(ckpt, dict) and 'state_dict' in ckpt:
         ckpt = ckpt['state_dict']
-    if 'segformer' in os.path.basename(path):
+    if 'segformer' in os.path.basename(modelpath):
         for k in ('decode_head.conv_seg.weight', 'decode_head.conv_seg.bias'):
             ckpt.pop(k, None)
     return ckpt
@@ -236,3 +237,69 @@ def get_pth_file(folder):
         if f.endswith('.pth'):
             return f
     return None
+
+
+def get_model_size(model):
+    """Size of the serialised state_dict in MB (util/utils.py:334-342)."""
+    import io
+    buf = io.BytesIO()
+    if isinstance(model, torch.jit.ScriptModule):
+        torch.jit.save(model, buf)
+    else:
+        torch.save(model.state_dict(), buf)
+    return buf.getbuffer().nbytes / 1e6
+
+
+def cleanup_ddp():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def time_sync() -> float:
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return time.time()
+
+
+@torch.no_grad()
+def throughput(dataloader, model, times: int = 30, lowres: bool = False):
+    """util/utils.py:356-367: eval-mode forwards of the first batch, `times` times, images/s printed in the reference's wording (and
+    returned).  `model(images)` is the reference's call: full-resolution fp32 logits are produced.  lowres=True times what
+    `evaluate` actually runs on this path -- `forward_lowres`, the head output the fused argmax / confusion-matrix kernel consumes."""
+    model.eval()
+    images, _ = next(iter(dataloader))
+    images = images.cuda(non_blocking=True)
+    B = images.shape[0]
+    core = model.module if hasattr(model, 'module') else model
+    fwd = core.forward_lowres if (lowres and hasattr(core, 'forward_lowres')) else model
+    fwd(images)                                             # first call: lazy initialisation is not throughput
+    print(f"Throughput averaged with {times} times")
+    start = time_sync()
+    for _ in range(times):
+        fwd(images)
+    end = time_sync()
+    ips = times * B / (end - start)
+    print(f"Batch Size {B} throughput {ips} images/s")
+    return ips
+
+
+@torch.no_grad()
+def test_model_latency(model, inputs, use_cuda: bool = False) -> float:
+    """util/utils.py:370-374: one profiled forward, total self CPU time in ms (torch.autograd.profiler).  use_cuda=True returns the
+    DEVICE time of the forward instead, measured with events on the launch stream (the kernels of this path are launched through the
+    C ABI and are invisible to torch's profiler)."""
+    if use_cuda:
+        model(inputs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        model(inputs)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+    with torch.autograd.profiler.profile(use_cuda=False) as prof:
+        _ = model(inputs)
+    return prof.self_cpu_time_total / 1000  # ms
+
+
+test_model_latency.__test__ = False          # (the reference's name; not a pytest case)

@@ -31,7 +31,10 @@ def _build(backbone, head, nc, sd, dtype, B, deterministic=True):
 
 
 E2E_TAGS = ['segformer_b0_64', 'segformer_b0_96x128', 'convnext_uper_64', 'convnextv2_tiny_uper_64', 'mbv2_fpn_64',
-            'convnext_uper_128', 'convnextv2_tiny_uper_128', 'mbv2_fpn_128']
+            'convnext_uper_128', 'convnextv2_tiny_uper_128', 'mbv2_fpn_128',
+            # H, W that are not multiples of 32 (datasets/build_datasets.py:24-29 keeps the aspect ratio, train_gpu.py:72 evaluates at
+            # batch 1): 19 x 25 -> 10 x 13 -> 5 x 7 -> 3 x 4 maps, remainder-dropping spatial-reduction convs, non-2/4/8 head resizes
+            'segformer_b0_75x100', 'convnext_uper_90x123', 'mbv2_fpn_70x94']
 # Gradient tolerances (fraction `rt` of a parameter's gradient scale, see `tol` below), set from tools/grad_parity_report.py on
 # the MI355X with ~2x margin.  Measured worst sample error / scale: fp32 segformer 1e-4, convnext_64 3e-3, convnext*_128 2e-3,
 # mbv2_64 8e-3, mbv2_128 1.3e-2; bf16 segformer 0.064, convnext_uper_128 0.115, convnextv2_tiny_uper_128 0.133.
@@ -43,6 +46,7 @@ def _kind(tag):
         return 'segformer'
     if tag.startswith('mbv2'):
         return 'mbv2'
+    # convnext_uper_90x123 (batch 2, 22 x 30 ... 2 x 3 maps) is as BatchNorm-ill-conditioned as the 64 x 64 fixture
     return 'convnext_128' if tag.endswith('_128') else 'convnext_64'
 
 
@@ -541,7 +545,8 @@ def test_folded_head_equals_literal_head(dtype):
 @pytest.mark.parametrize('graph', [False, True])
 def test_train_gpu_cli_synthetic(tmp_path, graph):
     """train_gpu.py end to end on generated data: two epochs of MiT-B0 + SegFormerHead at 64x64, checkpoint written with
-    the reference's keys (train_gpu.py:354-362), auto-resume picks it up (train_gpu.py:281-307)."""
+    the reference's keys (train_gpu.py:354-362), auto-resume picks it up (train_gpu.py:281-307).  The command as the reference's
+    README launches it -- NO extra flag -- takes the replayed-hipGraph step and the graphed eval forward; --no-hip-graph the eager launches."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -549,11 +554,12 @@ def test_train_gpu_cli_synthetic(tmp_path, graph):
     cmd = [sys.executable, os.path.join(root, 'train_gpu.py'), '--dataset', 'synthetic', '--data_len', '8', '--image_size', '64',
            '--nb_classes', '5', '--backbone', 'MiT-B0', '--heads', 'SegFormerHead', '--batch-size', '2', '--val_batch_size', '2',
            '--epochs', '2', '--save_weights_dir', str(out), '--writer_output', str(tmp_path), '--train_print_freq', '1',
-           '--val_print_freq', '1', '--lr', '1e-3'] + (['--hip-graph'] if graph else [])
+           '--val_print_freq', '1', '--lr', '1e-3'] + ([] if graph else ['--no-hip-graph'])
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'Start training for 2 epochs' in r.stdout and 'Val_mIOU' in r.stdout
+    assert ('train step captured as one hipGraph' in r.stdout) == graph, r.stdout[-2000:]
     ck = torch.load(str(out / 'MiT-B0_SegFormerHead_best_model.pth'), map_location='cpu', weights_only=False)
     assert {'model_state', 'optimizer_state', 'scheduler_state', 'best_mIoU', 'F1_Score', 'Acc', 'scaler'} <= set(ck)
     assert (out / 'model.txt').exists() and (out / 'args.txt').exists()
@@ -789,7 +795,7 @@ def test_two_rank_eager_ddp_finetune_freeze(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = ['--dataset', 'synthetic', '--data_len', '8', '--image_size', '64', '--nb_classes', str(nc), '--backbone', 'MiT-B0',
             '--heads', 'SegFormerHead', '--batch-size', '2', '--val_batch_size', '2', '--epochs', '1', '--save_weights_dir', '',
-            '--writer_output', str(tmp_path), '--train_print_freq', '1', '--val_print_freq', '1', '--finetune', str(ft)]
+            '--writer_output', str(tmp_path), '--train_print_freq', '1', '--val_print_freq', '1', '--finetune', str(ft), '--no-hip-graph']
     env = dict(os.environ, PYTHONPATH=root, MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', WORLD_SIZE='2',
                SEGFAC_DIST_BACKEND='gloo')
     procs = [subprocess.Popen([sys.executable, os.path.join(root, 'train_gpu.py')] + args, cwd=str(tmp_path),
@@ -801,7 +807,7 @@ def test_two_rank_eager_ddp_finetune_freeze(tmp_path):
 
 
 def test_two_rank_graph_mode_cli(tmp_path):
-    """`train_gpu.py --hip-graph` under two ranks (gloo, sharing this box's GPU): one epoch of the graphed step with the bucketed
+    """`train_gpu.py` with NO extra flag under two ranks (gloo, sharing this box's GPU): one epoch of the graphed step with the bucketed
     exchange, then `evaluate` with the C2 buffer broadcast, the graphed eval forward and the C4 - C6 reductions
     (train_gpu.py:211-236,322-336; util/utils.py:125-131; util/metrics.py:108-114).  Both ranks must print the same validation line."""
     import re
@@ -810,7 +816,7 @@ def test_two_rank_graph_mode_cli(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = ['--dataset', 'synthetic', '--data_len', '8', '--image_size', '64', '--nb_classes', '5', '--backbone', 'MiT-B0',
             '--heads', 'SegFormerHead', '--batch-size', '2', '--val_batch_size', '2', '--epochs', '1', '--save_weights_dir', '',
-            '--writer_output', str(tmp_path), '--train_print_freq', '1', '--val_print_freq', '1', '--lr', '1e-3', '--hip-graph']
+            '--writer_output', str(tmp_path), '--train_print_freq', '1', '--val_print_freq', '1', '--lr', '1e-3']
     env = dict(os.environ, PYTHONPATH=root, MASTER_ADDR='127.0.0.1', MASTER_PORT='29579', WORLD_SIZE='2',
                SEGFAC_DIST_BACKEND='gloo', SEGFAC_PRINT_ALL_RANKS='1')
     procs = [subprocess.Popen([sys.executable, os.path.join(root, 'train_gpu.py')] + args, cwd=str(tmp_path),
@@ -819,6 +825,7 @@ def test_two_rank_graph_mode_cli(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-2000:]
     assert 'Epoch: [0]  [1/2]' in outs[0] and 'Val_mIOU' in outs[0]
+    assert 'train step captured as one hipGraph' in outs[0]          # the default command took the graph path
     vals = [re.findall(r'Val_mIOU[^\n]*', o) for o in outs]
     assert vals[0] and vals[0] == vals[1], vals                     # the reduced matrices (hence every printed figure) agree
 
@@ -1037,3 +1044,186 @@ def test_fp8_training_curve_tracks_bf16(geom):
         assert all(np.isfinite(c)) and c[-1] < (0.05 if backbone == 'ConvNeXt' else 0.6) * c[0], c
     # ConvNeXt-T: measured 8.5 % at step 4 (loss falling 4x per 2 steps), <= 0.6 % at the end
     assert max(dev) <= 0.12 and max(dev[-10:]) <= (0.015 if backbone == 'ConvNeXt' else 0.05), dev
+
+
+def test_default_step_is_the_graph_and_a_failed_capture_falls_back_to_eager(capsys):
+    """engine.train_one_epoch with args that carry NO hip_graph attribute (what a caller written against the reference passes,
+    engine.py:18-70): the step is the replayed hipGraph.  A model whose forward cannot be captured (stand-in: a plugin op that
+    refuses to run while the stream is capturing) makes the same call print the reason and train with eager launches -- in this
+    process, with the optimizer's direct gradient placement disarmed -- while args.hip_graph=True turns the failure into the error."""
+    import types
+    from segmentation_factory_amd import engine
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler
+    backbone, head, nc, B, H, W, seed = 'MiT-B0', 'SegFormerHead', 5, 2, 64, 64, 8
+    sd = OW.make_state_dict(backbone, head, nc, seed, lively=True)
+    x, y = OW.learnable_batch(B, H, W, nc, seed)
+    args = types.SimpleNamespace(nb_classes=nc, dice=True, ignore_index=255, ignore_label=255, local_rank=0, device='cuda')
+
+    def run(model, a, steps=6):
+        opt = FusedAGCAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+        losses = []
+
+        class Rec:
+            def add_scalar(self, name, v, it=None):
+                if name == 'train_loss':
+                    losses.append(float(v))
+        engine.train_one_epoch(model, opt, [(x, y)] * steps, 0, 'cuda', 1, None, None, NativeScaler(), Rec(), a)
+        return losses, opt
+
+    good = _build(backbone, head, nc, sd, torch.float32, B)
+    l_graph, _ = run(good, args)
+    assert getattr(good, '_graphed_step', None) is not None and 'captured as one hipGraph' in capsys.readouterr().out
+
+    def refuse_capture(model):
+        real = model.forward_lowres
+
+        def fwd(img):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('plugin op: not capturable')
+            return real(img)
+        model.forward_lowres = fwd
+        return model
+
+    bad = refuse_capture(_build(backbone, head, nc, sd, torch.float32, B))
+    l_eager, opt = run(bad, args)
+    out = capsys.readouterr().out
+    assert 'hipGraph capture of the train step failed' in out and 'not capturable' in out and 'eager launches' in out
+    assert getattr(bad, '_graphed_step', None) is None and bad._graph_disabled and not opt.direct
+    assert all(not hasattr(p, '_segf_grad') for p in bad.parameters())
+    # same arithmetic either way (fp32 mode): the fallback trained the model the graph would have trained
+    np.testing.assert_allclose(l_eager, l_graph, rtol=2e-4)
+    assert l_eager[-1] < l_eager[0]
+    l_again, _ = run(bad, args, steps=2)                    # later epochs stay eager without a second attempt
+    assert 'capture of the train step failed' not in capsys.readouterr().out and len(l_again) == 2
+
+    bad2 = refuse_capture(_build(backbone, head, nc, sd, torch.float32, B))
+    with pytest.raises(RuntimeError, match='not capturable'):
+        run(bad2, types.SimpleNamespace(**vars(args), hip_graph=True))
+
+
+def test_graphed_eval_session_capture_policy():
+    """validation images keep their aspect ratio (datasets/build_datasets.py:24-29) at --val_batch_size 1
+    (train_gpu.py:72), so `evaluate` meets MANY shapes.  A shape is captured on its SECOND sighting, a session captures at most
+    `max_captures` graphs and holds `max_graphs` (least recently used goes first); 24 distinct shapes, each seen once, run eagerly
+    without a single capture.  Results equal the eager forward bit for bit throughout."""
+    from segmentation_factory_amd.graph import GraphedEvalSession
+    backbone, head, nc, seed = 'MiT-B0', 'SegFormerHead', 5, 9
+    sd = OW.make_state_dict(backbone, head, nc, seed)
+    model = _build(backbone, head, nc, sd, torch.bfloat16, 1).eval()
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64 + 4 * i, 96 + 8 * (i % 5)) for i in range(24)]
+    assert len(set(shapes)) == 24
+    with torch.inference_mode():
+        sess = GraphedEvalSession(model, max_graphs=3, max_captures=4)
+        for h, w in shapes:                                   # every shape once: nothing is captured
+            sess(torch.randn(1, 3, h, w, generator=g).cuda())
+        assert (sess.captures, sess.replays, sess.eager) == (0, 0, 24)
+        xs = [torch.randn(1, 3, h, w, generator=g).cuda() for h, w in shapes[:6]]
+        for x in xs[:4]:                                      # second sighting of four shapes: four captures (the session's cap) ...
+            assert torch.equal(sess(x).data, model.forward_lowres(x).data)
+        assert sess.captures == 4 and len(sess.graphs) == 3   # ... of which the three most recent are kept
+        assert torch.equal(sess(xs[3]).data, model.forward_lowres(xs[3]).data) and sess.replays == 1
+        n_eager = sess.eager
+        assert torch.equal(sess(xs[4]).data, model.forward_lowres(xs[4]).data)     # cap reached: a recurring shape stays eager
+        assert sess.captures == 4 and sess.eager == n_eager + 1
+        # the next session (next epoch's evaluate) finds graphs and sighting counts on the model
+        sess2 = GraphedEvalSession(model, max_graphs=3, max_captures=4)
+        assert torch.equal(sess2(xs[2]).data, model.forward_lowres(xs[2]).data) and sess2.replays == 1
+        assert torch.equal(sess2(xs[5]).data, model.forward_lowres(xs[5]).data) and sess2.captures == 1
+        # another compute dtype is another graph (evaluate runs fp32 by default, --eval-dtype bf16 on request)
+        model.set_compute_dtype(torch.float32)
+        a = sess2(xs[2])
+        assert a.data.dtype == torch.float32 and sess2.replays == 1
+        model.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize('family', ['segformer', 'convnext_uper', 'mbv2_fpn'])
+def test_evaluate_batch1_over_odd_sizes_against_oracle(family):
+    """What `evaluate` sees in a real run (datasets/build_datasets.py:24-29: ExtResize keeps the aspect ratio; train_gpu.py:72:
+    --val_batch_size 1): three images of three different sizes, none a multiple of 32, each size twice, in ONE session (default
+    arguments: fp32 forward, graph per recurring shape).  Confusion matrix and histogram against the CPU oracle's on the same
+    weights and inputs: logits agree to ~1e-6, so at most a handful of near-tie pixels may flip."""
+    import types
+    from segmentation_factory_amd import engine
+    backbone, head, nc = {'segformer': ('MiT-B0', 'SegFormerHead', 7), 'convnext_uper': ('ConvNeXt', 'UPerHead', 9),
+                          'mbv2_fpn': ('MobileNetV2', 'FPNHead', 6)}[family]
+    seed = 41
+    sd = OW.make_state_dict(backbone, head, nc, seed, lively=True)
+    sizes = [(75, 100), (90, 123), (67, 131)]
+    batches = []
+    for i, (h, w) in enumerate(sizes * 2):
+        x, y = OW.learnable_batch(1, h, w, nc, seed + i)
+        batches.append((x, y))
+    model = _build(backbone, head, nc, sd, torch.bfloat16, 1)          # trained-in-bf16 model; evaluate switches to fp32 like the reference
+    args = types.SimpleNamespace(nb_classes=nc, ignore_label=255)
+    confmat, metric = engine.evaluate(args, model, batches, 'cuda', 10, None)
+    assert model.compute_dtype == torch.bfloat16                       # restored
+    sess = model.__dict__['_graphed_eval']
+    assert len(sess['graphs']) == 3                                     # each size captured at its second sighting
+    mat = np.zeros((nc, nc), np.int64)
+    hist = np.zeros((nc, nc), np.int64)
+    with torch.no_grad():
+        for x, y in batches:
+            o, _ = ON.model_forward(sd, x, backbone, head, training=False)
+            m, h_ = OL.confusion_counts(o, y, nc, 255)
+            mat += m
+            hist += h_
+    total = mat.sum()
+    got = confmat.mat.cpu().numpy()
+    assert got.sum() == total
+    flips = np.abs(got - mat).sum() / 2
+    print(f'[{family}] {int(total)} valid pixels over {len(batches)} images, {flips:.0f} arg-max decisions differ from the oracle')
+    assert flips <= 2e-4 * total + 2
+    o_iou, _, _ = OL.metrics_from_hist(torch.from_numpy(hist).float())
+    assert abs(metric.compute_iou()[1] - o_iou[1]) <= 0.1 + 1e-9
+
+
+EVAL_PRECISION = {'cfg2': ('MiT-B0', 'SegFormerHead', 150, 2, 512, 512, 60), 'cfg4': ('MiT-B2', 'SegFormerHead', 19, 1, 1024, 2048, 40)}
+
+
+@pytest.mark.parametrize('cfg', sorted(EVAL_PRECISION))
+def test_evaluate_in_fp32_like_the_reference_and_what_bf16_flips(cfg):
+    """The reference evaluates in fp32 with autocast off (engine.py:86-88); so does engine.evaluate by default.  At BASELINE's cfg2 /
+    cfg4 full size on TRAINED-LIKE logits with small top-2 margins (a model trained for a few dozen steps in bf16 on a learnable batch,
+    evaluated on a held-out batch with extra input noise): (a) the default (fp32) confusion matrix against the CPU oracle's on the
+    trained weights -- mIoU within the north star's +-0.1; (b) --eval-dtype bf16 against the same oracle: how many arg-max decisions
+    the production storage type flips (reported), mIoU within +-0.1 as well on this fixture."""
+    import types
+    from segmentation_factory_amd import engine
+    from segmentation_factory_amd.optim import FusedAGCAdamW, NativeScaler
+    backbone, head, nc, B, H, W, steps = EVAL_PRECISION[cfg]
+    seed = 97
+    sd = OW.make_state_dict(backbone, head, nc, seed, lively=True)
+    x, y = OW.learnable_batch(B, H, W, nc, seed, block=32)
+    model = _build(backbone, head, nc, sd, torch.bfloat16, B)
+    opt = FusedAGCAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    args = types.SimpleNamespace(nb_classes=nc, dice=True, ignore_index=255, ignore_label=255, local_rank=0, device='cuda')
+    engine.train_one_epoch(model, opt, [(x, y)] * steps, 0, 'cuda', 1000, None, None, NativeScaler(), None, args)
+    xv, yv = OW.learnable_batch(B, H, W, nc, seed + 1, block=32, noise=0.6)      # held out, 4x the training noise: small margins
+    res = {}
+    for dt in ('fp32', 'bf16'):
+        a = types.SimpleNamespace(**vars(args), eval_dtype=dt)
+        confmat, metric = engine.evaluate(a, model, [(xv, yv)], 'cuda', 10, None)
+        res[dt] = (confmat.mat.cpu().numpy(), metric.compute_iou()[1])
+    trained = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    trained = {k: (v.long() if k.endswith('num_batches_tracked') else v) for k, v in trained.items()}
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    with torch.no_grad():
+        o, _ = ON.model_forward(trained, xv, backbone, head, training=False)
+    mat, hist = OL.confusion_counts(o, yv, nc, 255)
+    o_miou = OL.metrics_from_hist(torch.from_numpy(hist).float())[0][1]
+    top2 = o.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).flatten()
+    total = mat.sum()
+    acc = np.trace(mat) / total
+    line = [f'[{cfg}] oracle mIoU {o_miou}, pixel accuracy {acc:.3f}, median top-2 margin {margin.median().item():.3f} '
+            f'(logit scale {o.abs().max().item():.1f}), {int(total)} valid pixels']
+    for dt in ('fp32', 'bf16'):
+        flips = np.abs(res[dt][0] - mat).sum() / 2
+        line.append(f'{dt}: mIoU {res[dt][1]} ({res[dt][1] - o_miou:+.2f}), {flips:.0f} flipped decisions = {100 * flips / total:.3f} %')
+        res[dt] += (flips,)
+    print('; '.join(line))
+    assert 0.05 < acc < 0.999                                             # trained-like, not decisive: the fixture measures something
+    assert res['fp32'][0].sum() == total and res['bf16'][0].sum() == total
+    assert abs(res['fp32'][1] - o_miou) <= 0.1 + 1e-9 and res['fp32'][2] <= 1e-4 * total + 2
+    assert abs(res['bf16'][1] - o_miou) <= 0.1 + 1e-9, line

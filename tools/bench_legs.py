@@ -6,8 +6,10 @@
   train_loop  the loop a user runs -- `engine.train_one_epoch(..., args.hip_graph=True)` over a `DeviceBatchLoader` (the device-side
               transform stack writes every batch straight into the captured step's input buffers; /root/reference/engine.py:36-56,
               train_gpu.py:322-336) -- in steady state, next to the replay-only rate of the same captured step in the same process
-  eval        `engine.evaluate` (/root/reference/engine.py:74-104) images/s with the eval forward replayed as a hipGraph and launched
-              eagerly, plus the fused upsample + argmax + confusion-matrix kernel against the HBM roofline
+  eval        `engine.evaluate` (/root/reference/engine.py:74-104) images/s in fp32 (the reference's eval precision, the default) and in
+              bf16, with the eval forward replayed as a hipGraph and launched eagerly, plus the fused upsample + argmax +
+              confusion-matrix kernel against the HBM roofline
+  default_cli `engine.train_one_epoch` as the README command runs it (DataLoader-fed, batch 4, no flag = graph) next to --no-hip-graph
 
 python tools/bench_legs.py config cfg3 --batch 32 [--fp8] | train_loop --batch 128 | eval --batch 1      -> one JSON line
 """
@@ -61,6 +63,8 @@ def build(cfg, fp8=False):
     core = SegmentationModel(bb, num_classes=nc, seg_head=head, compute_dtype=torch.bfloat16).cuda().train()
     if fp8:
         core.set_fp8(True)
+    from bench import numpy_seed_weights
+    numpy_seed_weights(core, 0)          # the headline's initialisation (numpy default_rng(0)), not torch's RNG order
     opt = FusedAGCAdamW(param_groups_weight_decay(core, 0.025), lr=2e-4)
     return core, opt, nc, H, W
 
@@ -203,6 +207,8 @@ def leg_train_loop(a):
 
 
 def leg_eval(a):
+    """engine.evaluate in the reference's precision (fp32: engine.py:86-88 switches autocast off) and in the bf16 production type
+    (--eval-dtype bf16), each with the eval forward replayed as a hipGraph (the default) and launched eagerly."""
     from segmentation_factory_amd import hip
     from segmentation_factory_amd.engine import evaluate
     core, opt, nc, H, W = build('cfg2')
@@ -213,17 +219,20 @@ def leg_eval(a):
     data = [(x, y)] * nb                                          # batches already resident in HBM
     res = {}
     sink = io.StringIO()
-    for mode in ('graph', 'eager'):
-        args = SimpleNamespace(nb_classes=nc, ignore_label=255, hip_graph=(mode == 'graph'))
-        with contextlib.redirect_stdout(sink):
-            _, mw = evaluate(args, core, data[:3], torch.device('cuda'), a.print_freq)        # warm (captures the eval forward in graph mode)
-            mw.compute_iou()                                                          # ... including the first use of the summary's own kernels
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            confmat, metric = evaluate(args, core, data, torch.device('cuda'), a.print_freq)
-            miou = metric.compute_iou()[1]                        # reads the histogram: the synchronisation a user's loop ends with
-            el = time.perf_counter() - t0
-        res[mode] = {"images_per_sec": round(a.batch * nb / el, 2), "ms_per_batch": round(1e3 * el / nb, 3), "mIoU": miou}
+    for dt in ('fp32', 'bf16'):
+        res[dt] = {}
+        for mode in ('graph', 'eager'):
+            args = SimpleNamespace(nb_classes=nc, ignore_label=255, hip_graph=(mode == 'graph'), eval_dtype=dt)
+            with contextlib.redirect_stdout(sink):
+                _, mw = evaluate(args, core, data[:3], torch.device('cuda'), a.print_freq)    # warm (graph mode: eager first sighting, capture on the second)
+                mw.compute_iou()                                                          # ... including the first use of the summary's own kernels
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                confmat, metric = evaluate(args, core, data, torch.device('cuda'), a.print_freq)
+                miou = metric.compute_iou()[1]                    # reads the histogram: the synchronisation a user's loop ends with
+                el = time.perf_counter() - t0
+            res[dt][mode] = {"images_per_sec": round(a.batch * nb / el, 2), "ms_per_batch": round(1e3 * el / nb, 3), "mIoU": miou}
+        res[dt]["speedup_graph_over_eager"] = round(res[dt]['graph']['images_per_sec'] / res[dt]['eager']['images_per_sec'], 3)
     hq, wq = H // 4, W // 4
     lo = core.forward_lowres(x)
     mat = torch.zeros(nc, nc, dtype=torch.int64, device='cuda')
@@ -232,8 +241,9 @@ def leg_eval(a):
     ms = ev_time(lambda: hip.argmax_confmat(lo.data, a.batch, nc, hq, wq, H, W, y, 255, mat, cnt, flag), 10, warm=2)
     nbytes = a.batch * (hq * wq * nc * 2 + H * W * 8)             # low-res logits read + int64 labels read (SURVEY 8(d) definition)
     return {"leg": "eval", "what": "engine.evaluate (eval forward + fused upsample/argmax/confusion matrices), SegFormer-B0 512x512 150 classes, "
-                                   f"{nb} batches resident in HBM", "per_gpu_batch": a.batch, "graph": res['graph'], "eager": res['eager'],
-            "speedup_graph_over_eager": round(res['graph']['images_per_sec'] / res['eager']['images_per_sec'], 3),
+                                   f"{nb} batches resident in HBM; fp32 = the default (the reference's eval precision), bf16 = --eval-dtype bf16",
+            "per_gpu_batch": a.batch, "eval_dtype_default": "fp32", "fp32": res['fp32'], "bf16": res['bf16'],
+            "bf16_over_fp32": round(res['bf16']['graph']['images_per_sec'] / res['fp32']['graph']['images_per_sec'], 3),
             "roofline": {"kernel": "argmax_confmat_pix_kernel (fused bilinear upsample + argmax + int64 confusion matrices, engine.py:89-91; lane = pixel, "
                                    "counts privatised in LDS)",
                          "bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -242,9 +252,49 @@ def leg_eval(a):
                          "note": "VALU / LDS-latency-bound, not HBM-bound: 1 mul + 3 fma + compare + 2 selects per full-resolution (pixel, class) pair"}}
 
 
+def leg_default_cli(a):
+    """What `python train_gpu.py ...` as the reference's README launches it delivers per step (train_gpu.py:71,322-336; engine.py:36-56):
+    engine.train_one_epoch fed by a torch DataLoader (host tensors, pinned, batch 4 = the reference default), args WITHOUT a hip_graph
+    attribute (AUTO: the replayed graph) next to args.hip_graph=False (--no-hip-graph: per-kernel launches, one loss.item() per step)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from segmentation_factory_amd.engine import train_one_epoch
+    from segmentation_factory_amd.optim import NativeScaler
+    res = {}
+    n_img = a.steps * a.batch
+    sink = io.StringIO()
+    for mode in ('auto', 'eager'):
+        core, opt, nc, H, W = build('cfg2')
+        x, y = synthetic_batch(min(n_img, 64), nc, H, W, 0)
+        reps = -(-n_img // x.shape[0])
+        ds = TensorDataset(x.repeat(reps, 1, 1, 1)[:n_img], y.repeat(reps, 1, 1)[:n_img])
+        loader = DataLoader(ds, batch_size=a.batch, shuffle=True, drop_last=True, pin_memory=True, num_workers=0)
+        args = SimpleNamespace(nb_classes=nc, dice=True, ignore_index=255, local_rank=0)
+        if mode == 'eager':
+            args.hip_graph = False
+        scaler = NativeScaler()
+        with contextlib.redirect_stdout(sink):
+            train_one_epoch(core, opt, loader, 0, torch.device('cuda'), a.print_freq, 0.02, 'agc', scaler, None, args)   # capture / warm
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for ep in range(1, 1 + a.epochs):
+                mean_loss, lr = train_one_epoch(core, opt, loader, ep, torch.device('cuda'), a.print_freq, 0.02, 'agc', scaler, None, args)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        n_steps = a.epochs * len(loader)
+        res[mode] = {"images_per_sec": round(a.batch * n_steps / el, 2), "ms_per_step": round(1e3 * el / n_steps, 3),
+                     "graphed": getattr(core, '_graphed_step', None) is not None, "mean_loss_last_epoch": round(float(mean_loss), 4)}
+        del core, opt, loader, ds
+        torch.cuda.empty_cache()
+    return {"leg": "default_cli", "what": "engine.train_one_epoch over a torch DataLoader (pinned host tensors, H2D copy per step), SegFormer-B0 "
+                                         "512x512 150 classes: 'auto' = the default command (hipGraph step, one host sync per logging interval), "
+                                         "'eager' = --no-hip-graph", "per_gpu_batch": a.batch, "steps_timed": n_steps, "print_freq": a.print_freq,
+            "auto": res['auto'], "eager": res['eager'],
+            "speedup_auto_over_eager": round(res['auto']['images_per_sec'] / res['eager']['images_per_sec'], 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('leg', choices=['config', 'train_loop', 'eval'])
+    ap.add_argument('leg', choices=['config', 'train_loop', 'eval', 'default_cli'])
     ap.add_argument('config', nargs='?', default='cfg2')
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--fp8', action='store_true')
@@ -256,7 +306,7 @@ def main():
     assert torch.cuda.is_available(), 'bench legs need the MI355X (there is no CPU fallback)'
     if a.batch is None:
         a.batch = {'cfg2': 128, 'cfg3': 32, 'cfg4': 16, 'cfg5': 8}[a.config]
-    out = {'config': leg_config, 'train_loop': leg_train_loop, 'eval': leg_eval}[a.leg](a)
+    out = {'config': leg_config, 'train_loop': leg_train_loop, 'eval': leg_eval, 'default_cli': leg_default_cli}[a.leg](a)
     print('LEG_JSON ' + json.dumps(out))
 
 

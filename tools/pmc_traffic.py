@@ -3,12 +3,14 @@
 do not fit one pass; both are reported in KB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so it is doubled).
 
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs
   python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --batch 128 --out profiles/pmc_traffic_b128.json
 
 Per kernel name the LARGEST launch is kept (the full-size in-graph one).  The JSON is stamped with the hash of the kernel
-sources (bench.kernel_source_hash); bench.py reports `traffic` only when that hash matches the library it is running."""
+sources, one hash per reported kernel (bench.kernel_source_hash); bench.py reports a kernel's `traffic` only when ITS hash matches the
+library it is running.  (bench.py started under rocprofv3 must not spawn its child legs: --no-extra-legs; it also skips them by itself
+when it sees the profiler's environment.)"""
 import argparse
 import csv
 import glob
@@ -57,7 +59,7 @@ def main():
     out = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py defaults (cfg2); KB -> bytes; FETCH_SIZE doubled '
                    '(gfx950 correction, MI355X_MICROARCH.md HBM section); Infinity-Cache hits are included; per kernel name the largest '
                    'launch (= the full-size in-graph one)',
-           'batch': a.batch, 'source_hash': kernel_source_hash(), 'kernels': kernels}
+           'batch': a.batch, 'source_hashes': kernel_source_hash(), 'kernels': kernels}
     with open(a.out, 'w') as fh:
         json.dump(out, fh, indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['total_bytes'])[:25]:

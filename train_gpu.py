@@ -12,9 +12,10 @@ text files, same auto-resume from the first *.pth in --save_weights_dir.  Differ
   * data: the reference's `datasets` package (PIL / torchvision pipelines, out of scope here) is used unchanged when it is
     importable (put the reference checkout on PYTHONPATH); `--dataset synthetic` runs on generated tensors with the same
     tensor contract (fp32 [3,S,S] image, int64 [S,S] label, ignore 255);
-  * --hip-graph replays each step as one hipGraph (segmentation_factory_amd/graph.py); data parallelism is then a bucketed RCCL
-    exchange of the flat gradient buffer released by in-graph events (--grad-exchange, --grad-payload) instead of
-    DistributedDataParallel hooks;
+  * the train step and the eval forward are replayed as hipGraphs BY DEFAULT (segmentation_factory_amd/graph.py; --no-hip-graph
+    for per-kernel launches, --hip-graph to make a capture failure an error instead of a fallback); data parallelism is then a
+    bucketed RCCL exchange of the flat gradient buffer released by in-graph events (--grad-exchange, --grad-payload) instead of
+    DistributedDataParallel hooks; evaluate() runs in fp32 as the reference does (--eval-dtype bf16 for the production type);
   * --finetune defaults to '' (the reference's default path makes the run fail unless that file exists, quirk Q10).
 
 Launch: `python train_gpu.py ...` or `python -m torch.distributed.run --nproc-per-node N train_gpu.py ...` (RCCL).
@@ -114,7 +115,15 @@ def get_args_parser():
     parser.add_argument('--save_freq', default=1, type=int)
     # MI355X-path extras
     parser.add_argument('--compute-dtype', default='bf16', choices=['bf16', 'fp32'], help='activation storage (fp32 = exact-parity mode)')
-    parser.add_argument('--hip-graph', action='store_true', help='replay each train step as one hipGraph')
+    parser.add_argument('--hip-graph', dest='hip_graph', action='store_const', const=True, default=None,
+                        help='REQUIRE the replayed-hipGraph train step / eval forward (a capture failure is an error).  Without either flag '
+                             'the graph is used whenever the model offers forward_lowres and the optimizer is the fused AGC/AdamW one, and '
+                             'a capture failure falls back to eager launches with a printed reason')
+    parser.add_argument('--no-hip-graph', dest='hip_graph', action='store_const', const=False,
+                        help='per-kernel (eager) launches; under several ranks the model is wrapped in DistributedDataParallel as in the reference')
+    parser.add_argument('--eval-dtype', default='fp32', choices=['fp32', 'bf16'],
+                        help="precision of evaluate()'s forward: fp32 as the reference (engine.py:86-88 switches autocast off), or the "
+                             'bf16 production storage type')
     parser.add_argument('--grad-exchange', default='all_reduce', choices=['all_reduce', 'rs_ag'],
                         help='--hip-graph data parallelism: one all-reduce per gradient bucket, or in-place reduce-scatter + all-gather')
     parser.add_argument('--grad-payload', default='fp32', choices=['fp32', 'bf16'],
@@ -237,7 +246,7 @@ def main(args):
                               seg_head=args.heads, compute_dtype=dtype, args=args).to(device)
     model_without_ddp = model
     if args.finetune:       # train_gpu.py:238-260
-        checkpoint_model = utils.load_model(args.finetune)
+        checkpoint_model = utils.load_model(args.finetune, model)
         for k in list(checkpoint_model.keys()):
             if 'linear_pred' in k:
                 print(f"Removing key {k} from pretrained checkpoint")
@@ -248,7 +257,7 @@ def main(args):
                 para.requires_grad_('linear_pred' in name)
                 if 'linear_pred' in name:
                     print('training {}'.format(name))
-    if args.distributed and not args.hip_graph:
+    if args.distributed and args.hip_graph is False:
         # wrapped AFTER the finetune load / freeze (the reducer must see the final requires_grad flags), and with
         # find_unused_parameters=True as the reference does (train_gpu.py:233-236: e.g. FPNHead.output_convs[0] is never used)
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.gpu] if device == 'cuda' else None,
