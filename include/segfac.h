@@ -401,9 +401,11 @@ int segf_fuse_map_248(int B, int H, int W, int C, int C1, const void* x1, int64_
                       void* out, int64_t ldo, float* sums, float* ws, void* stream);
 int segf_bn_stats_from_sums(const float* sums, int64_t rows, int C, float* mean, float* rstd, float* running_mean,
                             float* running_var, float momentum, float eps, void* stream);
-/* Nearest-neighbour upsampling by an integer factor on dense NHWC (F.interpolate mode='nearest': the top-down step of FPNHead,
- * heads/fpn.py:31,35).  bwd=0: out[B][H][W][C] = in[B][h][w][C] replicated (+ base[B][H][W][C], nullable: the `out + lateral`
- * of fpn.py:34 fused); bwd=1: out[B][h][w][C] = block sums of in[B][H][W][C].  H % h == 0, W % w == 0, C % 8 == 0. */
+/* Nearest-neighbour resize on dense NHWC (F.interpolate mode='nearest': the top-down step of FPNHead, heads/fpn.py:31,35).
+ * bwd=0: out[B][H][W][C] = in[B][src(Y)][src(X)][C] (+ base[B][H][W][C], nullable: the `out + lateral` of fpn.py:34 fused);
+ * bwd=1: out[B][h][w][C] = sums of in[B][H][W][C] over the destinations of each source.  Integer ratios: src(Y) = Y / (H / h); any
+ * other (h, H) -- inputs that are not multiples of 32 give 3 x 3 -> 5 x 6 and 10 x 12 -> 9 x 12 steps, fpn.py:30-31 -- follows ATen:
+ * src(Y) = min((int)floorf(Y * ((float)h / H)), h - 1).  C % 8 == 0. */
 int segf_nearest_up(int dt, int bwd, int B, int h, int w, int C, int H, int W, const void* in, const void* base, void* out,
                     void* stream);
 /* out (fp32 NCHW [B][C][H][W]) = bilinear(in NHWC [B][h][w][ldi]) -- materialised logits for API parity */

@@ -527,13 +527,30 @@ extern "C" int segf_adaptive_avgpool(int dt, int bwd, int B, int H, int W, int C
     return 0;
 }
 
-// ---- nearest-neighbour upsampling by an integer factor on NHWC (F.interpolate mode='nearest', heads/fpn.py:31,35): the
-// top-down step of FPNHead, `out = nearest(out, size of lateral)`, `out = out + lateral`, `out = nearest(out, x2)`.
-// Forward (bwd=0): out[b][Y][X] = in[b][Y / ry][X / rx] (+ base[b][Y][X] when base != NULL); ry = H / h, rx = W / w exact.
-// Backward (bwd=1): out[b][y][x] = sum of in[b][y*ry .. y*ry+ry)[x*rx .. x*rx+rx) (gather form, deterministic).
-template <typename T, bool BWD>
+// ---- nearest-neighbour upsampling on NHWC (F.interpolate mode='nearest', heads/fpn.py:31,35): the top-down step of FPNHead,
+// `out = nearest(out, size of lateral)`, `out = out + lateral`, `out = nearest(out, x2)`.
+// Forward (bwd=0): out[b][Y][X] = in[b][src(Y)][src(X)] (+ base[b][Y][X] when base != NULL).  Integer ratios (H % h == 0): src(Y) =
+// Y / (H / h).  Any other pair of sizes (GEN; inputs that are not multiples of 32 give FPNHead 3 x 3 -> 5 x 6, 10 x 12 -> 9 x 12
+// steps, fpn.py:30-31) follows ATen's nearest_neighbor_compute_source_index in its float arithmetic: src(Y) = min((int)floorf(Y *
+// scale), h - 1) with scale = (float)h / H.
+// Backward (bwd=1): out[b][y][x] = sum of in[b][Y][X] over the (contiguous) destination rows / columns whose source is (y, x) --
+// gather form, deterministic.
+__device__ __forceinline__ int nearest_src(int d, float scale, int n_in) {
+    const int s = (int)floorf((float)d * scale);
+    return s < n_in - 1 ? s : n_in - 1;
+}
+// first destination index in [0, n_out] whose source is >= y (n_out when there is none): a short scan around y / scale
+__device__ __forceinline__ int nearest_first_dst(int y, float scale, int n_in, int n_out) {
+    int d = (int)floorf((float)y / scale) - 1;
+    d = d < 0 ? 0 : (d > n_out ? n_out : d);
+    while (d > 0 && nearest_src(d - 1, scale, n_in) >= y) --d;
+    while (d < n_out && nearest_src(d, scale, n_in) < y) ++d;
+    return d;
+}
+
+template <typename T, bool BWD, bool GEN>
 __global__ void __launch_bounds__(256) nearest_up_kernel(const T* __restrict__ in, const T* __restrict__ base, T* __restrict__ out,
-                                                          int B, int h, int w, int C, int H, int W) {
+                                                          int B, int h, int w, int C, int H, int W, float sy, float sx) {
     const int nch = C / 8, ry = H / h, rx = W / w;
     const int oh = BWD ? h : H, ow = BWD ? w : W;
     const int64_t total = (int64_t)B * oh * ow * nch;
@@ -545,7 +562,8 @@ __global__ void __launch_bounds__(256) nearest_up_kernel(const T* __restrict__ i
         const int64_t b = t / oh;
         float acc[8];
         if (!BWD) {
-            load8<T>(in + ((b * h + Y / ry) * w + X / rx) * C + c0, acc);
+            const int ys = GEN ? nearest_src(Y, sy, h) : Y / ry, xs = GEN ? nearest_src(X, sx, w) : X / rx;
+            load8<T>(in + ((b * h + ys) * w + xs) * C + c0, acc);
             if (base) {
                 float v[8];
                 load8<T>(base + ((b * H + Y) * W + X) * C + c0, v);
@@ -555,10 +573,12 @@ __global__ void __launch_bounds__(256) nearest_up_kernel(const T* __restrict__ i
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-            for (int dy = 0; dy < ry; ++dy)
-                for (int dx = 0; dx < rx; ++dx) {
+            const int y0 = GEN ? nearest_first_dst(Y, sy, h, H) : Y * ry, y1 = GEN ? nearest_first_dst(Y + 1, sy, h, H) : Y * ry + ry;
+            const int x0 = GEN ? nearest_first_dst(X, sx, w, W) : X * rx, x1 = GEN ? nearest_first_dst(X + 1, sx, w, W) : X * rx + rx;
+            for (int yy = y0; yy < y1; ++yy)
+                for (int xx = x0; xx < x1; ++xx) {
                     float v[8];
-                    load8<T>(in + ((b * H + Y * ry + dy) * W + X * rx + dx) * C + c0, v);
+                    load8<T>(in + ((b * H + yy) * W + xx) * C + c0, v);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] += v[j];
                 }
@@ -570,15 +590,22 @@ __global__ void __launch_bounds__(256) nearest_up_kernel(const T* __restrict__ i
 extern "C" int segf_nearest_up(int dt, int bwd, int B, int h, int w, int C, int H, int W, const void* in, const void* base,
                                void* out, void* stream) {
     if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return 0;
-    if (C % 8 != 0 || H < h || W < w || H % h != 0 || W % w != 0) return SEGF_ERR_SHAPE;
+    if (C % 8 != 0 || H <= 0 || W <= 0) return SEGF_ERR_SHAPE;
     if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)base) % 16 != 0) return SEGF_ERR_SHAPE;
     if (bwd && base) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)B * (bwd ? h : H) * (bwd ? w : W) * (C / 8);
     const int blocks = (int)imin64(cdiv64(total, 256), 8192);
+    const bool gen = (H % h != 0) || (W % w != 0);        // (a size that shrinks, 10 x 12 -> 9 x 12, is never a multiple)
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     SEGF_DISPATCH_DT(dt, T, {
-        if (bwd) hipLaunchKernelGGL((nearest_up_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)nullptr, (T*)out, B, h, w, C, H, W);
-        else hipLaunchKernelGGL((nearest_up_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, C, H, W);
+        if (gen) {
+            if (bwd) hipLaunchKernelGGL((nearest_up_kernel<T, true, true>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)nullptr, (T*)out, B, h, w, C, H, W, sy, sx);
+            else hipLaunchKernelGGL((nearest_up_kernel<T, false, true>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, C, H, W, sy, sx);
+        } else {
+            if (bwd) hipLaunchKernelGGL((nearest_up_kernel<T, true, false>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)nullptr, (T*)out, B, h, w, C, H, W, sy, sx);
+            else hipLaunchKernelGGL((nearest_up_kernel<T, false, false>), dim3(blocks), dim3(256), 0, st, (const T*)in, (const T*)base, (T*)out, B, h, w, C, H, W, sy, sx);
+        }
     })
     SEGF_CHECK_LAUNCH();
     return 0;

@@ -1032,8 +1032,8 @@ def bilinear_bwd(dout, B, h, w, Cc, H, W, align_corners=False, ld_in=None):
 
 
 def nearest_up(x, B, h, w, Cc, H, W, base=None, bwd=False):
-    """bwd=False: x [B*h*w, C] -> [B*H*W, C] replicated by the integer factors H/h, W/w (+ base); bwd=True: x = dout [B*H*W, C]
-    -> block sums [B*h*w, C]."""
+    """bwd=False: x [B*h*w, C] -> [B*H*W, C], nearest source per destination (integer factors or ATen's floorf(dst * in / out) for
+    any other pair of sizes) (+ base); bwd=True: x = dout [B*H*W, C] -> sums over each source's destinations [B*h*w, C]."""
     _need_cuda(x, base)
     assert x.is_contiguous() and (base is None or base.is_contiguous())
     out = torch.empty(((B * h * w) if bwd else (B * H * W), Cc), dtype=x.dtype, device=x.device)
