@@ -510,6 +510,83 @@ int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, i
                    int out_w, void* ws, const float* mean3, const float* std3, const int64_t* label_lut, float* out_img,
                    int64_t* out_lbl, void* stream);
 
+/* ---- Dispatch policy and launch trace (csrc/policy.h, csrc/policy.hip) -------------------------------------------------------------
+ * Every switch that can change WHICH kernel (or which form of a kernel) a call takes lives in one table, csrc/policy.h, and is read
+ * from the environment ONCE, at first use, into one struct: nothing on the launch path calls getenv().  A set variable that is not a
+ * number counts as 1; "0" equals unset for the on/off switches.  The table (the reference has no counterpart: it dispatches through
+ * ATen; models/build_models.py:43-54 is where the BASELINE shapes these rules were measured on come from):
+ *
+ *   SEGFAC_GEMM_NO_BIG           never take the 256 x 256-tile kernel (gemm_bf16_big_kernel): everything on the 128-tile one
+ *   SEGFAC_GEMM_NO_SKINNY        no streaming products for K, N <= 128 (gemm_skinny_kernel and its relatives)
+ *   SEGFAC_GEMM_NO_SKINNY_ROWS   the [tokens x 32] -> 768 projection on gemm_skinny_kernel instead of the whole-row form
+ *   SEGFAC_GEMM_NO_SKINNY_K      no K-split streaming product for 32- / 64-wide outputs (gemm_skinny_k_kernel)
+ *   SEGFAC_GEMM_NO_DW_SKINNY     small-output weight gradients on the tiled split-K kernel instead of gemm_dw_skinny_kernel
+ *   SEGFAC_GEMM_NO_NARROW        256-tile kernel: full 128 x 64 wave tiles also for outputs <= 160 wide (bit-identical results)
+ *   SEGFAC_GEMM_NO_DEEP          256-tile forward: one K step of operand loads in flight instead of two
+ *   SEGFAC_GEMM_NO_DEEP128       128-tile kernel: one K step in flight instead of two
+ *   SEGFAC_GEMM_NO_FASTLOAD      guarded tile loads everywhere (no workgroup-uniform guard-free full-K-step loads)
+ *   SEGFAC_GEMM_NO_TR            debugging: reduction-major fragments by scalar LDS reads instead of ds_read_b64_tr_b16; disables every kernel built on the transposed read
+ *   SEGFAC_GEMM_NO_PRO           segf_gemm_pro_supported answers 0: BatchNorm + ReLU + Dropout2d are applied by their own pass
+ *   SEGFAC_GEMM_NO_FUSED_DB      bias gradient as its own column-sum launch instead of riding on the weight-gradient product
+ *   SEGFAC_NO_GROUPED_DW         segf_gemm_dw_db_grouped runs its members one by one
+ *   SEGFAC_DW_NO_SHARED_SPLIT    grouped weight gradients keep their per-layer slice counts (also read by the host layer)
+ *   SEGFAC_NO_WIDE_REDUCE        split-K partials of large outputs summed by the 16 x 16 form instead of whole rows
+ *   SEGFAC_NO_REDUCE4            split-K reduce: one output per thread instead of four (bitwise the same sums)
+ *   SEGFAC_GEMM8_LINEAR          OPT-IN: plain nn.Linear products with whole 256 x 256 tiles on the eight-phase kernel (loses 0.5 - 2 % on the BASELINE models)
+ *   SEGFAC_NO_GEMM8              no eight-phase kernel at all (gemm8_kernel): the two-phase 256-tile kernel everywhere
+ *   SEGFAC_NO_GEMM8T             no eight-phase kernel for weight gradients (reduction-major operands)
+ *   SEGFAC_CONV_NO_FWD_SPLIT     3 x 3 forward / data gradient with few output tiles: no split over the (channel block, tap) walk
+ *   SEGFAC_G8_STAGGER            eight-phase kernel: 1 = wave groups one barrier apart, 0 = lockstep, -1 = staggered for bf16 and the per-device choice (segf_gemm8_option) for fp8  (default -1)
+ *   SEGFAC_NO_FP8                segf_gemm_fp8_supported answers 0 (block-scaled 128-tile fp8 GEMM)
+ *   SEGFAC_NO_FP8_CONV           segf_conv3x3_fp8*_supported answer 0
+ *   SEGFAC_NO_FP8_WGRAD          fp8 3 x 3 convolutions keep a bf16 weight gradient
+ *   SEGFAC_NO_FP8_LINEAR         segf_linear_fp8_supported answers 0
+ *   SEGFAC_ATTN_NO_MFMA          attention on the VALU reference kernels (attention.hip) also in bf16
+ *   SEGFAC_ATTN_NO_FUSED_BWD     head dim 32, <= 256 keys: query-side + key-side backward kernels instead of the one-kernel backward
+ *   SEGFAC_DW_NO_WALK            depthwise 3 x 3: the round-1 strip kernels instead of the vertical-walk kernels
+ *   SEGFAC_DW_WALK_ROWS          depthwise 3 x 3 walk: rows per segment (0 = chosen from the map size)
+ *   SEGFAC_DW_NO_SMALL           depthwise 3 x 3 backward of small maps: three passes instead of the one-launch LDS form
+ *   SEGFAC_DW_SMALL_ALWAYS       ... the one-launch form beyond one round of workgroups as well
+ *   SEGFAC_NO_FUSE_MAP           folded SegFormerHead map: streaming product + VALU upsample-add instead of fuse_map_kernel
+ *   SEGFAC_NO_BWD248_MFMA        transposed 1/2-1/4-1/8 resizes on the VALU kernel instead of fuse_map_bwd_kernel
+ *   SEGFAC_UPADD_GENERIC         upsample-add: the generic per-source kernels also for the 2-4-8 pyramid
+ *   SEGFAC_NO_HEAD_FUSED         segf_bn_cls_bwd_supported answers 0: classifier data gradient and BatchNorm backward as separate passes
+ *   SEGFAC_NO_HEAD_FUSED_DW      the folded head's stage-1 weight gradient does not ride on pass 2 of the fused BatchNorm backward
+ *   SEGFAC_LOSS_NO_BAND          CE / Dice forward and backward on the tile kernels instead of the band sweep
+ *   SEGFAC_LOSS_NO_BAND_FWD      ... the forward only
+ *   SEGFAC_LOSS_BAND_ROWS        band sweep: rows per segment (0 = 16)
+ *   SEGFAC_LOSS_NO_MFMA          ratio-4 loss kernels on the VALU cells form (fp32 storage)
+ *   SEGFAC_LOSS_NO_RETRY         no exact per-pixel retry pass behind the flagged cells
+ *   SEGFAC_LOSS_NO_LSE           the backward recomputes the softmax normalisation instead of taking the forward's per-pixel log-sum
+ *   SEGFAC_NO_WIDE_FINALIZE      column-reduction finalize: one output per thread instead of four (bitwise the same sums)
+ *   SEGFAC_NO_LN_PATCH           [host] MiT blocks: im2col / col2im around the spatial-reduction conv instead of the patch-major LayerNorm output
+ *   SEGFAC_NO_SCALED_LN_BWD      [host] DropPath backward as its own scale_rows launch instead of riding on the LayerNorm backward
+ *   SEGFAC_NO_DEFERRED_DW        [host] weight gradients issued layer by layer inside the captured step (no grouped launches)
+ *   SEGFAC_NO_DEFERRED_FINALIZE  [host] LayerNorm dgamma / dbeta finalizes issued one by one
+ *   SEGFAC_NO_HEAD_FUSED_CW      [host] the classifier's weight gradient as its own product instead of riding on pass 1 of the fused BatchNorm backward
+ *   SEGFAC_NO_BWD248             [host] folded head backward: three segf_bilinear_bwd launches instead of the one-pass segf_bilinear_bwd_248
+ *   SEGFAC_NO_GELU_GRN           [host] ConvNeXtV2 blocks: GELU as its own pass in front of the GRN kernels
+ *   SEGFAC_NO_WEIGHT_SHADOW      [host] captured step: weights cast to bf16 per use instead of one cast of the flat buffer
+ *   SEGFAC_NO_DERIVED_WEIGHTS    [host] captured step: derived weight layouts built in front of each layer instead of one grouped launch
+ *
+ * segf_policy_count / segf_policy_describe enumerate the table (field name, environment name, current value, default, description);
+ * segf_policy_get / segf_policy_set read / change one value in the running process by field or environment name (INT_MIN: no such
+ * switch; set returns the previous value); segf_policy_reload re-reads the environment (tests, A/B scripts).
+ *
+ * Launch trace: between segf_trace_begin(dry_run) and segf_trace_end(buf, cap) every kernel launched by the library ON THE CALLING
+ * THREAD is recorded by its instantiated name (template arguments included), one per line in buf; segf_trace_end returns the number of
+ * launches and closes the trace.  With dry_run != 0 the launches themselves (and the launch-error checks) are skipped: an entry point
+ * can then be called with any non-null, 16-byte-aligned pointer values on a machine WITHOUT a GPU to learn which kernels a shape takes
+ * -- tests/test_host_cpu.py::test_dispatch_of_baseline_shapes pins the BASELINE shapes against tests/golden/dispatch_table.json, so a
+ * dispatch edit shows up as a diff. */
+int segf_policy_count(void);
+int segf_policy_describe(int i, const char** field, const char** env, int* value, int* def, const char** doc);
+int segf_policy_get(const char* name);
+int segf_policy_set(const char* name, int value);
+void segf_policy_reload(void);
+void segf_trace_begin(int dry_run);
+int segf_trace_end(char* buf, int cap);
+
 #ifdef __cplusplus
 }
 #endif

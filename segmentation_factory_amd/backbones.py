@@ -5,7 +5,6 @@ Internally every activation is a token-major ``[B*H*W, C]`` tensor in the comput
 a HIP kernel (segmentation_factory_amd.functional).  The NCHW maps handed to the head are zero-copy
 permuted views of those token buffers.
 """
-import os
 
 import torch
 from torch import nn
@@ -283,7 +282,7 @@ class ConvNeXtBlock(nn.Module):
         h = Fh.linear(h, self.pwconv1.weight, self.pwconv1.bias, fp8=self.fp8)
         if self.v2:
             # act -> grn (convnextv2.py:92-94) as one op: the GELU is applied inside the GRN kernels, gelu(h) is never written
-            if os.environ.get('SEGFAC_NO_GELU_GRN'):
+            if Fh.hip.policy('no_gelu_grn'):
                 h = Fh.grn(Fh.gelu(h), self.grn.gamma, self.grn.beta, B, H * W)
             else:
                 h = Fh.grn(h, self.grn.gamma, self.grn.beta, B, H * W, pre_gelu=True)

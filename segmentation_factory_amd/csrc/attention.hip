@@ -289,7 +289,7 @@ extern "C" int segf_attention_fwd(int dt, int B, int heads, int N, int Nkv, int 
     if (Nkv <= 0 || (hd != 32 && hd != 64) || heads > 65535 || B > 65535) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int vec = attn_vec_ok(dt, q, ldq) && attn_vec_ok(dt, k, ldk) && attn_vec_ok(dt, v, ldv) && attn_vec_ok(dt, o, ldo);
-    if (dt == SEGF_BF16 && vec && !getenv("SEGFAC_ATTN_NO_MFMA"))
+    if (dt == SEGF_BF16 && vec && !POL(attn_no_mfma))
         return attn_mfma_fwd(hd, B, heads, N, Nkv, q, ldq, k, ldk, v, ldv, scale, o, ldo, lse, st);
     const int qpb = AT_THREADS / (hd / 32);
     dim3 grid((N + qpb - 1) / qpb, heads, B);
@@ -334,7 +334,7 @@ extern "C" int segf_attention_bwd(int dt, int B, int heads, int N, int Nkv, int 
     const int C = heads * hd;
     const int64_t rows = (int64_t)B * Nkv;
     const int rblocks = (int)imin64(cdiv64(rows * 2 * C, 256), 2048);
-    if (dt == SEGF_BF16 && vec && attn_vec_ok(dt, dk, lddk) && attn_vec_ok(dt, dv, lddv) && !getenv("SEGFAC_ATTN_NO_MFMA")) {
+    if (dt == SEGF_BF16 && vec && attn_vec_ok(dt, dk, lddk) && attn_vec_ok(dt, dv, lddv) && !POL(attn_no_mfma)) {
         // the slab rows are written with 16-byte stores: 2*C*4 bytes per row is always a multiple of 16
         const int rc = attn_mfma_bwd(hd, B, heads, N, Nkv, q, ldq, k, ldk, v, ldv, scale, o, ldo, d_o, lddo, lse, dq, lddq, Dbuf,
                                      slab, nchunk, qchunk, st);

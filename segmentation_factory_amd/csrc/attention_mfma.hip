@@ -561,12 +561,7 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
     }
 }
 
-// A/B switch (SEGFAC_ATTN_VARIANT) for the head-dim-64 kernels: bit 0 = compile for three waves per SIMD instead of four (query-side
-// kernels), bit 1 = dense (unswizzled) LDS tiles
-static int am_variant() {           // unset / negative: the shipped choice (pipelined LDS-DMA kernels where they apply)
-    const char* e = getenv("SEGFAC_ATTN_VARIANT");
-    return e ? (atoi(e) < 0 ? -1 : (atoi(e) & 3)) : -1;
-}
+// (r04's A/B variants of the head-dim-64 kernels -- three waves per SIMD, dense LDS tiles -- lost and are no longer instantiated)
 static bool am_is_pow2(float s) {
     int e;
     return s > 0.f && frexpf(s, &e) == 0.5f && e > -60 && e < 60;
@@ -578,17 +573,13 @@ int attn_mfma_fwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
     dim3 grid((unsigned)cdiv64(N, 4 * 16 * QW), heads, B);      // (one query tile per wave measured 2 % slower at head dim 64)
 #define AM_FWD(HDv, P2, OCCv, SWv) hipLaunchKernelGGL((attn_mfma_fwd_kernel<HDv, QW, P2, OCCv, SWv>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, \
         (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale)
-    const int var = am_variant();
     if (hd == 32) AM_FWD(32, false, 4, false);
-    else if (var < 0 && Nkv >= 2 * AMP_KC) {
+    else if (Nkv >= 2 * AMP_KC) {
         hipLaunchKernelGGL((attn_fwd64p_kernel<QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
                            (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
     }
     else if (!am_is_pow2(scale)) AM_FWD(64, false, 4, true);
-    else if (var <= 0) AM_FWD(64, true, 4, true);
-    else if (var == 1) AM_FWD(64, true, 3, true);
-    else if (var == 2) AM_FWD(64, true, 4, false);
-    else AM_FWD(64, true, 3, false);
+    else AM_FWD(64, true, 4, true);
 #undef AM_FWD
     SEGF_CHECK_LAUNCH();
     return 0;
@@ -1112,7 +1103,7 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
     dim3 g2((unsigned)cdiv64(Nkv, hd == 32 ? 256 : 128), nchunk, B * heads);      // keys per workgroup = 4 waves x 16 KW
     const bf16_t* Q = (const bf16_t*)q; const bf16_t* K = (const bf16_t*)k; const bf16_t* V = (const bf16_t*)v;
     const bf16_t* O = (const bf16_t*)o; const bf16_t* DO = (const bf16_t*)d_o;
-    if (hd == 32 && Nkv <= 256 && !getenv("SEGFAC_ATTN_NO_FUSED_BWD")) {      // one workgroup owns all keys: dQ, dK, dV in one kernel
+    if (hd == 32 && Nkv <= 256 && !POL(attn_no_fused_bwd)) {      // one workgroup owns all keys: dQ, dK, dV in one kernel
         dim3 g3(1, nchunk, B * heads);
         hipLaunchKernelGGL((attn_mfma_bwd_fused_kernel<32, 4>), g3, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
                            (bf16_t*)dq, lddq, slab, heads, N, Nkv, B, qchunk, scale);
@@ -1126,8 +1117,7 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
         DO, lddo, lse, (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale)
 #define AM_DKV(P2, SWv, EXv) hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64, P2, SWv, EXv>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf, \
         slab, heads, N, Nkv, B, qchunk, scale)
-        const int var = am_variant();
-        if (var < 0 && Nkv >= 2 * AMP_KC) {
+        if (Nkv >= 2 * AMP_KC) {
             hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
                                (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
             // (a barrier-free form -- every wave staging its own copy of the Q / dO tile by LDS-DMA into a private double-buffered slab --
@@ -1135,10 +1125,7 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
             AM_DKV(false, true, true);
         }
         else if (!am_is_pow2(scale)) { AM_DQ(false, 4, true); AM_DKV(false, true, false); }
-        else {
-            if (var <= 0) AM_DQ(true, 4, true); else if (var == 1) AM_DQ(true, 3, true); else if (var == 2) AM_DQ(true, 4, false); else AM_DQ(true, 3, false);
-            if (var & 2) AM_DKV(true, false, false); else AM_DKV(true, true, false);
-        }
+        else { AM_DQ(true, 4, true); AM_DKV(true, true, false); }
 #undef AM_DQ
 #undef AM_DKV
     }

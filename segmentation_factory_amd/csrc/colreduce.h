@@ -241,7 +241,7 @@ colreduce_finalize_wide_kernel(const float* __restrict__ partial, int nblk, int6
     }
 }
 static inline void colreduce_finalize_launch(const float* partial, int nblk, int64_t n, float* out, hipStream_t st, int nbatch = 1) {
-    if (n >= 16384 && n % 4 == 0 && !((uintptr_t)partial & 15) && !((uintptr_t)out & 15) && !getenv("SEGFAC_NO_WIDE_FINALIZE")) {
+    if (n >= 16384 && n % 4 == 0 && !((uintptr_t)partial & 15) && !((uintptr_t)out & 15) && !POL(no_wide_finalize)) {
         hipLaunchKernelGGL(colreduce_finalize_wide_kernel, dim3((unsigned)cdiv64(n, 4 * CRF_OUT), nbatch), dim3(CRF_OUT * CRF_SL), 0, st,
                            partial, nblk, n, out);
         return;

@@ -6,10 +6,26 @@
 
 typedef uint16_t bf16_t;   // raw bfloat16 bits
 
+#include "policy.h"
+
+// Every kernel launch of the library goes through this form of hipLaunchKernelGGL: while a launch trace is open on the calling thread
+// (segf_trace_begin, include/segfac.h) the kernel's name is recorded as the launch site spells it (plus the template arguments of the
+// launching host function where the spelling uses them), and in a dry run the launch itself is skipped --
+// which is how tests/test_host_cpu.py::test_dispatch_of_baseline_shapes reads the dispatch decisions without a GPU.
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                               \
+    do {                                                                                                                \
+        SegfTrace& tr__ = segf_trace();                                                                                 \
+        if (tr__.on) segf_trace_note(#kernelName, __PRETTY_FUNCTION__);                                                 \
+        if (!tr__.dry) { kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__); }          \
+    } while (0)
+
 #define SEGF_CHECK_LAUNCH()                                   \
     do {                                                      \
-        hipError_t e__ = hipGetLastError();                   \
-        if (e__ != hipSuccess) return (int)e__;               \
+        if (!segf_trace().dry) {                              \
+            hipError_t e__ = hipGetLastError();               \
+            if (e__ != hipSuccess) return (int)e__;           \
+        }                                                     \
     } while (0)
 
 #define SEGF_DISPATCH_DT(dt, T, ...)                          \

@@ -258,10 +258,10 @@ static inline void dw_walk_plan(int H, int& R, int& nseg, int64_t columns = 0) {
     // have too few threads to fill the chip (columns = batch x 4-pixel strips x channel chunks; small batches)
     nseg = (H + 63) / 64;
     while (columns > 0 && columns * nseg < 131072 && (H + nseg - 1) / nseg > 8) nseg *= 2;
-    if (const char* e = getenv("SEGFAC_DW_WALK_ROWS")) { const int v = atoi(e); if (v > 0) nseg = (H + v - 1) / v; }
+    if (POL(dw_walk_rows) > 0) nseg = (H + POL(dw_walk_rows) - 1) / POL(dw_walk_rows);
     R = (H + nseg - 1) / nseg;
 }
-static inline bool dw_use_walk() { return !getenv("SEGFAC_DW_NO_WALK"); }
+static inline bool dw_use_walk() { return !POL(dw_no_walk); }
 template <typename T, int MODE>
 static inline void dw_walk_launch(hipStream_t st, const T* x, const float* w, const float* bias, int apply_gelu, const T* dy, T* y,
                                   int B, int H, int W, int C) {
@@ -679,7 +679,7 @@ __global__ void __launch_bounds__(256) dwconv3x3_bwd_small_kernel(const T* __res
 }
 // nch (8-channel chunks per workgroup) of the one-launch form, 0 when the map does not take it
 static inline int dw_small_nch(int dt, int B, int H, int W, int C) {
-    if (getenv("SEGFAC_DW_NO_SMALL") || C % 8 || B > 4096) return 0;
+    if (POL(dw_no_small) || C % 8 || B > 4096) return 0;
     const int HW = H * W, umax = dt == SEGF_BF16 ? 1024 : 512;
     if (HW > umax || HW < 16) return 0;
     for (int nch = 4; nch >= 1; nch >>= 1)
@@ -687,7 +687,7 @@ static inline int dw_small_nch(int dt, int B, int H, int W, int C) {
             // one round of workgroups at most: a workgroup walks its map serially (26 - 33 us whatever the batch), which beats the three
             // launches (39 - 42 us) only while the launch chain, not the arithmetic, is what the step waits for (measured: batch 4 +0.6 %,
             // batch 16 -0.7 %, batch 128 -1.8 % without this bound)
-            if ((int64_t)B * (C / (8 * nch)) > 512 && !getenv("SEGFAC_DW_SMALL_ALWAYS")) return 0;
+            if ((int64_t)B * (C / (8 * nch)) > 512 && !POL(dw_small_always)) return 0;
             return nch;
         }
     return 0;
@@ -1185,8 +1185,7 @@ extern "C" int segf_im2col(int dt, int in_nchw_f32, int B, int H, int W, int Cin
         const int64_t esz0 = dt == SEGF_BF16 ? 2 : 4;
         if (ldcol % 8 || ((uintptr_t)col % 16) || ((ldcol * esz0) % 16)) return SEGF_ERR_SHAPE;
         const int64_t lds_bytes = (int64_t)kh * Cin * (W + IM2COL_ROW_PAD) * esz0;
-        if (W % 4 == 0 && ((uintptr_t)x % 16) == 0 && lds_bytes <= 64 * 1024 && (int64_t)B * Ho <= 0x7fffffff &&
-            !getenv("SEGFAC_IM2COL_GATHER")) {
+        if (W % 4 == 0 && ((uintptr_t)x % 16) == 0 && lds_bytes <= 64 * 1024 && (int64_t)B * Ho <= 0x7fffffff) {
             SEGF_DISPATCH_DT(dt, T, {
                 hipLaunchKernelGGL((im2col_nchw_rows_kernel<T>), dim3((unsigned)(B * Ho)), dim3(256), (size_t)lds_bytes, st,
                                    (const float*)x, (T*)col, ldcol, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);
@@ -1307,7 +1306,7 @@ extern "C" int segf_col2im(int dt, int B, int H, int W, int Cin, int kh, int kw,
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)imin64(cdiv64((int64_t)B * H * W * (Cin / 8), 256), 8192);
     const int nc = (kh > kw ? kh : kw) <= stride ? 1 : ((kh > kw ? kh : kw) <= 2 * stride ? 2 : 0);
-    const bool small = (int64_t)B * H * W * (Cin / 8) < (1ll << 32) && !getenv("SEGFAC_COL2IM_GENERIC");
+    const bool small = (int64_t)B * H * W * (Cin / 8) < (1ll << 32);
     SEGF_DISPATCH_DT(dt, T, {
         if (nc == 1 && small)
             hipLaunchKernelGGL((col2im_nc_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, (const T*)dcol, ldcol, (T*)dx, B, H, W, Cin, kh, kw, stride, pad, Ho, Wo);

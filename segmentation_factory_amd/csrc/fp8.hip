@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) gemm_fp8_kernel(Fp8Args a) {
 }
 
 extern "C" int segf_gemm_fp8_supported(int64_t M, int64_t N, int64_t K) {
-    return (M > 0 && N > 0 && K >= F8_BK && K % F8_BK == 0 && !getenv("SEGFAC_NO_FP8")) ? 1 : 0;
+    return (M > 0 && N > 0 && K >= F8_BK && K % F8_BK == 0 && !POL(no_fp8)) ? 1 : 0;
 }
 extern "C" int segf_gemm_fp8(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const float* scale_a, const void* B,
                              int64_t ldb, const float* scale_b, const float* bias, const void* residual, int64_t ldr,

@@ -273,7 +273,7 @@ static int fuse_map_streams(int B, int H, int W, int C) {
 
 extern "C" int segf_fuse_map_248_supported(int dt, int B, int H, int W, int C, int C1) {
     return dt == SEGF_BF16 && B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0 && C % FM_SLICE == 0 && (C1 == 32 || C1 == 64) &&
-           (int64_t)B * (H / 8) * (W / 8) < (1ll << 31) && !getenv("SEGFAC_NO_FUSE_MAP");
+           (int64_t)B * (H / 8) * (W / 8) < (1ll << 31) && !POL(no_fuse_map);
 }
 extern "C" int64_t segf_fuse_map_248_ws(int B, int H, int W, int C) {
     return (int64_t)fuse_map_streams(B, H, W, C) * 2 * C;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(256, 2) fuse_map_bwd_kernel(FuseMapBwdArgs a) 
 
 int fuse_map_bwd_supported(int dt, int B, int H, int W, int C) {
     return dt == SEGF_BF16 && B > 0 && H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8 && C % FM_SLICE == 0 &&
-           (int64_t)H * W < (1ll << 30) && !getenv("SEGFAC_NO_BWD248_MFMA");
+           (int64_t)H * W < (1ll << 30) && !POL(no_bwd248_mfma);
 }
 int fuse_map_bwd_launch(int B, int H, int W, int C, const void* dy, int64_t ldo, void* d2, void* d4, void* d8, hipStream_t st) {
     FuseMapBwdArgs a{(const bf16_t*)dy, ldo, (bf16_t*)d2, (bf16_t*)d4, (bf16_t*)d8, B, H, W, C, C / FM_SLICE};

@@ -1017,7 +1017,7 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
 // one decision for both the launcher and the split-K / workspace sizing: the 256^2 tile when both dimensions exceed one
 // 128 tile, K spans more than one step, and the launch still has enough workgroups for 256 CUs
 static inline bool gemm_use_big(int layout, int64_t M, int64_t N, int64_t K) {
-    if (getenv("SEGFAC_GEMM_NO_BIG")) return false;
+    if (POL(gemm_no_big)) return false;
     if (M <= 128 || N <= 128 || K <= GB_BK) return false;
     const int64_t tiles = cdiv64(M, GG_B) * cdiv64(N, GG_B);
     if (layout == 2) return K >= 65536;                       // token-count K: split-K supplies the parallelism (at K = 16384 the
@@ -1243,12 +1243,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_group_kernel(const ReduceGr
     else splitk_reduce_body<float>(bid, r.ws[i], r.split[i], r.M[i], r.N[i], r.C[i], r.ldc[i], r.main_blocks[i], r.cs_ws[i], r.cs_out[i], r.cs_n[i]);
 }
 static inline bool splitk_reduce_is_wide(const float* ws, int64_t M, int64_t N, const void* C, int64_t ldc) {
-    return M * N >= 65536 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !getenv("SEGFAC_NO_WIDE_REDUCE");
+    return M * N >= 65536 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !POL(no_wide_reduce);
 }
 // form of an fp32 reduce: 1 = wide (slices in order), 2 = 16 x 16 with four outputs per thread, 0 = 16 x 16; and its block counts
 static inline int splitk_reduce_form(const float* ws, int64_t M, int64_t N, const void* C, int64_t ldc) {
     if (splitk_reduce_is_wide(ws, M, N, C, ldc)) return 1;
-    if (M * N >= 4096 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !getenv("SEGFAC_NO_REDUCE4")) return 2;
+    if (M * N >= 4096 && N % 4 == 0 && ldc % 4 == 0 && !((uintptr_t)ws & 15) && !((uintptr_t)C & 15) && !POL(no_reduce4)) return 2;
     return 0;
 }
 static inline unsigned splitk_reduce_main_blocks(int form, int64_t total) { return (unsigned)cdiv64(total, form == 1 ? 1024 : (form == 2 ? 64 : 16)); }
@@ -1681,7 +1681,7 @@ __global__ void __launch_bounds__(256, 2) gemm_skinny_k_kernel(GemmArgs a) {
     }
 }
 static bool gemm_skinny_k_ok(int layout, int64_t M, int64_t N, int64_t K) {
-    if (getenv("SEGFAC_GEMM_NO_SKINNY_K")) return false;
+    if (POL(gemm_no_skinny_k)) return false;
     if (N == 64 && K > 768) return false;       // 64 outputs: the weight fragments of K / 4 > 192 columns pass the register file
     return (layout == 0 || layout == 1) && (N == 32 || N == 64) && M >= 65536 && K % 128 == 0 && K >= 256 && K <= 1024;
 }
@@ -1848,7 +1848,7 @@ __global__ void __launch_bounds__(256) gemm_dw_skinny_kernel(GemmArgs a, int sli
 // Shapes the streaming weight-gradient kernel takes and its blocking; slices = waves along K
 struct DwSkinny { int mt, nt, rowblocks, colblocks, slices; };
 static bool gemm_dw_skinny_plan(int64_t M, int64_t N, int64_t K, bool colsum, DwSkinny& p) {
-    if (getenv("SEGFAC_GEMM_NO_DW_SKINNY")) return false;
+    if (POL(gemm_no_dw_skinny)) return false;
     if (K < 65536 || M > 256 || N > 288) return false;
     (void)colsum;                                 // the bias gradient costs no output column (all-ones B fragment)
     if (K % 32) return false;                     // whole 32-token groups only (no masking in the kernel)
@@ -1868,7 +1868,6 @@ static bool gemm_dw_skinny_plan(int64_t M, int64_t N, int64_t K, bool colsum, Dw
                                                                        // the tiled kernel ([64 x 256]: 108 vs 94 us, [256 x 64]: 89 vs 93)
     int64_t sl = K / 512;                                                // >= 16 groups of 32 tokens per wave
     int64_t capw = 2048;
-    if (const char* e = getenv("SEGFAC_DW_SKINNY_SLICES")) { const int v = atoi(e); if (v > 0) { capw = v; sl = K / 128; } }
     const int64_t cap = capw / ((int64_t)p.rowblocks * p.colblocks);
     if (sl > cap) sl = cap;
     if (sl < 4) return false;
@@ -1899,8 +1898,8 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     // one wave of workgroups: 256 CUs x (1 big-tile | 2 small-tile) resident workgroups.  Rounded DOWN: 3 tiles x 86 slices =
     // 258 workgroups would run as two rounds (256 + 2) and take twice as long as 3 x 85
     const int64_t res = big ? 256 : 512;                          // resident workgroups
-    int64_t s = getenv("SEGFAC_SPLITK_CEIL") ? cdiv64(res, tiles) : res / tiles;
-    if (tiles > res && !getenv("SEGFAC_SPLITK_NO_TAIL")) {
+    int64_t s = res / tiles;
+    if (tiles > res) {
         // more tiles than one round of workgroups (UPerHead's 3072 -> 768 3x3 conv: 3 x 108 = 324 tiles of 256^2 run as 256 + 68,
         // 63 % of the machine on average: 565 vs 787 TFLOP/s measured against the forward of the same shape): the smallest slice
         // count whose last round is >= 93 % full (324 x 3 = 972 workgroups = 3.8 rounds; the extra reduce pass is ~0.1 ms of 39)
@@ -1953,11 +1952,11 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
     DwSkinny sk;
     const bool skinny = dt == SEGF_BF16 && c_dt == SEGF_F32 && gemm_dw_skinny_plan(M, N, K, true, sk) && sk.slices == split_k &&
                         (uintptr_t)A % 16 == 0 && (lda * 2) % 16 == 0 && (uintptr_t)B % 16 == 0 && (ldb * 2) % 16 == 0 &&
-                        !(getenv("SEGFAC_GEMM_NO_TR") && getenv("SEGFAC_GEMM_NO_TR")[0] == '1');
+                        !POL(gemm_no_tr);
     // fused in the streaming kernel (all-ones fragment), in the 128-tile kernel (all-ones column when N leaves one free, extra
     // MFMAs when it does not); the 256-tile kernel has no registers to spare for it
     const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (skinny || !gemm_use_big(2, M, N, K)) &&
-                       !getenv("SEGFAC_GEMM_NO_FUSED_DB");
+                       !POL(gemm_no_fused_db);
     if (!fused) {       // big-tile / fp32 kernels: separate column reduction (still one C-ABI call)
         const int rc = gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, nullptr, stream);
         if (rc) return rc;
@@ -1970,19 +1969,17 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
 // column (what segf_gemm_dw_db launches for them) are gathered into grouped launches of up to GDW_MAX members -- one product launch and
 // one reduce launch per group instead of two launches per layer; every other item is executed by segf_gemm_dw_db itself.  Each item's
 // result is bitwise what segf_gemm_dw_db computes for it.
-// largest output (elements) of a member that alone would take the 256-tile kernel and still joins a group (A/B: SEGFAC_DW_GROUP_BIG_MAX)
-static inline int64_t dw_group_big_max() {
-    if (const char* e = getenv("SEGFAC_DW_GROUP_BIG_MAX")) return atoll(e);
-    return 1024 * 1024;
-}
+// largest output (elements) of a member that alone would take the 256-tile kernel and still joins a group (measured flat between 256 K
+// and 4 M elements)
+static inline int64_t dw_group_big_max() { return 1024 * 1024; }
 extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, void* stream) {
     if (n <= 0) return 0;
     if (!items) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     GemmDwGroup g; ReduceGroup r;
     int pend[GDW_MAX], npend = 0;                 // indices of the groupable items of the open group
-    const bool no_group = getenv("SEGFAC_NO_GROUPED_DW") != nullptr;
-    const bool no_shared = getenv("SEGFAC_DW_NO_SHARED_SPLIT") != nullptr;
+    const bool no_group = POL(no_grouped_dw) != 0;
+    const bool no_shared = POL(dw_no_shared_split) != 0;
     auto flush = [&]() -> int {
         if (npend == 0) return 0;
         // Slice counts.  Each item arrives with the count segf_gemm_pick_splitk gives a product that runs ALONE (enough slices to fill the
@@ -2081,9 +2078,8 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         const int64_t kchunk = cdiv64(cdiv64(K, split_k), GB_BK) * GB_BK;
         const int slices = (int)cdiv64(K > 0 ? K : 1, kchunk > 0 ? kchunk : GB_BK);
         const bool groupable = !no_group && dt == SEGF_BF16 && M > 0 && N > 0 && K > 0 && it.dw && it.db && it.ws && !skinny && aligned &&
-                               (!gemm_use_big(2, M, N, K) || (!getenv("SEGFAC_DW_GROUP_NO_BIG") && it.shared_split && M * N <= dw_group_big_max())) && !getenv("SEGFAC_GEMM_NO_FUSED_DB") && !getenv("SEGFAC_GEMM_NO_FASTLOAD") &&
-                               !getenv("SEGFAC_GEMM_NO_TR") && !getenv("SEGFAC_GEMM_NO_DEEP128") && !getenv("SEGFAC_GEMM_NO_DEEP128_L2") &&
-                               !getenv("SEGFAC_GEMM_FASTLOAD_L2") && M % 8 == 0 && N % 8 == 0 && slices > 1 && cdiv64(M, GB_BM) <= 65535;
+                               (!gemm_use_big(2, M, N, K) || (it.shared_split && M * N <= dw_group_big_max())) && !POL(gemm_no_fused_db) && !POL(gemm_no_fastload) &&
+                               !POL(gemm_no_tr) && !POL(gemm_no_deep128) && M % 8 == 0 && N % 8 == 0 && slices > 1 && cdiv64(M, GB_BM) <= 65535;
         // (a member that alone would take the 256-tile kernel + a separate column-sum pass -- the stage-3 / 4 layers at batch 128 -- joins the
         // group too when it lets the library choose its split: one pass over dy for both gradients; batch 128 +0.5 %)
         if (!groupable) {                        // (the items are independent of each other: no need to close the open group)
@@ -2111,8 +2107,7 @@ extern "C" int segf_gemm_pro_supported(int dt, int layout, int64_t M, int64_t N,
     // 19-class heads of the Cityscapes configurations run its narrow wave shapes with some waves idle, which a product that
     // streams a [tokens x 768] operand does not notice)
     if ((layout == 0 ? M : K) < 4096 || K % GB_BK || (layout == 2 && K < 32768)) return 0;
-    { const char* e = getenv("SEGFAC_GEMM_NO_TR"); if (e && e[0] == '1') return 0; }
-    if (getenv("SEGFAC_GEMM_NO_PRO")) return 0;
+    if (POL(gemm_no_tr) || POL(gemm_no_pro)) return 0;
     if (layout == 0) return (rows_per_group % GG_B == 0 && K % 8 == 0) ? 1 : 0;
     return (rows_per_group % GB_BK == 0 && N % 8 == 0) ? 1 : 0;
 }
@@ -2152,10 +2147,10 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     const size_t esz = dt == SEGF_BF16 ? 2 : 4, csz = c_dt == SEGF_BF16 ? 2 : 4;
     a.a_vec = ((uintptr_t)A % 16 == 0) && ((lda * esz) % 16 == 0);
     a.b_vec = ((uintptr_t)B % 16 == 0) && ((ldb * esz) % 16 == 0);
-    a.fast = getenv("SEGFAC_GEMM_NO_FASTLOAD") ? 0 : 1;
+    a.fast = POL(gemm_no_fastload) ? 0 : 1;
     // bit 0: vector loads allowed, bit 1: guard-free full-K-step loads.  Layouts 0 / 1 gain 25-45 % from the latter; the split-K
     // weight-gradient launches (layout 2) measured 8-15 % SLOWER with every load in flight, so they keep the guarded loads
-    if (a.fast && (layout != 2 || getenv("SEGFAC_GEMM_FASTLOAD_L2"))) { a.a_vec *= 3; a.b_vec *= 3; }
+    if (a.fast && layout != 2) { a.a_vec *= 3; a.b_vec *= 3; }
     a.c_vec = ((uintptr_t)C % (4 * csz) == 0) && ((ldc * csz) % (4 * csz) == 0);
     a.r_vec = residual ? (((uintptr_t)residual % 16 == 0) && ((ldr * esz) % 16 == 0)) : 0;
     a.c_vec16 = ((uintptr_t)C % 16 == 0) && ((ldc * csz) % 16 == 0);
@@ -2165,14 +2160,11 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     a.pro_scale = pro ? pro->scale : nullptr; a.pro_shift = pro ? pro->shift : nullptr;
     a.pro_rpg = pro ? pro->rpg : 1; a.pro_ld = pro ? pro->ld : 0; a.pro_act = pro ? pro->act : 0;
     a.f8_sa = nullptr; a.f8_sb = nullptr;
-    {   // debugging switch: SEGFAC_GEMM_NO_TR=1 reads transposed fragments with scalar LDS loads instead of ds_read_b64_tr_b16
-        const char* e = getenv("SEGFAC_GEMM_NO_TR");
-        a.use_tr = (e && e[0] == '1') ? 0 : 1;
-    }
+    a.use_tr = POL(gemm_no_tr) ? 0 : 1;      // debugging switch: transposed fragments by scalar LDS loads instead of ds_read_b64_tr_b16
     if (dt == SEGF_BF16) {
         if (!pro && c_dt == SEGF_BF16 && split_k == 1 && a.a_vec && a.c_vec16 && (!residual || a.r_vec) &&
-            (layout == 1 || a.b_vec) && !getenv("SEGFAC_GEMM_NO_SKINNY")) {
-            if (layout == 0 && !residual && K == 32 && N == 768 && M >= 65536 && a.b_vec && !getenv("SEGFAC_GEMM_NO_SKINNY_ROWS")) {
+            (layout == 1 || a.b_vec) && !POL(gemm_no_skinny)) {
+            if (layout == 0 && !residual && K == 32 && N == 768 && M >= 65536 && a.b_vec && !POL(gemm_no_skinny_rows)) {
                 const int64_t groups = cdiv64(M, 16);
                 int64_t gx = cdiv64(groups, 4 * 8);
                 if (gx > 1024) gx = 1024;
@@ -2216,7 +2208,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
         // (tests), but on the nn.Linear shapes of the BASELINE models (K = 6 .. 48 tiles of 64) its 12-load prologue, the drain
         // at the end and the direct 8-byte stores of its epilogue eat what the schedule gains: cfg3 247 -> 242, cfg4 114.2 -> 113.5,
         // cfg5 76.5 -> 76.1 img/s with it; the convolutions (K = 108 .. 648 tiles) are where it pays
-        if (!pro && a.use_tr && !colsum && (a.a_vec & 1) && (a.b_vec & 1) && gemm_use_big(layout, M, N, K) && getenv("SEGFAC_GEMM8_LINEAR")) {
+        if (!pro && a.use_tr && !colsum && (a.a_vec & 1) && (a.b_vec & 1) && gemm_use_big(layout, M, N, K) && POL(gemm8_linear)) {
             const bool f32o8 = c_dt == SEGF_F32 || a.ws;
             if (layout != 2 && !f32o8 && split_k == 1 && gemm8_supported(layout, 0, M, N, K, a.kchunk, 0) && (!residual || a.r_vec)) {
                 const int rc8 = gemm8_launch(layout, 0, 0, M, N, K, a.kchunk, 1, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, nullptr, nullptr, bias, residual,
@@ -2234,7 +2226,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
         // exposes every load -> LDS -> MFMA round trip; two workgroups per CU with two K steps in flight: cfg2 +0.4 %, batch 16
         // +0.7 %, cfg4 +0.2 % (same box).  The narrow shapes (N <= 160) keep their one-tile kernel; the implicit-GEMM convolutions
         // (other entry points) are not concerned.
-        static const int smallk = getenv("SEGFAC_GEMM_SMALLK_128") ? atoi(getenv("SEGFAC_GEMM_SMALLK_128")) : 704;
+        const int smallk = 704;
         const bool short_k = layout != 2 && K <= smallk && N > 160 && !pro;
         if (((gemm_use_big(layout, M, N, K) && !short_k) || pro) && a.use_tr) {
             dim3 gridb((unsigned)cdiv64(N, GG_B), (unsigned)cdiv64(M, GG_B), (unsigned)split_k);
@@ -2246,11 +2238,11 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
         else hipLaunchKernelGGL((gemm_bf16_big_kernel<L, bf16_t, false>), gridb, dim3(GG_THREADS), 0, st, a);      \
     } while (0)
             // partly filled workgroup tiles: the narrow wave shapes (see the kernel's header)
-            const bool narrow_n = layout == 0 && !f32o && N <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
-            const bool narrow_n1 = layout == 1 && !f32o && !a.pro_scale && N <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
-            const bool narrow_m = layout == 2 && f32o && M <= 160 && !getenv("SEGFAC_GEMM_NO_NARROW");
+            const bool narrow_n = layout == 0 && !f32o && N <= 160 && !POL(gemm_no_narrow);
+            const bool narrow_n1 = layout == 1 && !f32o && !a.pro_scale && N <= 160 && !POL(gemm_no_narrow);
+            const bool narrow_m = layout == 2 && f32o && M <= 160 && !POL(gemm_no_narrow);
             const bool deep = layout == 0 && split_k == 1 && (a.a_vec & 2) && (a.b_vec & 2) && K % GB_BK == 0 && K >= 2 * GB_BK &&
-                              (!a.pro_scale || a.pro_ld <= 1024) && !getenv("SEGFAC_GEMM_NO_DEEP");
+                              (!a.pro_scale || a.pro_ld <= 1024) && !POL(gemm_no_deep);
             if (a.pro_scale) {
                 if (layout == 0 && !f32o) {
                     if (narrow_n && deep) hipLaunchKernelGGL((gemm_bf16_big_kernel<0, bf16_t, false, true, 1, true>), gridb, dim3(GG_THREADS), 0, st, a);
@@ -2278,8 +2270,8 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
         // (same box, on / off): batch 4 836 / 814 img/s, 16: 2249 / 2211, 32: 3054 / 3014, 128: neutral; cfg5 86.0 / 84.2; the
         // split-K weight gradients (layout 2) add +1 % at batch 4 and are neutral elsewhere
         const bool vec_ab = a.a_vec && a.b_vec;
-        const bool deep128 = !one_step && a.use_tr && a.fast && vec_ab && !getenv("SEGFAC_GEMM_NO_DEEP128") &&
-                             (layout == 2 ? (M % 8 == 0 && N % 8 == 0 && !getenv("SEGFAC_GEMM_NO_DEEP128_L2"))
+        const bool deep128 = !one_step && a.use_tr && a.fast && vec_ab && !POL(gemm_no_deep128) &&
+                             (layout == 2 ? (M % 8 == 0 && N % 8 == 0)
                                           : (K % 8 == 0 && (layout == 0 || N % 8 == 0) && split_k == 1));
 #define LAUNCH_B(L, OT)                                                                                      \
     do {                                                                                                     \
@@ -2325,14 +2317,14 @@ reduce:
 // gemm_use_big's token-count rule (made for the small outputs of nn.Linear) sends it to -- [8 x 80 x 80, 768 -> 768]: 381 -> 577 TFLOP/s.
 static inline bool conv3x3_wgrad_big(int64_t M, int64_t N, int64_t K) {
     if (gemm_use_big(2, M, N, K)) return true;
-    return !getenv("SEGFAC_GEMM_NO_BIG") && !getenv("SEGFAC_CONV_WGRAD_OLD_RULE") && M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 48 && K >= 4096;
+    return !POL(gemm_no_big) && M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 48 && K >= 4096;
 }
 // Forward / data gradient of a 3x3 convolution whose output has too few 256 x 256 tiles to fill the chip but a long reduction (UPerHead's PPM
 // bottleneck 3840 -> 768 on a 16 x 16 map, ppm.py:19: 96 tiles at batch 32; the 40 x 40 / 20 x 20 levels of cfg5): split the (channel block,
 // tap) walk over 2 - 8 slices of the eight-phase tile, fp32 partials, one reduce pass to bf16.  0 / 1 = no split (the caller passes ws
 // of split * P * Cout floats otherwise; no bias in this form).
 extern "C" int segf_conv3x3_fwd_splitk(int mode, int B, int H, int W, int Cin, int Cout) {
-    if (mode < 0 || mode > 1 || getenv("SEGFAC_CONV_NO_FWD_SPLIT") || getenv("SEGFAC_NO_GEMM8")) return 1;
+    if (mode < 0 || mode > 1 || POL(conv_no_fwd_split) || POL(no_gemm8)) return 1;
     const int64_t M = (int64_t)B * H * W, N = mode == 0 ? Cout : Cin, Kc = mode == 0 ? Cin : Cout, K = 9 * Kc;
     if (N % 256 || Kc % 64 || M <= 0) return 1;                  // (any pixel count: the last row tile may be ragged)
     const int64_t tiles = cdiv64(M, 256) * (N / 256);
@@ -2455,7 +2447,7 @@ reduce3:
 // Same kernel, loaders and LDS images as the bf16 path (gemm_bf16_big_kernel<0, bf16, CONV, .., FP8>): the operands are addressed in
 // 2-byte units, a K step of 64 units = 128 fp8 values.  Channel counts must be multiples of 16, rows 16-byte aligned.  Output bf16.
 extern "C" int segf_conv3x3_fp8_supported(int mode, int B, int H, int W, int Cin, int Cout) {
-    if (getenv("SEGFAC_NO_FP8_CONV") || mode < 0 || mode > 1 || B <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % 16) return 0;
+    if (POL(no_fp8_conv) || mode < 0 || mode > 1 || B <= 0 || H <= 0 || W <= 0 || Cin % 16 || Cout % 16) return 0;
     const int64_t P = (int64_t)B * H * W, N = mode == 0 ? Cout : Cin, K = 9 * (int64_t)(mode == 0 ? Cin : Cout) / 2;
     return gemm_use_big(0, P, N, K) ? 1 : 0;
 }
@@ -2493,7 +2485,7 @@ extern "C" int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout
 // forward and the data gradient already quantised; one byte per element, row strides in bytes).  fp32 out [Cout][9*Cin]; split over K
 // (pixels) into fp32 slabs: ws >= split_k * Cout * 9 * Cin floats when split_k > 1 (segf_gemm_pick_splitk(Cout, 9 * Cin, B*H*W)).
 extern "C" int segf_conv3x3_fp8_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
-    if (getenv("SEGFAC_NO_FP8_CONV") || getenv("SEGFAC_NO_FP8_WGRAD") || B <= 0 || H <= 0 || W <= 0) return 0;
+    if (POL(no_fp8_conv) || POL(no_fp8_wgrad) || B <= 0 || H <= 0 || W <= 0) return 0;
     const int64_t P = (int64_t)B * H * W, M = Cout, N = 9 * (int64_t)Cin;
     if (!gemm_use_big(2, M, N, P)) return 0;
     return gemm8_supported(3, 1, M, N, P, 512, Cin);
@@ -2527,7 +2519,7 @@ extern "C" int segf_conv3x3_fp8_wgrad(int B, int H, int W, int Cin, int Cout, co
 //           already hold), fp32 out, split over the tokens: ws >= split_k * N * K floats (segf_gemm_pick_splitk(N, K, T))
 // Row strides in bytes (= elements).  Not a reference feature -- an option of this build (SegmentationModel.set_fp8).
 extern "C" int segf_linear_fp8_supported(int mode, int64_t M, int64_t N, int64_t K) {
-    if (getenv("SEGFAC_NO_FP8_LINEAR") || M <= 0 || N <= 0 || K <= 0) return 0;
+    if (POL(no_fp8_linear) || M <= 0 || N <= 0 || K <= 0) return 0;
     if (mode == 2) {                     // M = tokens (the reduction), N x K = the weight
         if (N % 256 || K % 256 || (N / 256) * (K / 256) * (M / 1024) < 128) return 0;       // enough 256 x 256 x >= 1024-token pieces
         return gemm8_supported(3, 0, N, K, M, 512, 0);

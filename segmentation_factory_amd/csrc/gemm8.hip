@@ -458,19 +458,12 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 // kind 1: C[m][n] = sum_k A[m][k] B[k][n]   (layout 1: data gradient of nn.Linear)                           bf16 out
 // kind 2: C[m][n] = sum_k A[k][m] B[k][n]   (layout 2; conv = weight-gradient gather on B), split-K          fp32 out
 // kind 3: the same on fp8 operands (A e5m2, B e4m3, one byte per element, K tiles of 128 rows), scaled by f8_sa[0] * f8_sb[0]
-static int g8_stagger_fp8 = 1;
-extern "C" int segf_gemm8_option(int what, int value) {      // what 0: stagger of the fp8 kernels (returns the previous value)
-    if (what != 0) return SEGF_ERR_SHAPE;
-    const int prev = g8_stagger_fp8;
-    if (value == 0 || value == 1) g8_stagger_fp8 = value;
-    return prev;
-}
 int gemm8_supported(int kind, int conv, int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC) {
-    if (getenv("SEGFAC_NO_GEMM8")) return 0;
+    if (POL(no_gemm8)) return 0;
     if (M % 256 || N % 256 || K % 64 || kchunk % 64 || kchunk < 256 || M / 256 > 65535) return 0;
-    if (kind == 3) return (K % 128 || kchunk % 128 || kchunk < 512 || (conv && cC % 128) || getenv("SEGFAC_NO_GEMM8T")) ? 0 : 1;     // fp8 weight gradient
+    if (kind == 3) return (K % 128 || kchunk % 128 || kchunk < 512 || (conv && cC % 128) || POL(no_gemm8t)) ? 0 : 1;     // fp8 weight gradient
     if (conv && (cC % (kind == 2 ? 128 : 64))) return 0;
-    if (kind == 2) return getenv("SEGFAC_NO_GEMM8T") ? 0 : 1;
+    if (kind == 2) return POL(no_gemm8t) ? 0 : 1;
     return (M / 256) * (N / 256) >= 192;
 }
 int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, int64_t kchunk, int split_k, const void* A, int64_t lda,
@@ -487,10 +480,8 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     // fp8 operands: on some MI355X devices the staggered schedule (26 % fewer cycles) makes the chip drop its clock from 2.4 to 1.5 GHz
     // and ends up SLOWER than the lockstep one (12.7 vs 10.9 ms on the UPerHead bottleneck; 8.3 ms on devices that hold their clock).
     // g8_stagger_fp8 is set per process by the host layer after timing both on the device at hand (hip.py: autotune_gemm8_fp8).
-    if (fp8) a.stagger = g8_stagger_fp8;
-    if (const char* e = getenv("SEGFAC_G8_STAGGER")) a.stagger = atoi(e);
-    if (const char* e = getenv("SEGFAC_G8_KORDER")) a.korder = atoi(e);
-    if (const char* e = getenv("SEGFAC_G8_TILE_ORDER")) a.tile_order = atoi(e);
+    if (fp8) a.stagger = POL(g8_stagger_fp8);        // (segf_gemm8_option, policy.hip)
+    if (POL(g8_stagger) >= 0) a.stagger = POL(g8_stagger);
     if (conv && kind < 2 && cC > 0) { a.kper = (unsigned)(cC / 64); a.kmagic = (unsigned)(0x100000000ull / a.kper) + 1u; }
     const dim3 grid((unsigned)(N / 256), (unsigned)((M + 255) / 256), (unsigned)split_k);      // (a ragged last row tile: the gathered forward only)
 #define G8_GO(...) hipLaunchKernelGGL((gemm8_kernel<__VA_ARGS__>), grid, dim3(512), 0, st, a)

@@ -394,15 +394,14 @@ __global__ void hf_split_kernel(const float* __restrict__ sums, int C, float* __
 static int hf_chunks(int B, int groups_per_sample, int ny, bool cw = false) {
     // ~3000 workgroups in flight, at least 8 token groups per workgroup; with the classifier's weight gradient riding on pass 1
     // every workgroup leaves a [32 KS][256] fp32 partial: three rounds of workgroups (768) keep those at ~0.1 GB
-    const char* e = getenv("SEGFAC_HF_WGS");
-    const int budget = e ? atoi(e) : (cw ? 768 : 3072);
+    const int budget = cw ? 768 : 3072;
     int s = (budget / ny + B - 1) / B;
     if (s > groups_per_sample / 8) s = groups_per_sample / 8;
     return s < 1 ? 1 : s;
 }
 
 extern "C" int segf_bn_cls_bwd_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample) {
-    if (dt != SEGF_BF16 || getenv("SEGFAC_NO_HEAD_FUSED")) return 0;
+    if (dt != SEGF_BF16 || POL(no_head_fused)) return 0;
     if (K % 32 || K < 32 || K > 192 || C % (32 * HF_WAVES) || rows_per_sample <= 0 || rows_per_sample % 16 || M % rows_per_sample) return 0;
     if (M / rows_per_sample > 65535 || M < 16384) return 0;
     return 1;
@@ -424,7 +423,7 @@ extern "C" int64_t segf_bn_cls_bwd_full_ws(int64_t M, int C, int K, int64_t rows
 }
 
 extern "C" int segf_bn_cls_bwd_dw_supported(int dt, int64_t M, int C, int K, int64_t rows_per_sample, int C1) {
-    if (getenv("SEGFAC_NO_HEAD_FUSED_DW")) return 0;
+    if (POL(no_head_fused_dw)) return 0;
     return segf_bn_cls_bwd_supported(dt, M, C, K, rows_per_sample) && C1 == DW_C1 && K <= 160;     // K = 192: the tiles pass 160 KB of LDS
 }
 extern "C" int64_t segf_bn_cls_bwd_dw_ws(int64_t M, int C, int64_t rows_per_sample) {

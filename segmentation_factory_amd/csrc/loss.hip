@@ -1154,7 +1154,7 @@ __global__ void zero_ints_kernel(int* p, int n) {
 
 #define LS_NT_DISPATCH(C, CALL) do { const int nt_ = ((C) + 15) / 16;                                                             \
         if (nt_ <= 2) { CALL(2); } else if (nt_ <= 4) { CALL(4); } else if (nt_ <= 10) { CALL(10); } else { CALL(12); } } while (0)
-static bool loss_use_mfma(int sc) { return sc == 4 && !getenv("SEGFAC_LOSS_NO_MFMA"); }
+static bool loss_use_mfma(int sc) { return sc == 4 && !POL(loss_no_mfma); }
 
 template <typename T>
 static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
@@ -1179,7 +1179,7 @@ static void fwd_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logit
                                                  g, target, ignore_index, cw, partial, retry);                                  \
             else hipLaunchKernelGGL((ce_dice_fwd_cells16_kernel<T, NS, 8>), grid, dim3(LS_THREADS), 0, st, logits, g, target,    \
                                     ignore_index, cw, partial, retry);                                                          \
-            if (!getenv("SEGFAC_LOSS_NO_RETRY"))                                                                                \
+            if (!POL(loss_no_retry))                                                                                \
             hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc, target,         \
                                ignore_index, cw, partial, (const int*)retry);                                                   \
         } else if (sc) hipLaunchKernelGGL((ce_dice_fwd_cells_kernel<T, NS>), grid, dim3(LS_THREADS), 0, st, logits, g, sc,       \
@@ -1235,7 +1235,7 @@ static void bwd_generic_launch(int ns, dim3 grid, hipStream_t st, const T* logit
 
 // floats of the per-pixel log-sum buffer the forward can leave for the backward (0: this configuration does not produce one)
 extern "C" int64_t segf_ce_dice_lse_floats(int dt, int B, int C, int h, int w, int H, int W, const void* logits, int64_t ldl) {
-    if (dt != SEGF_BF16 || B <= 0 || C <= 0 || h <= 0 || w <= 0 || getenv("SEGFAC_LOSS_NO_LSE")) return 0;
+    if (dt != SEGF_BF16 || B <= 0 || C <= 0 || h <= 0 || w <= 0 || POL(loss_no_lse)) return 0;
     if (!loss_use_mfma(pow2_scale(h, w, H, W))) return 0;
     LossGeom g{B, C, h, w, H, W, ldl};
     if (!loss_band_fwd_covers((const bf16_t*)logits, g)) return 0;
@@ -1544,7 +1544,7 @@ __global__ void __launch_bounds__(64 * AMX_WAVES) argmax_confmat_pix_kernel(cons
 template <typename T>
 static void argmax_launch(int ns, int sc, dim3 grid, hipStream_t st, const T* logits, LossGeom g, const int64_t* target,
                           int64_t ign, unsigned long long* mat, unsigned long long* hist, int* flag, int64_t* pred_out) {
-    if ((sc == 4 || sc == 8) && g.C <= AMX_CT && !getenv("SEGFAC_ARGMAX_CELLS")) {
+    if ((sc == 4 || sc == 8) && g.C <= AMX_CT) {
         // persistent workgroups (one per CU at most: 150 KB of LDS each), fewer when the batch is small so that the final flush of the
         // per-workgroup matrices (C^2 entries each) does not outweigh the counting
         const int cpw = 64 / (sc * sc);

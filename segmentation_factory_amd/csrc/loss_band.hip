@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
 }
 
 bool loss_band_fwd_covers(const bf16_t* logits, LossGeom g) {
-    if (getenv("SEGFAC_LOSS_NO_BAND") || getenv("SEGFAC_LOSS_NO_BAND_FWD")) return false;
+    if (POL(loss_no_band) || POL(loss_no_band_fwd)) return false;
     if (g.H != 4 * g.h || g.W != 4 * g.w || g.C > 192) return false;
     if (g.ldl % 8 || g.ldl < g.C || ((uintptr_t)logits & 15)) return false;
     if ((int64_t)g.h * g.w * g.ldl >= (1ll << 30) || (int64_t)g.H * g.W >= (1ll << 28)) return false;
@@ -672,7 +672,7 @@ bool loss_band_fwd_launch(const bf16_t* logits, LossGeom g, const int64_t* targe
 }
 
 static int band_seg_rows(int B, int h, int nbands) {
-    if (const char* e = getenv("SEGFAC_LOSS_BAND_ROWS")) { const int v = atoi(e); if (v > 0) return v; }
+    if (POL(loss_band_rows) > 0) return POL(loss_band_rows);
     // enough wave tasks for several rounds of the chip (256 CUs x 8 resident waves of this kernel) so that the tail evens out;
     // segments of at least 8 tap rows (each segment recomputes one cell row).  Measured at B = 128, 128 x 128 taps: 16 rows
     // 2.29 ms, 32 rows 2.33 ms, 64 rows 2.35 ms, 128 rows 2.93 ms
@@ -684,7 +684,7 @@ static int band_seg_rows(int B, int h, int nbands) {
 bool loss_band_bwd_launch(const bf16_t* logits, LossGeom g, const int64_t* target, int64_t ignore_index, const float* cw, int dice,
                           const float* stats, const float* grad_out, bf16_t* dlow, int64_t ldd, int* retry, const float* lse,
                           hipStream_t st) {
-    if (getenv("SEGFAC_LOSS_NO_BAND")) return false;
+    if (POL(loss_no_band)) return false;
     if (lse && !loss_band_fwd_covers(logits, g)) return false;        // (the caller has checked this: the buffer was never written)
     if (g.H != 4 * g.h || g.W != 4 * g.w || g.C > 192) return false;
     const int nt = (g.C + 15) / 16;

@@ -273,7 +273,7 @@ static inline int ln_bwd_blocks(int64_t rows, int C) {
     const int64_t b4 = cdiv64(rows, (int64_t)rows_per_block * 4);
     // few rows (the stage-3 / 4 maps at the reference's default batch of 4, train_gpu.py:71): one row group per wave instead of four --
     // the launch is a chain of dependent load rounds on a fraction of the chip, and four rounds cost 10 us where one costs 6
-    if (b4 < 256 && !getenv("SEGFAC_LN_BWD_FOUR_ROUNDS")) return (int)imin64(cdiv64(rows, (int64_t)rows_per_block), LN_BWD_MAX_BLOCKS);
+    if (b4 < 256) return (int)imin64(cdiv64(rows, (int64_t)rows_per_block), LN_BWD_MAX_BLOCKS);
     return (int)imin64(b4, LN_BWD_MAX_BLOCKS);
 }
 extern "C" int64_t segf_layernorm_bwd_ws(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(rows, C) * 2 * C; }

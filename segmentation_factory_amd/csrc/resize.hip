@@ -201,14 +201,15 @@ __global__ void __launch_bounds__(256) upsample_add_248_kernel(const T* __restri
 
 static bool upsample_add_is_248(int H, int W, int C, int nsrc, int h0, int w0, int h1, int w1, int h2, int w2, int align_corners) {
     return nsrc == 3 && !align_corners && W % 8 == 0 && H % 8 == 0 && h0 * 2 == H && w0 * 2 == W && h1 * 4 == H && w1 * 4 == W &&
-           h2 * 8 == H && w2 * 8 == W && C % 8 == 0 && !getenv("SEGFAC_UPADD_GENERIC");
+           h2 * 8 == H && w2 * 8 == W && C % 8 == 0 && !POL(upadd_generic);
 }
 static int upsample_add_248_groups(int C) {        // channel groups of 8 chunks (128 bytes per pixel) when C allows it
     const int nch = C / 8;
     // measured on MI355X (cfg2, batch 128): 128-byte channel groups leave the launch at 1.77 ms (4.2 TB/s) with or without them and
     // slow the fused-statistics variant (1.99 -> 2.26 ms: 8 instead of 96 reducing threads per workgroup), i.e. the 2.5x source
     // re-fetches that FETCH_SIZE reports are served by the Infinity Cache and are not what bounds the kernel: opt-in only
-    return (nch % 8 == 0 && getenv("SEGFAC_UPADD_GROUP")) ? nch / 8 : 1;
+    (void)nch;
+    return 1;
 }
 static int upsample_add_248_blocks(int B, int H, int W, int C) {
     return colfixed_blocks((int64_t)B * H * (W / 4), C / 8 / upsample_add_248_groups(C), 2, 16384);
@@ -655,7 +656,7 @@ template <typename T> __device__ __forceinline__ void store4v(T* p, const f32x2_
 }
 template <typename T>
 __global__ void __launch_bounds__(256, 2) bilinear_bwd_248_kernel(const T* __restrict__ dy, int64_t ldo, T* __restrict__ d2, T* __restrict__ d4,
-                                                                T* __restrict__ d8, int B, int H, int W, int C, int getenv_noflip,
+                                                                T* __restrict__ d8, int B, int H, int W, int C, int no_flip,
                                                                 int ring_only) {
     constexpr int CW = 4;
     const int h8 = H / 8, w8 = W / 8, h4 = H / 4, w4 = W / 4, h2 = H / 2, w2 = W / 2;
@@ -740,7 +741,7 @@ __global__ void __launch_bounds__(256, 2) bilinear_bwd_248_kernel(const T* __res
         // with the row below (other workgroups, dispatched next to this one on the same XCD); with opposite walking directions
         // both neighbours touch a shared band during the same half of their loops, which keeps it in the 4 MB L2 between the two
         // reads (all top-down the reuse distance was 8 row steps = 8 MB streamed per XCD: FETCH_SIZE 1.7x the gradient)
-        const bool up = (y8 & 1) && !getenv_noflip;
+        const bool up = (y8 & 1) && !no_flip;
 #pragma unroll 1
         for (int ii = 0; ii < 16; ++ii) {
             const int i = up ? 15 - ii : ii;
@@ -817,19 +818,14 @@ extern "C" int segf_bilinear_bwd_248(int dt, int B, int H, int W, int C, const v
     if (H % 8 || W % 8 || C % 8 || ldo < C || (ldo % 8)) return SEGF_ERR_SHAPE;
     if (((uintptr_t)dout | (uintptr_t)d2 | (uintptr_t)d4 | (uintptr_t)d8) % 16) return SEGF_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
-    // bf16, C % 128 == 0: on the matrix pipe (fuse_map.hip); SEGFAC_BWD248_RING=1 keeps the border ring on the VALU kernel below
-    // (the two must agree there: tests)
-    const int mfma = fuse_map_bwd_supported(dt, B, H, W, C);
-    if (mfma) {
-        const int rc = fuse_map_bwd_launch(B, H, W, C, dout, ldo, d2, d4, d8, st);
-        if (rc || !getenv("SEGFAC_BWD248_RING") || H < 24 || W < 24) return rc;
-    }
-    const int ring = mfma;
+    // bf16, C % 128 == 0: on the matrix pipe (fuse_map.hip), every block including the border ring
+    if (fuse_map_bwd_supported(dt, B, H, W, C)) return fuse_map_bwd_launch(B, H, W, C, dout, ldo, d2, d4, d8, st);
+    const int ring = 0;
     const int64_t total = ring ? (int64_t)B * (2 * (W / 8) + 2 * (H / 8 - 2)) * (C / 4) : (int64_t)B * (H / 8) * (W / 8) * (C / 4);
     const int blocks = (int)imin64(cdiv64(total, 256), 32768);
     SEGF_DISPATCH_DT(dt, T, {
         hipLaunchKernelGGL((bilinear_bwd_248_kernel<T>), dim3(blocks), dim3(256), 0, st, (const T*)dout, ldo, (T*)d2, (T*)d4, (T*)d8, B, H, W, C,
-                           getenv("SEGFAC_BWD248_NO_FLIP") ? 1 : 0, ring);
+                           0, ring);
     })
     SEGF_CHECK_LAUNCH();
     return 0;

@@ -6,7 +6,6 @@ Every forward/backward below is a hand-written formula over C-ABI kernel calls -
 only sequences them.  Nothing here falls back to eager PyTorch math.
 """
 import contextlib
-import os
 
 import torch
 from torch.autograd import Function
@@ -227,7 +226,7 @@ def flush_weight_grads():
     if not q:
         return
     # (the members' split-K counts were chosen per layer; inside a group they may share one smaller count: hip / segfac.h shared_split)
-    hip.gemm_dw_db_grouped([e[0] for e in q], shared_split=not os.environ.get('SEGFAC_DW_NO_SHARED_SPLIT'))
+    hip.gemm_dw_db_grouped([e[0] for e in q], shared_split=not hip.policy('dw_no_shared_split'))
     # the layout passes behind the products (the [O][k k][Cin] -> OIHW permutes of the patch convolutions' weight gradients): one launch
     hip.prep_grouped([post for _, _, post in q if post is not None])
     for _, infos, post in q:
@@ -240,8 +239,8 @@ def flush_weight_grads():
 def defer_weight_grads():
     global _DW_QUEUE, _FIN_QUEUE
     prev, prevf = _DW_QUEUE, _FIN_QUEUE
-    _DW_QUEUE = [] if not os.environ.get('SEGFAC_NO_DEFERRED_DW') else None
-    _FIN_QUEUE = [] if not os.environ.get('SEGFAC_NO_DEFERRED_FINALIZE') else None
+    _DW_QUEUE = [] if not hip.policy('no_deferred_dw') else None
+    _FIN_QUEUE = [] if not hip.policy('no_deferred_finalize') else None
     try:
         yield
         flush_weight_grads()
@@ -553,7 +552,7 @@ class LayerNormFn(Function):
 def _dp_of(x):
     """(rscale, rows_per_group) when x is the output of a `residual + DropPath-scaled branch` product (functional.linear tags it)"""
     dp = getattr(x, '_segf_dp', None)
-    return dp if dp is not None and not os.environ.get('SEGFAC_NO_SCALED_LN_BWD') else (None, 1)
+    return dp if dp is not None and not hip.policy('no_scaled_ln_bwd') else (None, 1)
 
 
 def layer_norm(x, gamma, beta, eps):
@@ -628,7 +627,7 @@ class LayerNormResPatchFn(Function):
 def patch_layout_ok(W, H, sr):
     """layer_norm_res_patch covers maps whose width and reduction ratio are powers of two (every BASELINE geometry)"""
     return (sr > 1 and (sr & (sr - 1)) == 0 and (W & (W - 1)) == 0 and W >= sr and H % sr == 0
-            and not os.environ.get('SEGFAC_NO_LN_PATCH'))
+            and not hip.policy('no_ln_patch'))
 
 
 def layer_norm_res_patch(x, gamma, beta, eps, W, sr):
@@ -981,7 +980,7 @@ class BnActLinearFn(Function):
             slot = ctx.fold_slot
             x1 = slot.get('x1') if slot is not None else None
             ride_dg = x1 is not None and x1.shape[0] == M and hip.bn_cls_bwd_dw_supported(x.dtype, M, K, Np, rps, x1.shape[1])
-            if act in (0, 1) and not os.environ.get('SEGFAC_NO_HEAD_FUSED_CW'):
+            if act in (0, 1) and not hip.policy('no_head_fused_cw'):
                 # ... and the classifier's own weight gradient rides on the first pass (it has the x and dy tiles on chip), as the
                 # stage-1 weight gradient of the folded head rides on the second: no separate pass over x for either
                 dx, dg, dbeta, dG, dwc = hip.bn_cls_bwd_full(dyp, w, x, mean, rstd, g, b, act, chan_scale, rps, eval_mode,
@@ -1165,7 +1164,7 @@ class SegformerFoldedFuseFn(Function):
         dwf = torch.empty((E, 4 * E), dtype=torch.float32, device=dev)
         dxs, dws, dbs = [], [], []
         dts = None
-        if (H1 % 8 == 0 and W1 % 8 == 0 and E % 8 == 0 and not os.environ.get('SEGFAC_NO_BWD248')
+        if (H1 % 8 == 0 and W1 % 8 == 0 and E % 8 == 0 and not hip.policy('no_bwd248')
                 and all(geoms[i][1:] == (H1 >> i, W1 >> i) for i in (1, 2, 3))):
             dts = hip.bilinear_bwd_248(dy, B, H1, W1, E)          # the three transposed resizes in ONE pass over dy
         dGps = []

@@ -260,7 +260,7 @@ class GraphedTrainStep:
                                           device=self.opt.flat_grads_padded.device)
         # bf16 shadow of the flat parameter buffer, refreshed by one cast at the start of every step (functional.shadow_scope)
         self._shadow, self._shadow_map = None, None
-        if any(p.dtype == torch.float32 for p in self.opt._params) and not os.environ.get('SEGFAC_NO_WEIGHT_SHADOW'):
+        if any(p.dtype == torch.float32 for p in self.opt._params) and not hip.policy('no_weight_shadow'):
             flat = self.opt.flat_params
             self._shadow = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
             self._shadow_map = {}
@@ -268,7 +268,7 @@ class GraphedTrainStep:
                 self._shadow_map[p.data_ptr()] = self._shadow[o:o + p.numel()]
         self.opt.enable_direct_grads(self._on_grad_written if (self.exchanging and overlap) else None)
         self._seed = torch.full((), 1.0 / self.world, dtype=torch.float32, device=self.static_inputs[0].device)
-        self._derived = None if os.environ.get('SEGFAC_NO_DERIVED_WEIGHTS') else Fh.DerivedWeights()
+        self._derived = None if hip.policy('no_derived_weights') else Fh.DerivedWeights()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         # the warm-up passes run real train-mode forwards: snapshot every buffer (BatchNorm running_mean / running_var /

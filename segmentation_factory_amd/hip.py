@@ -129,6 +129,13 @@ _PROTOS = {
     'segf_event_record': (_i, [_p, _p, _i]),
     'segf_stream_wait_event': (_i, [_p, _p]),
     'segf_version': (C.c_char_p, []),
+    'segf_policy_count': (_i, []),
+    'segf_policy_describe': (_i, [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_char_p)]),
+    'segf_policy_get': (_i, [C.c_char_p]),
+    'segf_policy_set': (_i, [C.c_char_p, _i]),
+    'segf_policy_reload': (None, []),
+    'segf_trace_begin': (None, [_i]),
+    'segf_trace_end': (_i, [C.c_char_p, _i]),
 }
 
 
@@ -151,6 +158,78 @@ def lib():
 
 def exported_symbols():
     return sorted(_PROTOS)
+
+
+# ---- dispatch policy (csrc/policy.h; documented in include/segfac.h) and launch trace -------------------------------------------
+_NO_SUCH = -2 ** 31
+
+
+def policy(name):
+    """Current value of one dispatch switch (field name 'gemm_no_narrow' or environment name 'SEGFAC_GEMM_NO_NARROW').  The library
+    reads the environment once, at first use; `policy_set` / `policy_reload` change it afterwards."""
+    v = lib().segf_policy_get(name.encode())
+    if v == _NO_SUCH:
+        raise KeyError(f'no dispatch switch named {name!r} (csrc/policy.h)')
+    return v
+
+
+def policy_set(name, value):
+    prev = lib().segf_policy_set(name.encode(), int(value))
+    if prev == _NO_SUCH:
+        raise KeyError(f'no dispatch switch named {name!r} (csrc/policy.h)')
+    return prev
+
+
+def policy_reload():
+    """Re-read every switch from the environment (after os.environ / monkeypatch.setenv changed it)."""
+    lib().segf_policy_reload()
+
+
+def policy_table():
+    """[(field, environment name, value, default, description)] of every switch."""
+    out = []
+    for i in range(lib().segf_policy_count()):
+        f, e, d = C.c_char_p(), C.c_char_p(), C.c_char_p()
+        v, df = _i(), _i()
+        _chk(lib().segf_policy_describe(i, C.byref(f), C.byref(e), C.byref(v), C.byref(df), C.byref(d)), 'segf_policy_describe')
+        out.append((f.value.decode(), e.value.decode(), v.value, df.value, d.value.decode()))
+    return out
+
+
+class policy_override:
+    """with policy_override(gemm_no_narrow=1): ...   (tests, A/B scripts)"""
+
+    def __init__(self, **kw):
+        self.kw, self.prev = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.prev[k] = policy_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            policy_set(k, v)
+        return False
+
+
+class trace:
+    """Names of the kernels the library launches on this thread inside the block (instantiated names, template arguments included):
+    `with hip.trace() as t: hip.gemm(...)` -> t.kernels.  dry_run=True records the decisions WITHOUT launching (no GPU needed; the
+    entry points are then called through lib() with placeholder pointers, see tests/test_host_cpu.py)."""
+
+    def __init__(self, dry_run=False, cap=1 << 16):
+        self.dry, self.cap, self.kernels, self.launches = dry_run, cap, [], 0
+
+    def __enter__(self):
+        lib().segf_trace_begin(int(self.dry))
+        return self
+
+    def __exit__(self, *exc):
+        buf = C.create_string_buffer(self.cap)
+        self.launches = lib().segf_trace_end(buf, self.cap)
+        self.kernels = [l for l in buf.value.decode().split('\n') if l]
+        return False
 
 
 def dt_of(t: torch.Tensor) -> int:
@@ -464,9 +543,9 @@ def autotune_gemm8_fp8(force=False):
     global _G8_FP8_STAGGER
     if _G8_FP8_STAGGER is not None and not force:
         return _G8_FP8_STAGGER
-    env = os.environ.get('SEGFAC_G8_STAGGER')
-    if env is not None:
-        _G8_FP8_STAGGER = int(env != '0')
+    forced = policy('g8_stagger')
+    if forced >= 0:
+        _G8_FP8_STAGGER = int(forced != 0)
         lib().segf_gemm8_option(0, _G8_FP8_STAGGER)
         return _G8_FP8_STAGGER
     if torch.cuda.is_current_stream_capturing():

@@ -10,6 +10,29 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+# The library reads its dispatch switches (csrc/policy.h) from the environment ONCE.  The tests flip SEGFAC_* variables in the running
+# process (monkeypatch.setenv, os.environ[...] = ...): every such change -- and monkeypatch's undo -- is followed by a re-read, so a
+# test sees the switch it has just set and the next test sees the defaults again.
+class _PolicyFollowsEnviron(type(os.environ)):
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        _policy_sync(key)
+
+    def __delitem__(self, key):
+        super().__delitem__(key)
+        _policy_sync(key)
+
+
+def _policy_sync(key):
+    if isinstance(key, str) and key.startswith('SEGFAC_'):
+        hip = sys.modules.get('segmentation_factory_amd.hip')
+        if hip is not None and hip._lib is not None:
+            hip.policy_reload()
+
+
+os.environ.__class__ = _PolicyFollowsEnviron
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -61,7 +61,7 @@ def main():
         both = [torch.empty_like(after) for _ in range(world)]
         dist.all_gather(both, after)
         extra.update(buffers_equal_after=bool(all(torch.equal(both[0], t) for t in both)), hist=metric.hist.cpu(), mat=confmat.mat.cpu(),
-                     eval_graphs=len(model.__dict__.get('_graphed_eval', {})) - 1)
+                     eval_graphs=len(model.__dict__.get('_graphed_eval', {}).get('graphs', {})))      # (same shape twice: eager, then captured)
     if rank == 0:
         torch.save({'losses': losses, 'state': {k: v.detach().cpu() for k, v in model.state_dict().items()},
                     'n_buckets': len(gs.buckets), 'events': sum(e is not None for e in gs.events), 'ranges': gs.ranges,

@@ -382,3 +382,64 @@ def test_device_batch_loader_index_order_is_distributed_samplers():
                 sm.set_epoch(epoch)
                 assert ld.indices() == list(sm), (n, world, rank, epoch)
                 assert ld.num_samples() == len(sm) and len(ld) == len(sm) // 2
+
+
+def test_dispatch_policy_table_is_one_place():
+    """Every dispatch switch lives in csrc/policy.h, is read from the environment once and is documented in include/segfac.h; nothing
+    else in csrc/ calls getenv().  segf_policy_get / set / reload work without a GPU."""
+    import re
+    from segmentation_factory_amd import hip
+    table = hip.policy_table()
+    assert len(table) >= 40 and len({t[0] for t in table}) == len(table) and len({t[1] for t in table}) == len(table)
+    header = open(os.path.join(ROOT, 'include', 'segfac.h')).read()
+    for field, env, value, default, doc in table:
+        assert env.startswith('SEGFAC_') and env in header, env          # documented where the C ABI is declared
+        assert doc
+    csrc = os.path.join(ROOT, 'segmentation_factory_amd', 'csrc')
+    for fn in os.listdir(csrc):
+        if fn.endswith(('.hip', '.h')) and fn != 'policy.hip':
+            assert 'getenv' not in re.sub(r'//.*', '', open(os.path.join(csrc, fn)).read()), fn
+    pkg = os.path.join(ROOT, 'segmentation_factory_amd')
+    known = {t[1] for t in table} | {'SEGFAC_HIP_LIB', 'SEGFAC_VERBOSE', 'SEGFAC_EXCHANGE', 'SEGFAC_GRAD_PAYLOAD', 'SEGFAC_FORCE_EXCHANGE',
+                                      'SEGFAC_TEST_SPIN_US', 'SEGFAC_DIST_BACKEND', 'SEGFAC_PRINT_ALL_RANKS'}       # run-time plumbing, not dispatch
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            for name in re.findall(r'SEGFAC_[A-Z0-9_]+', open(os.path.join(pkg, fn)).read()):
+                assert name in known, (fn, name)
+    assert hip.policy('gemm_no_narrow') == 0 and hip.policy('SEGFAC_G8_STAGGER') == -1
+    with hip.policy_override(gemm_no_narrow=1):
+        assert hip.policy('SEGFAC_GEMM_NO_NARROW') == 1
+    assert hip.policy('gemm_no_narrow') == 0
+    os.environ['SEGFAC_GEMM_NO_NARROW'] = 'yes'                               # (conftest re-reads the policy after SEGFAC_* changes)
+    try:
+        assert hip.policy('gemm_no_narrow') == 1
+    finally:
+        del os.environ['SEGFAC_GEMM_NO_NARROW']
+    assert hip.policy('gemm_no_narrow') == 0
+    with pytest.raises(KeyError):
+        hip.policy('no_such_switch')
+
+
+def test_dispatch_of_baseline_shapes(golden_dir):
+    """The kernel every launching C-ABI call of one train step takes, for cfg2 at per-GPU batch 4 / 16 / 128 and cfg3 / cfg4 / cfg5
+    (+ the fp8 option), recorded on the MI355X by tools/make_dispatch_table.py (shapes from the reference's width rule,
+    models/build_models.py:43-54) -- replayed here as DRY RUNS through the C ABI: same entry point, same arguments, placeholder
+    pointers, nothing launched.  A dispatch edit that moves a BASELINE shape to another kernel fails this test and shows up as a diff
+    of tests/golden/dispatch_table.json when the table is regenerated."""
+    import json
+    from segmentation_factory_amd import dispatch
+    with open(os.path.join(golden_dir, 'dispatch_table.json')) as fh:
+        table = json.load(fh)
+    assert {'cfg2_b4', 'cfg2_b16', 'cfg2_b128', 'cfg3_b32', 'cfg4_b16', 'cfg5_b8'} <= set(table)
+    moved, n = [], 0
+    for case, entries in table.items():
+        fns = {e['fn'] for e in entries}
+        assert 'segf_gemm' in fns and 'segf_ce_dice_fwd' in fns, case
+        assert ('segf_attention_fwd' in fns) == case.startswith(('cfg2', 'cfg4')) and ('segf_conv3x3' in fns) == case.startswith(('cfg3', 'cfg5')), case
+        for e in entries:
+            got = dispatch.replay(e)
+            n += 1
+            if got != e['kernels']:
+                moved.append((case, e['fn'], e['args'], e['kernels'], got))
+    assert n > 500
+    assert not moved, moved[:5]

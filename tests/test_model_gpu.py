@@ -1227,3 +1227,22 @@ def test_evaluate_in_fp32_like_the_reference_and_what_bf16_flips(cfg):
     assert res['fp32'][0].sum() == total and res['bf16'][0].sum() == total
     assert abs(res['fp32'][1] - o_miou) <= 0.1 + 1e-9 and res['fp32'][2] <= 1e-4 * total + 2
     assert abs(res['bf16'][1] - o_miou) <= 0.1 + 1e-9, line
+
+
+def test_dispatch_table_is_what_the_step_launches(golden_dir):
+    """tests/golden/dispatch_table.json (replayed on the CPU by tests/test_host_cpu.py::test_dispatch_of_baseline_shapes) against a live
+    recording on this GPU: the train step of cfg2 at the reference's default batch 4 (train_gpu.py:71) makes exactly the calls the
+    table lists, and each launches exactly the kernels the table names."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import make_dispatch_table as mk
+    with open(os.path.join(golden_dir, 'dispatch_table.json')) as fh:
+        want = json.load(fh)['cfg2_b4']
+    got = mk.record_case('cfg2', 4, False)
+    key = lambda e: (e['fn'], json.dumps(e['args']))
+    w, g = {key(e): e for e in want}, {key(e): e for e in got}
+    assert set(w) == set(g), (sorted(set(w) - set(g))[:3], sorted(set(g) - set(w))[:3])
+    for k in w:
+        assert w[k]['kernels'] == g[k]['kernels'] and w[k]['count'] == g[k]['count'], (k, w[k], g[k])

@@ -19,6 +19,19 @@ def timed(fn, n):
     return e0.elapsed_time(e1) / n
 
 
+def ab_settings():
+    """PROBE_AB='g8_stagger=0;g8_stagger=1' -> the dispatch-policy settings (csrc/policy.h) to alternate between, in one process."""
+    v = os.environ.get('PROBE_AB')
+    return v.split(';') if v else [None]
+
+
+def apply_setting(setting):
+    if setting:
+        for kv in setting.split(','):
+            k, val = kv.split('=')
+            hip.policy_set(k.strip(), int(val))
+
+
 def conv(n):
     B, H, W, Cin, Cout = 32, 128, 128, 3072, 768
     P = B * H * W
@@ -28,11 +41,10 @@ def conv(n):
     wt = (torch.randn(Cin, 9 * Cout, device='cuda') * 0.01).to(torch.bfloat16)
     fl = 2.0 * P * 9 * Cin * Cout / 1e12
     xq, sx = hip.quant_tensor_fp8(x); wq, sw = hip.quant_rows_fp8(wm)
-    orders = os.environ.get('PROBE_G8_ORDERS', '').split(',') if os.environ.get('PROBE_G8_ORDERS') else [None]
+    orders = ab_settings()
     for rnd in range(2 if len(orders) > 1 else 1):
         for od in orders:
-            if od is not None:
-                os.environ['SEGFAC_G8_KORDER'] = od; os.environ['SEGFAC_G8_TILE_ORDER'] = od
+            apply_setting(od)
             t0 = timed(lambda: hip.conv3x3(0, x, wm, B, H, W, Cin, Cout), n)
             t1 = timed(lambda: hip.conv3x3(1, dy, wt, B, H, W, Cin, Cout), n)
             t2 = timed(lambda: hip.conv3x3(2, x, dy, B, H, W, Cin, Cout, split_k=hip.pick_splitk_conv3x3(Cin, Cout, P)), n)
@@ -42,7 +54,7 @@ def conv(n):
     # plain product of the same size class through the same kernel (no gather): [P x 3072] x [3072 -> 3072]^T
     M, N, K = 65536, 3072, 3072
     a = torch.randn(M, K, device='cuda').to(torch.bfloat16); w = (torch.randn(N, K, device='cuda') * 0.02).to(torch.bfloat16)
-    os.environ['SEGFAC_GEMM8_LINEAR'] = '1'
+    hip.policy_set('gemm8_linear', 1)
     try:
         tl = timed(lambda: hip.gemm(0, a, w, M, N, K), n)
         print(f'linear  [{M} x {K}] -> {N}: {tl:.3f} ms ({2.0 * M * N * K / tl / 1e9:.0f} TF/s)', flush=True)
@@ -60,11 +72,10 @@ def attn(n):
     o, lse = hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, scale)
     dk = torch.empty_like(k); dv = torch.empty_like(v)
     ff = 4.0 * B * heads * N * Nkv * hd / 1e12
-    variants = os.environ.get('PROBE_ATTN_VARIANTS', '').split(',') if os.environ.get('PROBE_ATTN_VARIANTS') else [None]
+    variants = ab_settings()
     for rnd in range(3 if len(variants) > 1 else 1):              # interleaved rounds in one process (same device, same clocks)
         for var in variants:
-            if var is not None:
-                os.environ['SEGFAC_ATTN_VARIANT'] = var
+            apply_setting(var)
             t0 = timed(lambda: hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, scale), n)
             t1 = timed(lambda: hip.attention_bwd(q, k, v, o, do, lse, B, heads, N, Nkv, hd, scale, dk, dv), n)
             print(f'attention [{B} x {heads} x {N} x {Nkv} x {hd}] variant {var} fwd {ff:.2f} TFLOP {t0:.3f} ms ({ff / t0 * 1e3:.0f} TF/s) | bwd {2.5 * ff:.2f} TFLOP '
