@@ -87,7 +87,9 @@ def cpu_baseline(sample_batch=2, timed_steps=3, loop_timed_steps=2):
     backward with the reference's B x C Python Dice loop (util/losses.py:141-170: its cost structure), and next to it the
     same with the vectorised closed-form Dice."""
     from oracle import loss as OL, nets as ON, weights as OW
-    # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share: oversubscribing stalls for minutes
+    # the GPU box exposes 256 logical CPUs but a 1-GPU job owns a 16-core share.  Measured on the box (tools/probe/cpu_threads_probe.py,
+    # profiles/r05_cpu_threads.txt; the same step with the vectorised Dice): 16 threads 1.05 images/s, 32 threads 0.93, 64 threads 0.81 --
+    # more threads than the share are SLOWER, so the cap is the fastest setting, not a handicap
     ncores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(ncores)
     sd = OW.make_state_dict('MiT-B0', 'SegFormerHead', 150, 0, lively=False)

@@ -532,6 +532,7 @@ int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, i
  *   SEGFAC_DW_NO_SHARED_SPLIT    grouped weight gradients keep their per-layer slice counts (also read by the host layer)
  *   SEGFAC_NO_WIDE_REDUCE        split-K partials of large outputs summed by the 16 x 16 form instead of whole rows
  *   SEGFAC_NO_REDUCE4            split-K reduce: one output per thread instead of four (bitwise the same sums)
+ *   SEGFAC_GEMM_F32_NO_MFMA      fp32 storage (exact-parity mode, evaluate): products on the vector FMA kernel instead of the f32 matrix instruction
  *   SEGFAC_GEMM8_LINEAR          OPT-IN: plain nn.Linear products with whole 256 x 256 tiles on the eight-phase kernel (loses 0.5 - 2 % on the BASELINE models)
  *   SEGFAC_NO_GEMM8              no eight-phase kernel at all (gemm8_kernel): the two-phase 256-tile kernel everywhere
  *   SEGFAC_NO_GEMM8T             no eight-phase kernel for weight gradients (reduction-major operands)

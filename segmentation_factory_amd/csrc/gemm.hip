@@ -1087,6 +1087,135 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs a) {
     }
 }
 
+// ---- exact fp32 on the MATRIX pipe (r05) -------------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate, bit for bit a k-ordered fmaf chain (one rounding per product, no wider internal
+// sum: cdna_hip_programming.md "FP32-input MFMA") at the fp32 VECTOR peak (64 FLOP / clk / SIMD) -- but with one operand register per
+// lane per instruction and the vector unit left free, where the FMA kernel above spends four LDS-fed fmaf per loaded value and runs at
+// a third of that peak on large shapes and far below it on the small ones (one 4-byte global load per thread and step).  `evaluate`
+// runs in fp32 like the reference (engine.py:86-88), so this kernel IS the eval forward's GEMM: 64 x 64 x 16 tiles, four waves of one
+// 32 x 32 tile each, operands staged through registers (next step's 16-byte loads in flight under this step's eight MFMAs) into LDS
+// images read by ds_read_b128 (K-contiguous operand: 20-float rows, conflict-free) or ds_read_b32 (reduction-major operand).
+// The k index of step s in lane half h is 8 h + s for BOTH operands (any pairing of the 16 k values is a valid order of the sum).
+// Product orientation: D[n][m] = sum_k W[n][k] X[m][k] -- the N-side operand is the MFMA's A (rows), so a lane ends up with four
+// consecutive n of one m per accumulator quad: the epilogue of the other kernels (bias / residual / DropPath scale / split-K slab).
+#define GFM_K 16
+#define GFM_LDK 20
+typedef float gfm_f32x16 __attribute__((ext_vector_type(16)));
+template <bool KC>
+__device__ __forceinline__ float4 gfm_load(const float* __restrict__ base, int64_t ld, int64_t r0, int64_t rows, int64_t k0, int64_t kend, bool vec, int t) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {                                        // [rows][K]: thread t -> row t >> 2, k chunk 4 (t & 3)
+        const int64_t r = r0 + (t >> 2), k = k0 + 4 * (t & 3);
+        if (r < rows) {
+            const float* p = base + r * ld + k;
+            if (vec && k + 3 < kend) v = *reinterpret_cast<const float4*>(p);
+            else { if (k < kend) v.x = p[0]; if (k + 1 < kend) v.y = p[1]; if (k + 2 < kend) v.z = p[2]; if (k + 3 < kend) v.w = p[3]; }
+        }
+    } else {                                         // [K][rows]: thread t -> k row t >> 4, column chunk 4 (t & 15)
+        const int64_t k = k0 + (t >> 4), r = r0 + 4 * (t & 15);
+        if (k < kend) {
+            const float* p = base + k * ld + r;
+            if (vec && r + 3 < rows) v = *reinterpret_cast<const float4*>(p);
+            else { if (r < rows) v.x = p[0]; if (r + 1 < rows) v.y = p[1]; if (r + 2 < rows) v.z = p[2]; if (r + 3 < rows) v.w = p[3]; }
+        }
+    }
+    return v;
+}
+// TM x TN tiles of 32 x 32 per wave: workgroup tile (64 TM) x (64 TN).  (2, 2) = 128 x 128 for the large products (32 FLOP per operand
+// byte from L2; the 64 x 64 tile's 16 FLOP / B bound the first version at ~64 TFLOP/s), (1, 1) for outputs with few tiles.
+// WM = waves along M (2 or 4; 4 / WM along N): (TM, TN, WM) = (1, 5, 4) is a 128 x 160 tile -- a narrow output (the 150 -> 160 classes of
+// the decode head, heads/segformer.py:57-58) in ONE column tile, so the [tokens x 768] operand is streamed once and only 6 % of the
+// MFMA columns are padding (two 128-wide tiles: 37 %).
+template <int LAYOUT, int TM, int TN, int WM = 2>
+__global__ void __launch_bounds__(256) gemm_f32_mfma_kernel(GemmArgs a) {
+    constexpr bool A_KC = LAYOUT != 2, B_KC = LAYOUT == 0;       // A: [M][K] (layouts 0, 1) or [K][M]; B: [N][K] (layout 0) or [K][N]
+    constexpr int WN = 4 / WM;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int PM = (BM + 63) / 64, PN = (BN + 63) / 64;      // 64-row loader passes (the LDS images hold whole passes)
+    constexpr int LDM = 64 * PM + 4, LDN = 64 * PN + 4;          // reduction-major row strides (floats)
+    __shared__ __attribute__((aligned(16))) float Xs[A_KC ? 64 * PM * GFM_LDK : GFM_K * LDM];
+    __shared__ __attribute__((aligned(16))) float Ws[B_KC ? 64 * PN * GFM_LDK : GFM_K * LDN];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave % WM, wn = wave / WM, i = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * a.kchunk;
+    const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
+    const float* A = reinterpret_cast<const float*>(a.A);
+    const float* B = reinterpret_cast<const float*>(a.B);
+    const bool avec = (a.a_vec & 1) != 0, bvec = (a.b_vec & 1) != 0;
+    gfm_f32x16 acc[TN][TM];
+#pragma unroll
+    for (int u = 0; u < TN; ++u)
+#pragma unroll
+        for (int v = 0; v < TM; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+    float4 xr[PM], wr[PN];
+#pragma unroll
+    for (int j = 0; j < PM; ++j) xr[j] = gfm_load<A_KC>(A, a.lda, m0 + 64 * j, a.M, kbeg, kend, avec, t);
+#pragma unroll
+    for (int j = 0; j < PN; ++j) wr[j] = gfm_load<B_KC>(B, a.ldb, n0 + 64 * j, a.N, kbeg, kend, bvec, t);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += GFM_K) {
+#pragma unroll
+        for (int j = 0; j < PM; ++j)
+            *reinterpret_cast<float4*>(Xs + (A_KC ? (64 * j + (t >> 2)) * GFM_LDK + 4 * (t & 3) : (t >> 4) * LDM + 64 * j + 4 * (t & 15))) = xr[j];
+#pragma unroll
+        for (int j = 0; j < PN; ++j)
+            *reinterpret_cast<float4*>(Ws + (B_KC ? (64 * j + (t >> 2)) * GFM_LDK + 4 * (t & 3) : (t >> 4) * LDN + 64 * j + 4 * (t & 15))) = wr[j];
+        __syncthreads();
+        if (k0 + GFM_K < kend) {                    // the next step's loads fly under this step's MFMAs
+#pragma unroll
+            for (int j = 0; j < PM; ++j) xr[j] = gfm_load<A_KC>(A, a.lda, m0 + 64 * j, a.M, k0 + GFM_K, kend, avec, t);
+#pragma unroll
+            for (int j = 0; j < PN; ++j) wr[j] = gfm_load<B_KC>(B, a.ldb, n0 + 64 * j, a.N, k0 + GFM_K, kend, bvec, t);
+        }
+        float xf[TM][8], wf[TN][8];
+#pragma unroll
+        for (int v = 0; v < TM; ++v) {
+            const int row = 32 * (TM * wm + v) + i;
+            if (A_KC) {
+                const float4 u0 = *reinterpret_cast<const float4*>(Xs + row * GFM_LDK + 8 * h);
+                const float4 u1 = *reinterpret_cast<const float4*>(Xs + row * GFM_LDK + 8 * h + 4);
+                xf[v][0] = u0.x; xf[v][1] = u0.y; xf[v][2] = u0.z; xf[v][3] = u0.w; xf[v][4] = u1.x; xf[v][5] = u1.y; xf[v][6] = u1.z; xf[v][7] = u1.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) xf[v][s] = Xs[(8 * h + s) * LDM + row];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int row = 32 * (TN * wn + u) + i;
+            if (B_KC) {
+                const float4 u0 = *reinterpret_cast<const float4*>(Ws + row * GFM_LDK + 8 * h);
+                const float4 u1 = *reinterpret_cast<const float4*>(Ws + row * GFM_LDK + 8 * h + 4);
+                wf[u][0] = u0.x; wf[u][1] = u0.y; wf[u][2] = u0.z; wf[u][3] = u0.w; wf[u][4] = u1.x; wf[u][5] = u1.y; wf[u][6] = u1.z; wf[u][7] = u1.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) wf[u][s] = Ws[(8 * h + s) * LDN + row];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+#pragma unroll
+                for (int v = 0; v < TM; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[u][s], xf[v][s], acc[u][v], 0, 0, 0);
+        __syncthreads();
+    }
+    // D[n][m]: column (lane & 31) = m, rows (r & 3) + 8 (r >> 2) + 4 h = n
+#pragma unroll
+    for (int v = 0; v < TM; ++v) {
+        const int64_t m = m0 + 32 * (TM * wm + v) + i;
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float c4[4] = {acc[u][v][4 * q], acc[u][v][4 * q + 1], acc[u][v][4 * q + 2], acc[u][v][4 * q + 3]};
+                gemm_epilogue4<float, float>(a, m, n0 + 32 * (TN * wn + u) + 8 * q + 4 * h, c4, blockIdx.z);
+            }
+    }
+}
+
 // ---- split-K reduction: C = sum_z ws[z] (fixed order): 16 outputs x 16 slice-lanes per workgroup, slice lane s adds
 // z = s, s+16, ... with independent loads in flight, then the 16 lane sums are added in fixed order --------------------
 // The workgroups past `main_blocks` reduce the bias-gradient slices that ride on the same product (cs_ws [split][cs_n] ->
@@ -2289,6 +2418,28 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     } else {
         dim3 grid((unsigned)cdiv64(N, GF_BN), (unsigned)cdiv64(M, GF_BM), (unsigned)split_k);
         if (grid.y > 65535u) return SEGF_ERR_SHAPE;
+        if (!POL(gemm_f32_no_mfma)) {               // exact fp32 on the matrix pipe
+            // 128 x 128 tiles when they still give every CU a workgroup (or the output is so large that operand traffic decides); a
+            // narrow output (N <= 160) over many rows in ONE column tile of 128 x (32 TN); 64 x 64 otherwise
+            const int64_t big_tiles = cdiv64(M, 128) * cdiv64(N, 128) * split_k;
+            const bool narrow = N <= 160 && cdiv64(M, 128) * split_k >= 192;
+            const int tn = (int)cdiv64(N, 32);
+            const bool big = !narrow && M >= 128 && N >= 96 && big_tiles >= 192;
+            const dim3 gm((unsigned)(narrow ? 1 : cdiv64(N, big ? 128 : 64)), (unsigned)cdiv64(M, (big || narrow) ? 128 : 64), (unsigned)split_k);
+            if (gm.y > 65535u) return SEGF_ERR_SHAPE;
+#define LAUNCH_FM(L)                                                                                          \
+    do {                                                                                                      \
+        if (narrow && tn == 1) hipLaunchKernelGGL((gemm_f32_mfma_kernel<L, 1, 1, 4>), gm, dim3(256), 0, st, a);      \
+        else if (narrow && tn == 2) hipLaunchKernelGGL((gemm_f32_mfma_kernel<L, 1, 2, 4>), gm, dim3(256), 0, st, a); \
+        else if (narrow && tn == 3) hipLaunchKernelGGL((gemm_f32_mfma_kernel<L, 1, 3, 4>), gm, dim3(256), 0, st, a); \
+        else if (narrow && tn == 4) hipLaunchKernelGGL((gemm_f32_mfma_kernel<L, 1, 4, 4>), gm, dim3(256), 0, st, a); \
+        else if (narrow) hipLaunchKernelGGL((gemm_f32_mfma_kernel<L, 1, 5, 4>), gm, dim3(256), 0, st, a);            \
+        else if (big) hipLaunchKernelGGL((gemm_f32_mfma_kernel<L, 2, 2>), gm, dim3(256), 0, st, a);           \
+        else hipLaunchKernelGGL((gemm_f32_mfma_kernel<L, 1, 1>), gm, dim3(256), 0, st, a);                    \
+    } while (0)
+            if (layout == 0) LAUNCH_FM(0); else if (layout == 1) LAUNCH_FM(1); else LAUNCH_FM(2);
+#undef LAUNCH_FM
+        } else
         if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<0>), grid, dim3(256), 0, st, a);
         else if (layout == 1) hipLaunchKernelGGL((gemm_f32_kernel<1>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((gemm_f32_kernel<2>), grid, dim3(256), 0, st, a);

@@ -124,6 +124,9 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     const unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);      // bijective XCD remap
     unsigned bx = wgid % gx, by = wgid / gx;
+    // (r05 experiment, removed: inside an XCD's share of the launch the ROW tiles as the fastest index -- one weight stream per XCD at a
+    // time.  L2 hit 77 -> 91 %, fabric fetch 38.6 -> 14.7 GB per launch of the UPerHead bottleneck conv, and NO change in time, held clock
+    // or MFMA-busy; fp8 2 % slower: profiles/r05_gemm8_pmc_summary.txt.  The forward is not bound by what it fetches.)
     if (CONV_B && a.tile_order && a.cC % 256 == 0 && gx == 9u * (unsigned)(a.cC / 256)) {
         // weight gradient: the 9 taps x gy row tiles of ONE 256-channel block are neighbours in the launch order (hence on one XCD, at
         // the same time): they read the same pixels of x shifted by a row / a column and the same dy tiles, so x is fetched once per

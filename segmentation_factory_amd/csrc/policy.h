@@ -32,6 +32,7 @@
     X(dw_no_shared_split, "SEGFAC_DW_NO_SHARED_SPLIT", 0, "grouped weight gradients keep their per-layer slice counts (also read by the host layer)") \
     X(no_wide_reduce, "SEGFAC_NO_WIDE_REDUCE", 0, "split-K partials of large outputs summed by the 16 x 16 form instead of whole rows")   \
     X(no_reduce4, "SEGFAC_NO_REDUCE4", 0, "split-K reduce: one output per thread instead of four (bitwise the same sums)")               \
+    X(gemm_f32_no_mfma, "SEGFAC_GEMM_F32_NO_MFMA", 0, "fp32 storage (exact-parity mode, evaluate): products on the vector FMA kernel instead of the f32 matrix instruction") \
     X(gemm8_linear, "SEGFAC_GEMM8_LINEAR", 0, "OPT-IN: plain nn.Linear products with whole 256 x 256 tiles on the eight-phase kernel (loses 0.5 - 2 % on the BASELINE models)") \
     /* ---- implicit-GEMM 3 x 3 convolution, eight-phase kernel, fp8 (gemm.hip, gemm8.hip, fp8.hip) ---- */                             \
     X(no_gemm8, "SEGFAC_NO_GEMM8", 0, "no eight-phase kernel at all (gemm8_kernel): the two-phase 256-tile kernel everywhere")           \

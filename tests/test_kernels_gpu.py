@@ -2027,3 +2027,34 @@ def test_nearest_up_any_size_pair_matches_aten(geom):
     assert torch.equal(got.cpu(), tok(ref).cpu())
     dx = hip.nearest_up(tok(dy), B, h, w, Cc, H, W, bwd=True)
     assert torch.allclose(dx.cpu(), tok(x.grad).cpu(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(25000, 19, 64), (25000, 40, 70), (24700, 70, 33), (25000, 100, 48), (25000, 150, 768), (25000, 160, 96),
+                                   (4096, 3000, 130), (300, 150, 147), (257, 32, 32)])
+def test_gemm_f32_matrix_pipe_forms(hipmod, shape):
+    """fp32 storage (exact-parity mode; evaluate runs in it like the reference, engine.py:86-88): the products run on v_mfma_f32_32x32x2_f32
+    -- exact f32, a k-ordered fmaf chain -- in three tile forms: one column tile of 128 x (32 .. 160) for narrow outputs over many rows
+    (19 / 150 classes), 128 x 128 for large outputs, 64 x 64 otherwise.  All three layouts (+ bias, residual with row scales, split-K)
+    against float64, at fp32 round-off; and against the vector FMA kernel (gemm_f32_no_mfma), which sums in another order."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    dy = torch.randn(M, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    rs = torch.rand(M // 100 + 1, generator=g)
+    tol = 2e-5 * (K ** 0.5)
+    y = hipmod.gemm(0, _dev(x), _dev(w), M, N, K, bias=_dev(bias), residual=_dev(res), rscale=_dev(rs), rows_per_group=100)
+    want = res.double() + rs.double().repeat_interleave(100)[:M, None] * (x.double() @ w.double().t() + bias.double())
+    assert (y.cpu().double() - want).abs().max().item() <= tol
+    with hipmod.policy_override(gemm_f32_no_mfma=1):
+        y0 = hipmod.gemm(0, _dev(x), _dev(w), M, N, K, bias=_dev(bias), residual=_dev(res), rscale=_dev(rs), rows_per_group=100)
+    assert (y - y0).abs().max().item() <= tol
+    dx = hipmod.gemm(1, _dev(dy), _dev(w), M, K, N)
+    assert (dx.cpu().double() - dy.double() @ w.double()).abs().max().item() <= 2e-5 * (N ** 0.5) * 4
+    for sk in (1, 3):
+        dw = hipmod.gemm(2, _dev(dy), _dev(x), N, K, M, out_dtype=torch.float32, split_k=sk)
+        ref = dy.double().t() @ x.double()
+        # (a chain of M fp32 additions: ~ sqrt(M) eps |sum| of accumulated round-off, x4 margin)
+        assert (dw.cpu().double() - ref).abs().max().item() <= 4 * (M ** 0.5) * 6e-8 * ref.abs().max().item()
