@@ -460,7 +460,17 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, gq = lane >> 4;
-    const int b = blockIdx.y;
+    // XCD-aware (image, block) assignment: the workgroups of ONE image run on ONE XCD.  Every tap row is read by the four cells
+    // around it, i.e. by waves of different workgroups; dealt round-robin, an image's 128 workgroups sit on all eight XCDs and every
+    // L2 fetches the whole image from the fabric (counter traffic was 1.94x the algorithmic bytes).  Hardware id -> (xcd = id % 8,
+    // slot = id / 8): image = 8 (slot / blocks per image) + xcd, block = slot % blocks per image -- a bijection when B % 8 == 0.
+    int b = blockIdx.y;
+    unsigned bx = blockIdx.x;
+    if ((gridDim.y & 7u) == 0u) {
+        const unsigned id = blockIdx.x + gridDim.x * blockIdx.y, slot = id >> 3;
+        b = (int)((slot / gridDim.x) * 8u + (id & 7u));
+        bx = slot % gridDim.x;
+    }
     for (int i = lane; i < NCOL; i += 64) { hI[wave][i] = 0.f; hT[wave][i] = 0.f; redP[wave][i] = 0.f; }
     const float wAL = tap_weight(gq, ((c >> 2) + 0.5f) * 0.25f, ((c & 3) + 0.5f) * 0.25f) * LS_LOG2E;
     const int kl = c & 3, pc = c >> 2;
@@ -513,7 +523,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
     float cel = 0.f, wsum = 0.f, nvalid = 0.f;
     bool bad = false, slow = false;
     const int stride = gridDim.x * 4;
-    int cell = blockIdx.x * 4 + wave;
+    int cell = (int)bx * 4 + wave;
     // the wave's cells are cell, cell + stride, cell + 2 stride, ...: their (row, column) advance by a fixed step with one carry --
     // no division per cell (it was two per cell: the cell's own and the prefetched one's, ~45 scalar instructions)
     const int dq = stride / ncx, dr = stride - dq * ncx;
@@ -636,7 +646,7 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
     const float ce = LS_LN2 * wave_sum_all(cel), ws = wave_sum_all(wsum), nv = wave_sum_all(nvalid);
     if (lane == 0) { redS[wave][0] = ce; redS[wave][1] = ws; redS[wave][2] = nv; redS[wave][3] = __any(bad) ? 1.f : 0.f; }
     __syncthreads();
-    float* dst = partial + ((int64_t)blockIdx.x * g.B + b) * (3 * g.C + 4);
+    float* dst = partial + ((int64_t)bx * g.B + b) * (3 * g.C + 4);
     for (int i = threadIdx.x; i < NCOL; i += LS_THREADS) {
         if (i < g.C) {
             dst[i] = (hI[0][i] + hI[1][i]) + (hI[2][i] + hI[3][i]);
