@@ -2,9 +2,11 @@
 # One gpurun call that produces the round's measurement artefacts under gpurun_out/m/ (copied into profiles/ afterwards):
 #   tools/measure_round.sh <tag> [sections]     e.g. r03 "main small cfgs parity" (default: all four)
 # default bench line (with the CPU baseline), kernel stats of the same command, PMC traffic (two passes), small-batch lines,
-# the other BASELINE configs.
+# the other BASELINE configs.  Run it as the LAST act of a round, on the committed sources: the counter file it leaves in
+# profiles/pmc_traffic_b128.json is stamped with one hash per reported kernel (bench.KERNEL_SOURCES) and bench.py reports a kernel's
+# traffic only while ITS sources are unchanged (r04's closing commit touched gemm.hip and voided the loss kernel's figure too).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 SECTIONS=${2:-main small cfgs parity}
 has() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 R=$GRAFT_REPO_ROOT
