@@ -47,10 +47,10 @@ struct Gemm8Args {
     const float* bias;               // [N] (bf16 output only)
     const bf16_t* residual; int64_t ldr; const float* rscale; int64_t rpg;      // C = residual + rscale[m / rpg] * (...)
     float* ws;                       // [z][M][N] fp32 when gridDim.z > 1
-    int korder;                      // CONV gather on A: 1 = K walks (channel block, tap), 0 = (tap, channel block) as the weights store it
-    unsigned kmagic, kper;           // korder 0: K tiles per tap and floor(2^32 / kper) + 1 (tile / kper by multiply-high)
     int tile_order;                  // CONV gather on B (weight gradient): 1 = the taps / row tiles of a channel block are launch neighbours
     int stagger;                     // 1 = waves 4-7 run one barrier behind waves 0-3 (see the main loop)
+    const unsigned char* zero;       // the zero page (CONV border taps); a kernel argument so that it sits in scalar registers -- as a global it
+                                     // was re-materialised (s_getpc_b64 + two adds + two moves) in front of every gathered load
 };
 // the zero page of the CONV border taps: LDS-DMA cannot write zeros itself, so lanes whose tap lies outside the image load from here
 __device__ __attribute__((aligned(256))) unsigned char g8_zero_page[256];
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     // counters do not show the L2 reuse this was meant to buy (FETCH_SIZE unchanged at ~20 M KB per launch), so the gain is elsewhere
     // (the scalar position arithmetic is a multiply-shift by the constant 9 here, by a run-time reciprocal there).
     // (The weight operand's K tile is then the 128-byte piece at (tap, channel block) of its row: a strided walk over the same bytes.)
-    const int64_t cv_row = CONV_A ? (int64_t)a.csign * a.lda * 2 : 0;          // bytes per pixel step, signed
+    const int cv_row32 = CONV_A ? a.csign * (int)a.lda * 2 : 0;               // bytes per pixel step, signed
     // RM operands (bf16): per-lane fragment addresses inside a half-tile, one per 16-column block of this wave (g8_frag_tr)
     uint32_t trA[4], trB[2];
     if (ALAY == 1 || BLAY == 1) {
@@ -205,7 +205,10 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         if (ALAY >= 1) rmoffA[i] = (uint32_t)((int64_t)(rm_row + RM_STEP * i) * a.lda * EBR + 16 * rm_chunk[i]);
         if (BLAY >= 1) rmoffB[i] = (uint32_t)((int64_t)(rm_row + RM_STEP * i) * a.ldb * EBR + 16 * rm_chunk[i]);
     }
-    int tdy[2], tdx[2], tci[2], py[2][2], px[2][2];
+    // (r05: ONE coordinate state for both halves.  B1 is always staged one K tile ahead of B0 -- prologue B1[0], B0[0], B1[1]; loop B0[kt + 1] in
+    // phase 1, B1[kt + 2] in phase 4 -- so the state holds "B0's next tile": a B0 stage uses it and advances it, the B1 stage that follows
+    // uses it as it stands.  Per K tile that is one coordinate update per staged row instead of two.)
+    int tdy[2], tdx[2], tci[2], py[2], px[2];
     int adv_q = 0, adv_r = 0;
     if (CONV_B) {
 #pragma unroll
@@ -218,38 +221,47 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         for (int i = 0; i < 2; ++i) {
             const int64_t t = kbeg + rm_row + RM_STEP * i;
             const int x = (int)(t % a.cW), y = (int)((t / a.cW) % a.cH);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { py[h][i] = y; px[h][i] = x; }
+            py[i] = y; px[i] = x;
         }
         adv_q = (KT / a.cW) % a.cH; adv_r = KT % a.cW;                      // y advances modulo the image height: one conditional wrap
     }
     auto lds_half = [&](int buf, int half) -> unsigned char* { return smem + buf * G8_BUF + half * G8_HALF; };
     // half: 0 = A0, 1 = A1, 2 = B0, 3 = B1.  The address uses the K tile clamped to the last one, the destination the tile's own buffer
-    auto stage = [&](int kt, int half) {
+    // CONV_A: where K tile T sits in the (channel block, tap) walk -- the gathered operand's byte offset from a row's own pixel, the weight
+    // row's byte offset, the tap's bit in the rows' validity masks.  Computed ONCE per K tile (r05; it was recomputed by each of the four
+    // half-stages: a multiply-high, two multiplies and the offset arithmetic, 4 x ~20 scalar instructions per K tile in the read sections
+    // that the partner wave's MFMA section has to cover) and handed to the stages of that tile.
+    struct G8Pos { int offA, offB; unsigned tap; };
+    auto pos_of = [&](int kt) -> G8Pos {
+        G8Pos p = {0, 0, 0u};
+        if (CONV_A) {
+            const int ktc = kt < nk ? kt : nk - 1;
+            const unsigned kabs = (unsigned)ktc + (unsigned)(kbeg / KT);          // (split-K: this slice starts at tile kbeg / KT of the walk)
+            const unsigned chb = __umulhi(kabs, 0x38E38E39u) >> 1, tap = kabs - 9u * chb;       // / 9 by multiply-shift
+            const int t3 = (int)((tap * 11u) >> 5);                                // tap / 3 for tap < 9
+            // (32-bit: the offset is relative to the row's own pixel, |(cW + 1) lda 2| < 2^31 is checked on the host)
+            p.offA = ((t3 - 1) * a.cW + ((int)tap - 3 * t3 - 1)) * cv_row32 + (int)chb * 128;
+            p.offB = ((int)tap * a.cC + (int)chb * 64) * 2;
+            p.tap = tap;
+        }
+        return p;
+    };
+    auto stage = [&](int kt, int half, const G8Pos& pos) {
         const int ktc = kt < nk ? kt : nk - 1;
         const bool isA = half < 2;
         const int h = half & 1;
         if ((isA ? ALAY : BLAY) == 0) {
             unsigned char* dst = lds_half(kt & 1, half) + (16 * wave) * 128;
             if (CONV_A) {
-                // wave-uniform (scalar): channel block and tap of K tile ktc; / 9 and / 3 by multiply-shift
-                // (split-K over the gathered K walk: this slice starts at tile kbeg / KT of the (channel block, tap) sequence)
-                const unsigned kabs = (unsigned)ktc + (unsigned)(kbeg / KT);
-                unsigned chb, tap;
-                if (a.korder) { chb = __umulhi(kabs, 0x38E38E39u) >> 1; tap = kabs - 9u * chb; }
-                else { tap = __umulhi(kabs, a.kmagic); chb = kabs - tap * a.kper; }
                 if (isA) {
-                    const int t3 = (int)((tap * 11u) >> 5);                             // tap / 3 for tap < 9
-                    const int64_t off = (int64_t)((t3 - 1) * a.cW + ((int)tap - 3 * t3 - 1)) * cv_row + (int64_t)chb * 128;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const unsigned char* p = ((amask[h][i] >> tap) & 1u) ? gA[h][i] + off : g8_zero_page;
+                        const unsigned char* p = ((amask[h][i] >> pos.tap) & 1u) ? gA[h][i] + pos.offA : a.zero;
                         G8_GLDS(p, dst + i * 1024);
                     }
                 } else {
-                    const int64_t off = ((int64_t)tap * a.cC + (int64_t)chb * 64) * 2;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) G8_GLDS(gB[h][i] + off, dst + i * 1024);
+                    for (int i = 0; i < 2; ++i) G8_GLDS(gB[h][i] + pos.offB, dst + i * 1024);
                 }
             } else {
 #pragma unroll
@@ -270,14 +282,16 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                 const unsigned char* base = a.B + ((t0 + (int64_t)tdy[h] * a.cW + tdx[h]) * a.ldb + tci[h]) * EB;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int yy = py[h][i] + tdy[h], xx = px[h][i] + tdx[h];
+                    const int yy = py[i] + tdy[h], xx = px[i] + tdx[h];
                     const bool ok = real && (unsigned)yy < (unsigned)a.cH && (unsigned)xx < (unsigned)a.cW;
-                    const void* src = ok ? (const void*)(base + rmoffB[i]) : (const void*)g8_zero_page;
+                    const void* src = ok ? (const void*)(base + rmoffB[i]) : (const void*)a.zero;
                     G8_GLDS(src, dst + i * 1024);
-                    int nx = px[h][i] + adv_r, ny = py[h][i] + adv_q;
-                    if (nx >= a.cW) { nx -= a.cW; ++ny; }
-                    if (ny >= a.cH) ny -= a.cH;
-                    px[h][i] = nx; py[h][i] = ny;
+                    if (h == 0) {                                   // (B0: the state moves on to the next K tile)
+                        int nx = px[i] + adv_r, ny = py[i] + adv_q;
+                        if (nx >= a.cW) { nx -= a.cW; ++ny; }
+                        if (ny >= a.cH) ny -= a.cH;
+                        px[i] = nx; py[i] = ny;
+                    }
                 }
             }
         }
@@ -361,7 +375,12 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     };
 
     // ---- prologue: K tiles 0 and 1 in the steady-state issue order A0, B1, B0, A1 | A0, B1 (B0[1], A1[1] follow in phases 1, 2)
-    stage(0, 0); stage(0, 3); stage(0, 2); stage(0, 1); stage(1, 0); stage(1, 3);
+    G8Pos p1;                                                           // position of K tile kt + 1 (carried from iteration to iteration)
+    {
+        const G8Pos p0 = pos_of(0);
+        p1 = pos_of(1);
+        stage(0, 0, p0); stage(0, 3, p0); stage(0, 2, p0); stage(0, 1, p0); stage(1, 0, p1); stage(1, 3, p1);
+    }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 // all of K tile 0 has landed (this wave's share)
     G8_BAR();
     // STAGGER: waves 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so that on every SIMD one wave is in its MFMA
@@ -376,25 +395,27 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
         const int b = kt & 1;
         // phase 1: quadrant (m0, n0)
         load_a(b, I0); load_b(b, I0, fb0);
-        stage(kt + 1, 2);
+        stage(kt + 1, 2, p1);
         G8_BAR(); G8_LGKM0();
         mma(0, 0, fb0);
         G8_BAR();
         // phase 2: quadrant (m0, n1)
         load_b(b, I1, fb1);
-        stage(kt + 1, 1);
+        stage(kt + 1, 1, p1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // A1[kt] (read in phase 3)
         G8_BAR(); G8_LGKM0();
         mma(0, 1, fb1);
         G8_BAR();
         // phase 3: quadrant (m1, n1)
         load_a(b, I1);
-        stage(kt + 2, 0);
+        const G8Pos p2 = pos_of(kt + 2);
+        stage(kt + 2, 0, p2);
         G8_BAR(); G8_LGKM0();
         mma(1, 1, fb1);
         G8_BAR();
         // phase 4: quadrant (m1, n0)
-        stage(kt + 2, 3);
+        stage(kt + 2, 3, p2);
+        p1 = p2;
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");             // A0[kt+1], B1[kt+1], B0[kt+1] have landed: read from the next phase on
         G8_BAR();
         mma(1, 0, fb0);
@@ -478,14 +499,23 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     if (kind < 2 && split_k != 1 && !(conv && kind == 0 && !fp8 && ws)) return SEGF_ERR_SHAPE;      // (the gathered forward has a split-K form)
     if (M % 256 && !(conv && kind == 0)) return SEGF_ERR_SHAPE;
     if (conv && kind < 2 && kchunk != K && (fp8 || split_k < 2 || !ws || bias || residual)) return SEGF_ERR_SHAPE;      // gathered forward / data gradient: all of K, or fp32 split-K partials (bf16 operands, plain epilogue)
+    if (conv && kind < 2 && ((int64_t)(cW + 1) * lda * 2 >= (1ll << 31) || (int64_t)9 * cC * 2 >= (1ll << 31))) return SEGF_ERR_SHAPE;      // 32-bit tap offsets in the gather
     Gemm8Args a{(const unsigned char*)A, (const unsigned char*)B, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, csign, f8_sa, f8_sb, bias,
-                (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr, 1, 0u, 1u, 1, 1};
+                (const bf16_t*)residual, ldr, rscale, rpg > 0 ? rpg : 1, split_k > 1 ? ws : nullptr, 1, 1, nullptr};
+    {   // device address of the zero page, looked up once per process (a plain pointer: a repeated first lookup is harmless)
+        static const unsigned char* zero_page = nullptr;
+        if (!zero_page && !segf_trace().dry) {
+            void* zp = nullptr;
+            if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g8_zero_page)) != hipSuccess || !zp) return SEGF_ERR_SHAPE;
+            zero_page = (const unsigned char*)zp;
+        }
+        a.zero = zero_page;
+    }
     // fp8 operands: on some MI355X devices the staggered schedule (26 % fewer cycles) makes the chip drop its clock from 2.4 to 1.5 GHz
     // and ends up SLOWER than the lockstep one (12.7 vs 10.9 ms on the UPerHead bottleneck; 8.3 ms on devices that hold their clock).
     // g8_stagger_fp8 is set per process by the host layer after timing both on the device at hand (hip.py: autotune_gemm8_fp8).
     if (fp8) a.stagger = POL(g8_stagger_fp8);        // (segf_gemm8_option, policy.hip)
     if (POL(g8_stagger) >= 0) a.stagger = POL(g8_stagger);
-    if (conv && kind < 2 && cC > 0) { a.kper = (unsigned)(cC / 64); a.kmagic = (unsigned)(0x100000000ull / a.kper) + 1u; }
     const dim3 grid((unsigned)(N / 256), (unsigned)((M + 255) / 256), (unsigned)split_k);      // (a ragged last row tile: the gathered forward only)
 #define G8_GO(...) hipLaunchKernelGGL((gemm8_kernel<__VA_ARGS__>), grid, dim3(512), 0, st, a)
     if (kind == 0) {

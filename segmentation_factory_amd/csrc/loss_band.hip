@@ -460,17 +460,13 @@ __global__ void __launch_bounds__(LS_THREADS) ce_dice_fwd_band_kernel(const bf16
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, gq = lane >> 4;
-    // XCD-aware (image, block) assignment: the workgroups of ONE image run on ONE XCD.  Every tap row is read by the four cells
-    // around it, i.e. by waves of different workgroups; dealt round-robin, an image's 128 workgroups sit on all eight XCDs and every
-    // L2 fetches the whole image from the fabric (counter traffic was 1.94x the algorithmic bytes).  Hardware id -> (xcd = id % 8,
-    // slot = id / 8): image = 8 (slot / blocks per image) + xcd, block = slot % blocks per image -- a bijection when B % 8 == 0.
-    int b = blockIdx.y;
-    unsigned bx = blockIdx.x;
-    if ((gridDim.y & 7u) == 0u) {
-        const unsigned id = blockIdx.x + gridDim.x * blockIdx.y, slot = id >> 3;
-        b = (int)((slot / gridDim.x) * 8u + (id & 7u));
-        bx = slot % gridDim.x;
-    }
+    // (r05 experiment, removed: one image per XCD -- hardware id -> (xcd = id % 8, slot = id / 8), image = 8 (slot / blocks per image) +
+    // xcd.  Every tap row is read by the four cells around it, i.e. by waves of different workgroups, and an image's 128 workgroups sit on
+    // all eight XCDs, so every L2 fetches the whole image: with the remap the counter traffic fell 1.74 -> 1.34 GB per launch at batch
+    // 128 -- and the launch got 3.5 % SLOWER in the captured step (1.358 -> 1.405 ms): the kernel is bound by VALU issue, not by what it
+    // fetches, and sixteen images queued behind each other on one XCD end less evenly than 128 images dealt over all of them.)
+    const int b = blockIdx.y;
+    const unsigned bx = blockIdx.x;
     for (int i = lane; i < NCOL; i += 64) { hI[wave][i] = 0.f; hT[wave][i] = 0.f; redP[wave][i] = 0.f; }
     const float wAL = tap_weight(gq, ((c >> 2) + 0.5f) * 0.25f, ((c & 3) + 0.5f) * 0.25f) * LS_LOG2E;
     const int kl = c & 3, pc = c >> 2;
