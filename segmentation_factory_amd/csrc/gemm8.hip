@@ -106,6 +106,25 @@ __device__ __forceinline__ g8_bf16x8 g8_frag_tr8(const unsigned char* tile, int 
     return __builtin_bit_cast(g8_bf16x8, g8_v4i{lo[0], lo[1], hi[0], hi[1]});
 }
 
+// The same read with the per-lane address split as for bf16 (r05): the swizzle term f(r) of rows r = 32 g + 16 s + q (+ 8) does not depend on
+// s or on the + 8 ((r >> 1) & 3 = (q >> 1) & 3, r >> 5 = g), so ONE base per 16-column block and lane, computed once per kernel, serves all
+// four reads of a fragment pair through immediates (+ 1024 for rows + 8, + 2048 for K sub-step 1, + the half-tile's own offset) -- the
+// form above recomputed two addresses per fragment, 48 vector adds per K tile in the read sections.
+__device__ __forceinline__ uint32_t g8_tr8_base(int cb, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 1, p = lane & 1, c = cb >> 4;
+    const int r0 = 32 * g + q;
+    return (uint32_t)(r0 * 128 + ((c ^ g8_rm8_swz(r0)) << 4) + 8 * p);
+}
+template <int OFF>
+__device__ __forceinline__ g8_bf16x8 g8_frag_tr8i(uint32_t addr) {
+    typedef int g8_v2i __attribute__((ext_vector_type(2)));
+    typedef int g8_v4i __attribute__((ext_vector_type(4)));
+    g8_v2i lo, hi;
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(OFF));
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(OFF + 1024));
+    return __builtin_bit_cast(g8_bf16x8, g8_v4i{lo[0], lo[1], hi[0], hi[1]});
+}
+
 // ALAY / BLAY: 0 = KC, 1 = RM (bf16), 2 = RM fp8 (K tile = 128 rows).  CONV gathers A when ALAY == 0 (forward / data gradient), B when
 // both are RM (weight gradient).
 template <int ALAY, int BLAY, bool CONV, int FP8, typename OutT>
@@ -195,6 +214,13 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) trB[u] = sb + g8_tr_base(32 * wn + 16 * u, lane);
     }
+    if (ALAY == 2) {
+        const uint32_t sb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)smem;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) trA[t] = sb + g8_tr8_base(64 * wm + 16 * t, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) trB[u] = sb + g8_tr8_base(32 * wn + 16 * u, lane);
+    }
     // CONV_B: tap of each B half (workgroup constant) and the pixel coordinates of this lane's two rows at the NEXT K tile of each
     // half (the tiles of a half are staged in increasing order), advanced by 64 pixels per tile without a division
     // RM staging: a lane's byte offset inside the (wave-uniform) K tile of each operand -- the tile's own position is scalar arithmetic
@@ -278,12 +304,13 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) G8_GLDS(base + (isA ? rmoffA[i] : rmoffB[i]), dst + i * 1024);
             } else {
-                const bool real = kt < nk;                              // wave-uniform: past the end only a dummy load (zero page)
+                // past the last K tile only a dummy load (zero page): folded into the row bound (a scalar select) instead of a branch
+                const unsigned lim_h = kt < nk ? (unsigned)a.cH : 0u;
                 const unsigned char* base = a.B + ((t0 + (int64_t)tdy[h] * a.cW + tdx[h]) * a.ldb + tci[h]) * EB;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int yy = py[i] + tdy[h], xx = px[i] + tdx[h];
-                    const bool ok = real && (unsigned)yy < (unsigned)a.cH && (unsigned)xx < (unsigned)a.cW;
+                    const bool ok = (unsigned)yy < lim_h && (unsigned)xx < (unsigned)a.cW;
                     const void* src = ok ? (const void*)(base + rmoffB[i]) : (const void*)a.zero;
                     G8_GLDS(src, dst + i * 1024);
                     if (h == 0) {                                   // (B0: the state moves on to the next K tile)
@@ -312,13 +339,20 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                 fa[t][0] = g8_frag_tr<MQ * G8_HALF>(va);
                 fa[t][1] = g8_frag_tr<MQ * G8_HALF + 8192>(va);
             }
+        } else if constexpr (ALAY == 2) {
+            const uint32_t bo = (uint32_t)buf << 16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t va = trA[t] + bo;
+                fa[t][0] = g8_frag_tr8i<MQ * G8_HALF>(va);
+                fa[t][1] = g8_frag_tr8i<MQ * G8_HALF + 2048>(va);
+            }
         } else {
             const unsigned char* h = lds_half(buf, MQ);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    fa[t][s] = ALAY == 0 ? g8_frag_kc(h, 64 * wm + 16 * t, s, lane) : g8_frag_tr8(h, 64 * wm + 16 * t, s, lane);
+                for (int s = 0; s < 2; ++s) fa[t][s] = g8_frag_kc(h, 64 * wm + 16 * t, s, lane);
         }
     };
     auto load_b = [&](int buf, auto nqc, g8_bf16x8 (&fb)[2][2]) {
@@ -331,13 +365,20 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                 fb[u][0] = g8_frag_tr<(2 + NQ) * G8_HALF>(va);
                 fb[u][1] = g8_frag_tr<(2 + NQ) * G8_HALF + 8192>(va);
             }
+        } else if constexpr (BLAY == 2) {
+            const uint32_t bo = (uint32_t)buf << 16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t va = trB[u] + bo;
+                fb[u][0] = g8_frag_tr8i<(2 + NQ) * G8_HALF>(va);
+                fb[u][1] = g8_frag_tr8i<(2 + NQ) * G8_HALF + 2048>(va);
+            }
         } else {
             const unsigned char* h = lds_half(buf, 2 + NQ);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    fb[u][s] = BLAY == 0 ? g8_frag_kc(h, 32 * wn + 16 * u, s, lane) : g8_frag_tr8(h, 32 * wn + 16 * u, s, lane);
+                for (int s = 0; s < 2; ++s) fb[u][s] = g8_frag_kc(h, 32 * wn + 16 * u, s, lane);
         }
     };
     auto mma = [&](int mq, int nq, const g8_bf16x8 (&fb)[2][2]) {
