@@ -18,6 +18,7 @@ BatchNorm stays per-rank, as in the reference (plain nn.BatchNorm2d, no SyncBN).
 """
 import collections
 import contextlib
+import gc
 import os
 
 import torch
@@ -73,6 +74,25 @@ def broadcast_buffers_(module, src: int = 0, group=None):
     return n
 
 
+@contextlib.contextmanager
+def _capture(graph):
+    """torch.cuda.graph(graph) with the cyclic garbage collector held off for the length of the capture.  On ROCm the destructor of
+    a torch CUDAGraph synchronises the DEVICE, which is illegal while this thread captures: an older graph (a previous model's
+    train step, an evicted eval graph) that the collector happens to free between two captured launches throws out of a
+    destructor and the process aborts ("Fatal Python error: Aborted ... Garbage-collecting", seen once in four full test runs).
+    Collect BEFORE the capture, at a point where a device synchronise is harmless, then keep the collector off until it ends."""
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        # thread_local: RCCL's watchdog thread polls events while we capture; in the default global mode that aborts the capture
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
 def _storage_signature(module):
     """Changes when any parameter / buffer moves (the optimizer re-homing parameters into its flat buffer, .to(), load into new
     tensors): captured graphs hold raw addresses."""
@@ -98,7 +118,7 @@ class GraphedEvalForward:
                 core.forward_lowres(self.x)
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+        with _capture(self.graph):
             self.out = core.forward_lowres(self.x)
 
     def __call__(self, images):
@@ -289,10 +309,9 @@ class GraphedTrainStep:
         for p in self.model.parameters():
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        # thread_local: RCCL's watchdog thread polls events while we capture; in the default global mode that aborts the capture
         self._capturing = True
         self._reset_pending()
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+        with _capture(self.graph):
             self.loss = self._forward_backward_eager()
             self.opt.gather_grads()          # only gradients that arrived as .grad (foreign plugin modules); normally nothing
         self._capturing = False

@@ -1137,6 +1137,36 @@ def test_graphed_eval_session_capture_policy():
         model.set_compute_dtype(torch.bfloat16)
 
 
+def test_capture_collects_dead_graphs_first_and_holds_the_collector_off():
+    """A torch CUDAGraph's destructor synchronises the device on ROCm -- illegal inside a capture, and an exception out of a
+    destructor aborts the process.  A dead graph kept alive only by a reference cycle (a dropped model <-> its graphed step) must
+    therefore be freed BEFORE the next capture starts, and the cyclic collector must not run during it (graph._capture)."""
+    import gc
+    import weakref
+    from segmentation_factory_amd.graph import GraphedEvalForward
+    model = _build('MiT-B0', 'SegFormerHead', 5, OW.make_state_dict('MiT-B0', 'SegFormerHead', 5, 9), torch.bfloat16, 1).eval()
+    x = torch.randn(1, 3, 64, 96).cuda()
+    seen = []
+    orig = model.forward_lowres
+
+    def spying(inp):
+        seen.append(gc.isenabled())
+        return orig(inp)
+    with torch.inference_mode():
+        old = GraphedEvalForward(model, x)
+        ring = [old]
+        ring.append(ring)                       # only the cyclic collector can free `old` now
+        dead = weakref.ref(old)
+        del old, ring
+        model.forward_lowres = spying
+        try:
+            new = GraphedEvalForward(model, x)   # warm-up call (collector on), captured call (collector off)
+        finally:
+            del model.forward_lowres
+        assert dead() is None and seen == [True, False] and gc.isenabled()
+        assert torch.equal(new(x).data, model.forward_lowres(x).data)
+
+
 @pytest.mark.parametrize('family', ['segformer', 'convnext_uper', 'mbv2_fpn'])
 def test_evaluate_batch1_over_odd_sizes_against_oracle(family):
     """What `evaluate` sees in a real run (datasets/build_datasets.py:24-29: ExtResize keeps the aspect ratio; train_gpu.py:72:
