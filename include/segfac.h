@@ -533,7 +533,11 @@ int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, i
  *   SEGFAC_NO_WIDE_REDUCE        split-K partials of large outputs summed by the 16 x 16 form instead of whole rows
  *   SEGFAC_NO_REDUCE4            split-K reduce: one output per thread instead of four (bitwise the same sums)
  *   SEGFAC_GEMM_F32_NO_MFMA      fp32 storage (exact-parity mode, evaluate): products on the vector FMA kernel instead of the f32 matrix instruction
- *   SEGFAC_GEMM8_LINEAR          OPT-IN: plain nn.Linear products with whole 256 x 256 tiles on the eight-phase kernel (loses 0.5 - 2 % on the BASELINE models)
+ *   SEGFAC_GEMM8_LINEAR          0: plain nn.Linear products never take the eight-phase kernel (the 256 / 128 tile kernels as in r04)  (default 1)
+ *   SEGFAC_GEMM8_LINEAR_MIN_TILES fewest 256 x 256 tiles for which a K >= 2048 nn.Linear product takes the eight-phase kernel (192 for shorter K)  (default 128)
+ *   SEGFAC_GEMM8_LINEAR_MIN_FILL smallest share (percent) of the launched 256 x 256 tiles that must be output for an nn.Linear product with ragged last tiles to take the eight-phase kernel  (default 60)
+ *   SEGFAC_GEMM8_LINEAR_MIN_K    shortest reduction for which an nn.Linear product takes the eight-phase kernel (its 12-load prologue and drain against K / 64 tiles)  (default 256)
+ *   SEGFAC_GEMM8_LINEAR_MIN_GFLOP smallest nn.Linear product (GFLOP, K >= 512; 100 for shorter K) that takes the eight-phase kernel  (default 36)
  *   SEGFAC_NO_GEMM8              no eight-phase kernel at all (gemm8_kernel): the two-phase 256-tile kernel everywhere
  *   SEGFAC_NO_GEMM8T             no eight-phase kernel for weight gradients (reduction-major operands)
  *   SEGFAC_CONV_NO_FWD_SPLIT     3 x 3 forward / data gradient with few output tiles: no split over the (channel block, tap) walk

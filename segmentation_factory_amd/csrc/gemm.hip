@@ -2048,6 +2048,7 @@ extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
 struct GemmPro { const float* scale; const float* shift; int64_t rpg; int64_t ld; int act; };
 // gemm8.hip: the eight-phase 256 x 256 tile (LDS-DMA staging, counted waits).  kind 0 / 1 / 2 = layout 0 / 1 / 2; conv = implicit 3x3
 int gemm8_supported(int kind, int conv, int64_t M, int64_t N, int64_t K, int64_t kchunk, int cC);
+int gemm8_linear_ok(int64_t M, int64_t N, int64_t K, int64_t kchunk);
 int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, int64_t kchunk, int split_k, const void* A, int64_t lda,
                  const void* B, int64_t ldb, void* C, int64_t ldc, int cH, int cW, int cC, int csign, const float* f8_sa,
                  const float* f8_sb, const float* bias, const void* residual, int64_t ldr, const float* rscale, int64_t rpg, float* ws,
@@ -2333,18 +2334,31 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                 if (ok) { SEGF_CHECK_LAUNCH(); goto reduce; }
             }
         }
-        // the eight-phase tile (gemm8.hip) for whole 256 x 256 tiles with plain epilogues -- OPT-IN (SEGFAC_GEMM8_LINEAR=1): correct
-        // (tests), but on the nn.Linear shapes of the BASELINE models (K = 6 .. 48 tiles of 64) its 12-load prologue, the drain
-        // at the end and the direct 8-byte stores of its epilogue eat what the schedule gains: cfg3 247 -> 242, cfg4 114.2 -> 113.5,
-        // cfg5 76.5 -> 76.1 img/s with it; the convolutions (K = 108 .. 648 tiles) are where it pays
-        if (!pro && a.use_tr && !colsum && (a.a_vec & 1) && (a.b_vec & 1) && gemm_use_big(layout, M, N, K) && POL(gemm8_linear)) {
+        // the eight-phase tile (gemm8.hip) for nn.Linear products with plain epilogues.  r03 measured it as a loss on every BASELINE model
+        // (12-load prologue, drain, direct 8-byte stores against 4 .. 48 K tiles); after the read-section diet of r05 it wins wherever it
+        // has >= 192 tiles to run, from K = 256 on, ragged last tiles included (tools/probe/linear8_probe.py, same process, us:
+        // [12800 x 3072] K = 768 102 -> 84; [12800 x 768] K = 3072 (150 tiles) 98 -> 69; [51200 x 384] K = 1536 (75 % of the launched tiles
+        // are output) 108 -> 77; [131072 x 320] K = 1280 (62.5 %) 219 -> 152; [131072 x 1280] K = 320 220 -> 197; [3200 x 6144] K = 1536
+        // 106 -> 80; [32768 x 512] K = 2048 74 -> 57 = 1.21 PFLOP/s).  Not taken: fewer than 128 tiles (78 .. 96 tiles: -2 .. +6 %), and
+        // 128 .. 191 tiles unless K >= 2048.  SEGFAC_GEMM8_LINEAR=0 switches it off (cfg5 101.8 -> 98.9 images/s, same box).
+        if (!pro && a.use_tr && !colsum && (a.a_vec & 1) && (a.b_vec & 1) && POL(gemm8_linear) && M > 128 && N > 128) {
             const bool f32o8 = c_dt == SEGF_F32 || a.ws;
-            if (layout != 2 && !f32o8 && split_k == 1 && gemm8_supported(layout, 0, M, N, K, a.kchunk, 0) && (!residual || a.r_vec)) {
+            // whole-tile count the launch pays for, and the share of it that is output (ragged last tiles: [51200 x 384] = 75 %)
+            const int64_t tiles8 = cdiv64(M, 256) * cdiv64(N, 256);
+            const bool dense = 100 * M * N >= (int64_t)POL(gemm8_linear_min_fill) * tiles8 * 65536;
+            // ... and only where the gain pays for what a launch of this kernel costs the kernels AFTER it (in-situ traces of the cfg2 / cfg4
+            // step, tools/probe/trace_ab.sh: the launches that followed an eight-phase launch ran 3 - 10 % longer -- the chip gives clock back
+            // after the dense MFMA burst -- ~10 us per launch summed over the step): the gain is ~20 - 30 % of the product's time, i.e. worth it
+            // from ~36 GFLOP on (K >= 512) and, for the 4 - 7 K tiles of a shorter reduction, from ~100 GFLOP on.
+            const double gflop = 2e-9 * (double)M * (double)N * (double)K;
+            const bool worth = gflop >= (K >= 512 ? (double)POL(gemm8_linear_min_gflop) : 100.0);
+            const bool fits = K >= POL(gemm8_linear_min_k) && dense && worth && (tiles8 >= 192 || (tiles8 >= POL(gemm8_linear_min_tiles) && K >= 2048));
+            if (layout != 2 && fits && !f32o8 && split_k == 1 && gemm8_linear_ok(M, N, K, a.kchunk) && (!residual || a.r_vec)) {
                 const int rc8 = gemm8_launch(layout, 0, 0, M, N, K, a.kchunk, 1, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, nullptr, nullptr, bias, residual,
                                              ldr, rscale, a.rpg, nullptr, st);
                 if (rc8 != SEGF_ERR_SHAPE) return rc8;
             }
-            if (layout == 2 && c_dt == SEGF_F32 && !bias && !residual && gemm8_supported(2, 0, M, N, K, a.kchunk, 0)) {
+            if (layout == 2 && gemm_use_big(layout, M, N, K) && c_dt == SEGF_F32 && !bias && !residual && gemm8_supported(2, 0, M, N, K, a.kchunk, 0)) {
                 const int rc8 = gemm8_launch(2, 0, 0, M, N, K, a.kchunk, split_k, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, nullptr, nullptr, nullptr,
                                              nullptr, 0, nullptr, 1, a.ws, st);
                 if (rc8 != SEGF_ERR_SHAPE) { if (rc8) return rc8; goto reduce; }

@@ -192,11 +192,16 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
                     amask[h][i] = m < a.M ? mk : 0u;
                     gA[h][i] = a.A + ((m < a.M ? m : 0) * a.lda + 8 * kc_chunk) * 2;           // the K position (tap, channel) joins per stage
                 } else {
-                    gA[h][i] = a.A + (m * a.lda + kbeg + 8 * kc_chunk) * 2;
+                    // (plain products with a ragged last row / column tile, r05: rows past the end re-read the last row -- finite values that
+                    // only reach accumulators the epilogue does not store)
+                    gA[h][i] = a.A + ((m < a.M ? m : a.M - 1) * a.lda + kbeg + 8 * kc_chunk) * 2;
                 }
             }
             // (CONV_A: the weight row's K position is the absolute (tap, channel block) piece of each stage -- kbeg joins there)
-            if (BLAY == 0) gB[h][i] = a.B + ((n0 + 128 * h + kc_row + 8 * i) * a.ldb + (CONV_A ? 0 : kbeg) + 8 * kc_chunk) * 2;
+            if (BLAY == 0) {
+                const int64_t n = n0 + 128 * h + kc_row + 8 * i;
+                gB[h][i] = a.B + ((CONV || n < a.N ? n : a.N - 1) * a.ldb + (CONV_A ? 0 : kbeg) + 8 * kc_chunk) * 2;
+            }
         }
     // CONV_A walks K with the CHANNEL BLOCK outermost and the nine taps innermost: K tile T = (64-channel block T / 9, tap T % 9), so
     // that the nine taps of one channel block -- the same pixels shifted by a row / a column -- are read back to back in time.  Same-
@@ -230,6 +235,20 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
     for (int i = 0; i < 2; ++i) {
         if (ALAY >= 1) rmoffA[i] = (uint32_t)((int64_t)(rm_row + RM_STEP * i) * a.lda * EBR + 16 * rm_chunk[i]);
         if (BLAY >= 1) rmoffB[i] = (uint32_t)((int64_t)(rm_row + RM_STEP * i) * a.ldb * EBR + 16 * rm_chunk[i]);
+    }
+    // layout 1 with a ragged last column tile: the 16-byte chunk of columns this lane stages must not run past the row (the very last row
+    // of B would be read past its end): such lanes re-read the row's last chunk, per half (N is a multiple of 8: host check)
+    constexpr bool RAG1 = ALAY == 0 && BLAY == 1 && !CONV;
+    int64_t rmoffB1[2] = {(int64_t)rmoffB[0], (int64_t)rmoffB[1]};          // (half 1; signed: a clamped chunk may lie before the half's base)
+    if (RAG1 && n0 + 256 > a.N) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t last = (a.N - 8) * 2;                                   // byte offset of the row's last chunk
+            const int64_t row = (int64_t)(rm_row + RM_STEP * i) * a.ldb * 2;
+            const int64_t c0 = n0 * 2 + 16 * rm_chunk[i], c1 = c0 + 256;          // this lane's chunk in half 0 / half 1, from the row start
+            rmoffB[i] = (uint32_t)(row + (c0 <= last ? c0 : last) - n0 * 2);
+            rmoffB1[i] = row + (c1 <= last ? c1 : last) - n0 * 2 - 256;
+        }
     }
     // (r05: ONE coordinate state for both halves.  B1 is always staged one K tile ahead of B0 -- prologue B1[0], B0[0], B1[1]; loop B0[kt + 1] in
     // phase 1, B1[kt + 2] in phase 4 -- so the state holds "B0's next tile": a B0 stage uses it and advances it, the B1 stage that follows
@@ -302,7 +321,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
             if (isA || !CONV_B) {
                 const unsigned char* base = (isA ? a.A + (t0 * a.lda + m0 + 128 * h) * EB : a.B + (t0 * a.ldb + n0 + 128 * h) * EB);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) G8_GLDS(base + (isA ? rmoffA[i] : rmoffB[i]), dst + i * 1024);
+                for (int i = 0; i < 2; ++i) G8_GLDS(base + (isA ? (int64_t)rmoffA[i] : ((RAG1 && h) ? rmoffB1[i] : (int64_t)rmoffB[i])), dst + i * 1024);
             } else {
                 // past the last K tile only a dummy load (zero page): folded into the row bound (a scalar select) instead of a branch
                 const unsigned lim_h = kt < nk ? (unsigned)a.cH : 0u;
@@ -492,6 +511,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int64_t n = n0 + 128 * nq + 32 * wn + 16 * u + 4 * fg;
+                if (!CONV && n >= a.N) continue;                                  // (ragged last column tile of a plain product; N % 4 == 0)
                 float sc[4] = {1.f, 1.f, 1.f, 1.f}, bs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -503,7 +523,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(Gemm8Args a) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int64_t m = m0 + 128 * mq + 64 * wm + 16 * t + fi;
-                        if (CONV_A && m >= a.M) continue;
+                        if ((CONV_A || (!CONV && sizeof(OutT) == 2)) && m >= a.M) continue;
                         const g8_f32x4 c = acc[2 * nq + u][4 * mq + t];
                         float v[4] = {fmaf(c[0], sc[0], bs[0]), fmaf(c[1], sc[1], bs[1]), fmaf(c[2], sc[2], bs[2]), fmaf(c[3], sc[3], bs[3])};
                         if (a.residual) {
@@ -531,6 +551,12 @@ int gemm8_supported(int kind, int conv, int64_t M, int64_t N, int64_t K, int64_t
     if (kind == 2) return POL(no_gemm8t) ? 0 : 1;
     return (M / 256) * (N / 256) >= 192;
 }
+// nn.Linear products (kind 0 / 1, no gather, bf16): any M, N a multiple of 8 -- ragged last row / column tiles (r05).  WHETHER the shape
+// should take this kernel is the caller's rule (gemm.hip: gemm_impl).
+int gemm8_linear_ok(int64_t M, int64_t N, int64_t K, int64_t kchunk) {
+    if (POL(no_gemm8)) return 0;
+    return M >= 1 && N >= 8 && N % 8 == 0 && K % 64 == 0 && kchunk % 64 == 0 && kchunk >= 256 && (M + 255) / 256 <= 65535;
+}
 int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, int64_t kchunk, int split_k, const void* A, int64_t lda,
                  const void* B, int64_t ldb, void* C, int64_t ldc, int cH, int cW, int cC, int csign, const float* f8_sa,
                  const float* f8_sb, const float* bias, const void* residual, int64_t ldr, const float* rscale, int64_t rpg, float* ws,
@@ -538,7 +564,8 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16 || (lda * (kind == 3 ? 1 : 2)) % 16 || (ldb * (kind == 3 ? 1 : 2)) % 16 || ldc % 4) return SEGF_ERR_SHAPE;
     if (residual && (((uintptr_t)residual % 8) || ldr % 4)) return SEGF_ERR_SHAPE;
     if (kind < 2 && split_k != 1 && !(conv && kind == 0 && !fp8 && ws)) return SEGF_ERR_SHAPE;      // (the gathered forward has a split-K form)
-    if (M % 256 && !(conv && kind == 0)) return SEGF_ERR_SHAPE;
+    if (M % 256 && !(kind == 0 || (kind == 1 && !conv))) return SEGF_ERR_SHAPE;      // ragged last row tile: the gathered forward and the plain products
+    if (N % 256 && (conv || kind >= 2 || fp8 || N % 8)) return SEGF_ERR_SHAPE;        // ragged last column tile: plain bf16 products only
     if (conv && kind < 2 && kchunk != K && (fp8 || split_k < 2 || !ws || bias || residual)) return SEGF_ERR_SHAPE;      // gathered forward / data gradient: all of K, or fp32 split-K partials (bf16 operands, plain epilogue)
     if (conv && kind < 2 && ((int64_t)(cW + 1) * lda * 2 >= (1ll << 31) || (int64_t)9 * cC * 2 >= (1ll << 31))) return SEGF_ERR_SHAPE;      // 32-bit tap offsets in the gather
     Gemm8Args a{(const unsigned char*)A, (const unsigned char*)B, C, M, N, K, lda, ldb, ldc, kchunk, cH, cW, cC, csign, f8_sa, f8_sb, bias,
@@ -557,7 +584,7 @@ int gemm8_launch(int kind, int conv, int fp8, int64_t M, int64_t N, int64_t K, i
     // g8_stagger_fp8 is set per process by the host layer after timing both on the device at hand (hip.py: autotune_gemm8_fp8).
     if (fp8) a.stagger = POL(g8_stagger_fp8);        // (segf_gemm8_option, policy.hip)
     if (POL(g8_stagger) >= 0) a.stagger = POL(g8_stagger);
-    const dim3 grid((unsigned)(N / 256), (unsigned)((M + 255) / 256), (unsigned)split_k);      // (a ragged last row tile: the gathered forward only)
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((M + 255) / 256), (unsigned)split_k);
 #define G8_GO(...) hipLaunchKernelGGL((gemm8_kernel<__VA_ARGS__>), grid, dim3(512), 0, st, a)
     if (kind == 0) {
         if (conv && fp8 == 0 && split_k > 1) G8_GO(0, 0, true, 0, float);          // split-K partials [z][M][N] in ws (summed by the caller)

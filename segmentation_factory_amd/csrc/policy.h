@@ -33,7 +33,11 @@
     X(no_wide_reduce, "SEGFAC_NO_WIDE_REDUCE", 0, "split-K partials of large outputs summed by the 16 x 16 form instead of whole rows")   \
     X(no_reduce4, "SEGFAC_NO_REDUCE4", 0, "split-K reduce: one output per thread instead of four (bitwise the same sums)")               \
     X(gemm_f32_no_mfma, "SEGFAC_GEMM_F32_NO_MFMA", 0, "fp32 storage (exact-parity mode, evaluate): products on the vector FMA kernel instead of the f32 matrix instruction") \
-    X(gemm8_linear, "SEGFAC_GEMM8_LINEAR", 0, "OPT-IN: plain nn.Linear products with whole 256 x 256 tiles on the eight-phase kernel (loses 0.5 - 2 % on the BASELINE models)") \
+    X(gemm8_linear, "SEGFAC_GEMM8_LINEAR", 1, "0: plain nn.Linear products never take the eight-phase kernel (the 256 / 128 tile kernels as in r04)") \
+    X(gemm8_linear_min_tiles, "SEGFAC_GEMM8_LINEAR_MIN_TILES", 128, "fewest 256 x 256 tiles for which a K >= 2048 nn.Linear product takes the eight-phase kernel (192 for shorter K)") \
+    X(gemm8_linear_min_fill, "SEGFAC_GEMM8_LINEAR_MIN_FILL", 60, "smallest share (percent) of the launched 256 x 256 tiles that must be output for an nn.Linear product with ragged last tiles to take the eight-phase kernel") \
+    X(gemm8_linear_min_k, "SEGFAC_GEMM8_LINEAR_MIN_K", 256, "shortest reduction for which an nn.Linear product takes the eight-phase kernel (its 12-load prologue and drain against K / 64 tiles)") \
+    X(gemm8_linear_min_gflop, "SEGFAC_GEMM8_LINEAR_MIN_GFLOP", 36, "smallest nn.Linear product (GFLOP, K >= 512; 100 for shorter K) that takes the eight-phase kernel") \
     /* ---- implicit-GEMM 3 x 3 convolution, eight-phase kernel, fp8 (gemm.hip, gemm8.hip, fp8.hip) ---- */                             \
     X(no_gemm8, "SEGFAC_NO_GEMM8", 0, "no eight-phase kernel at all (gemm8_kernel): the two-phase 256-tile kernel everywhere")           \
     X(no_gemm8t, "SEGFAC_NO_GEMM8T", 0, "no eight-phase kernel for weight gradients (reduction-major operands)")                         \

@@ -908,17 +908,22 @@ def test_gemm_big_tile_variant(hipmod, layout):
         assert err <= 1.2e-2 * full.abs().max().item()       # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize('ragged', [False, True])
 @pytest.mark.parametrize('layout', [0, 1, 2])
-def test_gemm_eight_phase_tile(hipmod, layout):
-    """gemm8.hip (256 x 256 tile in eight phases: LDS-DMA staging, counted waits) on whole-tile shapes of the ConvNeXt / MiT linears:
-    layout 0 with bias + residual + per-sample DropPath scale, layout 1 with a residual, layout 2 with split-K, against a float64
-    product of the bf16-rounded operands and against the two-phase 256-tile kernel (the default for plain products)."""
+def test_gemm_eight_phase_tile(hipmod, layout, ragged):
+    """gemm8.hip (256 x 256 tile in eight phases: LDS-DMA staging, counted waits) on shapes of the ConvNeXt / MiT linears -- since r05
+    the kernel plain products with K >= 512 take by default: layout 0 with bias + residual + per-sample DropPath scale, layout 1 with a
+    residual, layout 2 with split-K; whole tiles and (layouts 0 / 1) a RAGGED last row and column tile ([M x N] = [50 tiles + 72, 4 tiles
+    - 40]: rows / column chunks past the end are clamped on the load side and not stored).  Against a float64 product of the bf16-rounded
+    operands and against the two-phase 256-tile kernel (policy gemm8_linear = 0)."""
+    if layout == 2 and ragged:
+        pytest.skip('weight gradients: whole tiles only')
     g = torch.Generator().manual_seed(90 + layout)
     if layout == 2:
         M, N, K = 768, 3072, 65536 + 64 * 5
         sk = hipmod.pick_splitk(M, N, K)
     else:
-        M, N, K, sk = 256 * 50, 256 * 4, 64 * 6 if layout == 0 else 64 * 12, 1
+        M, N, K, sk = 256 * 50 + (72 if ragged else 0), 256 * 4 - (40 if ragged else 0), 64 * 8 if layout == 0 else 64 * 12, 1
     a = torch.randn((K, M) if layout == 2 else (M, K), generator=g)
     b = torch.randn((N, K) if layout == 0 else (K, N), generator=g)
     aq, bq = a.bfloat16().double(), b.bfloat16().double()
@@ -926,30 +931,39 @@ def test_gemm_eight_phase_tile(hipmod, layout):
     Bm = bq.t() if layout == 0 else bq
     ref = A @ Bm
     ad, bd = a.bfloat16().cuda(), b.bfloat16().cuda()
+    groups = (M + 255) // 256
 
     def run():
         if layout == 2:
             return hipmod.gemm(2, ad, bd, M, N, K, out_dtype=torch.float32, split_k=sk)
         bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda() if layout == 0 else None
         res = torch.randn(M, N, generator=torch.Generator().manual_seed(6)).bfloat16().cuda()
-        rs = (torch.rand(50, generator=torch.Generator().manual_seed(7)) + 0.5).cuda() if layout == 0 else None
+        rs = (torch.rand(groups, generator=torch.Generator().manual_seed(7)) + 0.5).cuda() if layout == 0 else None
         return hipmod.gemm(layout, ad, bd, M, N, K, bias=bias, residual=res, rscale=rs, rows_per_group=256 if layout == 0 else 1)
-    os.environ['SEGFAC_GEMM8_LINEAR'] = '1'              # opt-in for plain products (the convolutions take the kernel by default)
-    try:
+    with hipmod.trace() as tr:
         out = run()
-    finally:
-        os.environ.pop('SEGFAC_GEMM8_LINEAR', None)
-    old = run()
+    assert any('gemm8_kernel' in k for k in tr.kernels), tr.kernels
+    with hipmod.policy_override(gemm8_linear=0), hipmod.trace() as tr0:
+        old = run()
+    assert not any('gemm8_kernel' in k for k in tr0.kernels), tr0.kernels
     if layout == 2:
         assert (out.double().cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
         assert (out - old).abs().max().item() <= 1e-3 * old.abs().max().item()
     else:
         bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).double() if layout == 0 else 0.0
         res = torch.randn(M, N, generator=torch.Generator().manual_seed(6)).bfloat16().double()
-        rs = (torch.rand(50, generator=torch.Generator().manual_seed(7)) + 0.5).double().repeat_interleave(256)[:, None] if layout == 0 else 1.0
+        rs = (torch.rand(groups, generator=torch.Generator().manual_seed(7)) + 0.5).double().repeat_interleave(256)[:M, None] if layout == 0 else 1.0
         full = res + rs * (ref + bias)
         assert (out.double().cpu() - full).abs().max().item() <= 1.2e-2 * full.abs().max().item()
         assert (out.float() - old.float()).abs().max().item() <= 2 ** -7 * old.float().abs().max().item()
+    if ragged:           # nothing is written past the ragged edges: the same product into a view of a larger buffer filled with a sentinel
+        big = torch.full((M + 256, N + 264), 7.0, dtype=torch.bfloat16, device='cuda')
+        with hipmod.trace() as tr:
+            hipmod.gemm(layout, ad, bd, M, N, K, out=big[:M, :N])
+        assert any('gemm8_kernel' in k for k in tr.kernels), tr.kernels
+        assert bool((big[M:] == 7.0).all()) and bool((big[:, N:] == 7.0).all())
+        plain = ref.float().bfloat16()
+        assert (big[:M, :N].double().cpu() - ref).abs().max().item() <= 1.2e-2 * ref.abs().max().item(), plain.shape
 
 
 def test_gemm_streaming_whole_rows(hipmod, monkeypatch):
