@@ -730,19 +730,28 @@ template <int R> __device__ __forceinline__ bf16x8 frag_rm_tr_t(const unsigned c
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// The operand prologue on 8 bf16 values: y = act(x * sc + sh), rounded to bf16.  r05: the affine on the packed fp32 FMA (two values per
+// instruction), the activation AFTER the rounding on the packed 16-bit integer pipe -- a non-negative bf16 pattern orders like a signed
+// 16-bit integer and every negative one is < 0, so ReLU is max(pattern, 0) and the upper clamp of ReLU6 is min(pattern, bits(6.0)); both
+// commute with the (monotonic) rounding, and "no activation" is max with the most negative / min with the most positive integer:
+// 24 vector instructions per 8 values whatever `act` is (was ~54 with run-time selects: the classifier forward spent 39 % of its
+// cycles in this function against 19 % in its MFMAs).
 __device__ __forceinline__ void pro_apply(uint4& r, const float (&sc)[8], const float (&sh)[8], int act) {
-    float v[8];
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
-    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    const short lo_s = act >= 1 ? (short)0 : (short)-32768, hi_s = act == 2 ? (short)0x40C0 : (short)0x7FFF;
+    const s16x2_t lo = {lo_s, lo_s}, hi = {hi_s, hi_s};
+    uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        v[j] = fmaf(v[j], sc[j], sh[j]);
-        if (act >= 1) v[j] = fmaxf(v[j], 0.f);
-        if (act == 2) v[j] = fminf(v[j], 6.f);
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_t x = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+        const f32x2_t s2 = {sc[2 * j], sc[2 * j + 1]}, h2 = {sh[2 * j], sh[2 * j + 1]};
+        const f32x2_t y = __builtin_elementwise_fma(x, s2, h2);
+        s16x2_t q = __builtin_bit_cast(s16x2_t, pack2bf(y[0], y[1]));
+        q = __builtin_elementwise_min(__builtin_elementwise_max(q, lo), hi);
+        w[j] = __builtin_bit_cast(uint32_t, q);
     }
-    r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
+    r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3];
 }
 
 // SHAPE 0: the 8 waves as 2 (M) x 4 (N), wave tile 128 x 64.  SHAPE 1 (N <= 160, layout 0): 4 x 2 waves, wave tile 64 x 80 -- only
@@ -885,46 +894,100 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
             }
             __syncthreads();
         }
+        static_assert(!DEEP || SHAPE == 1, "DEEP: the narrow-output shape (N <= 160)");
+        // r05: THREE K steps of the streamed operand A in flight (was two), two of the weight operand B, and only the 160 weight rows the
+        // narrow shape multiplies are loaded and staged (was all 256, clamped).  The classifier forward was latency-bound: 64 KB of A in
+        // flight per CU against ~5 us of loaded-HBM latency is 3.3 TB/s over 256 CUs; 96 KB is the same latency at 1.5 x the rate.  Loads
+        // return in order, so a wait for B(t) also waits for every A issued before it: B(t + 2) is issued between A(t + 2) and A(t + 3)
+        // -- the wait in front of staging step t + 1 then leaves A(t + 2), B(t + 2), A(t + 3) in flight.  Step s lives in A set s % 3, B set
+        // s % 2, LDS buffer s & 1: the loop is unrolled six times so that every set is a fixed register array.
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 sa0[4], sb0[4], sa1[4], sb1[4];
+        u32x4 sa0[4], sa1[4], sa2[4], sb0[3], sb1[3];
         const int c8 = (threadIdx.x & 7) * 8, r0 = threadIdx.x >> 3;
-        // unconditional tile loads (rows clamped; K steps past the end re-read the last one and are never multiplied)
-#define DEEP_LOAD(SA, SB, T_)                                                                                          \
+        const bool b2 = r0 < 32;                     // weight rows 128 + r0 < 160: waves 0-3 (wave-uniform)
+        // addresses = a workgroup-uniform base (scalar registers; the K step joins there) + a per-thread 32-bit byte offset that never
+        // changes: one vector register per row instead of a 64-bit pointer and a 64-bit add per load
+        const unsigned char* baseA = reinterpret_cast<const unsigned char*>(A + m0 * a.lda + kbeg);
+        const unsigned char* baseB = reinterpret_cast<const unsigned char*>(B + n0 * a.ldb + kbeg);
+        uint32_t oa[4], ob[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t rr = r0 + (GG_THREADS / 8) * i, last = a.M - 1 - m0;
+            oa[i] = (uint32_t)(((rr < last ? rr : last) * a.lda + c8) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int64_t rr = r0 + (GG_THREADS / 8) * i, last = a.N - 1 - n0;
+            ob[i] = (uint32_t)(((rr < last ? rr : last) * a.ldb + c8) * 2);
+        }
+        // unconditional tile loads (K steps past the end re-read the last one and are never multiplied)
+#define DEEP_LOAD_A(SA, T_)                                                                                            \
         do {                                                                                                           \
-            const int64_t k_ = kbeg + (int64_t)((T_) < nk ? (T_) : nk - 1) * GB_BK + c8;                               \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
-                const int64_t ra_ = m0 + r0 + (GG_THREADS / 8) * i_, rb_ = n0 + r0 + (GG_THREADS / 8) * i_;            \
-                SA[i_] = *reinterpret_cast<const u32x4*>(A + (ra_ < a.M ? ra_ : a.M - 1) * a.lda + k_);                \
-                SB[i_] = *reinterpret_cast<const u32x4*>(B + (rb_ < a.N ? rb_ : a.N - 1) * a.ldb + k_);                \
-            }                                                                                                          \
+            const unsigned char* pk_ = baseA + (size_t)((T_) < nk ? (T_) : nk - 1) * (GB_BK * 2);                      \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) SA[i_] = *reinterpret_cast<const u32x4*>(pk_ + oa[i_]);   \
+        } while (0)
+#define DEEP_LOAD_B(SB, T_)                                                                                            \
+        do {                                                                                                           \
+            const unsigned char* pk_ = baseB + (size_t)((T_) < nk ? (T_) : nk - 1) * (GB_BK * 2);                      \
+            SB[0] = *reinterpret_cast<const u32x4*>(pk_ + ob[0]);                                                      \
+            SB[1] = *reinterpret_cast<const u32x4*>(pk_ + ob[1]);                                                      \
+            SB[2] = *reinterpret_cast<const u32x4*>(pk_ + ob[2]);        /* (rows >= 160: a clamped re-read, not staged) */ \
         } while (0)
 #define DEEP_WRITE(SA, SB, T_, BUF)                                                                                    \
         do {                                                                                                           \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
-                ra[i_] = make_uint4(SA[i_][0], SA[i_][1], SA[i_][2], SA[i_][3]);                                       \
-                rb[i_] = make_uint4(SB[i_][0], SB[i_][1], SB[i_][2], SB[i_][3]);                                       \
-            }                                                                                                          \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) ra[i_] = make_uint4(SA[i_][0], SA[i_][1], SA[i_][2], SA[i_][3]); \
             pro_k0 = kbeg + (int64_t)((T_) < nk ? (T_) : nk - 1) * GB_BK;                                              \
-            swrite(BUF);                                                                                               \
+            deep_write_a(BUF);                                                                                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                         \
+                const int row_ = r0 + (GG_THREADS / 8) * i_;                                                           \
+                if (i_ < 2 || b2)                                                                                      \
+                    *reinterpret_cast<uint4*>(smem[BUF][1] + row_ * 128 + (((threadIdx.x & 7) ^ (row_ & 7)) << 4)) =   \
+                        make_uint4(SB[i_][0], SB[i_][1], SB[i_][2], SB[i_][3]);                                        \
+            }                                                                                                          \
         } while (0)
-        DEEP_LOAD(sa0, sb0, 0);
-        DEEP_WRITE(sa0, sb0, 0, 0);
-        DEEP_LOAD(sa1, sb1, 1);
-        DEEP_LOAD(sa0, sb0, 2);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            compute(0);
-            DEEP_WRITE(sa1, sb1, kt + 1, 1);
-            DEEP_LOAD(sa1, sb1, kt + 3);
-            __syncthreads();
-            if (kt + 1 < nk) {
-                compute(1);
-                DEEP_WRITE(sa0, sb0, kt + 2, 0);
-                DEEP_LOAD(sa0, sb0, kt + 4);
-                __syncthreads();
+        auto deep_write_a = [&](int buf) {
+            if (PRO) {
+                float psc[8], psh[8];
+                int64_t f0 = pro_k0 + c8;
+                f0 = f0 + 8 <= a.pro_ld ? f0 : a.pro_ld - 8;
+                const float4 s0 = *reinterpret_cast<const float4*>(pro_lds + f0), s1 = *reinterpret_cast<const float4*>(pro_lds + f0 + 4);
+                const float4 h0 = *reinterpret_cast<const float4*>(pro_lds + 1024 + f0), h1 = *reinterpret_cast<const float4*>(pro_lds + 1024 + f0 + 4);
+                psc[0] = s0.x; psc[1] = s0.y; psc[2] = s0.z; psc[3] = s0.w; psc[4] = s1.x; psc[5] = s1.y; psc[6] = s1.z; psc[7] = s1.w;
+                psh[0] = h0.x; psh[1] = h0.y; psh[2] = h0.z; psh[3] = h0.w; psh[4] = h1.x; psh[5] = h1.y; psh[6] = h1.z; psh[7] = h1.w;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pro_apply(ra[i], psc, psh, a.pro_act);
             }
-        }
-#undef DEEP_LOAD
+            swrite_kc_t<GG_THREADS>(smem[buf][0], ra);
+        };
+        // step s computes from LDS buffer s & 1; behind it: stage step s + 1, then issue B(s + 3) and A(s + 4) into the sets just freed
+#define DEEP_STEP(KT, J, SAW, SBW)                                                                                     \
+        compute((J) & 1);                                                                                              \
+        DEEP_WRITE(SAW, SBW, (KT) + (J) + 1, ((J) + 1) & 1);                                                           \
+        DEEP_LOAD_B(SBW, (KT) + (J) + 3);                                                                              \
+        DEEP_LOAD_A(SAW, (KT) + (J) + 4);                                                                              \
+        __syncthreads();                                                                                               \
+        if ((KT) + (J) + 1 >= nk) break;
+#define DEEP_SIX(KT)                                                                                                   \
+        DEEP_STEP(KT, 0, sa1, sb1) DEEP_STEP(KT, 1, sa2, sb0) DEEP_STEP(KT, 2, sa0, sb1)                               \
+        DEEP_STEP(KT, 3, sa1, sb0) DEEP_STEP(KT, 4, sa2, sb1) DEEP_STEP(KT, 5, sa0, sb0)
+        DEEP_LOAD_B(sb0, 0);
+        DEEP_LOAD_A(sa0, 0);
+        DEEP_LOAD_B(sb1, 1);
+        DEEP_LOAD_A(sa1, 1);
+        DEEP_LOAD_A(sa2, 2);
+        DEEP_WRITE(sa0, sb0, 0, 0);
+        DEEP_LOAD_B(sb0, 2);
+        DEEP_LOAD_A(sa0, 3);
+        __syncthreads();
+        // The first 12 steps (K <= 768: the whole product) are STRAIGHT-LINE code: at a loop header the compiler's wait-count pass
+        // merges the positions of the loads in flight pessimistically and drains the queue (vmcnt(0)) once per trip -- with the two-step
+        // loop of r04 that was a full drain every other K step, which is what kept the classifier forward at 3.3 TB/s.
+        do { DEEP_SIX(0) DEEP_SIX(6) } while (0);
+        for (int kt = 12; kt < nk; kt += 6) { DEEP_SIX(kt) }
+#undef DEEP_SIX
+#undef DEEP_STEP
+#undef DEEP_LOAD_A
+#undef DEEP_LOAD_B
 #undef DEEP_WRITE
     } else {
         if (nk > 0) {

@@ -940,7 +940,7 @@ def test_gemm_eight_phase_tile(hipmod, layout, ragged):
         res = torch.randn(M, N, generator=torch.Generator().manual_seed(6)).bfloat16().cuda()
         rs = (torch.rand(groups, generator=torch.Generator().manual_seed(7)) + 0.5).cuda() if layout == 0 else None
         return hipmod.gemm(layout, ad, bd, M, N, K, bias=bias, residual=res, rscale=rs, rows_per_group=256 if layout == 0 else 1)
-    with hipmod.trace() as tr:
+    with hipmod.policy_override(gemm8_linear_min_gflop=0), hipmod.trace() as tr:          # (the dispatch rule wants >= 36 GFLOP; this is 13)
         out = run()
     assert any('gemm8_kernel' in k for k in tr.kernels), tr.kernels
     with hipmod.policy_override(gemm8_linear=0), hipmod.trace() as tr0:
@@ -958,7 +958,7 @@ def test_gemm_eight_phase_tile(hipmod, layout, ragged):
         assert (out.float() - old.float()).abs().max().item() <= 2 ** -7 * old.float().abs().max().item()
     if ragged:           # nothing is written past the ragged edges: the same product into a view of a larger buffer filled with a sentinel
         big = torch.full((M + 256, N + 264), 7.0, dtype=torch.bfloat16, device='cuda')
-        with hipmod.trace() as tr:
+        with hipmod.policy_override(gemm8_linear_min_gflop=0), hipmod.trace() as tr:
             hipmod.gemm(layout, ad, bd, M, N, K, out=big[:M, :N])
         assert any('gemm8_kernel' in k for k in tr.kernels), tr.kernels
         assert bool((big[M:] == 7.0).all()) and bool((big[:, N:] == 7.0).all())
@@ -1083,6 +1083,7 @@ def test_dwconv3x3_walk_equals_strip_form(dtype, shape, monkeypatch):
 
 
 @pytest.mark.parametrize('case', [(0, 256 * 40 + 72, 150, 768, 160), (0, 256 * 33, 160, 200, 160), (0, 256 * 34 + 8, 137, 136, 144),
+                                  (0, 256 * 20 + 8, 150, 64 * 15, 160), (0, 256 * 9 + 200, 152, 64 * 19, 152), (0, 256 * 12, 144, 64 * 5, 144),   # (the three-deep pipeline: 12 straight-line steps + the loop; an early exit)
                                   (1, 256 * 50 + 24, 160, 640, 160), (1, 256 * 49, 152, 328, 152),
                                   (2, 150, 768, 70000, 160), (2, 160, 392, 66000, 160), (2, 131, 520, 65536 + 8, 136), (2, 200, 392, 70000, 200)])
 def test_gemm_big_tile_narrow_shapes(hipmod, case, monkeypatch):

@@ -1,13 +1,13 @@
 #!/bin/bash
 # One gpurun call that produces the round's measurement artefacts under gpurun_out/m/ (copied into profiles/ afterwards):
-#   tools/measure_round.sh <tag> [sections]     e.g. r03 "main small cfgs parity" (default: all four)
+#   tools/measure_round.sh <tag> [sections]     e.g. r03 "main small cfgs parity" (default: all five)
 # default bench line (with the CPU baseline), kernel stats of the same command, PMC traffic (two passes), small-batch lines,
 # the other BASELINE configs.  Run it as the LAST act of a round, on the committed sources: the counter file it leaves in
 # profiles/pmc_traffic_b128.json is stamped with one hash per reported kernel (bench.KERNEL_SOURCES) and bench.py reports a kernel's
 # traffic only while ITS sources are unchanged (r04's closing commit touched gemm.hip and voided the loss kernel's figure too).
 set -u
 TAG=${1:-r05}
-SECTIONS=${2:-main small cfgs parity}
+SECTIONS=${2:-main small cfgs power parity}
 has() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/m
@@ -47,6 +47,41 @@ for cb in cfg3:32 cfg4:16 cfg5:8; do
   cd $R && python3 tools/pmc_traffic.py $O/pmcf_$c $O/pmcw_$c --batch $b --out $O/${TAG}_pmc_traffic_${c}_b${b}.json > $O/pmc_top_$c.txt 2>&1
   rm -rf $O/prof_$c $O/pmcf_$c $O/pmcw_$c
 done
+fi
+if has power; then
+cd $R
+# socket power and shader clock while each configuration's step replays (rocm-smi, one sample per second; r05: the MFMA-dense
+# configurations run at the package power limit and the clock the firmware grants, not at 2.4 GHz)
+P=$O/${TAG}_power_clock.txt
+rocm-smi --showmaxpower 2>/dev/null | grep -i "power" > $P
+for cbs in cfg2:128:400 cfg3:32:120 cfg4:16:120 cfg5:8:160; do
+  c=${cbs%%:*}; rest=${cbs#*:}; b=${rest%%:*}; n=${rest##*:}
+  echo "== $c batch $b" >> $P
+  touch $O/.sampling
+  ( while [ -e $O/.sampling ]; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Package Power|sclk" | sed -e 's/.*sclk clock level: [0-9]*: (\([0-9]*\)Mhz).*/sclk \1 MHz/' -e 's/.*Power (W): \([0-9.]*\).*/power \1 W/' | tr "\n" " "; echo; sleep 1; done ) >> $P &
+  python3 bench.py --config $c --batch $b --no-cpu-baseline --no-extra-legs --steps $n 2>> $O/bench.err | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench', d['value'], d['unit'], d['ms_per_step'], 'ms/step over', d['steps'], 'steps')" > $O/.bline
+  rm -f $O/.sampling; wait
+  cat $O/.bline >> $P; rm -f $O/.bline
+done
+python3 - $P <<'PY' >> $P
+import re, sys
+cur, rows = None, {}
+for ln in open(sys.argv[1]):
+    if ln.startswith('== '):
+        cur = ln[3:].strip(); rows[cur] = []
+    m = re.search(r'sclk (\d+) MHz.*power ([\d.]+) W', ln)
+    if m and cur:
+        rows[cur].append((int(m.group(1)), float(m.group(2))))
+print('-- summary (samples at >= 70 % of the largest power seen in the run = the replay phase)')
+for k, v in rows.items():
+    if not v:
+        continue
+    top = max(p for _, p in v)
+    hot = [(c, p) for c, p in v if p >= 0.7 * top]
+    print(f'{k}: {len(hot)} samples, mean power {sum(p for _, p in hot) / len(hot):.0f} W, mean sclk {sum(c for c, _ in hot) / len(hot):.0f} MHz (min {min(c for c, _ in hot)}, max {max(c for c, _ in hot)})')
+PY
 fi
 if has parity; then
 cd $R
