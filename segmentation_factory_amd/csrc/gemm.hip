@@ -959,9 +959,43 @@ __global__ void __launch_bounds__(GG_THREADS) gemm_bf16_big_kernel(GemmArgs a) {
             }
             swrite_kc_t<GG_THREADS>(smem[buf][0], ra);
         };
+        // Fragment reads of this path: ONE LDS address per (operand, K sub-step, buffer) and lane -- 8 registers -- with the row tile as the
+        // instruction's immediate offset (rows 16 apart = 2048 bytes; a row's swizzle term depends on lane & 7 only, and K sub-step 1 is
+        // sub-step 0 with bit 6 of the chunk offset flipped).  The generic compute() recomputes row * 128 + swizzle per fragment, and the
+        // compiler kept all 36 addresses in registers.
+        typedef __attribute__((address_space(3))) const u32x4* lds_frag_p;
+        lds_frag_p fpA[2][2], fpB[2][2];                     // [K sub-step][buffer]
+        {
+            const uint32_t sbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)&smem[0][0][0];
+            const int lr = lane & 15;
+            const uint32_t swz0 = (uint32_t)(((lane >> 4) ^ (lr & 7)) << 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const uint32_t sw = swz0 ^ (uint32_t)(s2 * 64);
+                    fpA[s2][b] = (lds_frag_p)(uintptr_t)(sbase + (uint32_t)b * 2 * GG_TILE_BYTES + (uint32_t)(wrow + lr) * 128 + sw);
+                    fpB[s2][b] = (lds_frag_p)(uintptr_t)(sbase + (uint32_t)b * 2 * GG_TILE_BYTES + GG_TILE_BYTES + (uint32_t)(wcol + lr) * 128 + sw);
+                }
+        }
+        auto compute_d = [&](auto bufc) {
+            constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 fb[TN], fa[TM];
+#pragma unroll
+                for (int t = 0; t < TN; ++t) fb[t] = __builtin_bit_cast(bf16x8, fpB[s2][BUF][t * 128]);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t] = __builtin_bit_cast(bf16x8, fpA[s2][BUF][t * 128]);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) acc[tn][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[tn], fa[t], acc[tn][t], 0, 0, 0);
+            }
+        };
         // step s computes from LDS buffer s & 1; behind it: stage step s + 1, then issue B(s + 3) and A(s + 4) into the sets just freed
 #define DEEP_STEP(KT, J, SAW, SBW)                                                                                     \
-        compute((J) & 1);                                                                                              \
+        compute_d(std::integral_constant<int, ((J) & 1)>{});                                                          \
         DEEP_WRITE(SAW, SBW, (KT) + (J) + 1, ((J) + 1) & 1);                                                           \
         DEEP_LOAD_B(SBW, (KT) + (J) + 3);                                                                              \
         DEEP_LOAD_A(SAW, (KT) + (J) + 4);                                                                              \
