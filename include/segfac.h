@@ -547,6 +547,7 @@ int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, i
  *   SEGFAC_NO_FP8_WGRAD          fp8 3 x 3 convolutions keep a bf16 weight gradient
  *   SEGFAC_NO_FP8_LINEAR         segf_linear_fp8_supported answers 0
  *   SEGFAC_ATTN_NO_MFMA          attention on the VALU reference kernels (attention.hip) also in bf16
+ *   SEGFAC_ATTN_F32_NO_MFMA      fp32 attention forward on the vector kernel (one query per lane) instead of the f32 matrix instruction
  *   SEGFAC_ATTN_NO_FUSED_BWD     head dim 32, <= 256 keys: query-side + key-side backward kernels instead of the one-kernel backward
  *   SEGFAC_DW_NO_WALK            depthwise 3 x 3: the round-1 strip kernels instead of the vertical-walk kernels
  *   SEGFAC_DW_WALK_ROWS          depthwise 3 x 3 walk: rows per segment (0 = chosen from the map size)

@@ -128,6 +128,104 @@ __global__ void __launch_bounds__(AT_THREADS) attn_fwd_kernel(const T* __restric
     }
 }
 
+// ---- r05: the fp32 forward on the f32 matrix instruction (what `evaluate` runs: engine.py:86-88 evaluates in fp32) -------------------
+// v_mfma_f32_32x32x2_f32 is exact fp32 (every product rounded once, fp32 accumulation) at twice the vector FMA rate, and -- what matters
+// at the reference's --val_batch_size 1 -- it replaces the vector kernel's 16 384 serial FMAs per lane (one query per lane, 256 keys x
+// 32 features, twice) by 32 MFMAs per 32 keys: the stage-1 call of SegFormer-B0 at batch 1 is 64 workgroups of that serial chain.
+// One wave = 32 queries, no LDS.  Scores are formed TRANSPOSED, S^T[key][query] = K Q^T, so that a lane ends up with 16 of the 32 keys
+// of ITS OWN query (column = lane & 31; the other 16 keys sit in lane ^ 32): the online-softmax state is per lane, one cross-half
+// exchange for the maximum and one for the sum.  The probabilities then ARE the B operand of the second product as they stand:
+// O^T[d][query] += V^T[d][key] P^T[key][query] with the keys taken in the order the score tile holds them (rows (r & 3) + 8 (r >> 2)
+// + 4 half: a sum over keys does not care), V rows read straight from global memory (128 contiguous bytes per half-wave).
+typedef float at_f32x16 __attribute__((ext_vector_type(16)));
+template <int HD>
+__global__ void __launch_bounds__(64) attn_f32_mfma_fwd_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                                int64_t ldk, const float* __restrict__ v, int64_t ldv,
+                                                                float* __restrict__ o, int64_t ldo, float* __restrict__ lse,
+                                                                int heads, int N, int Nkv, float scale) {
+    constexpr int KD = HD / 2, DT = HD / 32;
+    const int lane = threadIdx.x, j = lane & 31, h2 = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 32;
+    const int qi = q0 + j < N ? q0 + j : N - 1;
+    const float2* qrow = reinterpret_cast<const float2*>(q + ((int64_t)b * N + qi) * ldq + head * HD);
+    float qf[KD];
+#pragma unroll
+    for (int t = 0; t < KD; ++t) { const float2 u = qrow[t]; qf[t] = h2 ? u.y : u.x; }
+    at_f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float* kb = k + (int64_t)b * Nkv * ldk + head * HD;
+    const float* vb = v + (int64_t)b * Nkv * ldv + head * HD;
+    float kf[KD];
+    {
+        const int ki = j < Nkv ? j : Nkv - 1;
+        const float2* krow = reinterpret_cast<const float2*>(kb + (int64_t)ki * ldk);
+#pragma unroll
+        for (int t = 0; t < KD; ++t) { const float2 u = krow[t]; kf[t] = h2 ? u.y : u.x; }
+    }
+    for (int j0 = 0; j0 < Nkv; j0 += 32) {
+        at_f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < KD; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[t], s, 0, 0, 0);
+        // the V rows of this tile (keys in the order of the score registers) and the next tile's K rows fly under the softmax
+        float vf[DT][16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const float* vr = vb + (int64_t)(key < Nkv ? key : Nkv - 1) * ldv + j;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt][r] = vr[32 * dt];
+        }
+        if (j0 + 32 < Nkv) {
+            const int ki = j0 + 32 + j < Nkv ? j0 + 32 + j : Nkv - 1;
+            const float2* krow = reinterpret_cast<const float2*>(kb + (int64_t)ki * ldk);
+#pragma unroll
+            for (int t = 0; t < KD; ++t) { const float2 u = krow[t]; kf[t] = h2 ? u.y : u.x; }
+        }
+        float mb = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+            const float sv = key < Nkv ? s[r] * scale : -INFINITY;
+            s[r] = sv;
+            mb = fmaxf(mb, sv);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+        const float mn = fmaxf(m, mb);
+        const float alpha = __expf(m - mn);          // m = -inf on the first tile -> 0
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float p = __expf(s[r] - mn); s[r] = p; ps += p; }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[dt][r], s[r], oacc[dt], 0, 0, 0);
+    }
+    if (q0 + j < N) {
+        const float inv = 1.f / l;
+        float* orow = o + ((int64_t)b * N + q0 + j) * ldo + head * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)       // rows d = 32 dt + 8 g + 4 h2 + (0 .. 3) of this query's column
+                *reinterpret_cast<float4*>(orow + 32 * dt + 8 * g + 4 * h2) =
+                    make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+        if (h2 == 0) lse[((int64_t)b * heads + head) * N + q0 + j] = m + __logf(l);
+    }
+}
+
 // pass 1: D and dQ, one query per TPR lanes
 template <typename T, int HD>
 __global__ void __launch_bounds__(AT_THREADS) attn_bwd_dq_kernel(const T* __restrict__ q, int64_t ldq, const T* __restrict__ k,
@@ -291,6 +389,17 @@ extern "C" int segf_attention_fwd(int dt, int B, int heads, int N, int Nkv, int 
     const int vec = attn_vec_ok(dt, q, ldq) && attn_vec_ok(dt, k, ldk) && attn_vec_ok(dt, v, ldv) && attn_vec_ok(dt, o, ldo);
     if (dt == SEGF_BF16 && vec && !POL(attn_no_mfma))
         return attn_mfma_fwd(hd, B, heads, N, Nkv, q, ldq, k, ldk, v, ldv, scale, o, ldo, lse, st);
+    if (dt == SEGF_F32 && vec && !POL(attn_f32_no_mfma)) {
+        const dim3 gridm((unsigned)((N + 31) / 32), (unsigned)heads, (unsigned)B);
+        if (hd == 32)
+            hipLaunchKernelGGL((attn_f32_mfma_fwd_kernel<32>), gridm, dim3(64), 0, st, (const float*)q, ldq, (const float*)k, ldk,
+                               (const float*)v, ldv, (float*)o, ldo, lse, heads, N, Nkv, scale);
+        else
+            hipLaunchKernelGGL((attn_f32_mfma_fwd_kernel<64>), gridm, dim3(64), 0, st, (const float*)q, ldq, (const float*)k, ldk,
+                               (const float*)v, ldv, (float*)o, ldo, lse, heads, N, Nkv, scale);
+        SEGF_CHECK_LAUNCH();
+        return 0;
+    }
     const int qpb = AT_THREADS / (hd / 32);
     dim3 grid((N + qpb - 1) / qpb, heads, B);
     SEGF_DISPATCH_DT(dt, T, {

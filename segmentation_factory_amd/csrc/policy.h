@@ -49,6 +49,7 @@
     X(no_fp8_linear, "SEGFAC_NO_FP8_LINEAR", 0, "segf_linear_fp8_supported answers 0")                                                   \
     /* ---- attention (attention.hip, attention_mfma.hip) ---- */                                                                        \
     X(attn_no_mfma, "SEGFAC_ATTN_NO_MFMA", 0, "attention on the VALU reference kernels (attention.hip) also in bf16")                    \
+    X(attn_f32_no_mfma, "SEGFAC_ATTN_F32_NO_MFMA", 0, "fp32 attention forward on the vector kernel (one query per lane) instead of the f32 matrix instruction") \
     X(attn_no_fused_bwd, "SEGFAC_ATTN_NO_FUSED_BWD", 0, "head dim 32, <= 256 keys: query-side + key-side backward kernels instead of the one-kernel backward") \
     /* ---- depthwise / patch convolutions (conv.hip) ---- */                                                                            \
     X(dw_no_walk, "SEGFAC_DW_NO_WALK", 0, "depthwise 3 x 3: the round-1 strip kernels instead of the vertical-walk kernels")             \
