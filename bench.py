@@ -413,7 +413,7 @@ def main():
                                  "instructions (ISA count: 149 VALU + 41 transcendental + 20 MFMA per 16-pixel cell; the softmax normalisation arrives as the "
                                  "forward's per-pixel log-sum, +64 B per cell, not counted in the algorithmic bytes); interpolation / tap scatter on MFMA.  exp_per_second = %.3e (v_exp_f32 issue peak ~2.0e13/s)"
                                  % (loss_exps / (avg_ms * 1e-3))},
-            "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true, SHAPE=1, DEEP=true> (segf_gemm_pro, the in-graph variant; narrow 64x80 wave tiles, two K steps in flight): classifier 1x1 conv "
+            "roofline_gemm": {"kernel": "gemm_bf16_big_kernel<0, bf16, false, PRO=true, SHAPE=1, DEEP=true> (segf_gemm_pro, the in-graph variant; narrow 64x80 wave tiles, three K steps of the streamed operand in flight, packed operand prologue): classifier 1x1 conv "
                                         f"[B*{hq}*{wq},768]x[768,{ld}] with BatchNorm + ReLU + Dropout2d applied on the operand load" if use_pro else
                                         f"gemm_bf16_big_kernel<0>: classifier 1x1 conv [B*{hq}*{wq},768]x[768,{ld}]",
                               "bound": "hbm", "achieved": round(gemm_bytes / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9,
