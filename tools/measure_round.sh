@@ -67,20 +67,25 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench', d['value
 done
 python3 - $P <<'PY' >> $P
 import re, sys
-cur, rows = None, {}
+cur, rows, rate = None, {}, {}
 for ln in open(sys.argv[1]):
     if ln.startswith('== '):
         cur = ln[3:].strip(); rows[cur] = []
     m = re.search(r'sclk (\d+) MHz.*power ([\d.]+) W', ln)
     if m and cur:
         rows[cur].append((int(m.group(1)), float(m.group(2))))
+    m = re.match(r'bench ([0-9.]+) images/sec', ln)
+    if m and cur:
+        rate[cur] = float(m.group(1))
 print('-- summary (samples at >= 70 % of the largest power seen in the run = the replay phase)')
 for k, v in rows.items():
     if not v:
         continue
     top = max(p for _, p in v)
     hot = [(c, p) for c, p in v if p >= 0.7 * top]
-    print(f'{k}: {len(hot)} samples, mean power {sum(p for _, p in hot) / len(hot):.0f} W, mean sclk {sum(c for c, _ in hot) / len(hot):.0f} MHz (min {min(c for c, _ in hot)}, max {max(c for c, _ in hot)})')
+    mp = sum(p for _, p in hot) / len(hot)
+    print(f'{k}: {len(hot)} samples, mean power {mp:.0f} W, mean sclk {sum(c for c, _ in hot) / len(hot):.0f} MHz (min {min(c for c, _ in hot)}, max {max(c for c, _ in hot)})'
+          + (f', {mp / rate[k]:.2f} J per image' if k in rate else ''))
 PY
 fi
 if has parity; then
