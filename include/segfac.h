@@ -529,6 +529,7 @@ int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, i
  *   SEGFAC_GEMM_NO_PRO           segf_gemm_pro_supported answers 0: BatchNorm + ReLU + Dropout2d are applied by their own pass
  *   SEGFAC_GEMM_NO_FUSED_DB      bias gradient as its own column-sum launch instead of riding on the weight-gradient product
  *   SEGFAC_NO_GROUPED_DW         segf_gemm_dw_db_grouped runs its members one by one
+ *   SEGFAC_DW_NO_XCD_SLABS       split-K weight gradients (128-tile kernel) in hardware workgroup order instead of one K slab per XCD
  *   SEGFAC_DW_NO_SHARED_SPLIT    grouped weight gradients keep their per-layer slice counts (also read by the host layer)
  *   SEGFAC_NO_WIDE_REDUCE        split-K partials of large outputs summed by the 16 x 16 form instead of whole rows
  *   SEGFAC_NO_REDUCE4            split-K reduce: one output per thread instead of four (bitwise the same sums)

@@ -26,6 +26,7 @@ struct GemmArgs {
     float* ws;               // split-K partials [z][M][N] (nullptr when split_k == 1)
     int a_vec, b_vec, c_vec, r_vec, use_tr;
     int fast;                // uniform guard-free tile loads for full K steps (debug switch SEGFAC_GEMM_NO_FASTLOAD)
+    int xcd_slabs;           // layout 2, split-K: the tiles of one K slab on one XCD (gemm_bf16_tile)
     int c_vec16;             // C rows allow 16-byte stores (bf16 output, LDS-staged epilogue)
     // implicit 3x3 convolution (stride 1, pad 1) over an NHWC operand [B][cH][cW][ld >= cC]: the gathered operand's K (layout 0,
     // operand A) or N (layout 2, operand B) axis is (tap = ky*3+kx, channel); csign = +1 reads pixel + offset(tap) (forward,
@@ -345,7 +346,33 @@ __device__ __forceinline__ void gemm_bf16_tile(const GemmArgs& a, const unsigned
     const unsigned q = nwg >> 3, r8 = nwg & 7, xcd = orig & 7;
     // (split-K weight-gradient launches keep the hardware order: measured slower with the remap)
     const unsigned wgid = LAYOUT == 2 ? orig : (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (orig >> 3);
-    const unsigned bx = wgid % gx, by = (wgid / gx) % gy, bz = wgid / (gx * gy);
+    unsigned bx = wgid % gx, by = (wgid / gx) % gy, bz = wgid / (gx * gy);
+    if (LAYOUT == 2 && !CONV && a.xcd_slabs) {
+        // r05, split-K weight gradients: ids that are equal modulo 8 run on one XCD, so the K SLAB is made the index that moves with
+        // (id mod 8) and the tiles of a slab follow each other at a stride of 8 ids: all gx * gy tiles of a slab -- which read the same
+        // rows of dy and x -- run on ONE XCD at about the same time and share them through its L2, and every XCD gets the same number of
+        // slabs.  In hardware order the 30 tiles of a [1280 x 320] slab were dealt over all eight L2s: 2.8 x the operand bytes crossed
+        // the fabric (cfg4: 11.1 GB per grouped launch).  Slabs past the last multiple of 8 keep the hardware order.
+        const unsigned T = gx * gy, full = (gz >> 3) << 3;
+        if (orig < full * T) {
+            const unsigned t = (orig >> 3) % T;
+            bz = (orig & 7) + 8 * (orig / (8 * T));
+            bx = t % gx; by = t / gx;
+        } else {
+            // fewer than eight slabs (left): inside a slab, pin the tile index of the WIDER operand to the XCD -- the [K x 3072] operand of
+            // a [3072 x 768] gradient is then fetched by one L2 per row tile (its six column tiles run there) instead of by six, the
+            // narrow operand still by all eight: 2.4 x the operand bytes instead of 6.4 x.  Needs a multiple of 8 tiles along that index.
+            const unsigned r = orig - full * T;
+            const bool pin_y = gy >= gx;
+            const unsigned P = pin_y ? gy : gx, Q = pin_y ? gx : gy;
+            if ((P & 7u) == 0) {
+                const unsigned j = r >> 3, per = (P >> 3) * Q;
+                const unsigned sl = j / per, w = j - sl * per, pi = w / Q, qq = w - pi * Q, pp = (r & 7u) + 8 * pi;
+                bz = full + sl;
+                if (pin_y) { by = pp; bx = qq; } else { bx = pp; by = qq; }
+            }
+        }
+    }
     const int64_t m0 = (int64_t)by * GB_BM, n0 = (int64_t)bx * GB_BN;
     const int64_t kbeg = (int64_t)bz * a.kchunk;
     const int64_t kend = kbeg + a.kchunk < a.K ? kbeg + a.kchunk : a.K;
@@ -2252,7 +2279,7 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
             a.A = it.dy; a.B = it.x; a.C = it.dw; a.bias = nullptr; a.residual = nullptr; a.rscale = nullptr;
             a.M = M; a.N = N; a.K = K; a.lda = it.lddy; a.ldb = it.ldx; a.ldc = it.lddw; a.ldr = 0; a.rpg = 1;
             a.kchunk = kchunk; a.ws = it.ws;
-            a.a_vec = 1; a.b_vec = 1; a.fast = 1;
+            a.a_vec = 1; a.b_vec = 1; a.fast = 1; a.xcd_slabs = POL(dw_no_xcd_slabs) ? 0 : 1;
             a.c_vec = ((uintptr_t)it.dw % 16 == 0) && ((it.lddw * 4) % 16 == 0);
             a.r_vec = 0; a.c_vec16 = a.c_vec;
             a.use_tr = 1;
@@ -2375,6 +2402,7 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
     a.a_vec = ((uintptr_t)A % 16 == 0) && ((lda * esz) % 16 == 0);
     a.b_vec = ((uintptr_t)B % 16 == 0) && ((ldb * esz) % 16 == 0);
     a.fast = POL(gemm_no_fastload) ? 0 : 1;
+    a.xcd_slabs = (layout == 2 && split_k > 1 && !POL(dw_no_xcd_slabs)) ? 1 : 0;
     // bit 0: vector loads allowed, bit 1: guard-free full-K-step loads.  Layouts 0 / 1 gain 25-45 % from the latter; the split-K
     // weight-gradient launches (layout 2) measured 8-15 % SLOWER with every load in flight, so they keep the guarded loads
     if (a.fast && layout != 2) { a.a_vec *= 3; a.b_vec *= 3; }
@@ -2723,7 +2751,7 @@ extern "C" int segf_conv3x3_fp8(int mode, int B, int H, int W, int Cin, int Cout
     const int Kc = mode == 0 ? Cin : Cout;                      // channels of the gathered operand
     GemmArgs a;
     a.bias = nullptr; a.residual = nullptr; a.rscale = nullptr; a.ldr = 0; a.rpg = 1;
-    a.a_vec = 1; a.b_vec = 1; a.r_vec = 0; a.use_tr = 1; a.fast = 0;
+    a.a_vec = 1; a.b_vec = 1; a.r_vec = 0; a.use_tr = 1; a.fast = 0; a.xcd_slabs = 0;
     a.cH = H; a.cW = W; a.csign = mode == 1 ? -1 : 1;
     a.colsum = nullptr; a.colsum_ws = nullptr; a.pro_scale = nullptr; a.pro_shift = nullptr; a.pro_rpg = 1; a.pro_ld = 0; a.pro_act = 0;
     a.f8_sa = sx; a.f8_sb = sw;

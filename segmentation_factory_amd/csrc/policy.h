@@ -29,6 +29,7 @@
     X(gemm_no_pro, "SEGFAC_GEMM_NO_PRO", 0, "segf_gemm_pro_supported answers 0: BatchNorm + ReLU + Dropout2d are applied by their own pass") \
     X(gemm_no_fused_db, "SEGFAC_GEMM_NO_FUSED_DB", 0, "bias gradient as its own column-sum launch instead of riding on the weight-gradient product") \
     X(no_grouped_dw, "SEGFAC_NO_GROUPED_DW", 0, "segf_gemm_dw_db_grouped runs its members one by one")                                   \
+    X(dw_no_xcd_slabs, "SEGFAC_DW_NO_XCD_SLABS", 0, "split-K weight gradients (128-tile kernel) in hardware workgroup order instead of one K slab per XCD")                \
     X(dw_no_shared_split, "SEGFAC_DW_NO_SHARED_SPLIT", 0, "grouped weight gradients keep their per-layer slice counts (also read by the host layer)") \
     X(no_wide_reduce, "SEGFAC_NO_WIDE_REDUCE", 0, "split-K partials of large outputs summed by the 16 x 16 form instead of whole rows")   \
     X(no_reduce4, "SEGFAC_NO_REDUCE4", 0, "split-K reduce: one output per thread instead of four (bitwise the same sums)")               \
