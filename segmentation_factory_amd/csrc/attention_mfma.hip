@@ -281,16 +281,81 @@ __device__ __forceinline__ float am_max3(float a, float b, float c) { float r; a
 __device__ __forceinline__ float am_max2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 #define AMP_THR 6.0f        // lazy rescale: the running maximum is only raised when a score exceeds it by more than 2^6 (log2 units)
 
-// Forward at head dim 64, long key sequences.  The softmax runs in the exp2 domain with `scale` folded into the exponent's multiply-add:
-// p = exp2(s c - m), c = scale log2(e), m = the running maximum of s c -- one v_fma + one v_exp per (query, key) pair where the
-// form above spends a multiply (scale), a subtract, a multiply (log2 e) and the exponential.  The running maximum is raised LAZILY:
-// only when some score of the step exceeds it by more than AMP_THR does the wave rescale O and l (a wave-uniform branch); until then
-// p <= 2^AMP_THR, which the fp32 accumulators and the bf16 P operand (a floating-point format: its relative precision does not depend
-// on the magnitude) take without loss.  After the first few steps of a 2048-key row the branch is rarely taken, which removes the 16
-// accumulator multiplies per (query tile, step).  This changes the rounding order against the head-dim-32 kernels; head dim 64 only
-// occurs in MiT-B2 and up, whose parity is pinned against the fp32 oracle with the bf16 tolerance (tests: test_attention,
-// test_full_size_fp32_and_bf16_vs_oracle[cfg4]); the SegFormer-B0 fixtures never reach this kernel.
-template <int QW>
+// r05: every LDS address of the two kernels below is ONE per-lane base + an instruction immediate.  The stage loop is written out for
+// the two buffers (the buffer index is a template constant), so a 32-key step issues no address arithmetic at all: the forward spent
+// 16 of its 82 vector instructions per step rebuilding the eight swizzled transposed-read addresses from the buffer parity, the
+// query-side backward 16 of 113 (ISA count, tools/probe/isa_loop.py).  The compiler does not track these reads (inline asm): the caller
+// waits (AMP_LGKM0) before the first use.
+template <int OFF>
+__device__ __forceinline__ bf16x8 amp_lds128(uint32_t a) {
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "i"(OFF));
+    return r;
+}
+// transposed fragment: element j < 4 <- row r + j of the tile at OFF, j >= 4 <- row r + 16 + (j - 4) (16 rows of 128 bytes further on)
+template <int OFF>
+__device__ __forceinline__ bf16x8 amp_trs(uint32_t a) {
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "i"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "i"(OFF + 2048));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+template <int V> struct amp_ic { static constexpr int value = V; };
+// per-lane LDS byte addresses inside a swizzled [64 keys][64] tile pair (K at +0, V at +0x2000; second buffer at +0x4000):
+// kbase[s]: row-major fragment of row c, 16-byte chunk 4 s + g;  vbase[d]: transposed read of rows 4 g + (i >> 2), column block d
+struct AmpBases { uint32_t k[2], v[4]; };
+__device__ __forceinline__ AmpBases amp_bases(const bf16_t* tile0, int lane) {
+    const int g = lane >> 4, c = lane & 15, qq = c >> 2, p = c & 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)tile0;
+    AmpBases r;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) r.k[s] = lds0 + c * 128 + (((4 * s + g) ^ (c & 7)) << 4);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) r.v[d] = lds0 + (4 * g + qq) * 128 + ((2 * d + (p >> 1)) ^ ((4 * g + qq) & 7)) * 16 + 8 * (p & 1);
+    return r;
+}
+// the per-lane part of a stage's source addresses (8 rows x 128 bytes per piece, two pieces per wave and operand), as 32-bit element
+// offsets from the stage's first row: the stage's own part (kc0 * ld) is wave-uniform and stays on the scalar unit
+struct AmpSrc { int k[2], v[2]; };
+__device__ __forceinline__ AmpSrc amp_src(int64_t ldk, int64_t ldv, int wave, int lane) {
+    AmpSrc r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (4 * i + wave) + (lane >> 3), col = ((lane & 7) ^ (lane >> 3)) * 8;
+        r.k[i] = row * (int)ldk + col; r.v[i] = row * (int)ldv + col;
+    }
+    return r;
+}
+template <int BUF>
+__device__ __forceinline__ void amp_stage_fast(bf16_t (*KV)[2][AMP_KC * 64], const bf16_t* __restrict__ Kb, int64_t ldk, const bf16_t* __restrict__ Vb,
+                                               int64_t ldv, int kc0, int Nkv, const AmpSrc& so, int wave, int lane) {
+    if (kc0 + AMP_KC <= Nkv) {                      // (wave-uniform) a full stage: uniform row base + per-lane 32-bit offset
+        const bf16_t* ku = Kb + (int64_t)kc0 * ldk;
+        const bf16_t* vu = Vb + (int64_t)kc0 * ldv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            AMP_GLDS(ku + so.k[i], KV[BUF][0] + (4 * i + wave) * 512);
+            AMP_GLDS(vu + so.v[i], KV[BUF][1] + (4 * i + wave) * 512);
+        }
+    } else amp_stage(KV[BUF][0], KV[BUF][1], Kb, ldk, Vb, ldv, kc0, Nkv, wave, lane);       // last, partial stage: clamped rows
+}
+
+// Forward at head dim 64, long key sequences.  The softmax runs in the exp2 domain: p = exp2(s c - m), c = scale log2(e), m = the
+// running maximum of s c.  PRE = false: c sits in the exponent's multiply-add (one v_fma + one v_exp per (query, key) pair).
+// PRE = true (r05, policy attn64_prescale, OFF by default): c rides on the Q fragments (bf16(q c), rounded once when the fragments
+// are loaded) and -m is the INITIAL VALUE of the score accumulators (four registers per query tile holding -m, rewritten only when m
+// moves), so the matrix pipe delivers s c - m and the pair costs one v_exp: 66 -> 50 vector instructions per 32-key step, forward
+// 0.603 -> 0.557 ms on 8 x 131072 x 2048 keys.  The price is one more bf16 rounding per q element: against an fp32 reference the
+// error of O grows x 1.24 on unit-normal inputs and x 2.3 on four times larger queries (tools/probe/attn64_accuracy.py) -- still
+// below what rounding the SCORE to bf16 costs (the reference under autocast, models/backbones/mit.py:52-54), but parity comes
+// first, so the default keeps the multiply-add (PRE = false: the arithmetic of r04's kernel, bit for bit in O).
+// The running maximum is raised LAZILY: only when some score of the step exceeds it by more than AMP_THR does the wave rescale O and
+// l (a wave-uniform branch); until then p <= 2^AMP_THR, which the fp32 accumulators and the bf16 P operand (a floating-point format:
+// its relative precision does not depend on the magnitude) take without loss.  After the first few steps of a 2048-key row the
+// branch is rarely taken, which removes the 16 accumulator multiplies per (query tile, step).  This changes the rounding order
+// against the head-dim-32 kernels; head dim 64 only occurs in MiT-B2 and up, whose parity is pinned against the fp32 oracle with the
+// bf16 tolerance (tests: test_attention, test_full_size_fp32_and_bf16_vs_oracle[cfg4]); the SegFormer-B0 fixtures never reach this kernel.
+template <int QW, bool PRE>
 __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                     int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                                     bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse, int heads,
@@ -304,7 +369,9 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
     const bf16_t* Qb = q + (int64_t)b * N * ldq + h * HD;
     const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
     const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
-    amp_stage(KV[0][0], KV[0][1], Kb, ldk, Vb, ldv, 0, Nkv, wave, lane);
+    const AmpSrc so = amp_src(ldk, ldv, wave, lane);
+    amp_stage_fast<0>(KV, Kb, ldk, Vb, ldv, 0, Nkv, so, wave, lane);
+    const AmpBases ab = amp_bases(&KV[0][0][0], lane);
     const float cs = scale * 1.44269504088896340736f;              // scores -> log2 units
     bf16x8 Qf[QW][KS];
 #pragma unroll
@@ -313,72 +380,115 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
         for (int s = 0; s < KS; ++s) {
             const int row = q0 + 16 * t + c;
             Qf[t][s] = ld_frag_global(Qb + (int64_t)row * ldq + 32 * s + 8 * g, row < N);
+            if constexpr (PRE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Qf[t][s][j] = (__bf16)((float)Qf[t][s][j] * cs);
+            }
         }
     // the softmax denominators are a fifth "value column" of ones: L[t] = ones^T P^T accumulates sum_k p in every lane (the matrix pipe
     // sums over all 32 keys of a step, i.e. over the four lane groups too), on the SAME bf16-rounded probabilities that enter P V --
     // one MFMA per (query tile, step) instead of eight vector adds and, at the end, no cross-lane sum
-    f32x4 O[DT][QW], L[QW];
+    f32x4 O[DT][QW], L[QW], Cn[QW];     // Cn (PRE): -m in all four registers = the C operand of the score products
     float m[QW];
     const bf16x8 ones = __builtin_bit_cast(bf16x8, make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
 #pragma unroll
     for (int t = 0; t < QW; ++t) {
-        m[t] = -INFINITY; L[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m[t] = PRE ? 0.f : -INFINITY; L[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; Cn[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (PRE) asm volatile("" : "+v"(Cn[t]));          // (opaque: kept in four registers, not re-splatted per product)
 #pragma unroll
         for (int d = 0; d < DT; ++d) O[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const int nst = (Nkv + AMP_KC - 1) / AMP_KC;
-    for (int st = 0; st < nst; ++st) {
+    // one 32-key step of stage `st` in buffer BUF, keys KB .. KB + 31 of the stage
+    auto step = [&](auto bufc, auto kbc, int st) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, KB = decltype(kbc)::value;
+        constexpr int OK = BUF * 0x4000 + KB * 128, OV = OK + 0x2000;
         const int kc0 = st * AMP_KC;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage st have landed ...
-        __syncthreads();                                       // ... everyone's have, and nobody reads the other buffer any more
-        if (st + 1 < nst) amp_stage(KV[(st + 1) & 1][0], KV[(st + 1) & 1][1], Kb, ldk, Vb, ldv, kc0 + AMP_KC, Nkv, wave, lane);
-        if (q0 >= N) continue;                                 // wave-uniform; the wave still stages its pieces and joins the barriers
-        const bf16_t* Ks = KV[st & 1][0];
-        const bf16_t* Vs = KV[st & 1][1];
+        bf16x8 Kf[2][KS], Vf[DT];
+        Kf[0][0] = amp_lds128<OK>(ab.k[0]); Kf[0][1] = amp_lds128<OK>(ab.k[1]);
+        Kf[1][0] = amp_lds128<OK + 2048>(ab.k[0]); Kf[1][1] = amp_lds128<OK + 2048>(ab.k[1]);
+        Vf[0] = amp_trs<OV>(ab.v[0]); Vf[1] = amp_trs<OV>(ab.v[1]); Vf[2] = amp_trs<OV>(ab.v[2]); Vf[3] = amp_trs<OV>(ab.v[3]);
+        AMP_LGKM0();
+        float sv[QW][2][4], mx[QW];
 #pragma unroll
-        for (int kb = 0; kb < AMP_KC; kb += 32) {
-            bf16x8 Kf[2][KS], Vf[DT];
+        for (int t = 0; t < QW; ++t)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x4 S = PRE ? Cn[t] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < KS; ++s) Kf[kt][s] = ld_frag_lds(Ks + (kb + 16 * kt + c) * HD + (((4 * s + g) ^ (c & 7)) << 3));
+                for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
 #pragma unroll
-            for (int d = 0; d < DT; ++d) Vf[d] = amp_frag_trs(Vs, kb + 4 * g, kb + 16 + 4 * g, d, lane);
-            AMP_LGKM0();
-            float sv[QW][2][4], mx[QW];
+                for (int r = 0; r < 4; ++r) sv[t][kt][r] = S[r];
+            }
+        if (kc0 + KB + 32 > Nkv) {                          // last step of a key count that is not a multiple of 32 (wave-uniform)
 #pragma unroll
             for (int t = 0; t < QW; ++t)
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S, 0, 0, 0);
+                    for (int r = 0; r < 4; ++r)
+                        if (kc0 + KB + 16 * kt + 4 * g + r >= Nkv) sv[t][kt][r] = -INFINITY;
+        }
+        if constexpr (QW == 2) {
+            // The step's maxima, ONE asm block.  An inline-asm instruction that reads a matrix-instruction result is invisible to the
+            // compiler's hazard recogniser (it pads "XDL write -> VALU read" only in front of instructions it classifies as VALU), and
+            // the hardware does not interlock that read: r04's separate v_max3 statements sat two or three issue slots behind the
+            // last score product and, now and then, read the register's PREVIOUS content -- a stale score of similar size, so the
+            // running maximum moved differently and O / lse came out valid but not bit-reproducible (found in r05 as 5 of 16384 lse
+            // rows differing between two runs).  s_nop 7 = the 8 wait states a four-pass result needs, whatever order the products
+            // were issued in.
+            float t0, t1;
+            asm volatile("s_nop 7\n\t"
+                         "v_max3_f32 %0, %4, %5, %6\n\t"
+                         "v_max3_f32 %2, %7, %8, %9\n\t"
+                         "v_max3_f32 %1, %12, %13, %14\n\t"
+                         "v_max3_f32 %3, %15, %16, %17\n\t"
+                         "v_max3_f32 %0, %0, %10, %11\n\t"
+                         "v_max3_f32 %1, %1, %18, %19\n\t"
+                         "v_max_f32 %0, %0, %2\n\t"
+                         "v_max_f32 %1, %1, %3"
+                         : "=&v"(mx[0]), "=&v"(mx[1]), "=&v"(t0), "=&v"(t1)
+                         : "v"(sv[0][0][0]), "v"(sv[0][0][1]), "v"(sv[0][0][2]), "v"(sv[0][0][3]), "v"(sv[0][1][0]), "v"(sv[0][1][1]),
+                           "v"(sv[0][1][2]), "v"(sv[0][1][3]), "v"(sv[1][0][0]), "v"(sv[1][0][1]), "v"(sv[1][0][2]), "v"(sv[1][0][3]),
+                           "v"(sv[1][1][0]), "v"(sv[1][1][1]), "v"(sv[1][1][2]), "v"(sv[1][1][3]));
+            float a0 = mx[0], b0 = mx[0], a1 = mx[1], b1 = mx[1];
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1\n\tv_permlane16_swap_b32_e32 %2, %3\n\ts_nop 1" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+            a0 = b0 = am_max2(a0, b0); a1 = b1 = am_max2(a1, b1);
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1\n\tv_permlane32_swap_b32_e32 %2, %3\n\ts_nop 1" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
+            mx[0] = am_max2(a0, b0); mx[1] = am_max2(a1, b1);
+        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sv[t][kt][r] = S[r];
-                }
-            if (kc0 + kb + 32 > Nkv) {                          // last step of a key count that is not a multiple of 32 (wave-uniform)
+            for (int t = 0; t < QW; ++t) {
+                float r = fmaxf(fmaxf(fmaxf(sv[t][0][0], sv[t][0][1]), fmaxf(sv[t][0][2], sv[t][0][3])),
+                                fmaxf(fmaxf(sv[t][1][0], sv[t][1][1]), fmaxf(sv[t][1][2], sv[t][1][3])));
+                mx[t] = xgroup_max(r);
+            }
+        }
+        if constexpr (PRE) {
+            // the scores arrive as s c - m: mx is the step's maximum RELATIVE to the running one.  The very first step has m = 0 (not
+            // a maximum of anything): it always sets m to its own maximum, whatever the sign.
+            const bool first = KB == 0 && st == 0;
+            bool grow = false;
 #pragma unroll
-                for (int t = 0; t < QW; ++t)
+            for (int t = 0; t < QW; ++t) grow = grow || (mx[t] > AMP_THR);
+            if (first || __builtin_amdgcn_ballot_w64(grow) != 0) {
+#pragma unroll
+                for (int t = 0; t < QW; ++t) {
+                    const float delta = first ? mx[t] : fmaxf(mx[t], 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-fmaxf(delta, 0.f));      // (first step: O = l = 0, any finite factor will do)
+                    m[t] += delta;
+                    Cn[t] -= delta;
+                    asm volatile("" : "+v"(Cn[t]));
+                    L[t] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) O[d][t] *= alpha;
 #pragma unroll
                     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (kc0 + kb + 16 * kt + 4 * g + r >= Nkv) sv[t][kt][r] = -INFINITY;
+                        for (int r = 0; r < 4; ++r) sv[t][kt][r] -= delta;
+                }
             }
-#pragma unroll
-            for (int t = 0; t < QW; ++t)
-                mx[t] = am_max2(am_max3(sv[t][0][0], sv[t][0][1], sv[t][0][2]),
-                                am_max3(sv[t][1][0], sv[t][1][1], am_max3(sv[t][0][3], sv[t][1][2], sv[t][1][3])));
-            if constexpr (QW == 2) {
-                float a0 = mx[0], b0 = mx[0], a1 = mx[1], b1 = mx[1];
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1\n\tv_permlane16_swap_b32_e32 %2, %3\n\ts_nop 1" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-                a0 = b0 = am_max2(a0, b0); a1 = b1 = am_max2(a1, b1);
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1\n\tv_permlane32_swap_b32_e32 %2, %3\n\ts_nop 1" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));
-                mx[0] = am_max2(a0, b0); mx[1] = am_max2(a1, b1);
-            } else {
-#pragma unroll
-                for (int t = 0; t < QW; ++t) mx[t] = xgroup_max(mx[t]);
-            }
+        } else {
             bool grow = false;
 #pragma unroll
             for (int t = 0; t < QW; ++t) { mx[t] *= cs; grow = grow || (mx[t] > m[t] + AMP_THR); }
@@ -393,23 +503,37 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
                     for (int d = 0; d < DT; ++d) O[d][t] *= alpha;
                 }
             }
-            bf16x8 Pf[QW];
-#pragma unroll
-            for (int t = 0; t < QW; ++t) {
-                const float nm = -m[t];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sv[t][kt][r] = __builtin_amdgcn_exp2f(fmaf(sv[t][kt][r], cs, nm));
-                Pf[t] = pack_acc(sv[t][0], sv[t][1]);
-            }
-#pragma unroll
-            for (int t = 0; t < QW; ++t) L[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, Pf[t], L[t], 0, 0, 0);
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-#pragma unroll
-                for (int t = 0; t < QW; ++t) O[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[d], Pf[t], O[d][t], 0, 0, 0);
         }
+        bf16x8 Pf[QW];
+#pragma unroll
+        for (int t = 0; t < QW; ++t) {
+            const float nm = -m[t];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sv[t][kt][r] = __builtin_amdgcn_exp2f(PRE ? sv[t][kt][r] : fmaf(sv[t][kt][r], cs, nm));
+            Pf[t] = pack_acc(sv[t][0], sv[t][1]);
+        }
+#pragma unroll
+        for (int t = 0; t < QW; ++t) L[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, Pf[t], L[t], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int t = 0; t < QW; ++t) O[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[d], Pf[t], O[d][t], 0, 0, 0);
+    };
+    auto stage = [&](auto bufc, int st) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage st have landed ...
+        __syncthreads();                                       // ... everyone's have, and nobody reads the other buffer any more
+        if (st + 1 < nst) amp_stage_fast<BUF ^ 1>(KV, Kb, ldk, Vb, ldv, (st + 1) * AMP_KC, Nkv, so, wave, lane);
+        if (q0 >= N) return;                                   // wave-uniform; the wave still stages its pieces and joins the barriers
+        step(bufc, amp_ic<0>{}, st);
+        step(bufc, amp_ic<32>{}, st);
+    };
+    for (int st = 0; st < nst; st += 2) {
+        stage(amp_ic<0>{}, st);
+        if (st + 1 < nst) stage(amp_ic<1>{}, st + 1);
     }
     if (q0 >= N) return;
     bf16_t* Ob = o + (int64_t)b * N * ldo + h * HD;
@@ -433,7 +557,10 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_fwd64p_kernel(const bf16_t
 // Query-side backward at head dim 64, long key sequences: P = exp2(s c - lse log2(e)) (one v_fma + one v_exp per pair, the scale inside c),
 // dS = P (dP - D) unscaled (dQ is scaled once at the end), K^T fragments read only after the score products have consumed the
 // row-major K / V fragments (their registers are free by then: no spills under the three-waves-per-SIMD budget).
-template <int QW>
+// r05: LDS addresses as per-lane bases + immediates (amp_bases), stage sources as a scalar row base + 32-bit lane offsets; PRE = true:
+// c rides on the Q fragments exactly as in the forward (the SAME rounded bf16(q c), so the recomputed scores are the forward's) and
+// -lse log2(e) is the initial value of the score accumulators, as -D already was for dP: the pair costs one v_exp and one multiply.
+template <int QW, bool PRE>
 __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                        int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                                                        const bf16_t* __restrict__ o, int64_t ldo,
@@ -451,10 +578,13 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
     const bf16_t* dOb = dO + (int64_t)b * N * lddo + h * HD;
     const bf16_t* Kb = k + (int64_t)b * Nkv * ldk + h * HD;
     const bf16_t* Vb = v + (int64_t)b * Nkv * ldv + h * HD;
-    amp_stage(KV[0][0], KV[0][1], Kb, ldk, Vb, ldv, 0, Nkv, wave, lane);
+    const AmpSrc so = amp_src(ldk, ldv, wave, lane);
+    amp_stage_fast<0>(KV, Kb, ldk, Vb, ldv, 0, Nkv, so, wave, lane);
+    const AmpBases ab = amp_bases(&KV[0][0][0], lane);
     const float cs = scale * 1.44269504088896340736f;
     bf16x8 Qf[QW][KS], dOf[QW][KS];
-    float Dq[QW], nDq[QW], nl2[QW];         // nl2 = -lse in log2 units (+inf -> -inf for rows beyond N: their probabilities are 0)
+    float Dq[QW], nl2[QW];                  // nl2 = -lse in log2 units (+inf -> -inf for rows beyond N: their probabilities are 0)
+    f32x4 Cd[QW], Cl[QW];                   // -D (and, PRE, -lse log2 e) in all four registers: the C operands of the dP / score products
 #pragma unroll
     for (int t = 0; t < QW; ++t) {
         const int row = q0 + 16 * t + c;
@@ -466,11 +596,17 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
             const bf16x8 of = ld_frag_global(Ob + (int64_t)row * ldo + 32 * s + 8 * g, row < N);
 #pragma unroll
             for (int j = 0; j < 8; ++j) part += (float)dOf[t][s][j] * (float)of[j];
+            if constexpr (PRE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Qf[t][s][j] = (__bf16)((float)Qf[t][s][j] * cs);
+            }
         }
         Dq[t] = xgroup_sum(part);
-        nDq[t] = -Dq[t];
         nl2[t] = row < N ? -lse[((int64_t)b * heads + h) * N + row] * 1.44269504088896340736f : -INFINITY;
         if (g == 0 && row < N) Dbuf[((int64_t)b * heads + h) * N + row] = Dq[t];
+        Cd[t] = (f32x4){-Dq[t], -Dq[t], -Dq[t], -Dq[t]};
+        Cl[t] = PRE ? (f32x4){nl2[t], nl2[t], nl2[t], nl2[t]} : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (PRE) { asm volatile("" : "+v"(Cd[t])); asm volatile("" : "+v"(Cl[t])); }
     }
     f32x4 dQ[DT][QW];
 #pragma unroll
@@ -478,72 +614,74 @@ __global__ void __launch_bounds__(AM_THREADS, 3) attn_bwd_dq64p_kernel(const bf1
 #pragma unroll
         for (int d = 0; d < DT; ++d) dQ[d][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nst = (Nkv + AMP_KC - 1) / AMP_KC;
-    for (int st = 0; st < nst; ++st) {
+    auto step = [&](auto bufc, auto kbc, int st) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value, KB = decltype(kbc)::value;
+        constexpr int OK = BUF * 0x4000 + KB * 128, OV = OK + 0x2000;
         const int kc0 = st * AMP_KC;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + 1 < nst) amp_stage(KV[(st + 1) & 1][0], KV[(st + 1) & 1][1], Kb, ldk, Vb, ldv, kc0 + AMP_KC, Nkv, wave, lane);
-        if (q0 >= N) continue;
-        const bf16_t* Ks = KV[st & 1][0];
-        const bf16_t* Vs = KV[st & 1][1];
+        float ds[QW][2][4];
+        {
+            bf16x8 Kf[2][KS], Vf[2][KS];
+            Kf[0][0] = amp_lds128<OK>(ab.k[0]); Kf[0][1] = amp_lds128<OK>(ab.k[1]);
+            Vf[0][0] = amp_lds128<OV>(ab.k[0]); Vf[0][1] = amp_lds128<OV>(ab.k[1]);
+            Kf[1][0] = amp_lds128<OK + 2048>(ab.k[0]); Kf[1][1] = amp_lds128<OK + 2048>(ab.k[1]);
+            Vf[1][0] = amp_lds128<OV + 2048>(ab.k[0]); Vf[1][1] = amp_lds128<OV + 2048>(ab.k[1]);
+            AMP_LGKM0();
+            f32x4 S[QW][2], dP[QW][2];
 #pragma unroll
-        for (int kb = 0; kb < AMP_KC; kb += 32) {
-            float ds[QW][2][4];
-            {
-                bf16x8 Kf[2][KS], Vf[2][KS];
+            for (int t = 0; t < QW; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    // (-D is the initial value of the dP accumulators: dP - D comes out of the matrix pipe, no subtraction per score)
+                    S[t][kt] = Cl[t]; dP[t][kt] = Cd[t];
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        S[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S[t][kt], 0, 0, 0);
+                        dP[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP[t][kt], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int t = 0; t < QW; ++t)
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        const int off = (kb + 16 * kt + c) * HD + (((4 * s + g) ^ (c & 7)) << 3);
-                        Kf[kt][s] = ld_frag_lds(Ks + off);
-                        Vf[kt][s] = ld_frag_lds(Vs + off);
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(PRE ? S[t][kt][r] : fmaf(S[t][kt][r], cs, nl2[t]));
+                        ds[t][kt][r] = p * dP[t][kt][r];
                     }
-                f32x4 S[QW][2], dP[QW][2];
-#pragma unroll
-                for (int t = 0; t < QW; ++t)
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt) {
-                        // (-D is the initial value of the dP accumulators: dP - D comes out of the matrix pipe, no subtraction per score)
-                        S[t][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dP[t][kt] = (f32x4){nDq[t], nDq[t], nDq[t], nDq[t]};
-#pragma unroll
-                        for (int s = 0; s < KS; ++s) {
-                            S[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Kf[kt][s], Qf[t][s], S[t][kt], 0, 0, 0);
-                            dP[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Vf[kt][s], dOf[t][s], dP[t][kt], 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                for (int t = 0; t < QW; ++t)
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float p = __builtin_amdgcn_exp2f(fmaf(S[t][kt][r], cs, nl2[t]));
-                            ds[t][kt][r] = p * dP[t][kt][r];
-                        }
-            }
-            if (kc0 + kb + 32 > Nkv) {                          // keys beyond the last one carry no gradient (wave-uniform tail)
-#pragma unroll
-                for (int t = 0; t < QW; ++t)
-#pragma unroll
-                    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (kc0 + kb + 16 * kt + 4 * g + r >= Nkv) ds[t][kt][r] = 0.f;
-            }
-            __builtin_amdgcn_sched_barrier(0);                  // the K^T reads stay behind the score products (register budget)
-            bf16x8 KT[DT];
-#pragma unroll
-            for (int d = 0; d < DT; ++d) KT[d] = amp_frag_trs(Ks, kb + 4 * g, kb + 16 + 4 * g, d, lane);
-            bf16x8 dSf[QW];
-#pragma unroll
-            for (int t = 0; t < QW; ++t) dSf[t] = pack_acc(ds[t][0], ds[t][1]);
-            AMP_LGKM0();
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-#pragma unroll
-                for (int t = 0; t < QW; ++t) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf[t], dQ[d][t], 0, 0, 0);
         }
+        if (kc0 + KB + 32 > Nkv) {                          // keys beyond the last one carry no gradient (wave-uniform tail)
+#pragma unroll
+            for (int t = 0; t < QW; ++t)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kc0 + KB + 16 * kt + 4 * g + r >= Nkv) ds[t][kt][r] = 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // the K^T reads stay behind the score products (register budget)
+        bf16x8 KT[DT];
+        KT[0] = amp_trs<OK>(ab.v[0]); KT[1] = amp_trs<OK>(ab.v[1]); KT[2] = amp_trs<OK>(ab.v[2]); KT[3] = amp_trs<OK>(ab.v[3]);
+        bf16x8 dSf[QW];
+#pragma unroll
+        for (int t = 0; t < QW; ++t) dSf[t] = pack_acc(ds[t][0], ds[t][1]);
+        AMP_LGKM0();
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int t = 0; t < QW; ++t) dQ[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(KT[d], dSf[t], dQ[d][t], 0, 0, 0);
+    };
+    auto stage = [&](auto bufc, int st) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (st + 1 < nst) amp_stage_fast<BUF ^ 1>(KV, Kb, ldk, Vb, ldv, (st + 1) * AMP_KC, Nkv, so, wave, lane);
+        if (q0 >= N) return;
+        step(bufc, amp_ic<0>{}, st);
+        step(bufc, amp_ic<32>{}, st);
+    };
+    for (int st = 0; st < nst; st += 2) {
+        stage(amp_ic<0>{}, st);
+        if (st + 1 < nst) stage(amp_ic<1>{}, st + 1);
     }
     if (q0 >= N) return;
     bf16_t* dQb = dq + (int64_t)b * N * lddq + h * HD;
@@ -575,8 +713,12 @@ int attn_mfma_fwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
         (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale)
     if (hd == 32) AM_FWD(32, false, 4, false);
     else if (Nkv >= 2 * AMP_KC) {
-        hipLaunchKernelGGL((attn_fwd64p_kernel<QW>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                           (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
+        if (!POL(attn64_prescale))
+            hipLaunchKernelGGL((attn_fwd64p_kernel<QW, false>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                               (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
+        else
+            hipLaunchKernelGGL((attn_fwd64p_kernel<QW, true>), grid, dim3(AM_THREADS), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                               (const bf16_t*)v, ldv, (bf16_t*)o, ldo, lse, heads, N, Nkv, scale);
     }
     else if (!am_is_pow2(scale)) AM_FWD(64, false, 4, true);
     else AM_FWD(64, true, 4, true);
@@ -1118,8 +1260,12 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
 #define AM_DKV(P2, SWv, EXv) hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64, P2, SWv, EXv>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo, lse, Dbuf, \
         slab, heads, N, Nkv, B, qchunk, scale)
         if (Nkv >= 2 * AMP_KC) {
-            hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
-                               (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+            if (!POL(attn64_prescale))
+                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW, false>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
+                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
+            else
+                hipLaunchKernelGGL((attn_bwd_dq64p_kernel<QW, true>), g1, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo, DO, lddo, lse,
+                                   (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
             // (a barrier-free form -- every wave staging its own copy of the Q / dO tile by LDS-DMA into a private double-buffered slab --
             // measured 2 % SLOWER: nine DMA pieces per tile and wave cost more issue time than the per-tile barrier they remove)
             AM_DKV(false, true, true);

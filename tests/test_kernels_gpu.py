@@ -203,6 +203,62 @@ def test_attention(dtype, shape):
     _close(kvd.grad, kvr.grad, dtype, fac=4)
 
 
+def test_attention_head_dim_64_long_keys_is_bit_reproducible():
+    """Head dim 64 with >= 128 keys (MiT-B2 and up, csrc/attention_mfma.hip: attn_fwd64p / attn_bwd_dq64p / attn_mfma_bwd_dkv): repeated
+    runs on the same inputs agree bit for bit.  r05 found r04's forward NOT reproducible on a full chip (a few of 16384 log-sum-exp rows
+    per dozen runs): its inline-asm v_max3 read score accumulators behind the matrix instructions without the wait states the compiler
+    only pads in front of instructions it knows to be vector ones -- a stale (similar-sized) score moved the running maximum.  The
+    shape is the one that showed it: 2 heads x 128 query blocks = one workgroup per CU."""
+    from segmentation_factory_amd import hip
+    B, heads, N, Nkv, hd = 1, 2, 8192, 2048, 64
+    g = torch.Generator().manual_seed(5)
+    C = heads * hd
+    q, k, v, do = (torch.randn(n, C, generator=g).bfloat16().cuda() for n in (B * N, B * Nkv, B * Nkv, B * N))
+    first = None
+    for rep in range(12):
+        o, lse = hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, hd ** -0.5)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        dq = hip.attention_bwd(q, k, v, o, do, lse, B, heads, N, Nkv, hd, hd ** -0.5, dk, dv)
+        torch.cuda.synchronize()
+        cur = [t.clone() for t in (o, lse, dq, dk, dv)]
+        if first is None:
+            first = cur
+        else:
+            for name, a, b in zip(('o', 'lse', 'dq', 'dk', 'dv'), first, cur):
+                assert torch.equal(a, b), (rep, name, (a != b).sum().item())
+
+
+@pytest.mark.parametrize('shape', [(1, 2, 8192, 2048, 64), (1, 1, 8200, 2048, 64), (1, 2, 700, 300, 64), (2, 1, 1000, 130, 64)])
+def test_attention_head_dim_64_prescale_option(shape, monkeypatch):
+    """SEGFAC_ATTN64_PRESCALE=1 (csrc/policy.h: scale log2 e on the Q fragments, -max / -lse as the score accumulators' initial values;
+    off by default because it rounds q once more): same tolerance against the fp32 reference as the default path, and two runs agree
+    bitwise.  Key counts that are not multiples of 64 / 32 take the clamped last stage and the masked last step."""
+    from segmentation_factory_amd import functional as Fh
+    B, heads, N, Nkv, hd = shape
+    C = heads * hd
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B * N, C, generator=g)
+    kv = torch.randn(B * Nkv, 2 * C, generator=g)
+    do = torch.randn(B * N, C, generator=g)
+    dtype = torch.bfloat16
+    qr, kvr = _q(q, dtype).requires_grad_(True), _q(kv, dtype).requires_grad_(True)
+    ref = _attn_ref(qr, kvr, B, N, Nkv, heads)
+    ref.backward(_q(do, dtype))
+    monkeypatch.setenv('SEGFAC_ATTN64_PRESCALE', '1')
+    outs = []
+    for rep in range(2):
+        qd, kvd = _dev(q, dtype).requires_grad_(True), _dev(kv, dtype).requires_grad_(True)
+        o = Fh.attention(qd, kvd, B, N, Nkv, heads)
+        o.backward(_dev(do, dtype))
+        torch.cuda.synchronize()
+        outs.append((o.detach().clone(), qd.grad.clone(), kvd.grad.clone()))
+    _close(outs[0][0], ref, dtype)
+    _close(outs[0][1], qr.grad, dtype, fac=2)
+    _close(outs[0][2], kvr.grad, dtype, fac=4)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('shape', [(2, 1, 4096, 256, 32), (3, 2, 1000, 200, 32), (2, 5, 70, 64, 32), (1, 8, 256, 256, 32)])
 def test_attention_backward_one_kernel_form_equals_two_kernel_form(shape, monkeypatch):
     """Head dim 32 with at most 256 keys (every stage of the 512^2 configs): the backward runs as ONE kernel (dQ through a transposed

@@ -10,7 +10,16 @@ from segmentation_factory_amd import hip
 
 
 def timed(fn, n):
+    # warm up for >= 60 ms: the first loop of a fresh process runs while the shader clock is still ramping (r05: the first figure of a
+    # process read 0.77 ms for a kernel whose every later figure was 0.62 -- the round's earlier "held clock 1.59 GHz" was that ramp)
     fn(); torch.cuda.synchronize()
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0.record()
+    for _ in range(200):
+        fn()
+        w1.record(); w1.synchronize()
+        if w0.elapsed_time(w1) >= 60.0:
+            break
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
