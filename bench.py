@@ -136,7 +136,8 @@ def extra_legs(budget_s):
             ('other_configs', ['config', 'cfg5']), ('other_configs', ['config', 'cfg5', '--fp8']),
             ('other_configs', ['config', 'cfg2', '--batch', '4', '--steps', '40', '--warmup', '10']),
             ('other_configs', ['config', 'cfg2', '--batch', '16', '--steps', '20', '--warmup', '5']),
-            ('train_loop', ['train_loop', '--batch', '128', '--steps', '10', '--epochs', '2']),
+            ('other_configs', ['config', 'cfg2', '--batch', '128', '--steps', '20', '--warmup', '5']),
+            ('train_loop', ['train_loop', '--batch', '256', '--steps', '10', '--epochs', '2']),
             ('train_loop', ['train_loop', '--batch', '4', '--steps', '100', '--epochs', '2']),
             ('train_loop', ['default_cli', '--batch', '4', '--steps', '50', '--epochs', '2']),
             ('eval', ['eval', '--batch', '1', '--steps', '100']), ('eval', ['eval', '--batch', '32', '--steps', '10'])]
@@ -170,7 +171,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=128, help='per-GPU batch (BASELINE.json does not fix it; 128 x 512^2 peaks at ~22 of 288 GB; 64: -8 %%, 192: +0.3 %%)')
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE.json does not fix it; 256 x 512^2 peaks at ~44 of 288 GB; same box: 128: -2.6 %%, 192: -3 %%, 320: -1.8 %% -- '
+                    'powers of two fill the tile grids; profiles/r05_batch_sweep.txt)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimizer', action='store_true', help='time forward+loss+backward only')

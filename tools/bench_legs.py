@@ -305,7 +305,7 @@ def main():
     a = ap.parse_args()
     assert torch.cuda.is_available(), 'bench legs need the MI355X (there is no CPU fallback)'
     if a.batch is None:
-        a.batch = {'cfg2': 128, 'cfg3': 32, 'cfg4': 16, 'cfg5': 8}[a.config]
+        a.batch = {'cfg2': 256, 'cfg3': 32, 'cfg4': 16, 'cfg5': 8}[a.config]
     out = {'config': leg_config, 'train_loop': leg_train_loop, 'eval': leg_eval, 'default_cli': leg_default_cli}[a.leg](a)
     print('LEG_JSON ' + json.dumps(out))
 

@@ -19,11 +19,12 @@ def line(name):
     return json.loads(open(os.path.join(P, name)).read().strip().splitlines()[-1])
 
 
-final = line(f'{a.tag}_bench_b128_final.json')
-first = line(f'{a.tag}_bench_b128.json')
+HB = 256          # the headline per-GPU batch (bench.py default, tools/measure_round.sh)
+final = line(f'{a.tag}_bench_b{HB}_final.json')
+first = line(f'{a.tag}_bench_b{HB}.json')
 v = {'TAG': a.tag, 'HEAD_IPS': f"{final['value']:.0f}", 'HEAD_MS': f"{final['ms_per_step']:.2f}", 'HEAD_IPS_A': f"{first['value']:.0f}",
      'HEAD_X': f"{final['value'] / 200:.0f}"}
-for b in (4, 16, 32):
+for b in (4, 16, 32, 128):
     v[f'B{b}'] = f"{line(f'{a.tag}_bench_b{b}.json')['value']:.0f}"
 r, g = final['roofline'], final['roofline_gemm']
 v.update(LOSS_GBPS=f"{r['achieved']:.0f}", LOSS_FRAC=f"{r['frac']:.3f}", LOSS_TRAFFIC=f"{(r.get('traffic') or 0) / 1e9:.2f}",
@@ -43,7 +44,7 @@ names = {'CFG3': 'cfg3', 'CFG3F': 'cfg3 fp8', 'CFG4': 'cfg4', 'CFG5': 'cfg5', 'C
 v['TARGETS'] = a.targets or ('met for ' + (', '.join(names[k] for k in met) or 'none') + '; missed for '
                              + ', '.join(f'{names[k]} ({vals[k]:.0f})' for k in goal if k not in met))
 tl = {leg['per_gpu_batch']: leg for leg in final['train_loop'] if leg['leg'] == 'train_loop'}
-v['TL128'], v['TL4'] = f"{tl[128]['ratio_to_replay_only']:.3f}", f"{tl[4]['ratio_to_replay_only']:.3f}"
+v['TLH'], v['TL4'] = f"{tl[HB]['ratio_to_replay_only']:.3f}", f"{tl[4]['ratio_to_replay_only']:.3f}"
 cli = next(leg for leg in final['train_loop'] if leg['leg'] == 'default_cli')
 v['CLI_AUTO'], v['CLI_EAGER'] = f"{cli['auto']['images_per_sec']:.0f}", f"{cli['eager']['images_per_sec']:.0f}"
 ev = {leg['per_gpu_batch']: leg for leg in final['eval']}

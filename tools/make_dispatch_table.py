@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Record which kernel every C-ABI call of one train step takes, for every BASELINE configuration (cfg2 at per-GPU batch 4 / 16 / 128,
+"""Record which kernel every C-ABI call of one train step takes, for every BASELINE configuration (cfg2 at per-GPU batch 4 / 16 / 128 / 256,
 cfg3, cfg4, cfg5, and the fp8 option of cfg3 / cfg5), on the MI355X:
 
     python tools/make_dispatch_table.py [--out tests/golden/dispatch_table.json] [--only cfg2_b4 ...]
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
-CASES = {'cfg2_b4': ('cfg2', 4, False), 'cfg2_b16': ('cfg2', 16, False), 'cfg2_b128': ('cfg2', 128, False), 'cfg3_b32': ('cfg3', 32, False),
+CASES = {'cfg2_b4': ('cfg2', 4, False), 'cfg2_b16': ('cfg2', 16, False), 'cfg2_b128': ('cfg2', 128, False), 'cfg2_b256': ('cfg2', 256, False), 'cfg3_b32': ('cfg3', 32, False),
          'cfg4_b16': ('cfg4', 16, False), 'cfg5_b8': ('cfg5', 8, False), 'cfg3_b32_fp8': ('cfg3', 32, True), 'cfg5_b8_fp8': ('cfg5', 8, True)}
 # launches that are not dispatch decisions (one kernel whatever the shape): left out to keep the table readable
 ELEMENTWISE = {'segf_cast', 'segf_cast2d', 'segf_permute021', 'segf_add', 'segf_zero', 'segf_scale_rows', 'segf_add_i64', 'segf_gelu',

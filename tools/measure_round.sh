@@ -3,9 +3,10 @@
 #   tools/measure_round.sh <tag> [sections]     e.g. r03 "main small cfgs parity" (default: all five)
 # default bench line (with the CPU baseline), kernel stats of the same command, PMC traffic (two passes), small-batch lines,
 # the other BASELINE configs.  Run it as the LAST act of a round, on the committed sources: the counter file it leaves in
-# profiles/pmc_traffic_b128.json is stamped with one hash per reported kernel (bench.KERNEL_SOURCES) and bench.py reports a kernel's
+# profiles/pmc_traffic_b${HB}.json is stamped with one hash per reported kernel (bench.KERNEL_SOURCES) and bench.py reports a kernel's
 # traffic only while ITS sources are unchanged (r04's closing commit touched gemm.hip and voided the loss kernel's figure too).
 set -u
+HB=256          # the headline per-GPU batch (bench.py default)
 TAG=${1:-r05}
 SECTIONS=${2:-main small cfgs power parity}
 has() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
@@ -14,18 +15,18 @@ O=$R/gpurun_out/m
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 if has main; then
-python3 $R/bench.py > $O/${TAG}_bench_b128.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 10 --warmup 3 > $O/${TAG}_bench_b128_profiled.json 2>> $O/bench.err
-python3 $R/tools/rocpd_summary.py $O/prof/stats_results.db --csv $O/${TAG}_bench_b128_kernel_stats.csv --top 12 > $O/stats_top.txt 2>&1
+python3 $R/bench.py > $O/${TAG}_bench_b${HB}.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 10 --warmup 3 > $O/${TAG}_bench_b${HB}_profiled.json 2>> $O/bench.err
+python3 $R/tools/rocpd_summary.py $O/prof/stats_results.db --csv $O/${TAG}_bench_b${HB}_kernel_stats.csv --top 12 > $O/stats_top.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs --steps 2 --warmup 1 > /dev/null 2>> $O/bench.err
-cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch 128 --out $O/pmc_traffic_b128.json > $O/pmc_top.txt 2>&1
+cd $R && python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write --batch $HB --out $O/pmc_traffic_b${HB}.json > $O/pmc_top.txt 2>&1
 # the default line once more with the counter file just taken (same sources: bench.py reports roofline.traffic from it)
-cp $O/pmc_traffic_b128.json $R/profiles/pmc_traffic_b128.json && python3 bench.py > $O/${TAG}_bench_b128_final.json 2>> $O/bench.err
+cp $O/pmc_traffic_b${HB}.json $R/profiles/pmc_traffic_b${HB}.json && python3 bench.py > $O/${TAG}_bench_b${HB}_final.json 2>> $O/bench.err
 fi
 if has small; then
 cd $R
-for b in 4 16 32; do python3 bench.py --batch $b --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_b${b}.json 2>> $O/bench.err; done
+for b in 4 16 32 128; do python3 bench.py --batch $b --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_b${b}.json 2>> $O/bench.err; done
 fi
 if has cfgs; then
 cd $R
@@ -54,7 +55,7 @@ cd $R
 # configurations run at the package power limit and the clock the firmware grants, not at 2.4 GHz)
 P=$O/${TAG}_power_clock.txt
 rocm-smi --showmaxpower 2>/dev/null | grep -i "power" > $P
-for cbs in cfg2:128:400 cfg3:32:120 cfg4:16:120 cfg5:8:160; do
+for cbs in cfg2:$HB:200 cfg3:32:120 cfg4:16:120 cfg5:8:160; do
   c=${cbs%%:*}; rest=${cbs#*:}; b=${rest%%:*}; n=${rest##*:}
   echo "== $c batch $b" >> $P
   touch $O/.sampling

@@ -5,7 +5,7 @@ do not fit one pass; both are reported in KB; on gfx950 FETCH_SIZE counts 128-B 
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --batch 128 --out profiles/pmc_traffic_b128.json
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write --batch 256 --out profiles/pmc_traffic_b256.json
 
 Per kernel name the LARGEST launch is kept (the full-size in-graph one).  The JSON is stamped with the hash of the kernel
 sources, one hash per reported kernel (bench.kernel_source_hash); bench.py reports a kernel's `traffic` only when ITS hash matches the
