@@ -171,7 +171,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE.json does not fix it; 256 x 512^2 peaks at ~44 of 288 GB; same box: 128: -2.6 %%, 192: -3 %%, 320: -1.8 %% -- '
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch, default 256 / 64 / 32 / 32 for cfg2 / cfg3 / cfg4 / cfg5 (BASELINE.json does not fix it; 256 x 512^2 peaks at ~44 of 288 GB; same box: 128: -2.6 %%, 192: -3 %%, 320: -1.8 %% -- '
                     'powers of two fill the tile grids; profiles/r05_batch_sweep.txt)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -186,6 +186,8 @@ def main():
     ap.add_argument('--no-extra-legs', action='store_true', help='skip the secondary legs (other BASELINE configs, train loop, evaluate)')
     ap.add_argument('--legs-budget-s', type=float, default=210.0, help='wall-clock budget for the secondary legs; legs that do not fit are listed as skipped')
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}[args.config]          # sized for 288 GB: 44 / 41 / 84 / 65 GB peak
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

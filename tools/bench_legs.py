@@ -11,7 +11,7 @@
               confusion-matrix kernel against the HBM roofline
   default_cli `engine.train_one_epoch` as the README command runs it (DataLoader-fed, batch 4, no flag = graph) next to --no-hip-graph
 
-python tools/bench_legs.py config cfg3 --batch 32 [--fp8] | train_loop --batch 128 | eval --batch 1      -> one JSON line
+python tools/bench_legs.py config cfg3 --batch 64 [--fp8] | train_loop --batch 256 | eval --batch 1      -> one JSON line
 """
 import argparse
 import contextlib
@@ -305,7 +305,7 @@ def main():
     a = ap.parse_args()
     assert torch.cuda.is_available(), 'bench legs need the MI355X (there is no CPU fallback)'
     if a.batch is None:
-        a.batch = {'cfg2': 256, 'cfg3': 32, 'cfg4': 16, 'cfg5': 8}[a.config]
+        a.batch = {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}      # sized for 288 GB (profiles/r05_batch_sweep.txt): 41 / 84 / 65 GB[a.config]
     out = {'config': leg_config, 'train_loop': leg_train_loop, 'eval': leg_eval, 'default_cli': leg_default_cli}[a.leg](a)
     print('LEG_JSON ' + json.dumps(out))
 

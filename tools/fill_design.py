@@ -30,7 +30,7 @@ r, g = final['roofline'], final['roofline_gemm']
 v.update(LOSS_GBPS=f"{r['achieved']:.0f}", LOSS_FRAC=f"{r['frac']:.3f}", LOSS_TRAFFIC=f"{(r.get('traffic') or 0) / 1e9:.2f}",
          LOSS_TOA=str(r.get('traffic_over_algorithmic')), GEMM_GBPS=f"{g['achieved']:.0f}", GEMM_FRAC=f"{g['frac']:.2f}",
          GEMM_TOA=str(g.get('traffic_over_algorithmic')))
-cfg = {'CFG3': 'cfg3_b32', 'CFG3F': 'cfg3_b32_fp8', 'CFG4': 'cfg4_b16', 'CFG5': 'cfg5_b8', 'CFG5F': 'cfg5_b8_fp8'}
+cfg = {'CFG3': 'cfg3_b64', 'CFG3F': 'cfg3_b64_fp8', 'CFG4': 'cfg4_b32', 'CFG5': 'cfg5_b32', 'CFG5F': 'cfg5_b32_fp8'}
 vals = {}
 for k, f in cfg.items():
     d = line(f'{a.tag}_bench_{f}.json')

@@ -30,15 +30,15 @@ for b in 4 16 32 128; do python3 bench.py --batch $b --no-cpu-baseline --no-extr
 fi
 if has cfgs; then
 cd $R
-python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg3_b32.json 2>> $O/bench.err
-python3 bench.py --config cfg4 --batch 16 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg4_b16.json 2>> $O/bench.err
-python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg5_b8.json 2>> $O/bench.err
-python3 bench.py --config cfg5 --batch 8 --no-cpu-baseline --no-extra-legs --fp8 > $O/${TAG}_bench_cfg5_b8_fp8.json 2>> $O/bench.err
-python3 bench.py --config cfg3 --batch 32 --no-cpu-baseline --no-extra-legs --fp8 > $O/${TAG}_bench_cfg3_b32_fp8.json 2>> $O/bench.err
+python3 bench.py --config cfg3 --batch 64 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg3_b64.json 2>> $O/bench.err
+python3 bench.py --config cfg4 --batch 32 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg4_b32.json 2>> $O/bench.err
+python3 bench.py --config cfg5 --batch 32 --no-cpu-baseline --no-extra-legs > $O/${TAG}_bench_cfg5_b32.json 2>> $O/bench.err
+python3 bench.py --config cfg5 --batch 32 --no-cpu-baseline --no-extra-legs --fp8 > $O/${TAG}_bench_cfg5_b32_fp8.json 2>> $O/bench.err
+python3 bench.py --config cfg3 --batch 64 --no-cpu-baseline --no-extra-legs --fp8 > $O/${TAG}_bench_cfg3_b64_fp8.json 2>> $O/bench.err
 python3 tools/probe/fp8_conv_probe.py > $O/${TAG}_conv3x3_bf16_vs_fp8.txt 2>> $O/bench.err
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 # kernel statistics + counter traffic of the other BASELINE configs (the TFLOP/s and GB/s claims of DESIGN section 5 / 9)
-for cb in cfg3:32 cfg4:16 cfg5:8; do
+for cb in cfg3:64 cfg4:32 cfg5:32; do
   c=${cb%%:*}; b=${cb##*:}
   cd /tmp
   rocprofv3 --kernel-trace --stats -d $O/prof_$c -o stats -- python3 $R/bench.py --config $c --batch $b --no-cpu-baseline --no-extra-legs --steps 5 --warmup 2 > /dev/null 2>> $O/bench.err
@@ -55,7 +55,7 @@ cd $R
 # configurations run at the package power limit and the clock the firmware grants, not at 2.4 GHz)
 P=$O/${TAG}_power_clock.txt
 rocm-smi --showmaxpower 2>/dev/null | grep -i "power" > $P
-for cbs in cfg2:$HB:200 cfg3:32:120 cfg4:16:120 cfg5:8:160; do
+for cbs in cfg2:$HB:200 cfg3:64:60 cfg4:32:60 cfg5:32:40; do
   c=${cbs%%:*}; rest=${cbs#*:}; b=${rest%%:*}; n=${rest##*:}
   echo "== $c batch $b" >> $P
   touch $O/.sampling
