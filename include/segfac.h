@@ -538,6 +538,8 @@ int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, i
  *   SEGFAC_GEMM8_LINEAR_MIN_TILES fewest 256 x 256 tiles for which a K >= 2048 nn.Linear product takes the eight-phase kernel (192 for shorter K)  (default 128)
  *   SEGFAC_GEMM8_LINEAR_MIN_FILL smallest share (percent) of the launched 256 x 256 tiles that must be output for an nn.Linear product with ragged last tiles to take the eight-phase kernel  (default 60)
  *   SEGFAC_GEMM8_LINEAR_MIN_K    shortest reduction for which an nn.Linear product takes the eight-phase kernel (its 12-load prologue and drain against K / 64 tiles)  (default 256)
+ *   SEGFAC_GEMM8_DW              0: nn.Linear weight gradients never take the eight-phase kernel below 65536 tokens (the grouped 128-tile kernel as in r04)  (default 1)
+ *   SEGFAC_GEMM8_DW_MIN_GFLOP    smallest nn.Linear weight gradient (GFLOP; both feature counts multiples of 256, >= 256 FLOP per operand byte) that takes the eight-phase kernel + a column-sum pass instead of the grouped 128-tile kernel  (default 100)
  *   SEGFAC_GEMM8_LINEAR_MIN_GFLOP smallest nn.Linear product (GFLOP, K >= 512; 100 for shorter K) that takes the eight-phase kernel  (default 36)
  *   SEGFAC_NO_GEMM8              no eight-phase kernel at all (gemm8_kernel): the two-phase 256-tile kernel everywhere
  *   SEGFAC_NO_GEMM8T             no eight-phase kernel for weight gradients (reduction-major operands)

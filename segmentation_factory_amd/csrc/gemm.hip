@@ -2140,11 +2140,37 @@ static bool gemm_dw_skinny_launch_nt(int nt, dim3 grid, hipStream_t st, const Ge
     return false;
 }
 
+// nn.Linear weight gradients that are MATRIX-PIPE work, not streaming: dW [M x N] = dy^T x over K tokens with both feature counts
+// multiples of 256, >= 100 GFLOP and >= 256 FLOP per operand byte (ConvNeXtV2-L stage 3 / 4 at 640^2, batch 32: [3072 x 768] over
+// 51200 tokens = 241 GFLOP, 27 blocks x 2; MiT-B2 stage 4 at batch 32).  gemm_use_big's token-count rule (K >= 65536, made for the
+// SMALL outputs of the MiT linears, where split-K supplies the parallelism) left them on the 128-tile grouped kernel at ~630 TFLOP/s;
+// the eight-phase tile runs reduction-major x reduction-major products at ~1.2 PFLOP/s (gemm8.hip).  The bias gradient then takes its
+// own column-sum pass (one more read of dy: 0.3 GB against 241 GFLOP).  SEGFAC_GEMM8_DW=0 switches the rule off.
+static inline bool dw_on_gemm8(int64_t M, int64_t N, int64_t K) {
+    if (!POL(gemm8_dw) || POL(no_gemm8) || POL(no_gemm8t) || POL(gemm_no_big) || !POL(gemm8_linear)) return false;
+    if (M % 256 || N % 256 || K % 64 || K < 2048) return false;
+    const double gflop = 2e-9 * (double)M * (double)N * (double)K;
+    return gflop >= (double)POL(gemm8_dw_min_gflop) && M * N >= 256 * (M + N);
+}
 extern "C" int segf_gemm_pick_splitk(int64_t M, int64_t N, int64_t K) {
     // layout 2 (weight gradient): K = token count.  Aim for >= 512 workgroups, >= 4 K-steps per slice.
     {   // small outputs: the streaming kernel's slice count (one slice per wave); the bias-gradient column is assumed
         DwSkinny p;
         if (gemm_dw_skinny_plan(M, N, K, true, p)) return p.slices;
+    }
+    if (!gemm_use_big(2, M, N, K) && dw_on_gemm8(M, N, K)) {
+        // one 256 x 256 tile per CU and round: the smallest slice count (slices of >= 16 K tiles) whose last round is >= 90 % full, else
+        // the fullest ([6144 x 1536] = 144 tiles: 5 slices = 720 workgroups = 2.8 rounds; [3072 x 768] = 36 tiles: 7 slices = 252)
+        const int64_t tiles = (M / 256) * (N / 256);
+        int best = 1;
+        double bf = 0.0;
+        for (int c = 1; c <= 16 && K / c >= 16 * 64; ++c) {
+            const int64_t wg = tiles * c;
+            const double fill = (double)wg / (double)(cdiv64(wg, 256) * 256);
+            if (fill >= 0.9) { best = c; break; }
+            if (fill > bf + 1e-9) { bf = fill; best = c; }
+        }
+        return best;
     }
     const bool big = gemm_use_big(2, M, N, K);
     const int64_t tiles = big ? cdiv64(M, GG_B) * cdiv64(N, GG_B) : cdiv64(M, GB_BM) * cdiv64(N, GB_BN);
@@ -2209,7 +2235,7 @@ extern "C" int segf_gemm_dw_db(int dt, int64_t M, int64_t N, int64_t K, const vo
                         !POL(gemm_no_tr);
     // fused in the streaming kernel (all-ones fragment), in the 128-tile kernel (all-ones column when N leaves one free, extra
     // MFMAs when it does not); the 256-tile kernel has no registers to spare for it
-    const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (skinny || !gemm_use_big(2, M, N, K)) &&
+    const bool fused = dt == SEGF_BF16 && c_dt == SEGF_F32 && (skinny || !(gemm_use_big(2, M, N, K) || dw_on_gemm8(M, N, K))) &&
                        !POL(gemm_no_fused_db);
     if (!fused) {       // big-tile / fp32 kernels: separate column reduction (still one C-ABI call)
         const int rc = gemm_impl(dt, 2, M, N, K, A, lda, B, ldb, C, c_dt, ldc, nullptr, nullptr, 0, nullptr, 1, split_k, ws, nullptr, stream);
@@ -2332,7 +2358,8 @@ extern "C" int segf_gemm_dw_db_grouped(int dt, int n, const SegfDwItem* items, v
         const int64_t kchunk = cdiv64(cdiv64(K, split_k), GB_BK) * GB_BK;
         const int slices = (int)cdiv64(K > 0 ? K : 1, kchunk > 0 ? kchunk : GB_BK);
         const bool groupable = !no_group && dt == SEGF_BF16 && M > 0 && N > 0 && K > 0 && it.dw && it.db && it.ws && !skinny && aligned &&
-                               (!gemm_use_big(2, M, N, K) || (it.shared_split && M * N <= dw_group_big_max())) && !POL(gemm_no_fused_db) && !POL(gemm_no_fastload) &&
+                               (!gemm_use_big(2, M, N, K) || (it.shared_split && M * N <= dw_group_big_max())) && !dw_on_gemm8(M, N, K) &&
+                               !POL(gemm_no_fused_db) && !POL(gemm_no_fastload) &&
                                !POL(gemm_no_tr) && !POL(gemm_no_deep128) && M % 8 == 0 && N % 8 == 0 && slices > 1 && cdiv64(M, GB_BM) <= 65535;
         // (a member that alone would take the 256-tile kernel + a separate column-sum pass -- the stage-3 / 4 layers at batch 128 -- joins the
         // group too when it lets the library choose its split: one pass over dy for both gradients; batch 128 +0.5 %)
@@ -2483,7 +2510,8 @@ static int gemm_impl(int dt, int layout, int64_t M, int64_t N, int64_t K, const 
                                              ldr, rscale, a.rpg, nullptr, st);
                 if (rc8 != SEGF_ERR_SHAPE) return rc8;
             }
-            if (layout == 2 && gemm_use_big(layout, M, N, K) && c_dt == SEGF_F32 && !bias && !residual && gemm8_supported(2, 0, M, N, K, a.kchunk, 0)) {
+            if (layout == 2 && (gemm_use_big(layout, M, N, K) || dw_on_gemm8(M, N, K)) && c_dt == SEGF_F32 && !bias && !residual &&
+                gemm8_supported(2, 0, M, N, K, a.kchunk, 0)) {
                 const int rc8 = gemm8_launch(2, 0, 0, M, N, K, a.kchunk, split_k, A, lda, B, ldb, C, ldc, 0, 0, 0, 1, nullptr, nullptr, nullptr,
                                              nullptr, 0, nullptr, 1, a.ws, st);
                 if (rc8 != SEGF_ERR_SHAPE) { if (rc8) return rc8; goto reduce; }

@@ -38,6 +38,8 @@
     X(gemm8_linear_min_tiles, "SEGFAC_GEMM8_LINEAR_MIN_TILES", 128, "fewest 256 x 256 tiles for which a K >= 2048 nn.Linear product takes the eight-phase kernel (192 for shorter K)") \
     X(gemm8_linear_min_fill, "SEGFAC_GEMM8_LINEAR_MIN_FILL", 60, "smallest share (percent) of the launched 256 x 256 tiles that must be output for an nn.Linear product with ragged last tiles to take the eight-phase kernel") \
     X(gemm8_linear_min_k, "SEGFAC_GEMM8_LINEAR_MIN_K", 256, "shortest reduction for which an nn.Linear product takes the eight-phase kernel (its 12-load prologue and drain against K / 64 tiles)") \
+    X(gemm8_dw, "SEGFAC_GEMM8_DW", 1, "0: nn.Linear weight gradients never take the eight-phase kernel below 65536 tokens (the grouped 128-tile kernel as in r04)") \
+    X(gemm8_dw_min_gflop, "SEGFAC_GEMM8_DW_MIN_GFLOP", 100, "smallest nn.Linear weight gradient (GFLOP; both feature counts multiples of 256, >= 256 FLOP per operand byte) that takes the eight-phase kernel + a column-sum pass instead of the grouped 128-tile kernel") \
     X(gemm8_linear_min_gflop, "SEGFAC_GEMM8_LINEAR_MIN_GFLOP", 36, "smallest nn.Linear product (GFLOP, K >= 512; 100 for shorter K) that takes the eight-phase kernel") \
     /* ---- implicit-GEMM 3 x 3 convolution, eight-phase kernel, fp8 (gemm.hip, gemm8.hip, fp8.hip) ---- */                             \
     X(no_gemm8, "SEGFAC_NO_GEMM8", 0, "no eight-phase kernel at all (gemm8_kernel): the two-phase 256-tile kernel everywhere")           \

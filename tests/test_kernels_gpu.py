@@ -1733,6 +1733,45 @@ def test_hist_accum_matches_torch_promotion():
     assert torch.equal(h.cpu(), want) and c.abs().sum().item() == 0
 
 
+@pytest.mark.parametrize('shape', [(3072, 768, 51200), (768, 3072, 51200), (1536, 6144, 12800), (2048, 512, 65536 - 64)])
+def test_linear_weight_gradient_on_the_eight_phase_tile(hipmod, shape):
+    """r05: nn.Linear weight gradients that are matrix-pipe work (both feature counts multiples of 256, >= 100 GFLOP, >= 256 FLOP per
+    operand byte: ConvNeXtV2-L stage 3 / 4 at 640^2 batch 32, convnextv2.py:56-68 backward; MiT-B2 stage 4 at batch 32) take the
+    eight-phase kernel (gemm8.hip, reduction-major x reduction-major, split-K) + a column-sum pass for the bias gradient, alone and as
+    members of segf_gemm_dw_db_grouped (bitwise the same), instead of the grouped 128-tile kernel (policy gemm8_dw = 0): against
+    float64 on the rounded operands and against the 128-tile result."""
+    M, N, K = shape
+    g = torch.Generator(device='cuda').manual_seed(61)
+    dy = (torch.randn(K, M, device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+    x = torch.randn(K, N, device='cuda', generator=g).to(torch.bfloat16)
+    sk = hipmod.pick_splitk(M, N, K)
+    assert 1 <= sk <= 16
+    with hipmod.trace() as tr:
+        dw, db = hipmod.gemm_dw_db(dy, x, M, N, K, split_k=sk)
+    assert any('gemm8_kernel' in k for k in tr.kernels), tr.kernels
+    small = (256, 64, 16384)                                  # a groupable member beside it
+    dy2 = (torch.randn(small[2], small[0], device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+    x2 = torch.randn(small[2], small[1], device='cuda', generator=g).to(torch.bfloat16)
+    sk2 = hipmod.pick_splitk(*small)
+    dw2_ref, db2_ref = hipmod.gemm_dw_db(dy2, x2, *small, split_k=sk2)
+    items = [(dy2, x2, *small, sk2, torch.empty(small[0], small[1], device='cuda'), torch.empty(small[0], device='cuda')),
+             (dy, x, M, N, K, sk, torch.empty(M, N, device='cuda'), torch.empty(M, device='cuda'))]
+    hipmod.gemm_dw_db_grouped(items, shared_split=True)
+    torch.cuda.synchronize()
+    assert torch.equal(items[1][6], dw) and torch.equal(items[1][7], db)
+    assert torch.equal(items[0][6], dw2_ref) and torch.equal(items[0][7], db2_ref)
+    with hipmod.policy_override(gemm8_dw=0), hipmod.trace() as tr0:
+        sk0 = hipmod.pick_splitk(M, N, K)
+        dw0, db0 = hipmod.gemm_dw_db(dy, x, M, N, K, split_k=sk0)
+    assert not any('gemm8_kernel' in k for k in tr0.kernels), tr0.kernels
+    ref = (dy.double().t() @ x.double()).cpu()
+    rb = dy.double().sum(0).cpu()
+    assert (dw.double().cpu() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    assert (db.double().cpu() - rb).abs().max().item() <= 1e-4 * max(1.0, rb.abs().max().item())
+    assert (dw - dw0).abs().max().item() <= 1e-3 * dw0.abs().max().item()
+    assert (db - db0).abs().max().item() <= 1e-4 * max(1.0, db0.abs().max().item())
+
+
 def test_grouped_weight_gradients_equal_per_layer_launches():
     """segf_gemm_dw_db_grouped (the deferred weight gradients of the captured train step; mit.py:43-59,98-99 backward) must give, layer by
     layer, BITWISE what segf_gemm_dw_db gives: MiT stage-3 / 4 shapes at the reference's default batch 4 (groupable: 128-tile split-K
