@@ -430,7 +430,7 @@ def test_dispatch_of_baseline_shapes(golden_dir):
     from segmentation_factory_amd import dispatch
     with open(os.path.join(golden_dir, 'dispatch_table.json')) as fh:
         table = json.load(fh)
-    assert {'cfg2_b4', 'cfg2_b16', 'cfg2_b128', 'cfg2_b256', 'cfg3_b32', 'cfg4_b16', 'cfg5_b8'} <= set(table)
+    assert {'cfg2_b4', 'cfg2_b16', 'cfg2_b128', 'cfg2_b256', 'cfg3_b64', 'cfg4_b32', 'cfg5_b32', 'cfg3_b32', 'cfg4_b16', 'cfg5_b8'} <= set(table)
     moved, n = [], 0
     for case, entries in table.items():
         fns = {e['fn'] for e in entries}

@@ -20,7 +20,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 CASES = {'cfg2_b4': ('cfg2', 4, False), 'cfg2_b16': ('cfg2', 16, False), 'cfg2_b128': ('cfg2', 128, False), 'cfg2_b256': ('cfg2', 256, False), 'cfg3_b32': ('cfg3', 32, False),
-         'cfg4_b16': ('cfg4', 16, False), 'cfg5_b8': ('cfg5', 8, False), 'cfg3_b32_fp8': ('cfg3', 32, True), 'cfg5_b8_fp8': ('cfg5', 8, True)}
+         'cfg4_b16': ('cfg4', 16, False), 'cfg5_b8': ('cfg5', 8, False), 'cfg3_b64': ('cfg3', 64, False), 'cfg4_b32': ('cfg4', 32, False),
+         'cfg5_b32': ('cfg5', 32, False), 'cfg3_b32_fp8': ('cfg3', 32, True), 'cfg5_b8_fp8': ('cfg5', 8, True)}
 # launches that are not dispatch decisions (one kernel whatever the shape): left out to keep the table readable
 ELEMENTWISE = {'segf_cast', 'segf_cast2d', 'segf_permute021', 'segf_add', 'segf_zero', 'segf_scale_rows', 'segf_add_i64', 'segf_gelu',
                'segf_bn_affine_table', 'segf_bn_stats_from_sums', 'segf_hist_accum', 'segf_rowdot'}
