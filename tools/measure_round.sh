@@ -8,7 +8,7 @@
 set -u
 HB=256          # the headline per-GPU batch (bench.py default)
 TAG=${1:-r05}
-SECTIONS=${2:-main small cfgs power parity}
+SECTIONS=${2:-main small cfgs power parity check}
 has() { case " $SECTIONS " in *" $1 "*) return 0;; *) return 1;; esac; }
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/m
@@ -93,6 +93,11 @@ if has parity; then
 cd $R
 # per-tensor gradient errors at full size behind the bf16 bars of test_full_size_fp32_and_bf16_vs_oracle
 python3 tools/grad_parity_fullsize.py cfg2 cfg3 cfg4 cfg5 > $O/${TAG}_grad_parity_fullsize.txt 2>> $O/bench.err
+fi
+if has check; then
+cd $R
+# index widths at the benchmarked batches: a 2n-image batch against its n-image halves, eval mode (tools/check_large_batch.py)
+for nc in 128:cfg2 32:cfg3 16:cfg4 16:cfg5; do timeout 400 python3 tools/check_large_batch.py ${nc%%:*} ${nc##*:} 2>&1 | tail -2; done > $O/${TAG}_large_batch_check.txt
 fi
 ls -la $O; for f in $O/stats_top*.txt; do echo "== $f"; cut -c1-150 $f; done; for f in $O/pmc_top*.txt; do echo "== $f"; head -12 $f | cut -c1-150; done; head -60 $O/*grad_parity_fullsize.txt 2>/dev/null; for f in $O/*bench*.json; do python3 -c "
 import json,sys
