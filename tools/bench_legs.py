@@ -305,7 +305,7 @@ def main():
     a = ap.parse_args()
     assert torch.cuda.is_available(), 'bench legs need the MI355X (there is no CPU fallback)'
     if a.batch is None:
-        a.batch = {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}      # sized for 288 GB (profiles/r05_batch_sweep.txt): 41 / 84 / 65 GB[a.config]
+        a.batch = {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}[a.config]      # sized for 288 GB (profiles/r05_batch_sweep.txt): 38 / 41 / 84 / 65 GB
     out = {'config': leg_config, 'train_loop': leg_train_loop, 'eval': leg_eval, 'default_cli': leg_default_cli}[a.leg](a)
     print('LEG_JSON ' + json.dumps(out))
 
