@@ -61,6 +61,9 @@ def numpy_seed_weights(model, seed):
 
 # sources a kernel's counter traffic depends on (its own files + the shared headers + the build flags): a gemm.hip edit must not
 # void the loss kernel's figure and vice versa
+# per-GPU batch of each BASELINE configuration, sized for 288 GB of HBM by a same-box sweep (profiles/r05_batch_sweep.txt): 38 / 41 / 84 /
+# 65 GB peak; powers of two fill the tile grids (cfg2: 192 and 320 are slower than 128 and 256)
+DEFAULT_BATCH = {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}
 KERNEL_SOURCES = {'loss_bwd': ('loss.hip', 'loss_band.hip', 'loss_geom.h', 'common.h', 'Makefile'),
                   'gemm_pro': ('gemm.hip', 'common.h', 'colreduce.h', 'Makefile')}
 
@@ -187,7 +190,7 @@ def main():
     ap.add_argument('--legs-budget-s', type=float, default=210.0, help='wall-clock budget for the secondary legs; legs that do not fit are listed as skipped')
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}[args.config]          # sized for 288 GB: 44 / 41 / 84 / 65 GB peak
+        args.batch = DEFAULT_BATCH[args.config]
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -443,3 +443,17 @@ def test_dispatch_of_baseline_shapes(golden_dir):
                 moved.append((case, e['fn'], e['args'], e['kernels'], got))
     assert n > 500
     assert not moved, moved[:5]
+
+
+def test_bench_default_batches_resolve():
+    """bench.py / tools/bench_legs.py: a configuration without --batch runs at bench.DEFAULT_BATCH (r05: a misplaced comment once made the
+    legs' default the whole table, and the cfg3 / cfg4 / cfg5 legs of the default line failed on the GPU box only)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench
+    import bench_legs
+    assert bench.DEFAULT_BATCH == {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}
+    for cfg, b in bench.DEFAULT_BATCH.items():
+        assert bench_legs.resolve_batch(cfg) == b and isinstance(bench_legs.resolve_batch(cfg), int)
+        assert bench_legs.resolve_batch(cfg, 7) == 7
+    assert set(bench.DEFAULT_BATCH) == set(bench_legs.CONFIGS) | {'cfg2'} or set(bench.DEFAULT_BATCH) >= set(bench_legs.CONFIGS)

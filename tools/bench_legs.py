@@ -292,6 +292,14 @@ def leg_default_cli(a):
             "speedup_auto_over_eager": round(res['auto']['images_per_sec'] / res['eager']['images_per_sec'], 3)}
 
 
+def resolve_batch(config, batch=None):
+    """The per-GPU batch a configuration is benchmarked at unless --batch says otherwise (bench.DEFAULT_BATCH)."""
+    if batch is not None:
+        return int(batch)
+    from bench import DEFAULT_BATCH
+    return DEFAULT_BATCH[config]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('leg', choices=['config', 'train_loop', 'eval', 'default_cli'])
@@ -304,8 +312,7 @@ def main():
     ap.add_argument('--print-freq', type=int, default=100, help='the reference default (train_gpu.py:74 --train_print_freq 100)')
     a = ap.parse_args()
     assert torch.cuda.is_available(), 'bench legs need the MI355X (there is no CPU fallback)'
-    if a.batch is None:
-        a.batch = {'cfg2': 256, 'cfg3': 64, 'cfg4': 32, 'cfg5': 32}[a.config]      # sized for 288 GB (profiles/r05_batch_sweep.txt): 38 / 41 / 84 / 65 GB
+    a.batch = resolve_batch(a.config, a.batch)
     out = {'config': leg_config, 'train_loop': leg_train_loop, 'eval': leg_eval, 'default_cli': leg_default_cli}[a.leg](a)
     print('LEG_JSON ' + json.dumps(out))
 
