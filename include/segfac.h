@@ -552,6 +552,7 @@ int segf_input_val(const uint8_t* img, int64_t img_stride, const uint8_t* lbl, i
  *   SEGFAC_ATTN_NO_MFMA          attention on the VALU reference kernels (attention.hip) also in bf16
  *   SEGFAC_ATTN_F32_NO_MFMA      fp32 attention forward on the vector kernel (one query per lane) instead of the f32 matrix instruction
  *   SEGFAC_ATTN64_PRESCALE       head dim 64, >= 128 keys: scale log2(e) rides on the Q fragments (bf16(q c), one more rounding per q element) and -max / -lse are the score accumulators' initial values, instead of one multiply-add per score: forward + query-side backward, +8 % / +2 % per kernel, attention error x 1.2 - 2.3
+ *   SEGFAC_ATTN64_DKV_ROWS       head dim 64, >= 128 keys, key-side backward: query rows per staged Q / dO tile and barrier (128, 64 or 32: the same arithmetic, bit for bit)  (default 128)
  *   SEGFAC_ATTN_NO_FUSED_BWD     head dim 32, <= 256 keys: query-side + key-side backward kernels instead of the one-kernel backward
  *   SEGFAC_DW_NO_WALK            depthwise 3 x 3: the round-1 strip kernels instead of the vertical-walk kernels
  *   SEGFAC_DW_WALK_ROWS          depthwise 3 x 3 walk: rows per segment (0 = chosen from the map size)

@@ -851,7 +851,10 @@ __global__ void __launch_bounds__(AM_THREADS, OCC) attn_mfma_bwd_dq_kernel(const
 // wave per SIMD, nothing to overlap the Q / dO staging with) and 32 keys fit two waves per SIMD
 // EX2 (head dim 64): P = exp2(s c - lse log2(e)) with the scale inside c = scale log2(e) -- one v_fma + one v_exp per pair, the
 // log-sum-exp stored negated in log2 units when the tile is staged; dS unscaled, dK scaled once at the end (as P2S, for any scale)
-template <int HD, bool P2S, bool SWZ = true, bool EX2 = false, int KW = (HD == 32 ? 4 : 2)>
+// QR = query rows per staged tile and barrier: 32, or (r05, head dim 64) 64 / 128 walked as 32-query parts -- the same products in the same
+// order with a half / a quarter of the barriers and staging round trips: on 8 x 131072 queries x 2048 keys the backward 1.906 -> 1.753 ->
+// 1.728 ms, cfg4 156.7 -> 161.5 -> 162.5 images/s (same box); 66 KB of LDS per workgroup at 128 rows, two workgroups per CU as before
+template <int HD, bool P2S, bool SWZ = true, bool EX2 = false, int KW = (HD == 32 ? 4 : 2), int QR = 32>
 __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const bf16_t* __restrict__ q, int64_t ldq,
                                                                         const bf16_t* __restrict__ k, int64_t ldk,
                                                                         const bf16_t* __restrict__ v, int64_t ldv,
@@ -862,9 +865,11 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     // Q / dO tiles of 32 queries are double-buffered: the global loads of tile i + 1 are issued before the products of tile i and
     // written to the other buffer after them -- one barrier per tile, the load latency under the 32 MFMAs of a tile
     // (single-buffered, two barriers per tile with the loads in between: 2.16 ms per launch at head dim 64 on MiT-B2 1024 x 2048, batch 16; this form: +14 % images per second on that model)
-    __shared__ __attribute__((aligned(16))) bf16_t Qs2[2][32 * HD];
-    __shared__ __attribute__((aligned(16))) bf16_t dOs2[2][32 * HD];
-    __shared__ float Ls2[2][32], Ds2[2][32];
+    static_assert(QR == 32 || ((QR == 64 || QR == 128) && HD == 64), "64- / 128-query tiles: head dim 64 only");
+    constexpr int NH = QR / 32;                           // 32-query halves per tile
+    __shared__ __attribute__((aligned(16))) bf16_t Qs2[2][QR * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs2[2][QR * HD];
+    __shared__ float Ls2[2][QR], Ds2[2][QR];
     constexpr int KS = HD / 32, DT = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -900,7 +905,9 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     const int sid = HD == 64 ? threadIdx.x : (threadIdx.x & (NCH - 1));
     const int srow = sid / CPR, scol = (sid - srow * CPR) * 8;
     const bool doQ = HD == 64 || threadIdx.x < NCH, doO = HD == 64 || threadIdx.x >= NCH;
-    uint4 rq = make_uint4(0, 0, 0, 0), ro = make_uint4(0, 0, 0, 0);
+    uint4 rq[NH], ro[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) { rq[j] = make_uint4(0, 0, 0, 0); ro[j] = make_uint4(0, 0, 0, 0); }
     float rl = INFINITY, rd = 0.f;
     // Rows beyond the chunk are read from its LAST row (finite values) and carry lse = +inf: their probabilities are exactly 0, so they
     // add nothing -- no zero fill, no divergent loads.  The row pointers advance by a wave-uniform step per tile (the 64-bit
@@ -910,15 +917,18 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     const char* op = reinterpret_cast<const char*>(dOb + (int64_t)row0 * lddo + scol);
     const int64_t qstep = 64 * ldq, ostep = 64 * lddo;            // bytes per 32 rows
     auto fetch = [&](int qt0) {
-        const int row = qt0 + srow;
-        if (row >= qend) {                                   // (only in the last tile of a chunk whose length is not a multiple of 32)
-            qp = reinterpret_cast<const char*>(Qb + (int64_t)(qend - 1) * ldq + scol);
-            op = reinterpret_cast<const char*>(dOb + (int64_t)(qend - 1) * lddo + scol);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            const int row = qt0 + 32 * j + srow;
+            if (row >= qend) {                               // (only in the last tile of a chunk whose length is not a multiple of the tile)
+                qp = reinterpret_cast<const char*>(Qb + (int64_t)(qend - 1) * ldq + scol);
+                op = reinterpret_cast<const char*>(dOb + (int64_t)(qend - 1) * lddo + scol);
+            }
+            if (doQ) rq[j] = *reinterpret_cast<const uint4*>(qp);
+            if (doO) ro[j] = *reinterpret_cast<const uint4*>(op);
+            qp += qstep; op += ostep;
         }
-        if (doQ) rq = *reinterpret_cast<const uint4*>(qp);
-        if (doO) ro = *reinterpret_cast<const uint4*>(op);
-        qp += qstep; op += ostep;
-        if (threadIdx.x < 32) {
+        if (threadIdx.x < QR) {
             const int r2 = qt0 + threadIdx.x;
             rl = r2 < qend ? lb[r2] : INFINITY;          // exp(s - inf) = 0: rows beyond the chunk contribute nothing
             if (EX2) rl *= -1.44269504088896340736f;
@@ -928,9 +938,12 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     };
     const int sswz = srow * HD + (am_chunk<HD, SWZ>(scol >> 3, srow & 7) << 3);      // swizzled LDS position of this thread's chunk
     auto put = [&](int buf) {
-        if (doQ) *reinterpret_cast<uint4*>(Qs2[buf] + sswz) = rq;
-        if (doO) *reinterpret_cast<uint4*>(dOs2[buf] + sswz) = ro;
-        if (threadIdx.x < 32) { Ls2[buf][threadIdx.x] = rl; Ds2[buf][threadIdx.x] = rd; }
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {                       // (row 32 j + srow: the swizzle depends on the row's low three bits only)
+            if (doQ) *reinterpret_cast<uint4*>(Qs2[buf] + 32 * j * HD + sswz) = rq[j];
+            if (doO) *reinterpret_cast<uint4*>(dOs2[buf] + 32 * j * HD + sswz) = ro[j];
+        }
+        if (threadIdx.x < QR) { Ls2[buf][threadIdx.x] = rl; Ds2[buf][threadIdx.x] = rd; }
     };
     fetch(qbeg);
     put(0);
@@ -939,13 +952,16 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
     // base plus an immediate (it was ~35 integer instructions per tile, a quarter of the loop's VALU stream)
     auto tile = [&](auto BUF, int qt0) {
         constexpr int buf = decltype(BUF)::value;
-        const bool more = qt0 + 32 < qend;
-        if (more) fetch(qt0 + 32);
-        const bf16_t* Qs = Qs2[buf];
-        const bf16_t* dOs = dOs2[buf];
-        const float* Ls = Ls2[buf];
-        const float* Ds = Ds2[buf];
+        const bool more = qt0 + QR < qend;
+        if (more) fetch(qt0 + QR);
         if (key0 < Nkv) {
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+        if (hh > 0 && qt0 + 32 * hh >= qend) break;          // (workgroup-uniform: the chunk ended inside the tile's first half)
+        const bf16_t* Qs = Qs2[buf] + 32 * hh * HD;
+        const bf16_t* dOs = dOs2[buf] + 32 * hh * HD;
+        const float* Ls = Ls2[buf] + 32 * hh;
+        const float* Ds = Ds2[buf] + 32 * hh;
         float P[2][KW][4], dS[2][KW][4];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -993,12 +1009,13 @@ __global__ void __launch_bounds__(AM_THREADS, 2) attn_mfma_bwd_dkv_kernel(const 
             }
         }
         }
+        }
         if (more) put(buf ^ 1);          // the other buffer was last read before the barrier that ended the previous tile
         __syncthreads();
     };
-    for (int qt0 = qbeg; qt0 < qend; qt0 += 64) {
+    for (int qt0 = qbeg; qt0 < qend; qt0 += 2 * QR) {
         tile(std::integral_constant<int, 0>{}, qt0);
-        if (qt0 + 32 < qend) tile(std::integral_constant<int, 1>{}, qt0 + 32);       // (workgroup-uniform: the barrier inside is reached by all)
+        if (qt0 + QR < qend) tile(std::integral_constant<int, 1>{}, qt0 + QR);       // (workgroup-uniform: the barrier inside is reached by all)
     }
     if (key0 >= Nkv) return;
     const int C = heads * HD;
@@ -1268,7 +1285,15 @@ int attn_mfma_bwd(int hd, int B, int heads, int N, int Nkv, const void* q, int64
                                    (bf16_t*)dq, lddq, Dbuf, heads, N, Nkv, scale);
             // (a barrier-free form -- every wave staging its own copy of the Q / dO tile by LDS-DMA into a private double-buffered slab --
             // measured 2 % SLOWER: nine DMA pieces per tile and wave cost more issue time than the per-tile barrier they remove)
-            AM_DKV(false, true, true);
+            // (Q / dO tiles of 128 queries per barrier, walked as four 32-query quarters: policy attn64_dkv_rows)
+            if (POL(attn64_dkv_rows) >= 128)
+                hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64, false, true, true, 2, 128>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo,
+                                   lse, Dbuf, slab, heads, N, Nkv, B, qchunk, scale);
+            else if (POL(attn64_dkv_rows) >= 64)
+                hipLaunchKernelGGL((attn_mfma_bwd_dkv_kernel<64, false, true, true, 2, 64>), g2, dim3(AM_THREADS), 0, st, Q, ldq, K, ldk, V, ldv, DO, lddo,
+                                   lse, Dbuf, slab, heads, N, Nkv, B, qchunk, scale);
+            else
+                AM_DKV(false, true, true);
         }
         else if (!am_is_pow2(scale)) { AM_DQ(false, 4, true); AM_DKV(false, true, false); }
         else { AM_DQ(true, 4, true); AM_DKV(true, true, false); }

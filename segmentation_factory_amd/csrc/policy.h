@@ -54,6 +54,7 @@
     X(attn_no_mfma, "SEGFAC_ATTN_NO_MFMA", 0, "attention on the VALU reference kernels (attention.hip) also in bf16")                    \
     X(attn_f32_no_mfma, "SEGFAC_ATTN_F32_NO_MFMA", 0, "fp32 attention forward on the vector kernel (one query per lane) instead of the f32 matrix instruction") \
     X(attn64_prescale, "SEGFAC_ATTN64_PRESCALE", 0, "head dim 64, >= 128 keys: scale log2(e) rides on the Q fragments (bf16(q c), one more rounding per q element) and -max / -lse are the score accumulators' initial values, instead of one multiply-add per score: forward + query-side backward, +8 % / +2 % per kernel, attention error x 1.2 - 2.3") \
+    X(attn64_dkv_rows, "SEGFAC_ATTN64_DKV_ROWS", 128, "head dim 64, >= 128 keys, key-side backward: query rows per staged Q / dO tile and barrier (128, 64 or 32: the same arithmetic, bit for bit)") \
     X(attn_no_fused_bwd, "SEGFAC_ATTN_NO_FUSED_BWD", 0, "head dim 32, <= 256 keys: query-side + key-side backward kernels instead of the one-kernel backward") \
     /* ---- depthwise / patch convolutions (conv.hip) ---- */                                                                            \
     X(dw_no_walk, "SEGFAC_DW_NO_WALK", 0, "depthwise 3 x 3: the round-1 strip kernels instead of the vertical-walk kernels")             \

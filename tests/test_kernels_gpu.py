@@ -228,6 +228,29 @@ def test_attention_head_dim_64_long_keys_is_bit_reproducible():
                 assert torch.equal(a, b), (rep, name, (a != b).sum().item())
 
 
+@pytest.mark.parametrize('shape', [(1, 2, 8192, 2048, 64), (1, 1, 8200, 2048, 64), (1, 2, 700, 300, 64), (2, 1, 1000, 130, 64), (1, 1, 40, 128, 64), (1, 1, 100, 128, 64)])
+def test_attention_head_dim_64_key_side_backward_tile_rows(shape, monkeypatch):
+    """SEGFAC_ATTN64_DKV_ROWS (csrc/policy.h; default 128): the key-side backward stages Q / dO tiles of 128 or 64 queries per barrier
+    instead of 32 and walks them as 32-query parts -- the same products in the same order: dK / dV (and dQ, untouched) bit for bit, for
+    query counts that end inside a tile's first part, inside a later one and on a tile boundary."""
+    from segmentation_factory_amd import hip
+    B, heads, N, Nkv, hd = shape
+    C = heads * hd
+    g = torch.Generator().manual_seed(9)
+    q, k, v, do = (torch.randn(n, C, generator=g).bfloat16().cuda() for n in (B * N, B * Nkv, B * Nkv, B * N))
+    o, lse = hip.attention_fwd(q, k, v, B, heads, N, Nkv, hd, hd ** -0.5)
+    outs = []
+    for rows in ('32', '64', '128'):
+        monkeypatch.setenv('SEGFAC_ATTN64_DKV_ROWS', rows)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        dq = hip.attention_bwd(q, k, v, o, do, lse, B, heads, N, Nkv, hd, hd ** -0.5, dk, dv)
+        torch.cuda.synchronize()
+        outs.append((dq.clone(), dk.clone(), dv.clone()))
+    for other in outs[1:]:
+        for name, a, b in zip(('dq', 'dk', 'dv'), outs[0], other):
+            assert torch.equal(a, b), (name, (a != b).sum().item())
+
+
 @pytest.mark.parametrize('shape', [(1, 2, 8192, 2048, 64), (1, 1, 8200, 2048, 64), (1, 2, 700, 300, 64), (2, 1, 1000, 130, 64)])
 def test_attention_head_dim_64_prescale_option(shape, monkeypatch):
     """SEGFAC_ATTN64_PRESCALE=1 (csrc/policy.h: scale log2 e on the Q fragments, -max / -lse as the score accumulators' initial values;
