@@ -51,6 +51,12 @@ ev = {leg['per_gpu_batch']: leg for leg in final['eval']}
 v['EV1_F32'], v['EV32_F32'] = f"{ev[1]['fp32']['graph']['images_per_sec']:.0f}", f"{ev[32]['fp32']['graph']['images_per_sec']:.0f}"
 v['EV1_BF'], v['EV32_BF'] = f"{ev[1]['bf16']['graph']['images_per_sec']:.0f}", f"{ev[32]['bf16']['graph']['images_per_sec']:.0f}"
 
+# socket power / shader clock / energy per image during each configuration's replay (tools/measure_round.sh, section power)
+for ln in open(os.path.join(P, f'{a.tag}_power_clock.txt')):
+    m = re.match(r'(cfg\d) batch \d+: \d+ samples, mean power (\d+) W, mean sclk (\d+) MHz.*?(?:, ([\d.]+) J per image)?$', ln.strip())
+    if m:
+        c = m.group(1).upper()
+        v[f'{c}_W'], v[f'{c}_GHZ'], v[f'{c}_J'] = m.group(2), f'{int(m.group(3)) / 1000:.2f}', m.group(4) or '?'
 src = open(os.path.join(ROOT, 'tools', 'design_front.md')).read()
 missing = sorted(set(re.findall(r'\{\{(\w+)\}\}', src)) - set(v))
 if missing:
