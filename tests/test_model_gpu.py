@@ -1276,3 +1276,19 @@ def test_dispatch_table_is_what_the_step_launches(golden_dir):
     assert set(w) == set(g), (sorted(set(w) - set(g))[:3], sorted(set(g) - set(w))[:3])
     for k in w:
         assert w[k]['kernels'] == g[k]['kernels'] and w[k]['count'] == g[k]['count'], (k, w[k], g[k])
+
+
+def test_headline_batch_equals_its_halves():
+    """bench.py's per-GPU batch of the headline configuration (256 x 512 x 512: the 768-wide stride-4 map has 3.2 x 10^9 elements, past
+    2^31) against its 128-image halves in eval mode (tools/check_large_batch.py): bit-equal logits, equal mean loss, gradients within
+    the split-K round-off -- an index that overflows 32 bits reads other memory and is off by the scale of the tensor."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for d in (root, os.path.join(root, 'tools')):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    import check_large_batch
+    e_fwd, scale, l1, l2, e_g = check_large_batch.check(128, 'cfg2', verbose=False)
+    assert e_fwd == 0.0, (e_fwd, scale)
+    assert abs(l1 - l2) <= 1e-5 * abs(l1) and e_g < 2e-2
+    torch.cuda.empty_cache()
