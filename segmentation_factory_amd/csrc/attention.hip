@@ -368,15 +368,35 @@ static inline int attn_vec_ok(int dt, const void* p, int64_t ld) {
     const int64_t esz = dt == SEGF_BF16 ? 2 : 4;
     return ((uintptr_t)p % 16 == 0) && ((ld * esz) % 16 == 0);
 }
+// Query chunks of the key-side backward (grid = key blocks x chunks x (batch, head); every workgroup stages its keys once and walks its
+// chunk's queries; the chunks' partial dK / dV slabs are summed by attn_dkv_reduce_kernel).  r04's rule asked for >= 512 workgroups
+// (two per CU) and stopped there: 192 images x 1 head gave 3 chunks = 576 workgroups = one full round + one of 64 -- the kernel cost 28 %
+// more per image at batch 192 than at 256 (profiles/r05_batch_sweep.txt: why 192 was SLOWER than 128).  Now the count minimises
+// rounds x (queries per chunk + a fixed per-workgroup cost), the model of a grid that runs in whole rounds of 512 resident workgroups:
+// the same choices at power-of-two batches (256 x 1 head: 2 chunks = 512 workgroups), 8 chunks = three full rounds at 192.
 static inline void attn_chunks(int B, int heads, int N, int Nkv, int hd, int& nchunk, int& qchunk) {
     const int tpr = hd / 32, kpb = AT_THREADS / tpr;
     const int kvtiles = (Nkv + kpb - 1) / kpb;
-    int want = (512 + B * heads * kvtiles - 1) / (B * heads * kvtiles);
+    const int64_t base = (int64_t)B * heads * kvtiles;            // workgroups per chunk
     int maxc = (N + 63) / 64;
-    if (want > 64) want = 64;
-    if (want > maxc) want = maxc;
-    if (want < 1) want = 1;
-    qchunk = ((N + want - 1) / want + AT_QT - 1) / AT_QT * AT_QT;
+    if (maxc > 64) maxc = 64;
+    if (maxc < 1) maxc = 1;
+    const int64_t cap = 512;                                      // resident workgroups (two per CU)
+    const double fixed = 256.0;                                   // per-workgroup prologue (key staging) in units of one query's work
+    double best = 0.0;
+    int bc = 1;
+    for (int c = 1; c <= maxc; ++c) {
+        const int q = ((N + c - 1) / c + AT_QT - 1) / AT_QT * AT_QT;
+        const int n = (N + q - 1) / q;
+        if (n != c && c > 1) continue;                            // (the same partition as a smaller count)
+        const int64_t wg = base * n;
+        const int64_t rounds = (wg + cap - 1) / cap;
+        // below one round the chip is not full: time falls with every further chunk until it is (the r04 rule); the 0.5 % per chunk
+        // breaks ties towards fewer slabs to write and sum
+        const double t = (double)rounds * ((double)q + fixed) * (1.0 + 0.005 * n);
+        if (c == 1 || t < best) { best = t; bc = n; }
+    }
+    qchunk = ((N + bc - 1) / bc + AT_QT - 1) / AT_QT * AT_QT;
     nchunk = (N + qchunk - 1) / qchunk;
 }
 

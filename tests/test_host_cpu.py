@@ -457,3 +457,31 @@ def test_bench_default_batches_resolve():
         assert bench_legs.resolve_batch(cfg) == b and isinstance(bench_legs.resolve_batch(cfg), int)
         assert bench_legs.resolve_batch(cfg, 7) == 7
     assert set(bench.DEFAULT_BATCH) == set(bench_legs.CONFIGS) | {'cfg2'} or set(bench.DEFAULT_BATCH) >= set(bench_legs.CONFIGS)
+
+
+def test_attention_backward_query_chunks_fill_whole_rounds():
+    """csrc/attention.hip: attn_chunks (through segf_attention_bwd_ws, host arithmetic only).  The key-side backward runs in rounds of 512
+    resident workgroups; r04's rule stopped at ">= 512 workgroups" and gave 192 images x 1 head 3 chunks = 576 workgroups (a full round
+    and one of 64: that kernel cost 28 % more per image at batch 192 than at 256).  The count now minimises rounds x (queries per chunk +
+    a fixed cost): 8 chunks = three full rounds there, the r04 choices at the benchmarked power-of-two batches."""
+    from segmentation_factory_amd import hip
+    lib = hip.lib()
+
+    def nchunk(B, heads, N, Nkv, hd):
+        ws = lib.segf_attention_bwd_ws(B, heads, N, Nkv, hd)
+        per = B * Nkv * 2 * heads * hd
+        n, rem = divmod(ws - B * heads * N, per)
+        assert rem == 0 and n >= 1
+        return n
+    assert nchunk(192, 1, 16384, 256, 32) == 8          # 1536 workgroups = 3 rounds
+    assert nchunk(256, 1, 16384, 256, 32) == 2          # 512: as before
+    assert nchunk(128, 1, 16384, 256, 32) == 4
+    assert nchunk(4, 1, 16384, 256, 32) == 64           # far below one round: as many chunks as the rule allows
+    assert nchunk(32, 1, 131072, 2048, 64) == 1         # cfg4 stage 1 at batch 32: 16 key blocks x 32 images = 512
+    assert nchunk(16, 1, 131072, 2048, 64) == 2
+    for B in (3, 7, 24, 48, 100, 192, 200, 256, 384):
+        for heads, N in ((1, 16384), (2, 4096), (5, 1024), (8, 256)):
+            n = nchunk(B, heads, N, 256, 32)
+            wg = B * heads * n
+            if wg >= 512:
+                assert wg / (-(-wg // 512) * 512) >= 0.74, (B, heads, N, n, wg)
