@@ -485,3 +485,21 @@ def test_attention_backward_query_chunks_fill_whole_rounds():
             wg = B * heads * n
             if wg >= 512:
                 assert wg / (-(-wg // 512) * 512) >= 0.74, (B, heads, N, n, wg)
+
+
+def test_weight_gradient_slices_fill_whole_rounds_of_the_eight_phase_tile():
+    """segf_gemm_pick_splitk (host arithmetic): nn.Linear weight gradients that csrc/gemm.hip:dw_on_gemm8 sends to the eight-phase kernel
+    (both feature counts multiples of 256, >= 100 GFLOP, >= 256 FLOP per operand byte) get the smallest slice count whose last round of
+    256 tiles is >= 90 % full (else the fullest); smaller or thinner products keep the 128-tile kernel's rule (SEGFAC_GEMM8_DW=0: all do)."""
+    from segmentation_factory_amd import hip
+    assert hip.pick_splitk(3072, 768, 51200) == 7          # 36 tiles x 7 = 252 of 256
+    assert hip.pick_splitk(768, 3072, 51200) == 7
+    assert hip.pick_splitk(6144, 1536, 12800) == 5         # 144 tiles x 5 = 720 = 2.8 rounds
+    assert hip.pick_splitk(2048, 512, 65472) == 15         # 16 tiles x 15 = 240 of 256 (MiT-B2 stage 4 at batch 32)
+    with hip.policy_override(gemm8_dw=0):
+        assert hip.pick_splitk(3072, 768, 51200) != 7      # the 128-tile kernel's count (144 tiles of 128 x 128)
+    # below the rule: ConvNeXt-T stage 4 at batch 64 (77 GFLOP), a 384-wide operand (not a multiple of 256)
+    for shape in ((3072, 768, 16384), (1536, 384, 204800)):
+        with hip.policy_override(gemm8_dw=0):
+            want = hip.pick_splitk(*shape)
+        assert hip.pick_splitk(*shape) == want
