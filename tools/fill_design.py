@@ -26,6 +26,8 @@ v = {'TAG': a.tag, 'HEAD_IPS': f"{final['value']:.0f}", 'HEAD_MS': f"{final['ms_
      'HEAD_X': f"{final['value'] / 200:.0f}"}
 for b in (4, 16, 32, 128):
     v[f'B{b}'] = f"{line(f'{a.tag}_bench_b{b}.json')['value']:.0f}"
+v['B128_MS'] = f"{line(f'{a.tag}_bench_b128.json')['ms_per_step']:.1f}"
+v['HEAD_MS_HALF'] = f"{final['ms_per_step'] * 128 / HB:.1f}"
 r, g = final['roofline'], final['roofline_gemm']
 v.update(LOSS_GBPS=f"{r['achieved']:.0f}", LOSS_FRAC=f"{r['frac']:.3f}", LOSS_TRAFFIC=f"{(r.get('traffic') or 0) / 1e9:.2f}",
          LOSS_TOA=str(r.get('traffic_over_algorithmic')), GEMM_GBPS=f"{g['achieved']:.0f}", GEMM_FRAC=f"{g['frac']:.2f}",
